@@ -1,0 +1,237 @@
+/*
+ * ococc_hip.h -- C ABI of libococc_hip.so, the MI355X (gfx950) kernels behind
+ * the OcOccNet hot path of Ghostish/ObjectCentricOccCompletion.
+ *
+ * Drop-in boundary.  The reference binds this path through pybind11 torch
+ * extensions that take at::Tensor (mmdet3d/ops/voxel/src/voxelization.cpp:6-11,
+ * mmdet3d/ops/spconv/src/all.cc:21-51) plus three un-vendored CUDA packages
+ * (TorchEx, torch_scatter, SpConv2).  This header replaces those bindings with
+ * plain pointers and sizes; INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add in the mmdet3d/ops python files to call it.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the parameter is called host_*;
+ *   - the caller owns every buffer, including `workspace` whose size comes from
+ *     the matching *_workspace_bytes() query (pure host arithmetic);
+ *   - nothing allocates, frees, synchronises or throws; work is queued on
+ *     `stream` (a hipStream_t passed as void*, NULL = the null stream);
+ *   - variable-size results are written into worst-case sized buffers and
+ *     their length into a device int32 the caller reads back when it needs it;
+ *   - return 0 on success, a negative OCOCC_E* code otherwise;
+ *     ococc_last_error() returns the message of the calling thread's last
+ *     failure;
+ *   - row-major contiguous tensors; "bf16" buffers are uint16_t bit patterns.
+ */
+#ifndef OCOCC_HIP_H_
+#define OCOCC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCOCC_OK 0
+#define OCOCC_EINVAL (-1)      /* bad argument (message says which) */
+#define OCOCC_EHIP (-2)        /* HIP runtime error */
+#define OCOCC_EUNSUPPORTED (-3) /* shape / dtype outside the compiled kernels */
+
+/* element types of feature buffers */
+#define OCOCC_F32 0
+#define OCOCC_BF16 1
+
+/* reduce types; values follow reduce_t of the reference
+ * (mmdet3d/ops/voxel/src/scatter_points_cuda.cu:6) */
+#define OCOCC_REDUCE_SUM 0
+#define OCOCC_REDUCE_MEAN 1
+#define OCOCC_REDUCE_MAX 2
+
+typedef void* ococc_stream_t; /* hipStream_t */
+
+const char* ococc_last_error(void);
+int ococc_version(void);
+/* compiled for: returns "gfx950" */
+const char* ococc_arch(void);
+
+/* ------------------------------------------------------------------------ *
+ * B1  dynamic voxelisation
+ * replaces voxelization::dynamic_voxelize
+ *   (mmdet3d/ops/voxel/src/voxelization.h:77-88, kernels
+ *    voxelization_cuda.cu:25-65 / voxelization_cpu.cpp:8-41)
+ * coors[i] = (z,y,x) int32, c = floor((p - min) / voxel) CLAMPED to
+ * [0, grid-1] (this fork clamps; upstream mmdet3d writes -1),
+ * grid = ceil((max - min) / voxel)  (voxelization_cpu.cpp:155-158).
+ * points: [num_points, num_features] f32, first three columns are x,y,z.
+ * ------------------------------------------------------------------------ */
+int ococc_dynamic_voxelize_f32(const float* points, int64_t num_points, int32_t num_features,
+                               const float host_voxel_size[3], const float host_coors_range[6],
+                               int32_t* coors, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * hard voxelisation (max_points / max_voxels caps, first-come order)
+ * replaces voxelization::hard_voxelize
+ *   (voxelization.h:60-75, voxelization_cpu.cpp:44-143).
+ * grid = round((max - min) / voxel) (voxelization_cpu.cpp:119-122).
+ * voxels [max_voxels,max_points,num_features] f32 (caller zero-fills),
+ * coors [max_voxels,3] i32, num_points_per_voxel [max_voxels] i32 (zeroed),
+ * voxel_num: device int32 receiving the number of voxels produced.
+ * ------------------------------------------------------------------------ */
+int64_t ococc_hard_voxelize_workspace_bytes(int64_t num_points, const float host_voxel_size[3],
+                                            const float host_coors_range[6]);
+int ococc_hard_voxelize_f32(const float* points, int64_t num_points, int32_t num_features,
+                            const float host_voxel_size[3], const float host_coors_range[6],
+                            int32_t max_points, int32_t max_voxels, float* voxels, int32_t* coors,
+                            int32_t* num_points_per_voxel, int32_t* voxel_num, void* workspace,
+                            int64_t workspace_bytes, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * unique rows of integer coordinates on a bounded grid
+ * replaces at::unique_dim(coors, 0, sorted, inverse, counts) as used by
+ *   dynamic_point_to_voxel_forward (scatter_points_cuda.cu:199-210) and
+ *   torch.unique(coors, dim=0, return_inverse=True) in scatter_v2
+ *   (mmdet3d/ops/sst/sst_ops.py:150-181).
+ * coors [n, ndim] int32 (ndim 1..4), host_dims[ndim] = exclusive upper bound
+ * of each column.  Rows with any negative entry are dropped (inv = -1), as
+ * DynamicScatter does; rows with an entry >= its bound set *status to 1.
+ * Outputs are in lexicographic order of the rows (== torch.unique order):
+ * out_coors [>= num_unique, ndim], inv [n] (row -> unique row), counts
+ * [>= num_unique], num_unique (device int32).  out_capacity bounds the rows
+ * written to out_coors/counts (use min(n, prod(dims))).
+ * ------------------------------------------------------------------------ */
+int64_t ococc_grid_unique_workspace_bytes(int32_t ndim, const int32_t host_dims[4]);
+int ococc_grid_unique_i32(const int32_t* coors, int64_t n, int32_t ndim, const int32_t host_dims[4],
+                          int32_t* out_coors, int64_t out_capacity, int32_t* inv, int32_t* counts,
+                          int32_t* num_unique, int32_t* status, void* workspace,
+                          int64_t workspace_bytes, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * A5 / B2  segment (scatter) reduce, forward and backward
+ * replaces feats_reduce_kernel + traceback kernels
+ *   (scatter_points_cuda.cu:81-179) and torch_scatter.scatter_max /
+ *   scatter(reduce='mean'|'sum') called at sst_ops.py:171-174.
+ * feats [n, c] f32, inv [n] int32 in [-1, num_segments) (-1 rows ignored),
+ * out [num_segments, c] f32.  counts [num_segments] int32 is required for
+ * MEAN (divide) and optional otherwise (segments with count 0 -> 0 for MAX,
+ * as torch_scatter does).  arg [num_segments, c] int32 (MAX only, may be
+ * NULL): smallest row index attaining the max -- the tie rule of
+ * max_reduce_traceback_scatter_idx_kernel (scatter_points_cuda.cu:136-160).
+ * ------------------------------------------------------------------------ */
+int ococc_segment_count_i32(const int32_t* inv, int64_t n, int32_t* counts, int64_t num_segments,
+                            ococc_stream_t stream);
+int ococc_segment_reduce_f32(const float* feats, const int32_t* inv, int64_t n, int32_t c,
+                             int32_t reduce_type, const int32_t* counts, float* out, int32_t* arg,
+                             int64_t num_segments, ococc_stream_t stream);
+/* grad_feats [n, c] is fully written (no pre-zeroing needed).
+ * SUM:  g[i] = go[inv[i]];  MEAN: g[i] = go[inv[i]] / counts[inv[i]];
+ * MAX:  g[i][ch] = arg[inv[i]][ch] == i ? go[inv[i]][ch] : 0. */
+int ococc_segment_reduce_bwd_f32(const float* grad_out, const int32_t* inv, int64_t n, int32_t c,
+                                 int32_t reduce_type, const int32_t* counts, const int32_t* arg,
+                                 float* grad_feats, int64_t num_segments, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * B3  sub-manifold rulebook
+ * replaces spconv::getIndicePair<3>(subM) (include/spconv/spconv_ops.h:27-104
+ * -> geometry.h:247-297 CPU / indice.cu.h:147-234 GPU).
+ * indices [n, 4] int32 (batch, z, y, x); spatial shape host_shape[3] (D,H,W);
+ * kernel size host_ksize[3] (odd), dilation host_dilation[3].
+ * Products:
+ *   nbr_t     [kvol, n] int32  nbr_t[k][o] = input row feeding output row o
+ *                              through kernel offset k, or -1;
+ *   blockmask [ceil(n/16)] u32 bit k set iff rows 16b..16b+15 have any
+ *                              neighbour at offset k (kvol <= 32 only,
+ *                              otherwise pass NULL);
+ *   indice_pairs [kvol,2,n] int32 and indice_num [kvol] int32 -- the
+ *     reference rulebook, filled with -1 beyond indice_num[k], in the exact
+ *     order of the CPU functor (ascending input row within an offset).
+ * offset index k = sum_d m_d * (in_d - out_d + pad_d), last dim fastest
+ * (geometry.h:61-72).
+ * ------------------------------------------------------------------------ */
+int64_t ococc_subm_rulebook_workspace_bytes(int64_t n, int32_t batch_size,
+                                            const int32_t host_shape[3],
+                                            const int32_t host_ksize[3]);
+int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
+                              const int32_t host_shape[3], const int32_t host_ksize[3],
+                              const int32_t host_dilation[3], int32_t* nbr_t, uint32_t* blockmask,
+                              int32_t* indice_pairs, int32_t* indice_num, void* workspace,
+                              int64_t workspace_bytes, ococc_stream_t stream);
+
+/* Rebuild the gather tables from a reference-format rulebook (any conv type:
+ * regular / inverse / user supplied).  Each (row, offset) may appear at most
+ * once on the chosen side (true for every spconv rulebook).
+ * side = 1: table[k][pairs[k][1][p]] = pairs[k][0][p]  (forward: out <- in)
+ * side = 0: table[k][pairs[k][0][p]] = pairs[k][1][p]  (dgrad:   in  <- out)
+ * table [kvol, num_rows] int32 is fully written (-1 where empty). */
+int ococc_rulebook_pairs_to_table(const int32_t* indice_pairs, const int32_t* indice_num,
+                                  int32_t kvol, int64_t pair_capacity, int32_t side,
+                                  int64_t num_rows, int32_t* table, uint32_t* blockmask,
+                                  ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * B4  sparse convolution:  out[o] = sum_k  feat[table[k][o]] @ W[k]
+ * replaces indiceConv / indiceConvBackward (spconv_ops.h:260-456): the
+ * reference runs, per offset, gather kernel + GEMM + scatter-add kernel
+ * (reordering.cu.h:21-157); here one output-stationary kernel gathers rows
+ * straight into MFMA operand registers with the weights resident in LDS.
+ *
+ * feat   [n_in, kd] bf16        kd multiple of 16, <= 256
+ * wn     [kvol, ncols, kd] bf16 weights with the contraction dim innermost
+ *                               (forward: W[k]^T; dgrad: W[k'] as stored, see
+ *                               ococc_weight_prepare_bf16)
+ * table  [kvol, n_out] int32, blockmask [ceil(n_out/16)] (kvol <= 32)
+ * bias   [ncols] f32 or NULL
+ * out    [n_out, ncols] bf16 (out_dtype OCOCC_BF16) or f32; ncols mult. of 16
+ * ------------------------------------------------------------------------ */
+int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32_t kd,
+                                       const uint16_t* wn, int32_t kvol, int32_t ncols,
+                                       const int32_t* table, const uint32_t* blockmask,
+                                       int64_t n_out, const float* bias, void* out,
+                                       int32_t out_dtype, ococc_stream_t stream);
+
+/* weights [kvol, cin, cout] (the reference layout (kD,kH,kW,Cin,Cout),
+ * spconv/conv.py:98-99) in f32 or bf16 ->
+ *   mode 0 (forward): wn[k][cout][cin]  = W[k][cin][cout]
+ *   mode 1 (dgrad, sub-manifold): wn[k][cin][cout] = W[kvol-1-k][cin][cout]
+ *   mode 2 (dgrad, generic table side 0): wn[k][cin][cout] = W[k][cin][cout]
+ * always bf16 out. */
+int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t kvol, int32_t cin,
+                              int32_t cout, int32_t mode, uint16_t* wn, ococc_stream_t stream);
+
+/* dW[k] = sum_p x[pairs[k][0][p]]^T dy[pairs[k][1][p]]  over the rulebook.
+ * x [n_in, cin] bf16, dy [n_out, cout] bf16, cin/cout multiples of 16,
+ * dw [kvol, cin, cout] f32 (fully written).  Deterministic: partial sums go
+ * to per-workgroup slabs in `workspace` and are added in a fixed order. */
+int64_t ococc_sparse_conv_wgrad_workspace_bytes(int32_t kvol, int64_t pair_capacity, int32_t cin,
+                                                int32_t cout);
+int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, const uint16_t* dy,
+                                 int64_t n_out, int32_t cout, const int32_t* indice_pairs,
+                                 const int32_t* indice_num, int32_t kvol, int64_t pair_capacity,
+                                 float* dw, void* workspace, int64_t workspace_bytes,
+                                 ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * B5  fused LayerNorm + GELU(erf) over feature rows (the norm/act pair that
+ * make_sparse_convmodule appends to a sparse conv, ops/sparse_block.py:216-289;
+ * also every Linear->LN->GELU of build_mlp, sst_ops.py:333-360).
+ * x, y [n, c] in `dtype` (f32 or bf16); gamma, beta [c] f32.
+ * act: 0 = none (plain LayerNorm), 1 = GELU(erf).
+ * mean_rstd [n, 2] f32 is written by forward and read by backward.
+ * Backward: dx [n,c] in dtype; dgamma, dbeta [c] f32 are ACCUMULATED into
+ * (caller zero-fills) from per-workgroup partials in a fixed order.
+ * ------------------------------------------------------------------------ */
+int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, const float* gamma,
+                            const float* beta, float eps, int32_t act, void* y, float* mean_rstd,
+                            int32_t dtype, ococc_stream_t stream);
+int64_t ococc_layernorm_act_bwd_workspace_bytes(int64_t n, int32_t c);
+int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
+                            const float* gamma, const float* beta, const float* mean_rstd,
+                            int32_t act, void* dx, float* dgamma, float* dbeta, int32_t dtype,
+                            void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+
+/* f32 <-> bf16 row casts (round to nearest even) */
+int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
+int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCOCC_HIP_H_ */

@@ -1,0 +1,131 @@
+"""ctypes binding of ``libococc_hip.so`` (C ABI declared in ``include/ococc_hip.h``).
+
+The library is the product: there is no CPU or PyTorch fallback behind these
+calls.  Importing this module without the built library raises, and every op
+refuses tensors that do not live on a ROCm device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libococc_hip.so')
+
+F32, BF16 = 0, 1
+REDUCE = {'sum': 0, 'mean': 1, 'avg': 1, 'max': 2}
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+_F3 = ctypes.c_float * 3
+_F6 = ctypes.c_float * 6
+_I3 = ctypes.c_int32 * 3
+_I4 = ctypes.c_int32 * 4
+
+# name -> (restype, argtypes); one entry per function declared in ococc_hip.h
+SIGNATURES = {
+    'ococc_last_error': (ctypes.c_char_p, []),
+    'ococc_version': (c_i32, []),
+    'ococc_arch': (ctypes.c_char_p, []),
+    'ococc_dynamic_voxelize_f32': (c_i32, [c_vp, c_i64, c_i32, _F3, _F6, c_vp, c_vp]),
+    'ococc_hard_voxelize_workspace_bytes': (c_i64, [c_i64, _F3, _F6]),
+    'ococc_hard_voxelize_f32': (c_i32, [c_vp, c_i64, c_i32, _F3, _F6, c_i32, c_i32, c_vp, c_vp,
+                                        c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_grid_unique_workspace_bytes': (c_i64, [c_i32, _I4]),
+    'ococc_grid_unique_i32': (c_i32, [c_vp, c_i64, c_i32, _I4, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_i64, c_vp]),
+    'ococc_segment_count_i32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    'ococc_segment_reduce_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
+                                         c_vp]),
+    'ococc_segment_reduce_bwd_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                             c_i64, c_vp]),
+    'ococc_subm_rulebook_workspace_bytes': (c_i64, [c_i64, c_i32, _I3, _I3]),
+    'ococc_subm_rulebook_build': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, _I3, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_i64, c_vp]),
+    'ococc_rulebook_pairs_to_table': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp,
+                                              c_vp]),
+    'ococc_sparse_conv_gather_gemm_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp,
+                                                   c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
+    'ococc_weight_prepare_bf16': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'ococc_sparse_conv_wgrad_workspace_bytes': (c_i64, [c_i32, c_i64, c_i32, c_i32]),
+    'ococc_sparse_conv_wgrad_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp,
+                                             c_i32, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_layernorm_act_fwd': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp,
+                                        c_i32, c_vp]),
+    'ococc_layernorm_act_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
+    'ococc_layernorm_act_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                        c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+}
+
+
+class OcoccError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build the HIP kernels first '
+            '(python -c "import __graft_entry__ as g; g.build()" or '
+            '`make -C objectcentricocccompletion_amd/csrc`). There is no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.ococc_last_error().decode(errors='replace')
+        raise OcoccError(f'{what} failed with code {rc}: {msg}')
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise OcoccError('ococc ops run on a ROCm device only; got a CPU tensor '
+                             '(there is no CPU fallback)')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f3(v):
+    return _F3(*[float(x) for x in v])
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])
+
+
+def i3(v):
+    return _I3(*[int(x) for x in v])
+
+
+def i4(v):
+    v = list(v) + [1] * (4 - len(v))
+    return _I4(*[int(x) for x in v])
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise OcoccError(f'unsupported dtype {dt}; the kernels take float32 or bfloat16')
+
+
+def workspace(nbytes, device):
+    """Caller-owned scratch buffer (the C ABI never allocates)."""
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

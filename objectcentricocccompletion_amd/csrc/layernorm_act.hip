@@ -1,0 +1,283 @@
+// B5 fused LayerNorm (+ GELU) over feature rows, forward and backward.
+// Reference: the norm/act layers make_sparse_convmodule appends after a sparse
+// conv (mmdet3d/ops/sparse_block.py:216-289) and every Linear->LN->GELU stage
+// of build_mlp (mmdet3d/ops/sst/sst_ops.py:333-360): separate LayerNorm and GELU
+// kernels, each reading and writing the [n, c] activation.
+// Here: one pass per direction.  HBM-bound: forward moves 2*n*c*s bytes,
+// backward 3*n*c*s.  A row is spread over LPR lanes (power of two), lane li
+// owns channels li, li+LPR, ... so that a wave instruction touches whole rows
+// contiguously; row statistics are reduced with wave shuffles, never LDS.
+// dgamma/dbeta: per-lane running sums over the rows a workgroup owns, combined
+// through LDS, written to per-workgroup slabs and added in a fixed order.
+#include "common.hpp"
+
+namespace {
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<uint16_t>(const uint16_t* p) { return ococc_bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<uint16_t>(uint16_t* p, float v) { *p = ococc_f32_to_bf16(v); }
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int d = lpr >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu(float z) { return 0.5f * z * (1.f + erff(z * kInvSqrt2)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+  return 0.5f * (1.f + erff(z * kInvSqrt2)) + z * kInvSqrt2Pi * expf(-0.5f * z * z);
+}
+
+// VPL = channels per lane held in registers (c <= VPL * lpr)
+template <typename T, int VPL>
+__global__ void __launch_bounds__(256)
+ln_act_fwd_kernel(const T* __restrict__ x, int64_t n, int c, int lpr,
+                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                  int act, T* __restrict__ y, float* __restrict__ mean_rstd) {
+  const int rows_per_block = 256 / lpr;
+  const int li = threadIdx.x % lpr;
+  const int rloc = threadIdx.x / lpr;
+  const float inv_c = 1.f / (float)c;
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_block + rloc; r < n;
+       r += (int64_t)gridDim.x * rows_per_block) {
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ch = li + j * lpr;
+      v[j] = ch < c ? ld<T>(x + r * c + ch) : 0.f;
+      s += v[j];
+    }
+    const float mean = group_sum(s, lpr) * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ch = li + j * lpr;
+      const float d = ch < c ? v[j] - mean : 0.f;
+      sq += d * d;
+    }
+    const float rstd = rsqrtf(group_sum(sq, lpr) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ch = li + j * lpr;
+      if (ch < c) {
+        float z = (v[j] - mean) * rstd * gamma[ch] + beta[ch];
+        if (act == 1) z = gelu(z);
+        st<T>(y + r * c + ch, z);
+      }
+    }
+    if (mean_rstd && li == 0) {
+      mean_rstd[r * 2] = mean;
+      mean_rstd[r * 2 + 1] = rstd;
+    }
+  }
+}
+
+template <typename T, int VPL>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n, int c, int lpr,
+                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                  const float* __restrict__ mean_rstd, int act, T* __restrict__ dx,
+                  float* __restrict__ partials) {
+  __shared__ float red[256];
+  const int rows_per_block = 256 / lpr;
+  const int li = threadIdx.x % lpr;
+  const int rloc = threadIdx.x / lpr;
+  const float inv_c = 1.f / (float)c;
+  float dg[VPL], db[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) dg[j] = db[j] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rows_per_block + rloc; r < n;
+       r += (int64_t)gridDim.x * rows_per_block) {
+    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+    float xh[VPL], dzg[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ch = li + j * lpr;
+      xh[j] = 0.f;
+      dzg[j] = 0.f;
+      if (ch < c) {
+        const float g = gamma[ch];
+        xh[j] = (ld<T>(x + r * c + ch) - mean) * rstd;
+        float dz = ld<T>(dy + r * c + ch);
+        if (act == 1) dz *= gelu_grad(xh[j] * g + beta[ch]);
+        dg[j] += dz * xh[j];
+        db[j] += dz;
+        dzg[j] = dz * g;
+        s1 += dzg[j];
+        s2 += dzg[j] * xh[j];
+      }
+    }
+    s1 = group_sum(s1, lpr) * inv_c;
+    s2 = group_sum(s2, lpr) * inv_c;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int ch = li + j * lpr;
+      if (ch < c) st<T>(dx + r * c + ch, rstd * (dzg[j] - s1 - xh[j] * s2));
+    }
+  }
+  // combine the row groups of this block (fixed order), then one slab per block
+  float* slab = partials + (int64_t)blockIdx.x * 2 * c;
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) {
+    const int ch = li + j * lpr;
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+      red[threadIdx.x] = which ? db[j] : dg[j];
+      __syncthreads();
+      if (rloc == 0 && ch < c) {
+        float s = 0.f;
+        for (int g = 0; g < rows_per_block; ++g) s += red[g * lpr + li];
+        slab[which * c + ch] = s;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * c; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * 2 * c + i];
+    if (i < c) {
+      if (dgamma) dgamma[i] += s;
+    } else {
+      if (dbeta) dbeta[i - c] += s;
+    }
+  }
+}
+
+inline int pick_lpr(int c) {
+  int lpr = 1;
+  while (lpr * 4 < c && lpr < 64) lpr <<= 1;  // ~4 channels per lane
+  return lpr;
+}
+inline int bwd_blocks(int64_t n, int lpr) {
+  int64_t b = ococc_cdiv(n, 256 / lpr);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void __launch_bounds__(256)
+cast_f32_bf16_kernel(const float* __restrict__ s, uint16_t* __restrict__ d, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = ococc_f32_to_bf16(s[i]);
+}
+__global__ void __launch_bounds__(256)
+cast_bf16_f32_kernel(const uint16_t* __restrict__ s, float* __restrict__ d, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = ococc_bf16_to_f32(s[i]);
+}
+
+template <typename T>
+int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
+               int act, T* y, float* mean_rstd, hipStream_t stream) {
+  const int lpr = pick_lpr(c);
+  const int vpl = (int)ococc_cdiv(c, lpr);
+  const int grid = ococc_grid_1d(ococc_cdiv(n, 256 / lpr) * 256, 256);
+  if (vpl <= 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, stream, x, n, c, lpr, gamma, beta, eps, act, y, mean_rstd);
+  else if (vpl <= 8)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, stream, x, n, c, lpr, gamma, beta, eps, act, y, mean_rstd);
+  else if (vpl <= 32)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, x, n, c, lpr, gamma, beta, eps, act, y, mean_rstd);
+  else
+    return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "c must be <= 2048");
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+template <typename T>
+int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, const float* beta,
+               const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
+               hipStream_t stream) {
+  const int lpr = pick_lpr(c);
+  const int vpl = (int)ococc_cdiv(c, lpr);
+  const int grid = bwd_blocks(n, lpr);
+  if (vpl <= 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+  else if (vpl <= 8)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 8>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+  else if (vpl <= 32)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+  else
+    return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "c must be <= 2048");
+  OCOCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ococc_grid_1d(2 * c, 256, 16)), dim3(256), 0,
+                     stream, partials, grid, c, dgamma, dbeta);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+}  // namespace
+
+extern "C" int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, const float* gamma,
+                                       const float* beta, float eps, int32_t act, void* y,
+                                       float* mean_rstd, int32_t dtype, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n >= 0 && c >= 1, "bad sizes");
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(dtype == OCOCC_F32 || dtype == OCOCC_BF16, "dtype must be f32/bf16");
+  if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(x && y && gamma && beta, "null pointer");
+  if (dtype == OCOCC_F32)
+    return launch_fwd<float>((const float*)x, n, c, gamma, beta, eps, act, (float*)y, mean_rstd, stream);
+  return launch_fwd<uint16_t>((const uint16_t*)x, n, c, gamma, beta, eps, act, (uint16_t*)y, mean_rstd, stream);
+}
+
+extern "C" int64_t ococc_layernorm_act_bwd_workspace_bytes(int64_t n, int32_t c) {
+  if (n < 0 || c < 1) return -1;
+  return (int64_t)bwd_blocks(n, pick_lpr(c)) * 2 * c * (int64_t)sizeof(float);
+}
+
+extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
+                                       const float* gamma, const float* beta,
+                                       const float* mean_rstd, int32_t act, void* dx,
+                                       float* dgamma, float* dbeta, int32_t dtype, void* workspace,
+                                       int64_t workspace_bytes, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n >= 0 && c >= 1, "bad sizes");
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(dtype == OCOCC_F32 || dtype == OCOCC_BF16, "dtype must be f32/bf16");
+  if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(x && dy && dx && gamma && beta && mean_rstd, "null pointer");
+  OCOCC_REQUIRE(workspace && workspace_bytes >= ococc_layernorm_act_bwd_workspace_bytes(n, c),
+                "workspace too small");
+  if (dtype == OCOCC_F32)
+    return launch_bwd<float>((const float*)x, (const float*)dy, n, c, gamma, beta, mean_rstd, act,
+                             (float*)dx, dgamma, dbeta, (float*)workspace, stream);
+  return launch_bwd<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, n, c, gamma, beta, mean_rstd,
+                              act, (uint16_t*)dx, dgamma, dbeta, (float*)workspace, stream);
+}
+
+extern "C" int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count,
+                                      ococc_stream_t stream_) {
+  OCOCC_REQUIRE(count >= 0, "negative count");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(src && dst, "null pointer");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ococc_grid_1d(count, 256)), dim3(256), 0,
+                     (hipStream_t)stream_, src, dst, count);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count,
+                                      ococc_stream_t stream_) {
+  OCOCC_REQUIRE(count >= 0, "negative count");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(src && dst, "null pointer");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ococc_grid_1d(count, 256)), dim3(256), 0,
+                     (hipStream_t)stream_, src, dst, count);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}

@@ -1,0 +1,266 @@
+// B3 sub-manifold rulebook for gfx950.
+// Reference: spconv::getIndicePairsSubM (mmdet3d/ops/spconv/include/spconv/
+// geometry.h:247-297, CPU) and prepareSubMGridKernel / getSubMIndicePairsKernel
+// (include/spconv/indice.cu.h:147-234, GPU; pair order there is decided by
+// atomicAdd and is not reproducible).
+//
+// MI355X design.  The reference fills a dense int32 grid (16 MB for 64 x 40^3)
+// on every call.  Here the active set is a 1-bit-per-cell bitmap plus a
+// popcount prefix (1 MB, L2 resident): rank(cell) gives the voxel's position
+// in sorted order and perm[rank] its row.  The neighbour table
+//   nbr_t[k][o] = row of the active voxel at pos(o) + (k - centre), else -1
+// is written offset-major so that both this kernel's stores and the
+// convolution's index loads are contiguous.  A wave ballot over each table
+// row produces, for every 16-row block, the set of offsets that have any
+// neighbour (blockmask) -- the convolution skips the rest with scalar
+// branches.  The reference-format rulebook (indice_pairs / indice_num) is
+// derived by an order preserving stream compaction (prefix sum per offset),
+// which reproduces the CPU functor's order exactly: within offset k pairs are
+// in ascending input row j, and by symmetry of a sub-manifold
+// (in j feeds out o through k  <=>  nbr_t[K-1-k][j] = o).
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace {
+
+struct Geom {
+  int32_t batch, D, H, W;
+  int32_t kd, kh, kw;
+};
+
+__device__ __forceinline__ int32_t rank_of(const uint32_t* __restrict__ bitmap,
+                                           const uint32_t* __restrict__ prefix, int64_t cell) {
+  const uint32_t w = bitmap[cell >> 5];
+  const uint32_t bit = 1u << (cell & 31);
+  if (!(w & bit)) return -1;
+  return (int32_t)(prefix[cell >> 5] + __popc(w & (bit - 1u)));
+}
+
+__global__ void __launch_bounds__(256)
+mark_voxels_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
+                   uint32_t* __restrict__ bitmap, int32_t* __restrict__ status) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t b = indices[i * 4], z = indices[i * 4 + 1], y = indices[i * 4 + 2],
+                  x = indices[i * 4 + 3];
+    if ((unsigned)b >= (unsigned)g.batch || (unsigned)z >= (unsigned)g.D ||
+        (unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W) {
+      if (status) *status = 1;
+      continue;
+    }
+    const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
+    atomicOr(bitmap + (cell >> 5), 1u << (cell & 31));
+  }
+}
+
+// perm[rank(cell of row j)] = j  (largest j wins if a cell is listed twice)
+__global__ void __launch_bounds__(256)
+fill_perm_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
+                 const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
+                 int32_t* __restrict__ perm) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t b = indices[i * 4], z = indices[i * 4 + 1], y = indices[i * 4 + 2],
+                  x = indices[i * 4 + 3];
+    if ((unsigned)b >= (unsigned)g.batch || (unsigned)z >= (unsigned)g.D ||
+        (unsigned)y >= (unsigned)g.H || (unsigned)x >= (unsigned)g.W)
+      continue;
+    const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
+    const int32_t r = rank_of(bitmap, prefix, cell);
+    if (r >= 0) atomicMax(perm + r, (int32_t)i);
+  }
+}
+
+// grid (ceil(n/256), kvol): thread = (output row o, offset k)
+__global__ void __launch_bounds__(256)
+neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
+                       const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
+                       const int32_t* __restrict__ perm, int32_t* __restrict__ nbr_t,
+                       uint32_t* __restrict__ blockmask) {
+  const int k = blockIdx.y;
+  const int kx = k % g.kw, ky = (k / g.kw) % g.kh, kz = k / (g.kw * g.kh);
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t v = -1;
+  if (o < n) {
+    const int32_t b = indices[o * 4];
+    const int32_t z = indices[o * 4 + 1] + kz - g.kd / 2;
+    const int32_t y = indices[o * 4 + 2] + ky - g.kh / 2;
+    const int32_t x = indices[o * 4 + 3] + kx - g.kw / 2;
+    if ((unsigned)b < (unsigned)g.batch && (unsigned)z < (unsigned)g.D &&
+        (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) {
+      const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
+      const int32_t r = rank_of(bitmap, prefix, cell);
+      if (r >= 0) v = perm[r];
+    }
+    nbr_t[(int64_t)k * n + o] = v;
+  }
+  if (blockmask) {
+    const unsigned long long m = __ballot(v >= 0);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0 && o < n) {
+      if ((m >> lane) & 0xffffull) atomicOr(blockmask + (o >> 4), 1u << k);
+    }
+  }
+}
+
+// pairs[k][0][pos] = j, pairs[k][1][pos] = nbr_t[K-1-k][j]  for valid entries
+__global__ void __launch_bounds__(256)
+compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ pos,
+                     int64_t n, int kvol, int32_t* __restrict__ pairs) {
+  const int k = blockIdx.y;
+  const int src = kvol - 1 - k;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t o = nbr_t[(int64_t)src * n + j];
+    if (o < 0) continue;
+    const int64_t p = pos[(int64_t)src * n + j];
+    pairs[((int64_t)k * 2 + 0) * n + p] = (int32_t)j;
+    pairs[((int64_t)k * 2 + 1) * n + p] = o;
+  }
+}
+
+__global__ void reverse_totals_kernel(const uint32_t* __restrict__ totals, int kvol,
+                                      int32_t* __restrict__ indice_num) {
+  const int k = threadIdx.x;
+  if (k < kvol) indice_num[k] = (int32_t)totals[kvol - 1 - k];
+}
+
+// generic rulebook -> gather table
+__global__ void __launch_bounds__(256)
+pairs_to_table_kernel(const int32_t* __restrict__ pairs, const int32_t* __restrict__ num,
+                      int64_t cap, int side, int64_t rows, int32_t* __restrict__ table,
+                      uint32_t* __restrict__ blockmask) {
+  const int k = blockIdx.y;
+  const int32_t nk = num[k];
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nk;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = pairs[((int64_t)k * 2 + 0) * cap + p];
+    const int32_t b = pairs[((int64_t)k * 2 + 1) * cap + p];
+    const int32_t dst = side ? b : a, val = side ? a : b;
+    if ((unsigned)dst < (unsigned)rows) {
+      table[(int64_t)k * rows + dst] = val;
+      if (blockmask) atomicOr(blockmask + (dst >> 4), 1u << k);
+    }
+  }
+}
+
+struct Layout {
+  int64_t words, off_bitmap, off_prefix, off_perm, off_pos, off_scratch, off_totals, total;
+};
+
+inline bool make_layout(int64_t n, int32_t batch, const int32_t* shape, const int32_t* ksize,
+                        Layout* L) {
+  if (batch < 1 || !shape || !ksize) return false;
+  int64_t cells = batch;
+  for (int i = 0; i < 3; ++i) {
+    if (shape[i] < 1 || ksize[i] < 1 || !(ksize[i] & 1)) return false;
+    cells *= shape[i];
+    if (cells > 0x7fffffffLL) return false;
+  }
+  const int64_t kvol = (int64_t)ksize[0] * ksize[1] * ksize[2];
+  L->words = (cells + 31) / 32;
+  int64_t off = 0;
+  L->off_bitmap = off;  off += ococc_align_up(L->words * 4, 256);
+  L->off_prefix = off;  off += ococc_align_up(L->words * 4, 256);
+  L->off_perm = off;    off += ococc_align_up(n * 4, 256);
+  L->off_pos = off;     off += ococc_align_up(kvol * n * 4, 256);
+  int64_t sw = ococc_scan::scratch_words(L->words, 1);
+  int64_t sw2 = ococc_scan::scratch_words(n, (int)kvol);
+  L->off_scratch = off; off += ococc_align_up((sw > sw2 ? sw : sw2) * 4, 256);
+  L->off_totals = off;  off += ococc_align_up((kvol + 1) * 4, 256);
+  L->total = off;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int64_t ococc_subm_rulebook_workspace_bytes(int64_t n, int32_t batch_size,
+                                                       const int32_t host_shape[3],
+                                                       const int32_t host_ksize[3]) {
+  Layout L;
+  if (n < 0 || !make_layout(n, batch_size, host_shape, host_ksize, &L)) return -1;
+  return L.total;
+}
+
+extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
+                                         const int32_t host_shape[3], const int32_t host_ksize[3],
+                                         const int32_t host_dilation[3], int32_t* nbr_t,
+                                         uint32_t* blockmask, int32_t* indice_pairs,
+                                         int32_t* indice_num, void* workspace,
+                                         int64_t workspace_bytes, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  Layout L;
+  OCOCC_REQUIRE(n >= 0, "n < 0");
+  OCOCC_REQUIRE(make_layout(n, batch_size, host_shape, host_ksize, &L),
+                "need batch>=1, shape>=1, odd kernel sizes, batch*D*H*W < 2^31");
+  if (host_dilation)
+    OCOCC_REQUIRE(host_dilation[0] == 1 && host_dilation[1] == 1 && host_dilation[2] == 1,
+                  "sub-manifold dilation != 1 is not supported");
+  const int kvol = host_ksize[0] * host_ksize[1] * host_ksize[2];
+  OCOCC_REQUIRE(!blockmask || kvol <= 32, "blockmask needs kernel volume <= 32");
+  OCOCC_REQUIRE((indice_pairs == nullptr) == (indice_num == nullptr),
+                "indice_pairs and indice_num go together");
+  if (indice_num) OCOCC_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), stream));
+  if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(indices && nbr_t, "null indices/nbr_t");
+  OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
+  char* ws = (char*)workspace;
+  uint32_t* bitmap = (uint32_t*)(ws + L.off_bitmap);
+  uint32_t* prefix = (uint32_t*)(ws + L.off_prefix);
+  int32_t* perm = (int32_t*)(ws + L.off_perm);
+  uint32_t* pos = (uint32_t*)(ws + L.off_pos);
+  uint32_t* scratch = (uint32_t*)(ws + L.off_scratch);
+  uint32_t* totals = (uint32_t*)(ws + L.off_totals);
+  Geom g{batch_size, host_shape[0], host_shape[1], host_shape[2],
+         host_ksize[0], host_ksize[1], host_ksize[2]};
+
+  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.words * 4, stream));
+  OCOCC_HIP(hipMemsetAsync(perm, 0xff, n * 4, stream));
+  if (blockmask) OCOCC_HIP(hipMemsetAsync(blockmask, 0, ococc_cdiv(n, 16) * 4, stream));
+  const int g1 = ococc_grid_1d(n, 256);
+  hipLaunchKernelGGL(mark_voxels_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
+                     (int32_t*)nullptr);
+  OCOCC_CHECK_LAUNCH();
+  OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bitmap, L.words, L.words, 1, prefix,
+                                                         L.words, scratch, nullptr, stream));
+  hipLaunchKernelGGL(fill_perm_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
+                     prefix, perm);
+  OCOCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(neighbour_table_kernel, dim3((unsigned)ococc_cdiv(n, 256), kvol), dim3(256), 0,
+                     stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
+  OCOCC_CHECK_LAUNCH();
+  if (indice_pairs) {
+    OCOCC_HIP(hipMemsetAsync(indice_pairs, 0xff, (int64_t)kvol * 2 * n * 4, stream));
+    OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::NONNEG>((const uint32_t*)nbr_t, n, n, kvol,
+                                                             pos, n, scratch, totals, stream));
+    hipLaunchKernelGGL(compact_pairs_kernel, dim3(ococc_grid_1d(n, 256, 1024), kvol), dim3(256), 0,
+                       stream, nbr_t, pos, n, kvol, indice_pairs);
+    OCOCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reverse_totals_kernel, dim3(1), dim3(256), 0, stream, totals, kvol,
+                       indice_num);
+    OCOCC_CHECK_LAUNCH();
+  }
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_rulebook_pairs_to_table(const int32_t* indice_pairs,
+                                             const int32_t* indice_num, int32_t kvol,
+                                             int64_t pair_capacity, int32_t side,
+                                             int64_t num_rows, int32_t* table,
+                                             uint32_t* blockmask, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(kvol >= 1 && pair_capacity >= 0 && num_rows >= 0, "bad sizes");
+  OCOCC_REQUIRE(side == 0 || side == 1, "side must be 0 or 1");
+  OCOCC_REQUIRE(!blockmask || kvol <= 32, "blockmask needs kernel volume <= 32");
+  if (num_rows == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(table, "null table");
+  OCOCC_HIP(hipMemsetAsync(table, 0xff, (int64_t)kvol * num_rows * 4, stream));
+  if (blockmask) OCOCC_HIP(hipMemsetAsync(blockmask, 0, ococc_cdiv(num_rows, 16) * 4, stream));
+  if (pair_capacity == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(indice_pairs && indice_num, "null rulebook");
+  hipLaunchKernelGGL(pairs_to_table_kernel, dim3(ococc_grid_1d(pair_capacity, 256, 1024), kvol),
+                     dim3(256), 0, stream, indice_pairs, indice_num, pair_capacity, (int)side,
+                     num_rows, table, blockmask);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}

@@ -1,0 +1,505 @@
+// B4 sparse convolution on gfx950: forward / dgrad (gather-GEMM) and wgrad.
+//
+// Reference formulation (mmdet3d/ops/spconv/include/spconv/spconv_ops.h:260-456):
+// for each of the K^3 kernel offsets run a gather kernel (reordering.cu.h:21-97),
+// a dense GEMM and a scatter-add kernel (reordering.cu.h:99-157), moving
+// P*(Cin+2*Cout) elements through HBM and syncing with the host once per layer.
+//
+// MI355X formulation (one launch, compulsory traffic only):
+//   out[o] = sum_k feat[table[k][o]] @ W[k]        (output stationary)
+//   * a wave owns 16*RB consecutive output rows; accumulators never leave
+//     registers, so there is no scatter and no atomic: results are
+//     deterministic and each output row is written exactly once;
+//   * all kvol weight slices of a column slice are staged ONCE per workgroup
+//     into LDS (<= 144 KB of the 160 KB) and stay there while the workgroup
+//     walks its row tiles -- the k loop contains no barrier;
+//   * gathered rows go from L2/HBM straight into MFMA operand registers: the
+//     16x16x32 bf16 MFMA wants, per lane, 8 consecutive k of one row, which is
+//     exactly one 16-byte load from the gathered feature row, so no LDS
+//     staging or transposition of the activations is needed;
+//   * the MFMA is issued with the weights as the A operand and the gathered
+//     rows as B, so that a lane ends up with 4 consecutive output channels of
+//     one voxel and stores 8 B (bf16) / 16 B (f32) at a time;
+//   * per 16-row block a 32-bit mask (built with wave ballots by the rulebook
+//     kernel) says which offsets have any neighbour; the others are skipped
+//     with scalar branches.
+// dgrad is the same kernel run on dY with the gather table of the other side
+// and the weights in their stored [cin][cout] orientation.
+//
+// wgrad: dW[k] = sum_p x[in_p]^T dy[out_p] contracts over rulebook pairs, so it
+// walks the compacted pair lists (32 pairs per MFMA k-step, all useful).  Rows
+// are gathered into LDS row-major and read back with ds_read_b64_tr_b16, the
+// gfx950 transposing LDS read, which yields MFMA operands whose k index runs
+// over pairs.  Partial sums are written to per-workgroup slabs and added in a
+// fixed order (deterministic, no float atomics).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kConvThreads = 512;  // 8 waves, 2 per SIMD
+constexpr int kConvWaves = kConvThreads / 64;
+constexpr int kLdsBudget = 144 * 1024;
+
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8, z);
+}
+
+template <int KD, int CS, int RB, bool OUT_BF16>
+__global__ void __launch_bounds__(kConvThreads)
+gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ wn, int kvol,
+                   int ncols, const int32_t* __restrict__ table,
+                   const uint32_t* __restrict__ blockmask, int64_t n_out,
+                   const float* __restrict__ bias, void* __restrict__ out_) {
+  constexpr int KSTEPS = (KD + 31) / 32;
+  constexpr int NB = CS / 16;
+  constexpr int LDW = KD + 8;  // LDS row stride in elements (16 B pad)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* wl = (uint16_t*)smem;
+
+  const int cs0 = blockIdx.y * CS;
+  // ---- stage this column slice of all kvol weight matrices into LDS ----
+  {
+    constexpr int PPR = KD / 8;  // 16-byte pieces per row
+    const int total = kvol * CS * PPR;
+    for (int idx = threadIdx.x; idx < total; idx += kConvThreads) {
+      const int piece = idx % PPR;
+      const int row = (idx / PPR) % CS;
+      const int k = idx / (PPR * CS);
+      const u32x4 v = *(const u32x4*)(wn + ((int64_t)(k * ncols + cs0 + row)) * KD + piece * 8);
+      *(u32x4*)(wl + (k * CS + row) * LDW + piece * 8) = v;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lrow = lane & 15;       // voxel within the 16-row block / weight row
+  const int kg = lane >> 4;         // k group: elements 8*kg .. 8*kg+7 of a 32-deep k-step
+  const int64_t n_blocks = (n_out + 15) >> 4;
+  const int64_t n_tiles = (n_blocks + RB - 1) / RB;
+  const uint32_t all_mask = kvol >= 32 ? 0xffffffffu : ((1u << kvol) - 1u);
+
+  for (int64_t tile = (int64_t)blockIdx.x * kConvWaves + wave; tile < n_tiles;
+       tile += (int64_t)gridDim.x * kConvWaves) {
+    uint32_t m[RB];
+    uint32_t um = 0;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int64_t blk = tile * RB + rb;
+      uint32_t v = 0;
+      if (blk < n_blocks) v = blockmask ? blockmask[blk] : all_mask;
+      m[rb] = __builtin_amdgcn_readfirstlane(v);
+      um |= m[rb];
+    }
+    f32x4 acc[RB][NB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    while (um) {
+      const int k = __builtin_ctz(um);
+      um &= um - 1;
+      bf16x8 x[RB][KSTEPS];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        int32_t idx = -1;
+        if ((m[rb] >> k) & 1u) {
+          const int64_t r = (tile * RB + rb) * 16 + lrow;
+          if (r < n_out) idx = table[(int64_t)k * n_out + r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const int koff = ks * 32 + kg * 8;
+          bf16x8 v = zero_bf16x8();
+          if (idx >= 0 && koff < KD)
+            v = *(const bf16x8*)(feat + (int64_t)idx * KD + koff);
+          x[rb][ks] = v;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int koff = ks * 32 + kg * 8;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          bf16x8 w = zero_bf16x8();
+          if (koff < KD) w = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + koff);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) {
+            if ((m[rb] >> k) & 1u)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x[rb][ks], acc[rb][cb], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: lane holds channels cs0 + cb*16 + 4*kg + {0..3} of voxel lrow ----
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int64_t r = (tile * RB + rb) * 16 + lrow;
+      if (r >= n_out) continue;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int ch = cs0 + cb * 16 + kg * 4;
+        f32x4 v = acc[rb][cb];
+        if (bias) {
+          const f32x4 b = *(const f32x4*)(bias + ch);
+          v += b;
+        }
+        if (OUT_BF16) {
+          u32x2 p;
+          p.x = (uint32_t)ococc_f32_to_bf16(v.x) | ((uint32_t)ococc_f32_to_bf16(v.y) << 16);
+          p.y = (uint32_t)ococc_f32_to_bf16(v.z) | ((uint32_t)ococc_f32_to_bf16(v.w) << 16);
+          *(u32x2*)((uint16_t*)out_ + r * ncols + ch) = p;
+        } else {
+          *(f32x4*)((float*)out_ + r * ncols + ch) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int KD, int CS, int RB>
+int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols,
+                       const int32_t* table, const uint32_t* blockmask, int64_t n_out,
+                       const float* bias, void* out, int out_dtype, hipStream_t stream) {
+  const int lds = kvol * CS * (KD + 8) * 2;
+  const int n_slices = ncols / CS;
+  const int64_t n_tiles = ococc_cdiv(ococc_cdiv(n_out, 16), RB);
+  int occ = (160 * 1024) / (lds + 512);
+  if (occ < 1) occ = 1;
+  if (occ > 2) occ = 2;  // 512-thread blocks: at most 2 fit the 32-wave CU comfortably
+  int64_t gx = (int64_t)(256 * occ) / n_slices;
+  if (gx < 1) gx = 1;
+  const int64_t need = ococc_cdiv(n_tiles, kConvWaves);
+  if (gx > need) gx = need;
+  if (gx < 1) gx = 1;
+  dim3 grid((unsigned)gx, (unsigned)n_slices);
+  if (out_dtype == OCOCC_BF16) {
+    auto kern = gather_gemm_kernel<KD, CS, RB, true>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
+                       blockmask, n_out, bias, out);
+  } else {
+    auto kern = gather_gemm_kernel<KD, CS, RB, false>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
+                       blockmask, n_out, bias, out);
+  }
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+template <int KD>
+int dispatch_cs(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
+                const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
+                int out_dtype, hipStream_t stream) {
+  // widest column slice whose kvol weight slices fit the LDS budget
+  const int per_col = kvol * (KD + 8) * 2;
+  int cs = 0;
+  const int cands[3] = {64, 32, 16};
+  for (int i = 0; i < 3; ++i)
+    if (ncols % cands[i] == 0 && per_col * cands[i] <= kLdsBudget) {
+      cs = cands[i];
+      break;
+    }
+  if (cs == 64)
+    return launch_gather_gemm<KD, 64, (KD >= 128 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask,
+                                                          n_out, bias, out, out_dtype, stream);
+  if (cs == 32)
+    return launch_gather_gemm<KD, 32, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
+                                         out_dtype, stream);
+  if (cs == 16)
+    return launch_gather_gemm<KD, 16, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
+                                         out_dtype, stream);
+  return ococc_fail(OCOCC_EUNSUPPORTED, __func__,
+                    "kernel volume x channels does not fit the LDS-resident weight plan");
+}
+
+// ---------------------------------------------------------------- weights
+template <typename T>
+__global__ void __launch_bounds__(256)
+weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int mode,
+                      uint16_t* __restrict__ wn) {
+  const int64_t total = (int64_t)kvol * cin * cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // i indexes the destination
+    int64_t src;
+    if (mode == 0) {  // wn[k][co][ci] = W[k][ci][co]
+      const int ci = (int)(i % cin);
+      const int co = (int)((i / cin) % cout);
+      const int k = (int)(i / ((int64_t)cin * cout));
+      src = ((int64_t)k * cin + ci) * cout + co;
+    } else {  // wn[k][ci][co] = W[k' ][ci][co]
+      const int64_t rem = i % ((int64_t)cin * cout);
+      const int k = (int)(i / ((int64_t)cin * cout));
+      const int ks = mode == 1 ? kvol - 1 - k : k;
+      src = (int64_t)ks * cin * cout + rem;
+    }
+    float v;
+    if (sizeof(T) == 4)
+      v = ((const float*)w)[src];
+    else
+      v = ococc_bf16_to_f32(((const uint16_t*)w)[src]);
+    wn[i] = ococc_f32_to_bf16(v);
+  }
+}
+
+// ---------------------------------------------------------------- wgrad
+constexpr int kWgThreads = 256;
+constexpr int kWgSplits = 64;   // gridDim.x: workgroups per kernel offset
+constexpr int kWgMinSteps = 8;  // at least this many 32-pair steps per workgroup
+
+__device__ __forceinline__ int wg_steps_per_group(int ksteps) {
+  int q = (ksteps + kWgSplits - 1) / kWgSplits;
+  return q < kWgMinSteps ? kWgMinSteps : q;
+}
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(kWgThreads)
+wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int64_t cap,
+             float* __restrict__ slabs) {
+  constexpr int MB = CIN / 16, NB = COUT / 16;
+  constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
+  constexpr int WM = 4 / WN;            // waves along the cin blocks
+  constexpr int MBW = (MB + WM - 1) / WM, NBW = (NB + WN - 1) / WN;
+  constexpr int LDX = CIN + 8, LDY = COUT + 8;  // LDS row strides (elements)
+  constexpr int PX = 32 * CIN / 8, PY = 32 * COUT / 8;  // 16-byte pieces per step
+  constexpr int PT = (PX + PY + kWgThreads - 1) / kWgThreads;
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
+
+  const int k = blockIdx.y;
+  const int nk = num[k];
+  const int ksteps = (nk + 31) >> 5;
+  const int q = wg_steps_per_group(ksteps);
+  const int first = blockIdx.x * q;
+  if (first >= ksteps) return;
+  const int last = (first + q < ksteps) ? first + q : ksteps;
+  const int32_t* pin = pairs + ((int64_t)k * 2 + 0) * cap;
+  const int32_t* pout = pairs + ((int64_t)k * 2 + 1) * cap;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int grp = lane >> 4, li = lane & 15;
+
+  f32x4 acc[MBW][NBW];
+#pragma unroll
+  for (int i = 0; i < MBW; ++i)
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 stage[PT];
+  auto load_step = [&](int step) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pc = threadIdx.x + t * kWgThreads;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pc < PX) {
+        const int row = pc / (CIN / 8), piece = pc % (CIN / 8);
+        const int p = step * 32 + row;
+        if (p < nk) v = *(const u32x4*)(x + (int64_t)pin[p] * CIN + piece * 8);
+      } else if (pc < PX + PY) {
+        const int pc2 = pc - PX;
+        const int row = pc2 / (COUT / 8), piece = pc2 % (COUT / 8);
+        const int p = step * 32 + row;
+        if (p < nk) v = *(const u32x4*)(dy + (int64_t)pout[p] * COUT + piece * 8);
+      }
+      stage[t] = v;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pc = threadIdx.x + t * kWgThreads;
+      if (pc < PX) {
+        const int row = pc / (CIN / 8), piece = pc % (CIN / 8);
+        *(u32x4*)(&lds[buf][row * LDX + piece * 8]) = stage[t];
+      } else if (pc < PX + PY) {
+        const int pc2 = pc - PX;
+        const int row = pc2 / (COUT / 8), piece = pc2 % (COUT / 8);
+        *(u32x4*)(&lds[buf][32 * LDX + row * LDY + piece * 8]) = stage[t];
+      }
+    }
+  };
+
+  load_step(first);
+  int buf = 0;
+  for (int step = first; step < last; ++step) {
+    store_step(buf);
+    __syncthreads();
+    if (step + 1 < last) load_step(step + 1);
+    // transposing reads: lane (grp, li) with q_=li>>2, p_=li&3 addresses row 8*grp+4h+q_,
+    // columns 16*blk+4p_ .. +3 and receives column li of rows 8*grp+4h .. +3.
+    const int q_ = li >> 2, p_ = li & 3;
+    const uint16_t* xs = &lds[buf][0];
+    const uint16_t* ys = &lds[buf][32 * LDX];
+    bf16x8 bfrag[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int nb = wn + j * WN;
+      bf16x8 f = zero_bf16x8();
+      if (nb < NB) {
+        const uint16_t* a0 = ys + (8 * grp + q_) * LDY + nb * 16 + 4 * p_;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LDY));
+        f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      bfrag[j] = f;
+    }
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+      const int mb = wm + i * WM;
+      if (mb < MB) {
+        const uint16_t* a0 = xs + (8 * grp + q_) * LDX + mb * 16 + 4 * p_;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4*)(a0 + 4 * LDX));
+        const bf16x8 afrag = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+          if (wn + j * WN < NB)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+
+  // D[m = cin][n = cout]: lane holds rows 4*grp + {0..3}, column li of each 16x16 tile
+  float* slab = slabs + ((int64_t)k * kWgSplits + blockIdx.x) * CIN * COUT;
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) {
+    const int mb = wm + i * WM;
+    if (mb >= MB) continue;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int nb = wn + j * WN;
+      if (nb >= NB) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        slab[(int64_t)(mb * 16 + grp * 4 + r) * COUT + nb * 16 + li] = acc[i][j][r];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
+                    int64_t elems, float* __restrict__ dw) {
+  const int k = blockIdx.y;
+  const int ksteps = (num[k] + 31) >> 5;
+  const int q = wg_steps_per_group(ksteps);
+  const int nslabs = (ksteps + q - 1) / q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < nslabs; ++j) s += slabs[((int64_t)k * kWgSplits + j) * elems + i];
+    dw[(int64_t)k * elems + i] = s;
+  }
+}
+
+template <int CIN>
+int dispatch_wgrad_cout(const uint16_t* x, const uint16_t* dy, int cout, const int32_t* pairs,
+                        const int32_t* num, int kvol, int64_t cap, float* slabs,
+                        hipStream_t stream) {
+  dim3 grid(kWgSplits, kvol), block(kWgThreads);
+  switch (cout) {
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
+    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cout must be 16/32/64/128");
+  }
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+}  // namespace
+
+extern "C" int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32_t kd,
+                                                  const uint16_t* wn, int32_t kvol, int32_t ncols,
+                                                  const int32_t* table, const uint32_t* blockmask,
+                                                  int64_t n_out, const float* bias, void* out,
+                                                  int32_t out_dtype, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n_in >= 0 && n_out >= 0, "negative row count");
+  OCOCC_REQUIRE(kvol >= 1 && kvol <= 32, "kernel volume must be 1..32");
+  OCOCC_REQUIRE(ncols >= 16 && ncols % 16 == 0, "ncols must be a multiple of 16");
+  OCOCC_REQUIRE(out_dtype == OCOCC_BF16 || out_dtype == OCOCC_F32, "out_dtype must be f32/bf16");
+  if (n_out == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(wn && table && out, "null pointer");
+  OCOCC_REQUIRE(feat || n_in == 0, "null feat");
+  switch (kd) {
+    case 16: return dispatch_cs<16>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 32: return dispatch_cs<32>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 64: return dispatch_cs<64>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 128: return dispatch_cs<128>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 16/32/64/128");
+  }
+}
+
+extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t kvol, int32_t cin,
+                                         int32_t cout, int32_t mode, uint16_t* wn,
+                                         ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1, "bad sizes");
+  OCOCC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0/1/2");
+  OCOCC_REQUIRE(w_dtype == OCOCC_F32 || w_dtype == OCOCC_BF16, "w_dtype must be f32/bf16");
+  OCOCC_REQUIRE(w && wn, "null pointer");
+  const int64_t total = (int64_t)kvol * cin * cout;
+  const int grid = ococc_grid_1d(total, 256);
+  if (w_dtype == OCOCC_F32)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(weight_prepare_kernel<float>), dim3(grid), dim3(256), 0,
+                       stream, (const float*)w, (int)kvol, (int)cin, (int)cout, (int)mode, wn);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(weight_prepare_kernel<uint16_t>), dim3(grid), dim3(256), 0,
+                       stream, (const uint16_t*)w, (int)kvol, (int)cin, (int)cout, (int)mode, wn);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int64_t ococc_sparse_conv_wgrad_workspace_bytes(int32_t kvol, int64_t pair_capacity,
+                                                           int32_t cin, int32_t cout) {
+  (void)pair_capacity;
+  if (kvol < 1 || cin < 1 || cout < 1) return -1;
+  return (int64_t)kvol * kWgSplits * cin * cout * (int64_t)sizeof(float);
+}
+
+extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin,
+                                            const uint16_t* dy, int64_t n_out, int32_t cout,
+                                            const int32_t* indice_pairs, const int32_t* indice_num,
+                                            int32_t kvol, int64_t pair_capacity, float* dw,
+                                            void* workspace, int64_t workspace_bytes,
+                                            ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n_in >= 0 && n_out >= 0 && pair_capacity >= 0, "negative size");
+  OCOCC_REQUIRE(kvol >= 1, "kvol < 1");
+  OCOCC_REQUIRE(dw, "null dw");
+  const int64_t need = ococc_sparse_conv_wgrad_workspace_bytes(kvol, pair_capacity, cin, cout);
+  OCOCC_REQUIRE(workspace && workspace_bytes >= need, "workspace too small");
+  const int64_t elems = (int64_t)cin * cout;
+  if (pair_capacity == 0 || n_in == 0 || n_out == 0) {
+    OCOCC_HIP(hipMemsetAsync(dw, 0, (int64_t)kvol * elems * sizeof(float), stream));
+    return OCOCC_OK;
+  }
+  OCOCC_REQUIRE(x && dy && indice_pairs && indice_num, "null pointer");
+  int rc;
+  float* slabs = (float*)workspace;
+  switch (cin) {
+    case 16: rc = dispatch_wgrad_cout<16>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 32: rc = dispatch_wgrad_cout<32>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 64: rc = dispatch_wgrad_cout<64>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 128: rc = dispatch_wgrad_cout<128>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cin must be 16/32/64/128");
+  }
+  if (rc != OCOCC_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ococc_grid_1d(elems, 256, 64), kvol), dim3(256), 0,
+                     stream, slabs, indice_num, (int)kvol, elems, dw);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
