@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the OcOccNet hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 64 synthetic object grids per GPU, 0.2 m voxels,
+40^3 cells, 2000 random points each; SubMConv3d-only occupancy encoder
+(voxelise -> scatter-mean -> rulebook -> 3 x [SubMConv3d 3^3 -> LN -> GELU], channels
+16->32->64->128), bf16 features, forward + backward + optimizer step.
+Metric: object-grids / second (whole job, all ranks).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; tracklets (object grids) are sharded across ranks, the only
+collective is the gradient all-reduce over RCCL ("weak" scaling).  Rank 0 prints ONE JSON
+line with the contract fields plus "roofline" (dominant kernel, HIP-event timed inside
+the timed region) and "cpu_baseline" (the oracle port on one host core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GRIDS_PER_GPU = 64
+POINTS_PER_GRID = 2000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
+    ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_grids, points, model):
+    """The oracle port (oracle/encoder_ref.py, plain C + numpy, ONE core) on a bounded
+    sample of the same workload; baseline only."""
+    import numpy as np
+    from objectcentricocccompletion_amd.occ_encoder import synthetic_object_grids
+    from oracle.encoder_ref import encoder_forward_backward
+    torch.set_num_threads(1)
+    xyz, feats, bidx = synthetic_object_grids(sample_grids, points, seed=0, device='cpu')
+    ws = [l[0].weight.detach().float().cpu().numpy() for l in model.conv_layers]
+    gs = [l[1].weight.detach().float().cpu().numpy() for l in model.conv_layers]
+    bs = [l[1].bias.detach().float().cpu().numpy() for l in model.conv_layers]
+    args = (xyz.numpy(), feats.numpy(), bidx.numpy(), sample_grids, ws, gs, bs)
+    encoder_forward_backward(*args)  # warm-up (page-in, LUT allocation)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t0 < 10.0:
+        encoder_forward_backward(*args)
+        reps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {'value': round(sample_grids / dt, 2), 'unit': 'object-grids/s', 'cores': 1,
+            'kind': 'port',
+            'sample': f'{sample_grids} of the {GRIDS_PER_GPU} grids x {points} points, fwd+bwd, '
+                      f'{reps} repetitions, oracle/encoder_ref.py'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    from objectcentricocccompletion_amd.spconv import ops as sp_ops
+
+    torch.manual_seed(0)  # identical initial weights on every rank
+    model = SubMOccEncoder().to(dev)
+    params = [p for p in model.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    flat_numel = sum(p.numel() for p in params)
+    bucket = torch.zeros(flat_numel, dtype=torch.float32, device=dev)
+    B, P = args.grids, args.points
+    xyz, feats, bidx = synthetic_object_grids(B, P, seed=rank, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(xyz, feats, bidx, B)
+        loss = out.features.float().pow(2).mean()
+        loss.backward()
+        if world > 1:  # data parallel: one bucketed gradient all-reduce over RCCL / xGMI
+            off = 0
+            for p in params:
+                bucket[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                off += p.numel()
+            dist.all_reduce(bucket)
+            bucket.div_(world)
+            off = 0
+            for p in params:
+                p.grad.copy_(bucket[off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+        opt.step()
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    # dominant kernel: the 64->128 forward gather-GEMM; events on the launch stream
+    probe = sp_ops.KernelProbe(kd=64, ncols=128)
+    sp_ops.set_probe(probe)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    sp_ops.set_probe(None)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        n_vox = int(out.features.shape[0])
+        rb = out.indice_dict['subm1']
+        n_pairs = int(rb[3].sum().item())
+        kern_ms = probe.mean_ms()
+        # algorithmic (compulsory) bytes of one 64->128 forward launch, SURVEY.md 8d:
+        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
+        alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+        res = {
+            'metric': 'object-grids/sec (fwd+bwd)',
+            'value': round(world * B * args.steps / dt, 1),
+            'unit': 'object-grids/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'bf16',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'configs[1]: SubMConv3d-only occupancy encoder fwd+bwd+AdamW, '
+                            f'{B} object grids/GPU x {P} random points, 0.2 m voxels, 40^3 grid, '
+                            'channels 16-32-64-128, LN+GELU, bf16 features',
+                'grids_per_gpu': B, 'points_per_grid': P, 'active_voxels': n_vox,
+                'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}',
+            },
+            'roofline': {
+                'kernel': 'gather_gemm_kernel<64,32,4,bf16> (SubMConv3d 64->128 forward)',
+                'bound': 'hbm',
+                'achieved': round(achieved, 1) if achieved else None,
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                'traffic': None,
+                'algorithmic_bytes_per_launch': alg_bytes,
+                'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
+                'launches_timed': probe.count(),
+            },
+        }
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(4, P, model)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,71 @@
+"""SubMConv3d-only occupancy encoder over per-object voxel grids -- the workload
+BASELINE.json configs[1] names (64 object grids of 40^3 cells at 0.2 m).
+
+Built only from the reference's own operators, in the order its voxel pipelines use them:
+Voxelization (dynamic, mmdet3d/ops/voxel/voxelize.py:10-113) -> DynamicScatter mean
+(mmdet3d/ops/voxel/scatter_points.py:53-107) -> SparseConvTensor -> a stack of
+make_sparse_convmodule(SubMConv3d 3x3x3 -> LN(eps 1e-3) -> GELU) sharing one indice_key
+(mmdet3d/ops/sparse_block.py:216-289), channels 16 -> 32 -> 64 -> 128.
+"""
+import torch
+from torch import nn
+
+from .sparse_block import make_sparse_convmodule
+from .spconv import SparseConvTensor
+from .voxel import dynamic_scatter, voxelization
+
+
+class SubMOccEncoder(nn.Module):
+
+    def __init__(self, in_channels=16, channels=(32, 64, 128), voxel_size=(0.2, 0.2, 0.2),
+                 point_cloud_range=(-4, -4, -4, 4, 4, 4), norm_cfg=dict(type='LN', eps=1e-3),
+                 act_type='gelu', feature_dtype=torch.bfloat16):
+        super().__init__()
+        self.voxel_size = list(voxel_size)
+        self.point_cloud_range = list(point_cloud_range)
+        self.grid = [int(round((point_cloud_range[3 + i] - point_cloud_range[i]) / voxel_size[i]))
+                     for i in range(3)]  # x, y, z cells
+        self.sparse_shape = self.grid[::-1]  # (D, H, W) = (z, y, x)
+        self.feature_dtype = feature_dtype
+        layers = []
+        c = in_channels
+        for co in channels:
+            layers.append(make_sparse_convmodule(c, co, 3, 'subm1', padding=1,
+                                                 conv_type='SubMConv3d', act_type=act_type,
+                                                 norm_cfg=norm_cfg))
+            c = co
+        self.conv_layers = nn.ModuleList(layers)
+
+    def voxelize(self, points, batch_idx, batch_size):
+        """points [N, 3+] f32 in the object frame, batch_idx [N] int32 -> voxel features,
+        voxel coordinates (b,z,y,x)."""
+        zyx = voxelization(points, self.voxel_size, self.point_cloud_range, -1, -1)
+        coors = torch.cat([batch_idx.view(-1, 1).to(torch.int32), zyx], 1)
+        return coors
+
+    def forward(self, points, feats, batch_idx, batch_size):
+        coors = self.voxelize(points, batch_idx, batch_size)
+        vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
+                                         grid_shape=[batch_size] + self.sparse_shape)
+        x = SparseConvTensor(vfeats.to(self.feature_dtype), vcoors, self.sparse_shape, batch_size)
+        for layer in self.conv_layers:
+            x = layer(x)
+        return x
+
+
+def synthetic_object_grids(num_grids, points_per_grid, in_channels=16, half_extent=4.0, seed=0,
+                           device='cuda'):
+    """Random-point object grids of the benchmark shape: points uniform in the
+    [-4, 4)^3 m object box (40^3 cells at 0.2 m), features = xyz, two attributes
+    (intensity, elongation), offset to the voxel centre, zero padded to in_channels."""
+    g = torch.Generator().manual_seed(seed)
+    n = num_grids * points_per_grid
+    xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * half_extent
+    attr = torch.rand(n, 2, generator=g)
+    centre = (torch.floor((xyz + half_extent) / 0.2) + 0.5) * 0.2 - half_extent
+    feats = torch.zeros(n, in_channels)
+    feats[:, :3] = xyz
+    feats[:, 3:5] = attr
+    feats[:, 5:8] = xyz - centre
+    batch_idx = torch.arange(num_grids, dtype=torch.int32).repeat_interleave(points_per_grid)
+    return xyz.to(device), feats.to(device), batch_idx.to(device)

@@ -1,0 +1,69 @@
+"""Autograd wrappers -- host mirror of mmdet3d/ops/spconv/functional.py:20-101."""
+from torch.autograd import Function
+
+from . import ops
+
+
+class _IndiceConvBase(Function):
+    INVERSE = False
+    SUBM = False
+
+    @classmethod
+    def _fwd(cls, ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        saved = {}
+        out = ops.indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
+                              cls.INVERSE, cls.SUBM, _saved=saved)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters, saved['x_bf16'])
+        return out
+
+    @classmethod
+    def _bwd(cls, ctx, grad_output):
+        indice_pairs, indice_pair_num, features, filters, x_bf16 = ctx.saved_tensors
+        input_bp, filters_bp = ops.indice_conv_backward(
+            features, filters, grad_output.contiguous(), indice_pairs, indice_pair_num,
+            cls.INVERSE, cls.SUBM, _x_bf16=x_bf16, need_input_grad=ctx.needs_input_grad[0],
+            need_filter_grad=ctx.needs_input_grad[1])
+        return input_bp, filters_bp, None, None, None
+
+
+class SparseConvFunction(_IndiceConvBase):
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        return SparseConvFunction._fwd(ctx, features, filters, indice_pairs, indice_pair_num,
+                                       num_activate_out)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return SparseConvFunction._bwd(ctx, grad_output)
+
+
+class SparseInverseConvFunction(_IndiceConvBase):
+    INVERSE = True
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        return SparseInverseConvFunction._fwd(ctx, features, filters, indice_pairs,
+                                              indice_pair_num, num_activate_out)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return SparseInverseConvFunction._bwd(ctx, grad_output)
+
+
+class SubMConvFunction(_IndiceConvBase):
+    SUBM = True
+
+    @staticmethod
+    def forward(ctx, features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        return SubMConvFunction._fwd(ctx, features, filters, indice_pairs, indice_pair_num,
+                                     num_activate_out)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return SubMConvFunction._bwd(ctx, grad_output)
+
+
+indice_conv = SparseConvFunction.apply
+indice_inverse_conv = SparseInverseConvFunction.apply
+indice_subm_conv = SubMConvFunction.apply

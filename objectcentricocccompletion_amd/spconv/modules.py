@@ -1,0 +1,76 @@
+"""SparseModule / SparseSequential / ToDense -- host mirror of
+mmdet3d/ops/spconv/modules.py:44-214 (container logic only; no device code)."""
+from collections import OrderedDict
+
+from torch import nn
+
+from .structure import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base class: SparseSequential hands such modules the SparseConvTensor itself."""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """Sequential container: sparse modules receive the SparseConvTensor, dense ones
+    (norm, activation) its feature matrix (modules.py:127-140)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError('name exists.')
+            self.add_module(name, module)
+        self._sparity_dict = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    @property
+    def sparity_dict(self):
+        return self._sparity_dict
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError('name exists')
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                self._sparity_dict[k] = input.sparity
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input
+
+
+class ToDense(SparseModule):
+    """SparseConvTensor -> dense N C D H W tensor (modules.py:200-204)."""
+
+    def forward(self, x: SparseConvTensor):
+        return x.dense()

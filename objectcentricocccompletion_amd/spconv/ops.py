@@ -1,0 +1,286 @@
+"""Rulebook + sparse-conv operators -- host mirror of mmdet3d/ops/spconv/ops.py:19-180
+(get_indice_pairs, indice_conv, indice_conv_backward with the same argument order).
+
+Device work: ococc_subm_rulebook_build, ococc_rulebook_pairs_to_table,
+ococc_weight_prepare_bf16, ococc_sparse_conv_gather_gemm_bf16 (forward and dgrad),
+ococc_sparse_conv_wgrad_bf16.  The reference's per-offset gather/GEMM/scatter loop
+(include/spconv/spconv_ops.h:260-456) does not exist here.
+"""
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+_KD_OK = (16, 32, 64, 128)
+
+
+class KernelProbe(object):
+    """HIP-event timer for one gather-GEMM shape (bench.py's roofline line): events are
+    recorded on the stream the kernel is launched on, around every matching forward launch
+    inside the timed region, and read back after the final synchronize."""
+
+    def __init__(self, kd, ncols, max_events=4096):
+        self.kd, self.ncols, self.max_events = kd, ncols, max_events
+        self.pairs = []
+
+    def wrap(self, kd, ncols, launch):
+        if kd != self.kd or ncols != self.ncols or len(self.pairs) >= self.max_events:
+            return launch()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()  # torch's current stream == the stream handed to the C ABI (_lib.stream())
+        out = launch()
+        b.record()
+        self.pairs.append((a, b))
+        return out
+
+    def count(self):
+        return len(self.pairs)
+
+    def mean_ms(self):
+        if not self.pairs:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+
+
+_probe = None
+
+
+def set_probe(probe):
+    global _probe
+    _probe = probe
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """ops.py:19-30."""
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """ops.py:33-43."""
+    out = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+class RulebookTables(object):
+    """Device-side companions of a reference-format rulebook: the offset-major gather
+    tables and 16-row block masks the HIP convolution reads.  Attached to the
+    indice_pairs tensor (attribute ``_ococc``) so that the reference call signature
+    indice_conv(features, filters, indice_pairs, ...) keeps working unchanged."""
+
+    def __init__(self, subm, kvol):
+        self.subm = subm
+        self.kvol = kvol
+        self.tables = {}  # (inverse, direction) -> (table, blockmask, rows)
+
+
+def _ilist(v, ndim):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
+                     out_padding=0, subm=False, transpose=False, grid=None):
+    """ops.py:46-106 -> (outids, indice_pairs [K,2,N] int32, indice_pair_num [K] int32)."""
+    L.require_device(indices)
+    ndim = indices.shape[1] - 1
+    ksize, stride, padding = _ilist(ksize, ndim), _ilist(stride, ndim), _ilist(padding, ndim)
+    dilation, out_padding = _ilist(dilation, ndim), _ilist(out_padding, ndim)
+    for d, s in zip(dilation, stride):
+        assert any([s == 1, d == 1]), "don't support this."
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    if ndim == 2:  # a 2-D conv is a 3-D conv on a depth-1 volume
+        z = indices.new_zeros((indices.size(0), 1))
+        idx3 = torch.cat([indices[:, :1], z, indices[:, 1:]], 1).contiguous()
+        o, pairs, num = get_indice_pairs(idx3, batch_size, [1] + list(spatial_shape), [1] + ksize,
+                                         [1] + stride, [0] + padding, [1] + dilation,
+                                         [0] + out_padding, subm, transpose)
+        return (indices if subm else torch.cat([o[:, :1], o[:, 2:]], 1).contiguous()), pairs, num
+    if ndim != 3:
+        raise NotImplementedError('only 2-D and 3-D sparse convolutions are built')
+    if not subm:
+        from .rulebook_regular import build_regular_rulebook
+        if transpose:
+            out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation,
+                                               out_padding)
+        else:
+            out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+        return build_regular_rulebook(indices, batch_size, out_shape, ksize, stride, padding,
+                                      dilation, transpose)
+    n = indices.size(0)
+    kvol = int(np.prod(ksize))
+    dev = indices.device
+    nbytes = L.lib.ococc_subm_rulebook_workspace_bytes(n, int(batch_size), L.i3(spatial_shape),
+                                                       L.i3(ksize))
+    if nbytes < 0:
+        raise L.OcoccError('get_indice_pairs: unsupported geometry (odd kernel sizes, '
+                           'batch*D*H*W < 2^31 required)')
+    ws = L.workspace(nbytes, dev)
+    nbr_t = torch.empty((kvol, n), dtype=torch.int32, device=dev)
+    mask = torch.empty(((n + 15) // 16,), dtype=torch.int32, device=dev) if kvol <= 32 else None
+    pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
+    num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    L.check(L.lib.ococc_subm_rulebook_build(L.ptr(indices), n, int(batch_size),
+                                            L.i3(spatial_shape), L.i3(ksize), L.i3(dilation),
+                                            L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
+                                            L.ptr(ws), ws.numel(), L.stream()),
+            'subm_rulebook_build')
+    rb = RulebookTables(True, kvol)
+    rb.tables[(False, 'fwd')] = (nbr_t, mask, n)
+    rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights
+    pairs._ococc = rb
+    return indices, pairs, num
+
+
+def _tables_for(indice_pairs, indice_pair_num, inverse, direction, rows, subm):
+    rb = getattr(indice_pairs, '_ococc', None)
+    kvol = indice_pairs.size(0)
+    if rb is None:
+        rb = RulebookTables(False, kvol)  # user supplied rulebook: never assume symmetry
+        indice_pairs._ococc = rb
+    key = (bool(inverse), direction)
+    if key not in rb.tables:
+        # forward gathers from pairs[k][inverse] and writes rows pairs[k][1 - inverse]
+        side = (0 if inverse else 1) if direction == 'fwd' else (1 if inverse else 0)
+        dev = indice_pairs.device
+        table = torch.empty((kvol, rows), dtype=torch.int32, device=dev)
+        mask = torch.empty(((rows + 15) // 16,), dtype=torch.int32, device=dev) if kvol <= 32 else None
+        L.check(L.lib.ococc_rulebook_pairs_to_table(L.ptr(indice_pairs), L.ptr(indice_pair_num),
+                                                    kvol, indice_pairs.size(2), side, rows,
+                                                    L.ptr(table), L.ptr(mask), L.stream()),
+                'rulebook_pairs_to_table')
+        rb.tables[key] = (table, mask, rows)
+    return rb, rb.tables[key]
+
+
+def _round_kd(c):
+    for k in _KD_OK:
+        if c <= k:
+            return k
+    raise NotImplementedError(f'{c} channels: the LDS-resident weight plan covers <= 128 '
+                              'contraction channels per launch')
+
+
+def _to_bf16_padded(t, cols):
+    """[n, c] f32/bf16 -> contiguous bf16 [n, cols] (zero padded)."""
+    n, c = t.shape
+    if t.dtype == torch.bfloat16 and c == cols and t.is_contiguous():
+        return t
+    if c == cols:
+        if t.dtype == torch.float32 and t.is_contiguous():
+            out = torch.empty((n, cols), dtype=torch.bfloat16, device=t.device)
+            L.check(L.lib.ococc_cast_f32_to_bf16(L.ptr(t), L.ptr(out), t.numel(), L.stream()), 'cast')
+            return out
+        return t.to(torch.bfloat16).contiguous()
+    out = torch.zeros((n, cols), dtype=torch.bfloat16, device=t.device)
+    out[:, :c] = t
+    return out
+
+
+def _prep_weights(filters, mode, kd_pad, nc_pad):
+    """filters [..., cin, cout] -> bf16 wn [kvol, ncols, kd] for the gather-GEMM kernel."""
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    w = filters.reshape(-1, cin, cout)
+    kvol = w.size(0)
+    cin_p, cout_p = (kd_pad, nc_pad) if mode == 0 else (nc_pad, kd_pad)
+    if (cin_p, cout_p) != (cin, cout):
+        wp = torch.zeros((kvol, cin_p, cout_p), dtype=w.dtype, device=w.device)
+        wp[:, :cin, :cout] = w
+        w = wp
+    if w.dtype not in (torch.float32, torch.bfloat16):
+        w = w.float()
+    w = w.contiguous()
+    wn = torch.empty((kvol, nc_pad, kd_pad), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib.ococc_weight_prepare_bf16(L.ptr(w), L.dtype_code(w.dtype), kvol, cin_p, cout_p,
+                                            mode, L.ptr(wn), L.stream()), 'weight_prepare')
+    return wn
+
+
+def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype):
+    kvol, ncols, kd = wn.shape
+    out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
+    L.check(L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn),
+                                                     kvol, ncols, L.ptr(table), L.ptr(mask), rows,
+                                                     L.ptr(bias), L.ptr(out),
+                                                     L.dtype_code(out_dtype), L.stream()),
+            'sparse_conv_gather_gemm')
+    return out
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
+                inverse=False, subm=False, bias=None, _saved=None):
+    """ops.py:109-125.  features [n_in,Cin] (f32 or bf16), filters [kD,kH,kW,Cin,Cout];
+    returns [num_activate_out, Cout] in features.dtype (f32 accumulation either way)."""
+    L.require_device(features, filters, indice_pairs)
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    assert features.shape[1] == cin
+    rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd',
+                                          int(num_activate_out), subm)
+    kd = _round_kd(cin)
+    nc = (cout + 15) // 16 * 16
+    x = _to_bf16_padded(features, kd)
+    wn = _prep_weights(filters, 0, kd, nc)
+    b = None
+    if bias is not None:
+        b = torch.zeros((nc,), dtype=torch.float32, device=features.device)
+        b[:cout] = bias.float()
+    out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
+    if _probe is not None:
+        out = _probe.wrap(kd, nc, lambda: _gather_gemm(x, wn, table, mask, rows, b, out_dtype))
+    else:
+        out = _gather_gemm(x, wn, table, mask, rows, b, out_dtype)
+    if _saved is not None:
+        _saved['x_bf16'] = x
+    return out if nc == cout else out[:, :cout].contiguous()
+
+
+def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out,
+                      inverse, subm):
+    """ops.py:128-139: convolution with the bias folded into the output (here: added in the
+    kernel epilogue, from registers)."""
+    return indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse,
+                       subm, bias=bias)
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False,
+                         subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True):
+    """ops.py:142-160 -> (input_bp [n_in,Cin], filters_bp like filters)."""
+    L.require_device(features, filters, out_bp, indice_pairs)
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    n_in, n_out = features.size(0), out_bp.size(0)
+    kd_in, kd_out = _round_kd(cin), _round_kd(cout)
+    dy = _to_bf16_padded(out_bp, kd_out)
+    input_bp = filters_bp = None
+    if need_input_grad:
+        rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'bwd', n_in,
+                                              subm)
+        nc = (cin + 15) // 16 * 16
+        mode = 1 if (rb.subm and subm) else 2
+        wn = _prep_weights(filters, mode, kd_out, nc)
+        out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
+        gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype)
+        input_bp = gin if nc == cin else gin[:, :cin].contiguous()
+    if need_filter_grad:
+        x = _x_bf16 if _x_bf16 is not None else _to_bf16_padded(features, kd_in)
+        kvol = indice_pairs.size(0)
+        cap = indice_pairs.size(2)
+        pairs = indice_pairs
+        if inverse:  # wgrad pairs x rows with dy rows: swap the two pair rows
+            pairs = indice_pairs.flip(1).contiguous()
+        nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)
+        ws = L.workspace(nbytes, features.device)
+        dw = torch.empty((kvol, kd_in, kd_out), dtype=torch.float32, device=features.device)
+        L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
+                                                   L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
+                                                   L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
+                'sparse_conv_wgrad')
+        filters_bp = dw[:, :cin, :cout].reshape(filters.shape).to(filters.dtype)
+    return input_bp, filters_bp

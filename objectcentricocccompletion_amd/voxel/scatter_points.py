@@ -1,0 +1,135 @@
+"""Point -> voxel / RoI scatter-reduce -- host mirror of
+mmdet3d/ops/voxel/scatter_points.py:9-107 (dynamic_scatter / DynamicScatter) and of
+the torch_scatter calls inside scatter_v2 (mmdet3d/ops/sst/sst_ops.py:171-174).
+
+Kernels: ococc_grid_unique_i32 (sorted unique rows + inverse + counts),
+ococc_segment_reduce_f32 / _bwd_f32.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .. import _lib as L
+
+
+def grid_unique(coors, dims=None):
+    """Sorted unique rows of non-negative int coordinates.
+
+    Returns (out_coors [U,ndim] int32, inv [N] int32 (-1 for dropped rows), counts [U] int32).
+    ``dims`` (exclusive upper bound per column) avoids a device read-back; without it the
+    bounds come from coors.amax (one sync, as torch.unique has anyway)."""
+    L.require_device(coors)
+    squeeze = coors.dim() == 1
+    c = coors.reshape(coors.size(0), -1)
+    if c.dtype != torch.int32:
+        c = c.to(torch.int32)
+    c = c.contiguous()
+    n, ndim = c.shape
+    if n == 0:
+        z = c.new_zeros((0,), dtype=torch.int32)
+        return (c.new_zeros((0,) if squeeze else (0, ndim)), z, z.clone())
+    if dims is None:
+        dims = [int(v) + 1 for v in c.amax(0).clamp_min(0).tolist()]
+    dims = [int(d) for d in dims]
+    assert len(dims) == ndim
+    cells = 1
+    for d in dims:
+        cells *= d
+    cap = min(n, cells)
+    nbytes = L.lib.ococc_grid_unique_workspace_bytes(ndim, L.i4(dims))
+    if nbytes < 0:
+        raise L.OcoccError(f'grid_unique: coordinate space {dims} too large for the bitmap plan')
+    ws = L.workspace(nbytes, c.device)
+    out_coors = torch.empty((cap, ndim), dtype=torch.int32, device=c.device)
+    inv = torch.empty((n,), dtype=torch.int32, device=c.device)
+    counts = torch.empty((cap,), dtype=torch.int32, device=c.device)
+    meta = torch.zeros(2, dtype=torch.int32, device=c.device)  # [num_unique, status]
+    L.check(L.lib.ococc_grid_unique_i32(L.ptr(c), n, ndim, L.i4(dims), L.ptr(out_coors), cap,
+                                        L.ptr(inv), L.ptr(counts), meta.data_ptr(),
+                                        meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()),
+            'grid_unique')
+    num, status = meta.tolist()
+    if status:
+        raise L.OcoccError(f'grid_unique: a coordinate is outside the declared bounds {dims}')
+    out_coors = out_coors[:num]
+    if squeeze:
+        out_coors = out_coors[:, 0]
+    return out_coors, inv, counts[:num]
+
+
+class _SegmentReduce(Function):
+    """feats [N,C] f32, inv [N] int32 -> [G,C]; max routes the gradient to the smallest
+    row index attaining the maximum (scatter_points_cuda.cu:136-179)."""
+
+    @staticmethod
+    def forward(ctx, feats, inv, num_segments, mode, counts):
+        L.require_device(feats, inv)
+        code = L.REDUCE[mode]
+        assert feats.dtype == torch.float32, 'segment reduce computes in float32'
+        feats = feats.contiguous()
+        n, c = feats.shape
+        dev = feats.device
+        if counts is None and (code == 1 or code == 2):
+            counts = torch.empty((num_segments,), dtype=torch.int32, device=dev)
+            L.check(L.lib.ococc_segment_count_i32(L.ptr(inv), n, L.ptr(counts), num_segments,
+                                                  L.stream()), 'segment_count')
+        out = torch.empty((num_segments, c), dtype=torch.float32, device=dev)
+        need_arg = code == 2 and ctx.needs_input_grad[0]
+        arg = torch.empty((num_segments, c), dtype=torch.int32, device=dev) if need_arg else None
+        L.check(L.lib.ococc_segment_reduce_f32(L.ptr(feats), L.ptr(inv), n, c, code,
+                                               L.ptr(counts), L.ptr(out), L.ptr(arg),
+                                               num_segments, L.stream()), 'segment_reduce')
+        ctx.code, ctx.shape, ctx.num_segments = code, (n, c), num_segments
+        ctx.save_for_backward(inv, counts, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inv, counts, arg = ctx.saved_tensors
+        n, c = ctx.shape
+        grad_out = grad_out.contiguous().float()
+        grad = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+        L.check(L.lib.ococc_segment_reduce_bwd_f32(L.ptr(grad_out), L.ptr(inv), n, c, ctx.code,
+                                                   L.ptr(counts), L.ptr(arg), L.ptr(grad),
+                                                   ctx.num_segments, L.stream()),
+                'segment_reduce_bwd')
+        return grad, None, None, None, None
+
+
+def segment_reduce(feats, inv, num_segments, mode, counts=None):
+    """Reduce rows of feats into num_segments rows following the dense inverse map inv."""
+    if inv.dtype != torch.int32:
+        inv = inv.to(torch.int32)
+    return _SegmentReduce.apply(feats, inv.contiguous(), int(num_segments), mode, counts)
+
+
+def dynamic_scatter(feats, coors, reduce_type='max', grid_shape=None):
+    """mmdet3d/ops/voxel/scatter_points.py:9-50: (voxel_feats [M,C], voxel_coors [M,ndim]).
+    Rows of coors with a negative entry are dropped; output rows are in sorted order."""
+    voxel_coors, inv, counts = grid_unique(coors, grid_shape)
+    voxel_feats = segment_reduce(feats, inv, voxel_coors.size(0), reduce_type, counts)
+    return voxel_feats, voxel_coors.to(coors.dtype)
+
+
+class DynamicScatter(nn.Module):
+    """Same constructor / forward as mmdet3d/ops/voxel/scatter_points.py:53-107.  The
+    reference loops over the batch in Python (:86-100); here the batch column is part of
+    the key, which yields the same rows in the same order with one launch sequence."""
+
+    def __init__(self, voxel_size, point_cloud_range, average_points: bool):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        self.average_points = average_points
+
+    def forward_single(self, points, coors):
+        reduce = 'mean' if self.average_points else 'max'
+        return dynamic_scatter(points.contiguous(), coors.contiguous(), reduce)
+
+    def forward(self, points, coors):
+        return self.forward_single(points, coors)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(voxel_size={self.voxel_size}, '
+                f'point_cloud_range={self.point_cloud_range}, '
+                f'average_points={self.average_points})')

@@ -1,0 +1,239 @@
+"""GPU parity, sparse-conv side (B3, B4, B5): rulebook bit-exact vs the oracle, conv
+forward/backward vs the oracle on the same bf16-rounded operands, module level autograd,
+and size-independent properties at the benchmark shape (64 x 40^3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _voxels(rng, B, shape, density, shuffle):
+    mask = rng.random((B,) + tuple(shape)) < density
+    idx = np.argwhere(mask).astype(np.int32)
+    if shuffle:
+        idx = idx[rng.permutation(len(idx))]
+    return idx
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=1, shape=(4, 4, 4), density=0.5, shuffle=False, ks=(3, 3, 3)),
+    dict(B=3, shape=(9, 10, 11), density=0.2, shuffle=True, ks=(3, 3, 3)),
+    dict(B=2, shape=(40, 40, 40), density=0.03, shuffle=False, ks=(3, 3, 3)),
+    dict(B=2, shape=(12, 12, 12), density=0.9, shuffle=True, ks=(3, 3, 3)),
+    dict(B=2, shape=(1, 20, 20), density=0.3, shuffle=True, ks=(1, 3, 3)),
+    dict(B=1, shape=(6, 6, 6), density=0.4, shuffle=True, ks=(3, 1, 3)),
+])
+def test_subm_rulebook_bit_exact(dev, case):
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(11)
+    idx = _voxels(rng, case['B'], case['shape'], case['density'], case['shuffle'])
+    outids, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), case['B'], list(case['shape']),
+                                              list(case['ks']), 1, 0, 1, 0, subm=True)
+    ep, en = O.subm_rulebook(idx, case['B'], case['shape'], case['ks'])
+    assert np.array_equal(num.cpu().numpy(), en)
+    assert np.array_equal(pairs.cpu().numpy(), ep)       # same order as the CPU functor, -1 fill included
+    assert torch.equal(outids.cpu(), torch.from_numpy(idx))
+    # the gather table agrees with the pairs: table[k][out] = in
+    table, mask, rows = pairs._ococc.tables[(False, 'fwd')]
+    t = table.cpu().numpy()
+    for k in range(len(en)):
+        exp = np.full(len(idx), -1, np.int32)
+        exp[ep[k, 1, :en[k]]] = ep[k, 0, :en[k]]
+        assert np.array_equal(t[k], exp)
+    if mask is not None:
+        m = mask.cpu().numpy().view(np.uint32)
+        for b in range(len(m)):
+            exp = 0
+            for k in range(len(en)):
+                if (t[k, b * 16:(b + 1) * 16] >= 0).any():
+                    exp |= 1 << k
+            assert int(m[b]) == exp
+
+
+def test_rulebook_empty_and_single(dev):
+    from objectcentricocccompletion_amd.spconv import ops
+    o, p, n = ops.get_indice_pairs(torch.zeros((0, 4), dtype=torch.int32, device=dev), 1, [8, 8, 8], 3, subm=True)
+    assert p.shape == (27, 2, 0) and int(n.sum()) == 0
+    o, p, n = ops.get_indice_pairs(torch.tensor([[0, 7, 7, 7]], dtype=torch.int32, device=dev), 1, [8, 8, 8], 3, subm=True)
+    assert n.tolist() == [0] * 13 + [1] + [0] * 13 and p[13, :, 0].tolist() == [0, 0]
+
+
+def _conv_case(rng, dev, B, shape, density, cin, cout, shuffle=True):
+    from objectcentricocccompletion_amd.spconv import ops
+    idx = _voxels(rng, B, shape, density, shuffle)
+    n = len(idx)
+    x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+    w = O.bf16_round(rng.standard_normal((3, 3, 3, cin, cout)).astype(np.float32) * 0.2)
+    dy = O.bf16_round(rng.standard_normal((n, cout)).astype(np.float32))
+    _, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), 3, subm=True)
+    ep, en = O.subm_rulebook(idx, B, shape)
+    return idx, x, w, dy, pairs, num, ep, en
+
+
+# fp32 accumulation of exact bf16 products: only summation order differs from the oracle
+TOL = dict(rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (64, 128), (128, 128), (16, 16), (5, 7), (48, 96)])
+@pytest.mark.parametrize('density', [0.04, 0.6])
+def test_subm_conv_forward_backward_vs_oracle(dev, cin, cout, density):
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(cin * 1000 + cout)
+    idx, x, w, dy, pairs, num, ep, en = _conv_case(rng, dev, 2, (14, 15, 16), density, cin, cout)
+    n = len(idx)
+    xt, wt, dyt = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    y = ops.indice_conv(xt, wt, pairs, num, n, False, True)            # f32 in -> f32 out
+    ey = O.indice_conv(x, w, ep, en, n, subm=True)
+    assert y.dtype == torch.float32 and np.allclose(y.cpu().numpy(), ey, **TOL)
+    yb = ops.indice_conv(xt.bfloat16(), wt.bfloat16(), pairs, num, n, False, True)  # bf16 out
+    assert yb.dtype == torch.bfloat16
+    assert torch.equal(yb, y.bfloat16())    # bf16 output == RNE rounding of the f32 accumulators
+    din, dw = ops.indice_conv_backward(xt, wt, dyt, pairs, num, False, True)
+    edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
+    assert np.allclose(din.cpu().numpy(), edin, **TOL)
+    scale = max(1.0, float(np.abs(edw).max()))
+    assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * scale)
+
+
+def test_user_supplied_rulebook_without_cached_tables(dev):
+    """indice_conv called the reference way with bare pair tensors (e.g. produced elsewhere)."""
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(5)
+    idx, x, w, dy, pairs, num, ep, en = _conv_case(rng, dev, 1, (10, 10, 10), 0.3, 32, 32)
+    bare_pairs = torch.from_numpy(ep).to(dev)
+    bare_num = torch.from_numpy(en).to(dev)
+    xt, wt, dyt = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    y = ops.indice_conv(xt, wt, bare_pairs, bare_num, len(idx), False, True)
+    assert np.allclose(y.cpu().numpy(), O.indice_conv(x, w, ep, en, len(idx), subm=True), **TOL)
+    din, dw = ops.indice_conv_backward(xt, wt, dyt, bare_pairs, bare_num, False, True)
+    edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
+    assert np.allclose(din.cpu().numpy(), edin, **TOL) and np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('c', [16, 32, 128, 131, 1536])
+@pytest.mark.parametrize('act', ['none', 'gelu'])
+def test_layernorm_act_vs_torch(dev, dtype, c, act):
+    from objectcentricocccompletion_amd.norm import layer_norm_act
+    g = torch.Generator().manual_seed(c)
+    n = 1000 if c < 1000 else 67
+    x = (torch.randn(n, c, generator=g) * 2 + 0.5).to(dtype)
+    w = torch.rand(c, generator=g) + 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    dy = torch.randn(n, c, generator=g).to(dtype)
+    xd = x.to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = layer_norm_act(xd, wd, bd, 1e-3, act)
+    y.backward(dy.to(dev))
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (c,), wr, br, 1e-3)
+    if act == 'gelu':
+        yr = torch.nn.functional.gelu(yr)
+    yr.backward(dy.double())
+    if dtype == torch.float32:
+        tol = dict(rtol=1e-4, atol=1e-5)
+    else:  # output rounded to bf16 once: half an ulp = 2^-9 relative
+        tol = dict(rtol=2 ** -8, atol=2 ** -8)
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), **tol)
+    assert torch.allclose(xd.grad.cpu().double(), xr.grad, rtol=tol['rtol'], atol=tol['atol'] * 4)
+    assert torch.allclose(wd.grad.cpu().double(), wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+    assert torch.allclose(bd.grad.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
+
+
+def test_sparse_convmodule_autograd_vs_reference_math(dev):
+    """conv -> LN(eps 1e-3) -> GELU stack of make_sparse_convmodule, bf16 features, compared
+    with the same network evaluated in float64 from the oracle's rulebook."""
+    from objectcentricocccompletion_amd.sparse_block import make_sparse_convmodule
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor
+    rng = np.random.default_rng(21)
+    B, shape = 4, (16, 16, 16)
+    idx = _voxels(rng, B, shape, 0.15, False)
+    n = len(idx)
+    torch.manual_seed(0)
+    chans = [16, 32, 64]
+    layers = [make_sparse_convmodule(chans[i], chans[i + 1], 3, 'subm1', padding=1, conv_type='SubMConv3d',
+                                     act_type='gelu', norm_cfg=dict(type='LN', eps=1e-3)).to(dev)
+              for i in range(2)]
+    x = O.bf16_round(rng.standard_normal((n, 16)).astype(np.float32))
+    xt = torch.from_numpy(x).to(dev).bfloat16()
+    st = SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B)
+    for m in layers:
+        st = m(st)
+    out = st.features
+    assert out.dtype == torch.bfloat16 and 'subm1' in st.indice_dict
+    loss = (out.float() ** 2).sum()
+    loss.backward()
+    # float64 reference from the oracle rulebook
+    ep, en = O.subm_rulebook(idx, B, shape)
+    h = torch.from_numpy(x).double()
+    params = []
+    for m in layers:
+        w = m[0].weight.detach().cpu().double().requires_grad_(True)
+        g = m[1].weight.detach().cpu().double().requires_grad_(True)
+        b = m[1].bias.detach().cpu().double().requires_grad_(True)
+        params.append((w, g, b))
+        wb = w.bfloat16().double() + (w - w.detach())   # the kernel sees bf16-rounded weights
+        y = torch.zeros(n, w.shape[-1], dtype=torch.float64)
+        w27 = wb.reshape(27, w.shape[-2], w.shape[-1])
+        for k in range(27):
+            if en[k]:
+                y = y.index_add(0, torch.from_numpy(ep[k, 1, :en[k]]).long(),
+                                h[torch.from_numpy(ep[k, 0, :en[k]]).long()] @ w27[k])
+        h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(y, (y.shape[1],), g, b, 1e-3))
+    (h ** 2).sum().backward()
+    rel = lambda a, b_: float((a.double().cpu() - b_).abs().max() / (b_.abs().max() + 1e-12))
+    assert rel(out, h.detach()) < 2e-2          # two bf16 layers deep
+    for m, (w, g, b) in zip(layers, params):
+        assert rel(m[0].weight.grad, w.grad) < 5e-2
+        assert rel(m[1].weight.grad, g.grad) < 5e-2
+        assert rel(m[1].bias.grad, b.grad) < 5e-2
+
+
+def test_conv_properties_at_benchmark_scale(dev):
+    """64 grids x 40^3 with ~2000 active voxels each (the bench shape), where the oracle
+    would take minutes: linearity, determinism, rulebook symmetry, adjoint identity."""
+    from objectcentricocccompletion_amd.spconv import ops
+    g = torch.Generator().manual_seed(3)
+    B = 64
+    cells = torch.stack([torch.randperm(64000, generator=g)[:2000].sort().values + b * 64000 for b in range(B)]).flatten()
+    idx = torch.stack([cells // 64000, (cells // 1600) % 40, (cells // 40) % 40, cells % 40], 1).int().to(dev)
+    n = idx.shape[0]
+    _, pairs, num = ops.get_indice_pairs(idx, B, [40, 40, 40], 3, subm=True)
+    numc = num.cpu()
+    assert int(numc[13]) == n
+    assert torch.equal(numc, numc.flip(0))                       # offset k <-> 26-k symmetry
+    p = pairs.cpu()
+    for k in (0, 5, 12):
+        a = p[k, :, :numc[k]]
+        b = p[26 - k, :, :numc[k]]
+        sa = a[:, torch.argsort(a[0] * n + a[1])]
+        sb = b.flip(0)
+        sb = sb[:, torch.argsort(sb[0] * n + sb[1])]
+        assert torch.equal(sa, sb)
+    cin, cout = 64, 128
+    x1 = torch.randn(n, cin, generator=g).to(dev).bfloat16()
+    x2 = torch.randn(n, cin, generator=g).to(dev).bfloat16()
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.05).to(dev).bfloat16()
+    y1 = ops.indice_conv(x1.float(), w, pairs, num, n, False, True)
+    y1b = ops.indice_conv(x1.float(), w, pairs, num, n, False, True)
+    assert torch.equal(y1, y1b)                                   # deterministic, run to run
+    y2 = ops.indice_conv(x2.float(), w, pairs, num, n, False, True)
+    xs = (x1.float() + x2.float())
+    exact = xs.bfloat16().float() == xs                           # rows whose sum is bf16-exact
+    rows = exact.all(1)
+    ys = ops.indice_conv(xs, w, pairs, num, n, False, True)
+    # linearity on rows whose whole neighbourhood is exact is hard to isolate; check in the mean
+    assert float((ys - (y1 + y2)).abs().mean()) < 2e-2 * float(ys.abs().mean())
+    # adjoint identity <conv(x), dy> == <x, dgrad(dy)> ties forward and dgrad together
+    dy = torch.randn(n, cout, generator=g).to(dev).bfloat16().float()
+    din, dw = ops.indice_conv_backward(x1.float(), w, dy, pairs, num, False, True)
+    lhs = float((y1.double() * dy.double()).sum())
+    rhs = float((x1.double() * din.double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), 1.0)
+    # <dW, W> == <conv(x), dy>
+    rhs2 = float((dw.double() * w.double()).sum())
+    assert abs(lhs - rhs2) < 1e-3 * max(abs(lhs), 1.0)
