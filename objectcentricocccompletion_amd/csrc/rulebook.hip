@@ -198,10 +198,10 @@ extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int3
                   "sub-manifold dilation != 1 is not supported");
   const int kvol = host_ksize[0] * host_ksize[1] * host_ksize[2];
   OCOCC_REQUIRE(!blockmask || kvol <= 32, "blockmask needs kernel volume <= 32");
-  OCOCC_REQUIRE((indice_pairs == nullptr) == (indice_num == nullptr),
-                "indice_pairs and indice_num go together");
   if (indice_num) OCOCC_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), stream));
   if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE((indice_pairs == nullptr) == (indice_num == nullptr),
+                "indice_pairs and indice_num go together");
   OCOCC_REQUIRE(indices && nbr_t, "null indices/nbr_t");
   OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
   char* ws = (char*)workspace;

@@ -20,14 +20,14 @@ def grid_unique(coors, dims=None):
     bounds come from coors.amax (one sync, as torch.unique has anyway)."""
     L.require_device(coors)
     squeeze = coors.dim() == 1
+    if coors.size(0) == 0:
+        z = coors.new_zeros((0,), dtype=torch.int32)
+        return coors.to(torch.int32), z, z.clone()
     c = coors.reshape(coors.size(0), -1)
     if c.dtype != torch.int32:
         c = c.to(torch.int32)
     c = c.contiguous()
     n, ndim = c.shape
-    if n == 0:
-        z = c.new_zeros((0,), dtype=torch.int32)
-        return (c.new_zeros((0,) if squeeze else (0, ndim)), z, z.clone())
     if dims is None:
         dims = [int(v) + 1 for v in c.amax(0).clamp_min(0).tolist()]
     dims = [int(d) for d in dims]

@@ -176,7 +176,7 @@ def test_sparse_convmodule_autograd_vs_reference_math(dev):
         g = m[1].weight.detach().cpu().double().requires_grad_(True)
         b = m[1].bias.detach().cpu().double().requires_grad_(True)
         params.append((w, g, b))
-        wb = w.bfloat16().double() + (w - w.detach())   # the kernel sees bf16-rounded weights
+        wb = w.detach().bfloat16().double() + (w - w.detach())   # the kernel sees bf16-rounded weights
         y = torch.zeros(n, w.shape[-1], dtype=torch.float64)
         w27 = wb.reshape(27, w.shape[-2], w.shape[-1])
         for k in range(27):
@@ -185,7 +185,7 @@ def test_sparse_convmodule_autograd_vs_reference_math(dev):
                                 h[torch.from_numpy(ep[k, 0, :en[k]]).long()] @ w27[k])
         h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(y, (y.shape[1],), g, b, 1e-3))
     (h ** 2).sum().backward()
-    rel = lambda a, b_: float((a.double().cpu() - b_).abs().max() / (b_.abs().max() + 1e-12))
+    rel = lambda a, b_: float((a.detach().double().cpu() - b_).abs().max() / (b_.abs().max() + 1e-12))
     assert rel(out, h.detach()) < 2e-2          # two bf16 layers deep
     for m, (w, g, b) in zip(layers, params):
         assert rel(m[0].weight.grad, w.grad) < 5e-2
@@ -222,11 +222,9 @@ def test_conv_properties_at_benchmark_scale(dev):
     y1b = ops.indice_conv(x1.float(), w, pairs, num, n, False, True)
     assert torch.equal(y1, y1b)                                   # deterministic, run to run
     y2 = ops.indice_conv(x2.float(), w, pairs, num, n, False, True)
-    xs = (x1.float() + x2.float())
-    exact = xs.bfloat16().float() == xs                           # rows whose sum is bf16-exact
-    rows = exact.all(1)
+    xs = (x1.float() + x2.float())                                # rounded to bf16 inside the op
     ys = ops.indice_conv(xs, w, pairs, num, n, False, True)
-    # linearity on rows whose whole neighbourhood is exact is hard to isolate; check in the mean
+    # linearity up to that one bf16 rounding of the summed input
     assert float((ys - (y1 + y2)).abs().mean()) < 2e-2 * float(ys.abs().mean())
     # adjoint identity <conv(x), dy> == <x, dgrad(dy)> ties forward and dgrad together
     dy = torch.randn(n, cout, generator=g).to(dev).bfloat16().float()
