@@ -88,17 +88,23 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     model = SubMOccEncoder().to(dev)
     params = [p for p in model.parameters()]
-    opt = torch.optim.AdamW(params, lr=1e-4)
+    opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
     flat_numel = sum(p.numel() for p in params)
     bucket = torch.zeros(flat_numel, dtype=torch.float32, device=dev)
     B, P = args.grids, args.points
     xyz, feats, bidx = synthetic_object_grids(B, P, seed=rank, device=dev)
 
+    # Upstream gradient of the encoder output, as a downstream head would hand it back
+    # (fixed synthetic bf16 tensor; the voxel count of the fixed synthetic input is fixed).
+    with torch.no_grad():
+        n_act = model(xyz, feats, bidx, B).features.shape[0]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    d_out = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
+
     def step():
         opt.zero_grad(set_to_none=True)
         out = model(xyz, feats, bidx, B)
-        loss = out.features.float().pow(2).mean()
-        loss.backward()
+        out.features.backward(d_out)
         if world > 1:  # data parallel: one bucketed gradient all-reduce over RCCL / xGMI
             off = 0
             for p in params:

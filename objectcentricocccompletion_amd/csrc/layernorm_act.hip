@@ -140,12 +140,128 @@ ln_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n, 
   }
 }
 
+// ---- vectorised bf16 path: c = 8 * LPR with LPR a power of two <= 64.  Lane li owns the 8
+// contiguous channels 8*li .. 8*li+7 (one 16-byte load/store), so a wave instruction moves
+// 1 KiB of whole rows; gamma/beta live in registers for the whole kernel.
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+  v.x = (uint32_t)ococc_f32_to_bf16(f[0]) | ((uint32_t)ococc_f32_to_bf16(f[1]) << 16);
+  v.y = (uint32_t)ococc_f32_to_bf16(f[2]) | ((uint32_t)ococc_f32_to_bf16(f[3]) << 16);
+  v.z = (uint32_t)ococc_f32_to_bf16(f[4]) | ((uint32_t)ococc_f32_to_bf16(f[5]) << 16);
+  v.w = (uint32_t)ococc_f32_to_bf16(f[6]) | ((uint32_t)ococc_f32_to_bf16(f[7]) << 16);
+  return v;
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(256)
+ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, float eps, int act,
+                      uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
+  constexpr int C = LPR * 8, RPB = 256 / LPR;
+  const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
+  float g[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { g[j] = gamma[li * 8 + j]; b[j] = beta[li * 8 + j]; }
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
+    float v[8];
+    unpack8(*(const u32x4*)(x + r * C + li * 8), v);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+    const float mean = group_sum(s, LPR) * (1.f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; sq += d * d; }
+    const float rstd = rsqrtf(group_sum(sq, LPR) * (1.f / C) + eps);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float z = (v[j] - mean) * rstd * g[j] + b[j];
+      o[j] = act == 1 ? gelu(z) : z;
+    }
+    *(u32x4*)(y + r * C + li * 8) = pack8(o);
+    if (mean_rstd && li == 0) {
+      mean_rstd[r * 2] = mean;
+      mean_rstd[r * 2 + 1] = rstd;
+    }
+  }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
+                      float* __restrict__ partials) {
+  constexpr int C = LPR * 8, RPB = 256 / LPR;
+  __shared__ float red[256];
+  const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
+  float g[8], b[8], dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    g[j] = gamma[li * 8 + j];
+    b[j] = beta[li * 8 + j];
+    dg[j] = db[j] = 0.f;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
+    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+    float xv[8], dv[8], dzg[8];
+    unpack8(*(const u32x4*)(x + r * C + li * 8), xv);
+    unpack8(*(const u32x4*)(dy + r * C + li * 8), dv);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xv[j] = (xv[j] - mean) * rstd;  // xhat
+      float dz = dv[j];
+      if (act == 1) dz *= gelu_grad(xv[j] * g[j] + b[j]);
+      dg[j] += dz * xv[j];
+      db[j] += dz;
+      dzg[j] = dz * g[j];
+      s1 += dzg[j];
+      s2 += dzg[j] * xv[j];
+    }
+    s1 = group_sum(s1, LPR) * (1.f / C);
+    s2 = group_sum(s2, LPR) * (1.f / C);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[j] - s1 - xv[j] * s2);
+    *(u32x4*)(dx + r * C + li * 8) = pack8(o);
+  }
+  float* slab = partials + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+      red[threadIdx.x] = which ? db[j] : dg[j];
+      __syncthreads();
+      if (rloc == 0) {
+        float s = 0.f;
+        for (int q = 0; q < RPB; ++q) s += red[q * LPR + li];
+        slab[which * C + li * 8 + j] = s;
+      }
+    }
+  }
+}
+
+// 8 outputs per block, 32 lanes each: lane l adds partials l, l+32, ... (fixed order),
+// then a fixed-shape butterfly combines the 32 lanes -> deterministic.
 __global__ void __launch_bounds__(256)
 ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * c; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * 2 * c + i];
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int l = threadIdx.x & 31;
+  float s = 0.f;
+  if (i < 2 * c)
+    for (int b = l; b < nblocks; b += 32) s += partials[(int64_t)b * 2 * c + i];
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
+  if (l == 0 && i < 2 * c) {
     if (i < c) {
       if (dgamma) dgamma[i] += s;
     } else {
@@ -161,7 +277,7 @@ inline int pick_lpr(int c) {
 }
 inline int bwd_blocks(int64_t n, int lpr) {
   int64_t b = ococc_cdiv(n, 256 / lpr);
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -179,9 +295,34 @@ cast_bf16_f32_kernel(const uint16_t* __restrict__ s, float* __restrict__ d, int6
     d[i] = ococc_bf16_to_f32(s[i]);
 }
 
+inline bool vec_ok(int c) { return c % 8 == 0 && c >= 16 && c <= 512 && ((c / 8) & (c / 8 - 1)) == 0; }
+inline int vec_blocks(int64_t n, int c, int cap) {
+  int64_t b = ococc_cdiv(n, 256 / (c / 8));
+  if (b > cap) b = cap;
+  return (int)(b < 1 ? 1 : b);
+}
+
+#define OCOCC_LN_VEC_SWITCH(LPRV, CALL) \
+  switch (LPRV) {                        \
+    case 2: CALL(2); break;              \
+    case 4: CALL(4); break;              \
+    case 8: CALL(8); break;              \
+    case 16: CALL(16); break;            \
+    case 32: CALL(32); break;            \
+    default: CALL(64); break;            \
+  }
+
 template <typename T>
 int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                int act, T* y, float* mean_rstd, hipStream_t stream) {
+  if (sizeof(T) == 2 && vec_ok(c)) {
+    const int grid = vec_blocks(n, c, 4096);
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd)
+    OCOCC_LN_VEC_SWITCH(c / 8, CALL)
+#undef CALL
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = ococc_grid_1d(ococc_cdiv(n, 256 / lpr) * 256, 256);
@@ -201,6 +342,17 @@ template <typename T>
 int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, const float* beta,
                const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
                hipStream_t stream) {
+  if (sizeof(T) == 2 && vec_ok(c)) {
+    const int grid = vec_blocks(n, c, 512);
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
+    OCOCC_LN_VEC_SWITCH(c / 8, CALL)
+#undef CALL
+    OCOCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials,
+                       grid, c, dgamma, dbeta);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = bwd_blocks(n, lpr);
@@ -213,7 +365,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
   else
     return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "c must be <= 2048");
   OCOCC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ococc_grid_1d(2 * c, 256, 16)), dim3(256), 0,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0,
                      stream, partials, grid, c, dgamma, dbeta);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
@@ -237,7 +389,7 @@ extern "C" int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, cons
 
 extern "C" int64_t ococc_layernorm_act_bwd_workspace_bytes(int64_t n, int32_t c) {
   if (n < 0 || c < 1) return -1;
-  return (int64_t)bwd_blocks(n, pick_lpr(c)) * 2 * c * (int64_t)sizeof(float);
+  return (int64_t)512 * 2 * c * (int64_t)sizeof(float);
 }
 
 extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,

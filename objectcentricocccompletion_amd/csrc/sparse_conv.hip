@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return __builtin_bit_cast(bf16x8, z);
 }
 
-template <int KD, int CS, int RB, bool OUT_BF16>
+template <int KD, int CS, int RB, int G, bool OUT_BF16>
 __global__ void __launch_bounds__(kConvThreads)
 gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ wn, int kvol,
                    int ncols, const int32_t* __restrict__ table,
@@ -54,6 +54,7 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
   constexpr int KSTEPS = (KD + 31) / 32;
   constexpr int NB = CS / 16;
   constexpr int LDW = KD + 8;  // LDS row stride in elements (16 B pad)
+  static_assert(RB * 16 <= 64, "a wave loads the indices of its whole tile with one instruction");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* wl = (uint16_t*)smem;
 
@@ -98,39 +99,87 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    while (um) {
-      const int k = __builtin_ctz(um);
-      um &= um - 1;
-      bf16x8 x[RB][KSTEPS];
+    // Offsets are consumed in batches of G.  One coalesced load per offset brings the
+    // gather indices of the whole tile (lane -> row); the next batch's indices are in
+    // flight while this batch's rows are gathered and multiplied, and all row gathers
+    // of a batch (up to G*RB*KSTEPS 16-byte loads per lane) are issued back to back.
+    const int64_t row_l = tile * (RB * 16) + lane;
+    const bool row_ok = lane < RB * 16 && row_l < n_out;
+    int kcur[G], knxt[G];
+    int32_t icur[G], inxt[G];
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        int32_t idx = -1;
-        if ((m[rb] >> k) & 1u) {
-          const int64_t r = (tile * RB + rb) * 16 + lrow;
-          if (r < n_out) idx = table[(int64_t)k * n_out + r];
-        }
+    for (int s = 0; s < G; ++s) {
+      kcur[s] = -1;
+      if (um) { kcur[s] = __builtin_ctz(um); um &= um - 1; }
+      int32_t v = -1;
+      if (kcur[s] >= 0 && row_ok) v = table[(int64_t)kcur[s] * n_out + row_l];
+      icur[s] = v;
+    }
+    while (kcur[0] >= 0) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          const int koff = ks * 32 + kg * 8;
-          bf16x8 v = zero_bf16x8();
-          if (idx >= 0 && koff < KD)
-            v = *(const bf16x8*)(feat + (int64_t)idx * KD + koff);
-          x[rb][ks] = v;
+      for (int s = 0; s < G; ++s) {
+        knxt[s] = -1;
+        if (um) { knxt[s] = __builtin_ctz(um); um &= um - 1; }
+        int32_t v = -1;
+        if (knxt[s] >= 0 && row_ok) v = table[(int64_t)knxt[s] * n_out + row_l];
+        inxt[s] = v;
+      }
+      // x[s][rb][*] is written and read only under the same wave-uniform predicate
+      // on(s, rb), so inactive (offset, block) pairs cost no instruction at all.
+      bf16x8 x[G][RB][KSTEPS];
+      uint32_t onmask = 0;  // bit s*RB+rb
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          if (kcur[s] >= 0 && ((m[rb] >> (kcur[s] & 31)) & 1u)) onmask |= 1u << (s * RB + rb);
         }
       }
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int koff = ks * 32 + kg * 8;
+      for (int s = 0; s < G; ++s) {
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-          bf16x8 w = zero_bf16x8();
-          if (koff < KD) w = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + koff);
+        for (int rb = 0; rb < RB; ++rb) {
+          if (onmask & (1u << (s * RB + rb))) {
+            const int32_t ib = __shfl(icur[s], rb * 16 + lrow, 64);
+            const uint16_t* src = feat + (int64_t)(ib < 0 ? 0 : ib) * KD + kg * 8;
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) {
-            if ((m[rb] >> k) & 1u)
-              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x[rb][ks], acc[rb][cb], 0, 0, 0);
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+              bf16x8 v = zero_bf16x8();
+              if (ib >= 0 && ks * 32 + kg * 8 < KD) v = *(const bf16x8*)(src + ks * 32);
+              x[s][rb][ks] = v;
+            }
           }
         }
+      }
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+        if (!((onmask >> (s * RB)) & ((1u << RB) - 1u))) continue;
+        const int k = kcur[s];
+        bf16x8 w[KSTEPS][NB];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const int koff = ks * 32 + kg * 8;
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) {
+            w[ks][cb] = zero_bf16x8();
+            if (koff < KD) w[ks][cb] = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + koff);
+          }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          if (onmask & (1u << (s * RB + rb))) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+              for (int cb = 0; cb < NB; ++cb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cb], x[s][rb][ks], acc[rb][cb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+        kcur[s] = knxt[s];
+        icur[s] = inxt[s];
       }
     }
 
@@ -177,12 +226,12 @@ int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int n
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)n_slices);
   if (out_dtype == OCOCC_BF16) {
-    auto kern = gather_gemm_kernel<KD, CS, RB, true>;
+    auto kern = gather_gemm_kernel<KD, CS, RB, (KD >= 128 ? 2 : 4), true>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
                        blockmask, n_out, bias, out);
   } else {
-    auto kern = gather_gemm_kernel<KD, CS, RB, false>;
+    auto kern = gather_gemm_kernel<KD, CS, RB, (KD >= 128 ? 2 : 4), false>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
                        blockmask, n_out, bias, out);
@@ -249,19 +298,32 @@ weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int 
 
 // ---------------------------------------------------------------- wgrad
 constexpr int kWgThreads = 256;
-constexpr int kWgSplits = 64;   // gridDim.x: workgroups per kernel offset
-constexpr int kWgMinSteps = 8;  // at least this many 32-pair steps per workgroup
+constexpr int kWgSteps = 16;  // 32-pair MFMA k-steps per workgroup
 
-__device__ __forceinline__ int wg_steps_per_group(int ksteps) {
-  int q = (ksteps + kWgSplits - 1) / kWgSplits;
-  return q < kWgMinSteps ? kWgMinSteps : q;
+// Work item g of the flattened (offset, part) list: offset k owns
+// ceil(ceil(num[k]/32) / kWgSteps) consecutive items.  Returns false past the end.
+__device__ __forceinline__ bool wg_locate(const int32_t* __restrict__ num, int kvol, int g, int* k_out,
+                                          int* part_out, int* base_out) {
+  int base = 0;
+  for (int k = 0; k < kvol; ++k) {
+    const int ksteps = (num[k] + 31) >> 5;
+    const int groups = (ksteps + kWgSteps - 1) / kWgSteps;
+    if (g < base + groups) {
+      *k_out = k;
+      *part_out = g - base;
+      *base_out = base;
+      return true;
+    }
+    base += groups;
+  }
+  return false;
 }
 
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(kWgThreads)
 wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int64_t cap,
-             float* __restrict__ slabs) {
+             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
+             int64_t cap, float* __restrict__ slabs) {
   constexpr int MB = CIN / 16, NB = COUT / 16;
   constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
   constexpr int WM = 4 / WN;            // waves along the cin blocks
@@ -271,13 +333,12 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   constexpr int PT = (PX + PY + kWgThreads - 1) / kWgThreads;
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
 
-  const int k = blockIdx.y;
+  int k, part, base;
+  if (!wg_locate(num, kvol, blockIdx.x, &k, &part, &base)) return;
   const int nk = num[k];
   const int ksteps = (nk + 31) >> 5;
-  const int q = wg_steps_per_group(ksteps);
-  const int first = blockIdx.x * q;
-  if (first >= ksteps) return;
-  const int last = (first + q < ksteps) ? first + q : ksteps;
+  const int first = part * kWgSteps;
+  const int last = (first + kWgSteps < ksteps) ? first + kWgSteps : ksteps;
   const int32_t* pin = pairs + ((int64_t)k * 2 + 0) * cap;
   const int32_t* pout = pairs + ((int64_t)k * 2 + 1) * cap;
 
@@ -292,20 +353,32 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
     for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 stage[PT];
-  auto load_step = [&](int step) {
+  int32_t ridx[PT];  // row index of each piece, fetched one step ahead of the rows
+  auto load_idx = [&](int step) {
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pc = threadIdx.x + t * kWgThreads;
+      int32_t v = -1;
+      if (pc < PX) {
+        const int p = step * 32 + pc / (CIN / 8);
+        if (p < nk) v = pin[p];
+      } else if (pc < PX + PY) {
+        const int p = step * 32 + (pc - PX) / (COUT / 8);
+        if (p < nk) v = pout[p];
+      }
+      ridx[t] = v;
+    }
+  };
+  auto load_step = [&]() {
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int pc = threadIdx.x + t * kWgThreads;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (pc < PX) {
-        const int row = pc / (CIN / 8), piece = pc % (CIN / 8);
-        const int p = step * 32 + row;
-        if (p < nk) v = *(const u32x4*)(x + (int64_t)pin[p] * CIN + piece * 8);
-      } else if (pc < PX + PY) {
-        const int pc2 = pc - PX;
-        const int row = pc2 / (COUT / 8), piece = pc2 % (COUT / 8);
-        const int p = step * 32 + row;
-        if (p < nk) v = *(const u32x4*)(dy + (int64_t)pout[p] * COUT + piece * 8);
+      if (ridx[t] >= 0) {
+        if (pc < PX)
+          v = *(const u32x4*)(x + (int64_t)ridx[t] * CIN + (pc % (CIN / 8)) * 8);
+        else
+          v = *(const u32x4*)(dy + (int64_t)ridx[t] * COUT + ((pc - PX) % (COUT / 8)) * 8);
       }
       stage[t] = v;
     }
@@ -325,12 +398,17 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
     }
   };
 
-  load_step(first);
+  load_idx(first);
+  load_step();
+  if (first + 1 < last) load_idx(first + 1);
   int buf = 0;
   for (int step = first; step < last; ++step) {
     store_step(buf);
     __syncthreads();
-    if (step + 1 < last) load_step(step + 1);
+    if (step + 1 < last) {
+      load_step();  // rows of step+1 (their indices arrived during the previous step)
+      if (step + 2 < last) load_idx(step + 2);
+    }
     // transposing reads: lane (grp, li) with q_=li>>2, p_=li&3 addresses row 8*grp+4h+q_,
     // columns 16*blk+4p_ .. +3 and receives column li of rows 8*grp+4h .. +3.
     const int q_ = li >> 2, p_ = li & 3;
@@ -372,7 +450,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   }
 
   // D[m = cin][n = cout]: lane holds rows 4*grp + {0..3}, column li of each 16x16 tile
-  float* slab = slabs + ((int64_t)k * kWgSplits + blockIdx.x) * CIN * COUT;
+  float* slab = slabs + (int64_t)blockIdx.x * CIN * COUT;
 #pragma unroll
   for (int i = 0; i < MBW; ++i) {
     const int mb = wm + i * WM;
@@ -388,31 +466,44 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   }
 }
 
+// dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
+// block; lane p adds slabs p, p+16, ...; a fixed tree joins the 16 lanes.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
                     int64_t elems, float* __restrict__ dw) {
+  __shared__ float red[4][16];
   const int k = blockIdx.y;
-  const int ksteps = (num[k] + 31) >> 5;
-  const int q = wg_steps_per_group(ksteps);
-  const int nslabs = (ksteps + q - 1) / q;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < elems;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int j = 0; j < nslabs; ++j) s += slabs[((int64_t)k * kWgSplits + j) * elems + i];
-    dw[(int64_t)k * elems + i] = s;
-  }
+  int base = 0;
+  for (int j = 0; j < k; ++j) base += (((num[j] + 31) >> 5) + kWgSteps - 1) / kWgSteps;
+  const int nslabs = (((num[k] + 31) >> 5) + kWgSteps - 1) / kWgSteps;
+  const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < elems)
+    for (int j = part; j < nslabs; j += 16) s += slabs[(int64_t)(base + j) * elems + i];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][e] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < elems)
+    dw[(int64_t)k * elems + i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
+  // sum_k ceil(ceil(num[k]/32)/kWgSteps) <= kvol*cap/(32*kWgSteps) + kvol (+ slack)
+  return ococc_cdiv((int64_t)kvol * ococc_cdiv(cap, 32), kWgSteps) + kvol;
 }
 
 template <int CIN>
 int dispatch_wgrad_cout(const uint16_t* x, const uint16_t* dy, int cout, const int32_t* pairs,
                         const int32_t* num, int kvol, int64_t cap, float* slabs,
                         hipStream_t stream) {
-  dim3 grid(kWgSplits, kvol), block(kWgThreads);
+  dim3 grid((unsigned)wgrad_max_groups(kvol, cap)), block(kWgThreads);
   switch (cout) {
-    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
-    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
-    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, cap, slabs); break;
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cout must be 16/32/64/128");
   }
   OCOCC_CHECK_LAUNCH();
@@ -465,9 +556,8 @@ extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t
 
 extern "C" int64_t ococc_sparse_conv_wgrad_workspace_bytes(int32_t kvol, int64_t pair_capacity,
                                                            int32_t cin, int32_t cout) {
-  (void)pair_capacity;
-  if (kvol < 1 || cin < 1 || cout < 1) return -1;
-  return (int64_t)kvol * kWgSplits * cin * cout * (int64_t)sizeof(float);
+  if (kvol < 1 || cin < 1 || cout < 1 || pair_capacity < 0) return -1;
+  return wgrad_max_groups(kvol, pair_capacity) * cin * cout * (int64_t)sizeof(float);
 }
 
 extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin,
@@ -498,7 +588,7 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cin must be 16/32/64/128");
   }
   if (rc != OCOCC_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ococc_grid_1d(elems, 256, 64), kvol), dim3(256), 0,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ococc_cdiv(elems, 16), kvol), dim3(256), 0,
                      stream, slabs, indice_num, (int)kvol, elems, dw);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
