@@ -69,6 +69,16 @@ def cpu_baseline(sample_grids, points, model):
                       f'{reps} repetitions, oracle/encoder_ref.py'}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_pmc_gather_gemm_64_128.json)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gather_gemm_64_128.json')) as f:
+            return json.load(f)['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -176,7 +186,7 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': None,
+                'traffic': pmc_traffic(),
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
