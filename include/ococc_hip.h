@@ -227,6 +227,29 @@ int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
                             int32_t act, void* dx, float* dgamma, float* dbeta, int32_t dtype,
                             void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * A3  points-in-rotated-box pooling
+ * replaces TorchEx dynamic_point_pool_ext.dynamic_point_pool_mixed_gpu as called at
+ *   mmdet3d/ops/dynamic_point_pool_op.py:81-87 (source not vendored; contract from the
+ *   call site and the debug assertions of
+ *   models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py:222-234).
+ * rois [R,7] f32 (x,y,z_bottom,w,l,h,yaw), rois_key [R] i32, pts [N,3] f32, pts_key [N] i32.
+ * A pair (point, RoI) is emitted when the keys match and the point is inside the RoI
+ * enlarged by host_extra_wlh (w,l,h; extra/2 per side).  Rows are written SORTED by
+ * (RoI, point index): out_pts_idx / out_roi_idx [>= num_out] i64, out_pts_feats
+ * [>= num_out, 13] f32 = xyz, box-frame xyz, 6 face distances of the original box,
+ * is_in_margin.  Caps: max_inbox_point per RoI, max_all_pts rows in total (the smallest
+ * point indices / RoI indices are kept).  roi_counts [R] i32 (may be NULL) = rows kept per
+ * RoI; num_out = rows written (device int32).
+ * ------------------------------------------------------------------------ */
+int64_t ococc_point_pool_workspace_bytes(int64_t num_points, int64_t num_rois);
+int ococc_dynamic_point_pool_mixed(const float* rois, const int32_t* rois_key, int64_t num_rois,
+                                   const float* pts, const int32_t* pts_key, int64_t num_points,
+                                   const float host_extra_wlh[3], int32_t max_inbox_point,
+                                   int64_t max_all_pts, int64_t* out_pts_idx, int64_t* out_roi_idx,
+                                   float* out_pts_feats, int32_t* roi_counts, int32_t* num_out,
+                                   void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

@@ -1,0 +1,62 @@
+"""Box helpers on the hot path -- host mirror of rotation_3d_in_axis
+(mmdet3d/core/bbox/structures/utils.py:21-61) and DeltaXYZWLHRBBoxCoder
+(mmdet3d/core/bbox/coders/delta_xyzwhlr_bbox_coder.py:8-90).  Tiny elementwise math."""
+import torch
+
+from .registry import BBOX_CODERS
+
+
+def limit_period(val, offset=0.5, period=3.141592653589793):
+    return val - torch.floor(val / period + offset) * period
+
+
+def rotation_3d_in_axis(points, angles, axis=0):
+    """points [N,M,3] rotated by angles [N] about `axis`; note the reference multiplies by the
+    TRANSPOSED matrix (einsum 'aij,jka->aik'), i.e. a clockwise turn for axis 2."""
+    rot_sin, rot_cos = torch.sin(angles), torch.cos(angles)
+    ones, zeros = torch.ones_like(rot_cos), torch.zeros_like(rot_cos)
+    if axis == 1:
+        rows = [[rot_cos, zeros, -rot_sin], [zeros, ones, zeros], [rot_sin, zeros, rot_cos]]
+    elif axis == 2 or axis == -1:
+        rows = [[rot_cos, -rot_sin, zeros], [rot_sin, rot_cos, zeros], [zeros, zeros, ones]]
+    elif axis == 0:
+        rows = [[zeros, rot_cos, -rot_sin], [zeros, rot_sin, rot_cos], [ones, zeros, zeros]]
+    else:
+        raise ValueError(f'axis should in range [0, 1, 2], got {axis}')
+    rot_mat_T = torch.stack([torch.stack(r) for r in rows])
+    return torch.einsum('aij,jka->aik', (points, rot_mat_T))
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYZWLHRBBoxCoder(object):
+    """(x, y, z_bottom, w, l, h, r) deltas normalised by the anchor diagonal / height."""
+
+    def __init__(self, code_size=7):
+        self.code_size = code_size
+
+    @staticmethod
+    def encode(src_boxes, dst_boxes):
+        xa, ya, za, wa, la, ha, ra, *cas = torch.split(src_boxes, 1, dim=-1)
+        xg, yg, zg, wg, lg, hg, rg, *cgs = torch.split(dst_boxes, 1, dim=-1)
+        cts = [g - a for g, a in zip(cgs, cas)]
+        za = za + ha / 2
+        zg = zg + hg / 2
+        diagonal = torch.sqrt(la ** 2 + wa ** 2)
+        return torch.cat([(xg - xa) / diagonal, (yg - ya) / diagonal, (zg - za) / ha, torch.log(wg / wa),
+                          torch.log(lg / la), torch.log(hg / ha), rg - ra, *cts], dim=-1)
+
+    @staticmethod
+    def decode(anchors, deltas):
+        xa, ya, za, wa, la, ha, ra, *cas = torch.split(anchors, 1, dim=-1)
+        xt, yt, zt, wt, lt, ht, rt, *cts = torch.split(deltas, 1, dim=-1)
+        za = za + ha / 2
+        diagonal = torch.sqrt(la ** 2 + wa ** 2)
+        xg, yg, zg = xt * diagonal + xa, yt * diagonal + ya, zt * ha + za
+        lg, wg, hg = torch.exp(lt) * la, torch.exp(wt) * wa, torch.exp(ht) * ha
+        zg = zg - hg / 2
+        cgs = [t + a for t, a in zip(cts, cas)]
+        return torch.cat([xg, yg, zg, wg, lg, hg, rt + ra, *cgs], dim=-1)
+
+
+def build_bbox_coder(cfg):
+    return BBOX_CODERS.build(cfg)

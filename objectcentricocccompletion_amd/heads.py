@@ -1,0 +1,552 @@
+"""OcOccNet heads -- host mirror of OccAutoEncoder (mmdet3d/models/roi_heads/bbox_heads/
+occ_ae_head.py:28-264), OccBBoxHead (ococc_bbox_head.py:37-1309) and the few helpers they
+inherit from FullySparseBboxHead (fsd_bbox_head.py:238-272, 442-455, 595-689, 1075-1095).
+
+Same constructor arguments, parameter names (block_list.<i>..., occ_ae_head.point_encoder...,
+occ_ae_head.occ_decoder..., trans_enc.layers.<i>..., roi_pos_enc_mlp, conv_cls, conv_reg,
+conv_latent, conv_fused) and result dictionaries as the reference, so its configs build
+and its checkpoints load.  What differs is underneath:
+  * points arrive sorted by RoI from ococc_dynamic_point_pool_mixed, so every scatter is a
+    run-length segment reduction (ococc_segment_reduce_f32);
+  * every Linear->LN->GELU uses the fused ococc_layernorm_act kernels;
+  * the occupancy loss calls the decoder with (RoI features, query points, RoI index) and
+    the decoder's first layer is factorised, instead of materialising [R+,K,1536] copies.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .bbox import build_bbox_coder, rotation_3d_in_axis
+from .losses import build_loss, reduce_mean
+from .occ import occ_ops
+from .occ.layers import PositionalEncoding, SimpleEncoderLayer, TransformerEncoder
+from .occ.occ_base import OccDecoder
+from .registry import BACKBONES, HEADS
+from .sir import SIRLayer
+from .sst.sst_ops import build_mlp, unique_with_inverse
+
+
+class SparseHeadMixin(object):
+    """Helpers OccBBoxHead / OccAutoEncoder take from FullySparseBboxHead."""
+
+    def get_nonempty_roi_mask(self, out_coors, num_rois):
+        """fsd_bbox_head.py:238-250."""
+        out_coors = out_coors[out_coors >= 0].long()
+        mask = torch.zeros(num_rois, dtype=torch.bool, device=out_coors.device)
+        mask[out_coors] = True
+        return mask
+
+    def align_roi_feature_and_rois(self, features, out_coors, num_rois):
+        """Rows of `features` follow the sorted non-empty RoIs; put them at their RoI index,
+        zeros for empty RoIs (fsd_bbox_head.py:252-272)."""
+        new_feature = features.new_zeros((num_rois, features.size(1)))
+        coors_mask = out_coors >= 0
+        if not coors_mask.any():
+            new_feature[:len(features), :] = features * 0
+            return new_feature
+        new_feature[out_coors[coors_mask].long()] = features[coors_mask]
+        return new_feature
+
+    def filter_pos_assigned_but_empty_rois(self, pos_data, pos_batch_idx, filtered_pos_mask, roi_batch_idx):
+        """fsd_bbox_head.py:442-455."""
+        real_bsz = int(roi_batch_idx.max().item()) + 1
+        out = []
+        for b in range(real_bsz):
+            keep = torch.nonzero(filtered_pos_mask[roi_batch_idx == b]).reshape(-1)
+            out.append(pos_data[pos_batch_idx == b][keep])
+        return torch.cat(out, 0)
+
+    def get_class_wise_box_weights(self, weights, gt_labels, cfg):
+        class_wise_weight = cfg.get('class_wise_box_weights', None)
+        if class_wise_weight is None:
+            return weights
+        all_gt = torch.cat([gt_labels, gt_labels.new_full((len(weights) - len(gt_labels),), -1)], 0)
+        for i in range(self.num_classes):
+            weights[all_gt == i] *= class_wise_weight[i]
+        return weights
+
+    def get_multi_class_soft_label(self, ious, pos_gt_labels, cfg):
+        """IoU-interpolated soft labels between cls_neg_thr and cls_pos_thr
+        (fsd_bbox_head.py:627-689)."""
+        pos_thrs, neg_thrs = cfg['cls_pos_thr'], cfg['cls_neg_thr']
+        if isinstance(pos_thrs, float):
+            pos_thrs, neg_thrs = [pos_thrs] * self.num_classes, [neg_thrs] * self.num_classes
+        num_samples, num_pos = ious.size(0), pos_gt_labels.size(0)
+        all_gt = torch.cat([pos_gt_labels, pos_gt_labels.new_full((num_samples - num_pos,), -1)], 0)
+        all_label = ious.new_zeros(num_samples)
+        for i in range(self.num_classes):
+            m = all_gt == i
+            this = ious[m]
+            pos = this > pos_thrs[i]
+            interval = (~pos) & ~(this < neg_thrs[i])
+            lab = pos.float()
+            lab[interval] = (this[interval] - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i])
+            all_label[m] = lab
+        label_weights = (all_label >= 0).float()
+        cw = cfg.get('class_wise_cls_weights', None)
+        if cw is not None:
+            for i in range(self.num_classes):
+                label_weights[all_gt == i] *= cw[i]
+        return all_label, label_weights
+
+    def decode_from_rois(self, rois, bbox_pred):
+        """fsd_bbox_head.py:1075-1095: canonical deltas -> boxes in the ego frame."""
+        roi_boxes = rois[..., 1:]
+        roi_ry = roi_boxes[..., 6].view(-1)
+        roi_xyz = roi_boxes[..., 0:3].view(-1, 3)
+        local = roi_boxes.clone().detach()
+        local[..., 0:3] = 0
+        if local.size(1) == 9:
+            bbox_pred = torch.nn.functional.pad(bbox_pred, (0, 2), 'constant', 0)
+        boxes = self.bbox_coder.decode(local, bbox_pred)
+        boxes[..., 0:3] = rotation_3d_in_axis(boxes[..., 0:3].unsqueeze(1), roi_ry + np.pi / 2, axis=2).squeeze(1)
+        boxes[:, 0:3] += roi_xyz
+        return boxes
+
+
+@HEADS.register_module()
+class OccAutoEncoder(nn.Module, SparseHeadMixin):
+    """Point encoder (SIR) + implicit occupancy decoder (occ_ae_head.py:28-264)."""
+
+    def __init__(self, backbone, occ_decoder, voxel_size,
+                 loss_occ_ae=dict(type='CrossEntropyLoss', reduction='none', use_sigmoid=True, loss_weight=1.0),
+                 scale_wlh=[1.0, 1.0, 1.0], offset_wlh=[0.0, 0.0, 0.0], online_sample_size=-1,
+                 balance_sample=False, with_voxelize_centers=False, compensate_encoder_coors=False,
+                 add_train_prob=0.0, init_cfg=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.point_encoder = BACKBONES.build(backbone)
+        self.occ_decoder = OccDecoder(**occ_decoder)
+        self.loss_occ_ae = build_loss(loss_occ_ae)
+        self.voxel_size = voxel_size
+        self.scale_wlh, self.offset_wlh = scale_wlh, offset_wlh
+        self.online_sample_size, self.balance_sample = online_sample_size, balance_sample
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.with_voxelize_centers = with_voxelize_centers
+        self.compensate_encoder_coors = compensate_encoder_coors
+        self.add_train_prob = add_train_prob
+
+    def encode(self, pts_xyz, pts_features, pts_info, roi_inds, rois, point_encoder=None, cat_global_xyz=False):
+        """occ_ae_head.py:203-264 -> (local_roi_feats [R,D], nonempty mask [R], rotated local xyz)."""
+        local_xyz = pts_info['local_xyz']
+        if self.compensate_encoder_coors:  # the pi/2 frame fix the pooling op leaves to callers
+            r = local_xyz.new_tensor((np.pi / 2,))
+            local_xyz = rotation_3d_in_axis(local_xyz[None, :, :], r, axis=2).squeeze(0)
+        boundary_offset, is_in_margin = pts_info['boundary_offset'], pts_info['is_in_margin']
+        parts = [boundary_offset, is_in_margin[:, None]]
+        if pts_features is not None:
+            parts = [pts_features] + parts
+        if cat_global_xyz:
+            parts.append(pts_xyz)
+        if self.with_voxelize_centers:
+            assert self.compensate_encoder_coors
+            parts.append(occ_ops.quantize_points(local_xyz, rois, roi_inds, self.voxel_size, self.scale_wlh,
+                                                 self.offset_wlh, to_center=True))
+        out_feats = torch.cat(parts, 1)
+        if point_encoder is None:
+            point_encoder = self.point_encoder
+        out_feats, final_cluster_feats, out_coors = point_encoder(local_xyz, out_feats, roi_inds, dims=[len(rois)])
+        nonempty_roi_mask = self.get_nonempty_roi_mask(out_coors, len(rois))
+        final_cluster_feats = self.align_roi_feature_and_rois(final_cluster_feats, out_coors, len(rois))
+        return final_cluster_feats, nonempty_roi_mask, local_xyz
+
+    def decode(self, roi_feats, smp_pts_xyz_local, smp_pts_roi_inds):
+        return self.occ_decoder(roi_feats, smp_pts_xyz_local, smp_pts_roi_inds)
+
+
+class _Sampling(object):
+    """What get_targets reads from an mmdet SamplingResult (tracklet_roi_head_occ.py:880-991)."""
+
+    def __init__(self, pos_bboxes, pos_gt_bboxes, iou, pos_gt_labels, occ_labels, occ_scores):
+        self.pos_bboxes, self.pos_gt_bboxes, self.iou = pos_bboxes, pos_gt_bboxes, iou
+        self.pos_gt_labels, self.occ_labels, self.occ_scores = pos_gt_labels, occ_labels, occ_scores
+
+
+@HEADS.register_module()
+class OccBBoxHead(nn.Module, SparseHeadMixin):
+
+    def __init__(self, num_blocks, in_channels, feat_channels, rel_mlp_hidden_dims, rel_mlp_in_channels,
+                 with_rel_mlp=True, with_cluster_center=False, with_distance=False, mode='max',
+                 xyz_normalizer=[20, 20, 4], geo_input=True, dropout=0, unique_once=True, occ_ae_head=None,
+                 roi_feature_channels=None, init_cfg=None, debug=False, fixed_ae=True, attn_num_head=4,
+                 attn_ffn_dim=2048, attn_dropout=0.1,
+                 loss_occ_comp=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='none', loss_weight=1.0),
+                 num_classes=1, bbox_coder=dict(type='DeltaXYZWLHRBBoxCoder'), occ_label_thresh=0.8,
+                 reg_mlp=None, cls_mlp=None, latent_mlp=None, fusion_mlp=None, act='gelu',
+                 norm_cfg=dict(type='LN', eps=1e-3),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=2.0),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='none', loss_weight=1.0),
+                 cls_dropout=0, reg_dropout=0, latent_dropout=0, fusion_dropout=0, with_corner_loss=False,
+                 with_roi_pos_encoding=False, roi_pos_enc_mlp=None, roi_enc_dropout=0, num_enc_layers=1,
+                 fused_mode='residual', rcnn_trans=True, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.box_code_size = self.bbox_coder.code_size
+        self.occ_ae_head = HEADS.build(occ_ae_head)
+        self.debug, self.fixed_ae = debug, fixed_ae
+        if self.fixed_ae:
+            for p in self.occ_ae_head.parameters():
+                p.requires_grad = False
+            self.occ_ae_head.eval()
+        self.with_corner_loss = with_corner_loss
+        self.trans_enc = TransformerEncoder(
+            SimpleEncoderLayer(roi_feature_channels, attn_num_head, dim_feedforward=attn_ffn_dim,
+                               dropout=attn_dropout), num_enc_layers)
+        self.pos_enc = PositionalEncoding(roi_feature_channels)
+        self.loss_occ_comp = build_loss(loss_occ_comp)
+        self.num_classes = num_classes
+        self.occ_label_thresh = occ_label_thresh
+        self.with_roi_pos_encoding = with_roi_pos_encoding
+        self.roi_feature_channels = D = roi_feature_channels
+        if with_roi_pos_encoding:
+            self.roi_pos_enc_mlp = build_mlp(7, list(roi_pos_enc_mlp) + [D], norm_cfg, True, act=act,
+                                             dropout=roi_enc_dropout)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.conv_cls = build_mlp(D, list(cls_mlp) + [1], norm_cfg, True, act=act, dropout=cls_dropout) \
+            if cls_mlp is not None else nn.Linear(D, 1)
+        self.conv_reg = build_mlp(D, list(reg_mlp) + [self.box_code_size], norm_cfg, True, act=act,
+                                  dropout=reg_dropout) if reg_mlp is not None else nn.Linear(D, self.box_code_size)
+        self.fused_mode = fused_mode
+        if fused_mode == 'residual':
+            latent_in = D
+        elif fused_mode in ('concat', 'concat_residual'):
+            latent_in = D * 2
+        else:
+            raise NotImplementedError(f'Unknown fused_mode: {fused_mode}')
+        self.conv_latent = build_mlp(latent_in, list(latent_mlp) + [D], norm_cfg, True, act=act,
+                                     dropout=latent_dropout) if latent_mlp is not None else nn.Linear(latent_in, D)
+        self.conv_fused = build_mlp(D * 2, list(fusion_mlp) + [D], norm_cfg, True, act=act,
+                                    dropout=fusion_dropout) if fusion_mlp is not None else nn.Linear(D * 2, D)
+        self.geo_input, self.unique_once, self.num_blocks = geo_input, unique_once, num_blocks
+        self.block_list = nn.ModuleList([
+            SIRLayer(in_channels=in_channels[i], feat_channels=feat_channels[i], with_distance=with_distance,
+                     with_cluster_center=with_cluster_center, with_rel_mlp=with_rel_mlp,
+                     rel_mlp_hidden_dims=rel_mlp_hidden_dims[i], rel_mlp_in_channel=rel_mlp_in_channels[i],
+                     with_voxel_center=False, voxel_size=[0.1, 0.1, 0.1],
+                     point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4], norm_cfg=norm_cfg, mode=mode,
+                     fusion_layer=None, return_point_feats=i != num_blocks - 1, return_inv=False,
+                     rel_dist_scaler=10.0, xyz_normalizer=xyz_normalizer, act=act, dropout=dropout)
+            for i in range(num_blocks)])
+        self.rcnn_trans = rcnn_trans
+        self.train_cfg = train_cfg if train_cfg is not None else {}
+        self.test_cfg = test_cfg if test_cfg is not None else {}
+
+    # ------------------------------------------------------------------ forward
+    def roi_encode(self, pts_xyz, pts_features, pts_info, roi_inds, rois):
+        """ococc_bbox_head.py:237-316: 6 SIRLayers over the pooled points of each RoI."""
+        assert pts_features.size(0) > 0
+        rois = rois[:, 1:]
+        rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds.long()]
+        if self.unique_once:
+            new_coors, unq_inv = unique_with_inverse(roi_inds, [len(rois)])
+        else:
+            new_coors = unq_inv = None
+        out_feats = pts_features
+        f_cluster = torch.cat([pts_info['local_xyz'], pts_info['boundary_offset'],
+                               pts_info['is_in_margin'][:, None], rel_xyz], dim=-1)
+        cluster_feat_list = []
+        for i, block in enumerate(self.block_list):
+            in_feats = torch.cat([pts_xyz, out_feats], 1)
+            if self.geo_input:
+                in_feats = torch.cat([in_feats, f_cluster / 10], 1)
+            if i < self.num_blocks - 1:
+                out_feats, out_cluster_feats = block(in_feats, roi_inds, f_cluster, unq_inv_once=unq_inv,
+                                                     new_coors_once=new_coors)
+            else:
+                out_cluster_feats, out_coors = block(in_feats, roi_inds, f_cluster, unq_inv_once=unq_inv,
+                                                     new_coors_once=new_coors)
+            cluster_feat_list.append(out_cluster_feats)
+        final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
+        nonempty_roi_mask = self.get_nonempty_roi_mask(out_coors, len(rois))
+        final_cluster_feats = self.align_roi_feature_and_rois(final_cluster_feats, out_coors, len(rois))
+        return final_cluster_feats, nonempty_roi_mask, out_coors
+
+    def forward(self, pts_xyz, pts_features, pts_info, roi_inds, rois, roi_frame_inds):
+        """ococc_bbox_head.py:319-400 -> dict(fused_roi_feats, nonempty_roi_mask, ori_roi_feats,
+        cls_score, bbox_pred)."""
+        if pts_xyz.size(0) == 0:
+            final_cluster_feats = pts_features.new_zeros((len(rois), self.roi_feature_channels))
+            nonempty_roi_mask = pts_features.new_zeros(len(rois), dtype=torch.bool)
+        else:
+            final_cluster_feats, nonempty_roi_mask, _ = self.roi_encode(pts_xyz, pts_features, pts_info,
+                                                                        roi_inds, rois)
+        local_roi_feats, _, local_xyz = self.occ_ae_head.encode(pts_xyz, pts_features[:, :2], pts_info,
+                                                                roi_inds, rois)
+        roi_feats_fused = self.transformer_forward(rois, roi_frame_inds, final_cluster_feats, nonempty_roi_mask)
+        if self.fused_mode == 'residual':
+            shape_latent = local_roi_feats + self.conv_latent(roi_feats_fused)
+        elif self.fused_mode == 'concat':
+            shape_latent = self.conv_latent(torch.cat([local_roi_feats, roi_feats_fused], dim=1))
+        else:  # concat_residual
+            shape_latent = local_roi_feats + self.conv_latent(torch.cat([local_roi_feats, roi_feats_fused], dim=1))
+        ret = dict(fused_roi_feats=shape_latent, nonempty_roi_mask=nonempty_roi_mask, ori_roi_feats=local_roi_feats)
+        second = roi_feats_fused if self.rcnn_trans else final_cluster_feats
+        fused = self.conv_fused(torch.cat([shape_latent, second], dim=1))
+        ret.update(cls_score=self.conv_cls(fused), bbox_pred=self.conv_reg(fused))
+        return ret
+
+    # ------------------------------------------------------------------ temporal transformer
+    def transformer_forward(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):
+        if not self.training or self.train_cfg.get('fixed_length', True):
+            return self.transformer_forward_fixed_length(rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc)
+        return self.transformer_forward_various_length(rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc)
+
+    def reorder_feats(self, feats, roi_frame_inds, roi_batch_inds, sort_batch_indices=None,
+                      sort_frame_indices=None):
+        """Rows -> [B, L, C] sorted by (batch, frame) (ococc_bbox_head.py:997-1019)."""
+        B = int(roi_batch_inds.max().item() + 1)
+        L = roi_frame_inds.numel() // B
+        if sort_batch_indices is None or sort_frame_indices is None:
+            sort_batch_indices = torch.argsort(roi_batch_inds)
+            sort_frame_indices = torch.argsort(roi_frame_inds[sort_batch_indices].view(B, L), dim=1)
+        feats = feats[sort_batch_indices].view(B, L, -1)
+        feats = torch.gather(feats, 1, sort_frame_indices[:, :, None].expand(-1, -1, feats.shape[-1]))
+        return feats, sort_batch_indices, sort_frame_indices
+
+    def inverse_reorder_feats(self, feats, sort_batch_indices, sort_frame_indices):
+        B, L = sort_frame_indices.shape
+        inv = torch.argsort(sort_frame_indices.view(B, L), dim=1)
+        feats = feats.view(B, L, -1)
+        feats = torch.gather(feats, 1, inv[:, :, None].expand(-1, -1, feats.shape[-1]))
+        return feats.view(-1, feats.shape[-1])[sort_batch_indices.argsort()]
+
+    def get_future_mask(self, L, device, window_size=-1):
+        """True = may not attend: strictly future frames, optionally frames older than the window."""
+        if not self.training:
+            window_size = self.test_cfg.get('attn_window_size', -1)
+        mask = torch.triu(torch.ones(L, L, dtype=torch.bool, device=device), diagonal=1)
+        if window_size > 0:
+            for i in range(window_size - 1, L):
+                mask[i, :i - window_size + 1] = 1
+        return mask
+
+    def transformer_forward_fixed_length(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):
+        """ococc_bbox_head.py:849-908."""
+        rois_batch_idx = rois[:, 0]
+        B = int(rois_batch_idx.max().item() + 1)
+        L = roi_frame_inds.numel() // B
+        assert L * B == roi_frame_inds.numel()
+        re_feats, sb, sf = self.reorder_feats(roi_feats, roi_frame_inds, rois_batch_idx)
+        re_frames = self.reorder_feats(roi_frame_inds.clone(), roi_frame_inds, rois_batch_idx, sb, sf)[0].squeeze(-1)
+        re_feats = re_feats.view(B, L, re_feats.shape[-1]).permute(1, 0, 2)  # [L, B, D]
+        pos_embed = self.pos_enc(re_frames.transpose(0, 1))
+        if self.with_roi_pos_encoding:
+            re_rois = self.reorder_feats(rois[:, 1:], roi_frame_inds, rois_batch_idx, sb, sf)[0]
+            pos_embed = pos_embed + self.roi_pos_enc_mlp(re_rois).transpose(0, 1)
+        if not self.training and self.test_cfg.get('allow_attn_future', False):
+            future_mask = None
+        else:
+            future_mask = self.get_future_mask(L, re_feats.device)
+        enc = self.trans_enc if trans_enc is None else trans_enc
+        out = enc(re_feats, pos_enc=pos_embed, attn_mask=future_mask).transpose(0, 1)
+        return self.inverse_reorder_feats(out, sb, sf)
+
+    def transformer_forward_various_length(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):
+        """Tracklets of unequal length: pad to the longest, key-padding mask (ococc_bbox_head.py:911-995)."""
+        rois_batch_idx = rois[:, 0]
+        B = int(rois_batch_idx.max().item() + 1)
+        feats_l, rois_l, rev_l = [], [], []
+        for b in range(B):
+            m = rois_batch_idx == b
+            order = roi_frame_inds[m].argsort()
+            rev_l.append(order.argsort())
+            feats_l.append(roi_feats[m][order])
+            if self.with_roi_pos_encoding:
+                rois_l.append(rois[m][order][:, 1:])
+        max_len = max(len(x) for x in feats_l)
+        pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, max_len - len(t)), 'constant', 0)
+        feats = torch.stack([pad(f) for f in feats_l], 0)  # [B, max_len, D]
+        key_padding = torch.stack([torch.arange(max_len, device=feats.device) >= len(f) for f in feats_l], 0)
+        frame_inds = torch.arange(max_len, device=feats.device)[None, :].repeat(len(feats_l), 1)
+        pos_embed = self.pos_enc(frame_inds.transpose(0, 1))
+        if self.with_roi_pos_encoding:
+            pos_embed = pos_embed + self.roi_pos_enc_mlp(torch.stack([pad(r) for r in rois_l], 0)).transpose(0, 1)
+        enc = self.trans_enc if trans_enc is None else trans_enc
+        out = enc(feats.permute(1, 0, 2), pos_enc=pos_embed, key_padding_mask=key_padding,
+                  attn_mask=self.get_future_mask(max_len, feats.device)).transpose(0, 1)
+        return torch.cat([out[i][:len(feats_l[i])][rev_l[i]] for i in range(len(feats_l))], 0)
+
+    # ------------------------------------------------------------------ targets
+    def get_targets(self, sampling_results, rcnn_train_cfg, concat=True, transform_occ=True,
+                    num_occ_per_tracklet=-1):
+        """ococc_bbox_head.py:1045-1163 (concat=True form)."""
+        per = [self._get_target_single(r.pos_bboxes, r.pos_gt_bboxes, r.iou, r.pos_gt_labels, r.occ_labels,
+                                       r.occ_scores, cfg=rcnn_train_cfg, transform_occ=transform_occ,
+                                       num_occ_per_tracklet=num_occ_per_tracklet) for r in sampling_results]
+        (label, bbox_targets, pos_gt_bboxes, reg_mask, label_weights, bbox_weights, roi_local_xyz, gt_occ,
+         occ_score, occ_reg_mask, pos_gt_bboxes_occ) = [list(x) for x in zip(*per)]
+        pos_gt_labels = torch.cat([r.pos_gt_labels for r in sampling_results], 0)
+        label = torch.cat(label, 0)
+        bbox_target_batch_idx = torch.cat([t.new_ones(len(t), dtype=torch.int) * i for i, t in enumerate(bbox_targets)])
+        occ_target_batch_idx = torch.cat([t.new_ones(len(t), dtype=torch.int) * i
+                                          for i, t in enumerate(pos_gt_bboxes_occ)])
+        bbox_targets = torch.cat(bbox_targets, 0)
+        pos_gt_bboxes = torch.cat(pos_gt_bboxes, 0)
+        pos_gt_bboxes_occ = torch.cat(pos_gt_bboxes_occ, 0)
+        reg_mask = torch.cat(reg_mask, 0)
+        occ_reg_mask = torch.cat(occ_reg_mask, 0)
+        label_weights = torch.cat(label_weights, 0)
+        label_weights = label_weights / torch.clamp(label_weights.sum(), min=1.0)
+        bbox_weights = torch.cat(bbox_weights, 0)
+        bbox_weights = bbox_weights / torch.clamp(bbox_weights.sum(), min=1.0)
+        if len(pos_gt_bboxes_occ) > 0:
+            pos_roi_local_xyz = torch.cat([e for e in roi_local_xyz if e is not None], 0)
+            occ_score = torch.cat([e for e in occ_score if e is not None], 0)
+            gt_occ = torch.cat([e for e in gt_occ if e is not None], 0)
+        else:
+            pos_roi_local_xyz = pos_gt_bboxes.new_zeros(0, 0, 3)
+            occ_score = pos_gt_bboxes.new_zeros(0)
+            gt_occ = pos_gt_bboxes.new_zeros(0, 1)
+        return (label, bbox_targets, bbox_target_batch_idx, pos_gt_bboxes, pos_gt_labels, reg_mask, label_weights,
+                bbox_weights, pos_roi_local_xyz, gt_occ, occ_score, occ_reg_mask, occ_target_batch_idx,
+                pos_gt_bboxes_occ)
+
+    def _get_target_single(self, pos_bboxes, pos_gt_bboxes, ious, pos_labels, occ_label, occ_score, cfg,
+                           transform_occ=True, num_occ_per_tracklet=-1):
+        """Canonical-frame box deltas, soft IoU labels and the occupancy query points moved
+        from the GT-box frame to the RoI frame (ococc_bbox_head.py:1165-1309)."""
+        if pos_gt_bboxes.size(1) in (9, 10):
+            pos_bboxes, pos_gt_bboxes = pos_bboxes[:, :7], pos_gt_bboxes[:, :7]
+        label, label_weights = self.get_multi_class_soft_label(ious, pos_labels, cfg)
+        reg_mask = pos_bboxes.new_zeros(ious.size(0)).long()
+        reg_mask[0:pos_gt_bboxes.size(0)] = 1
+        bbox_weights = self.get_class_wise_box_weights((reg_mask > 0).float(), pos_labels, cfg)
+        occ_reg_mask = torch.zeros_like(reg_mask)
+        if reg_mask.bool().any():
+            gt_ct = pos_gt_bboxes.clone().detach()
+            roi_center = pos_bboxes[..., 0:3]
+            roi_ry = pos_bboxes[..., 6] % (2 * np.pi)
+            gt_ct[..., 0:3] -= roi_center
+            gt_ct[..., 6] -= roi_ry
+            gt_ct[..., 0:3] = rotation_3d_in_axis(gt_ct[..., 0:3].unsqueeze(1), -(roi_ry + np.pi / 2), axis=2).squeeze(1)
+            ry = gt_ct[..., 6] % (2 * np.pi)
+            opposite = (ry > np.pi * 0.5) & (ry < np.pi * 1.5)
+            ry[opposite] = (ry[opposite] + np.pi) % (2 * np.pi)
+            flag = ry > np.pi
+            ry[flag] = ry[flag] - np.pi * 2
+            gt_ct[..., 6] = torch.clamp(ry, min=-np.pi / 2, max=np.pi / 2)
+            anchor = pos_bboxes.clone().detach()
+            anchor[:, 0:3] = 0
+            anchor[:, 6] = 0
+            bbox_targets = self.bbox_coder.encode(anchor, gt_ct)
+            assert occ_label.dim() == 2 and occ_label.size(1) == 4
+            smp_pos, gt_occ = occ_label[:, 0:3], occ_label[:, 3:4]
+            with torch.no_grad():
+                num_gt = pos_gt_bboxes.size(0)
+                n_occ = min(num_occ_per_tracklet, num_gt) if num_occ_per_tracklet > 0 else num_gt
+                roi_local_xyz = smp_pos[None, ...].repeat(n_occ, 1, 1)
+                sel = torch.arange(num_gt, device=pos_bboxes.device)[-n_occ:]
+                gt_smp, roi_smp = pos_gt_bboxes[sel], pos_bboxes[sel]
+                occ_reg_mask[:num_gt][sel] = 1
+                if transform_occ:
+                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, gt_smp[:, 6], axis=2)
+                    roi_local_xyz += gt_smp[..., None, 0:3]
+                    roi_local_xyz[..., 2] += gt_smp[:, None, 5] / 2   # voxel centres are gravity centred
+                    roi_local_xyz -= roi_smp[..., None, :3]
+                    roi_local_xyz[..., 2] -= roi_smp[:, None, 5] / 2
+                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, -(roi_smp[:, 6]), axis=2)
+                gt_occ = gt_occ[None].repeat(len(gt_smp), 1, 1)
+                occ_score = occ_score.repeat(len(gt_smp)).float()
+        else:
+            bbox_targets = pos_gt_bboxes.new_empty((0, 7))
+            roi_local_xyz = gt_occ = occ_score = None
+            gt_smp = pos_gt_bboxes.new_empty((0, 7))
+        return (label, bbox_targets, pos_gt_bboxes, reg_mask, label_weights, bbox_weights, roi_local_xyz, gt_occ,
+                occ_score, occ_reg_mask, gt_smp)
+
+    # ------------------------------------------------------------------ losses
+    def loss(self, results_dict, rois, labels, bbox_targets, pos_batch_idx, pos_gt_bboxes, pos_gt_labels, reg_mask,
+             label_weights, bbox_weights, pos_roi_local_xyz, gt_occ, occ_scores, occ_reg_mask, occ_pos_batch_idx,
+             pos_gt_bboxes_occ, transform_occ=False, roi_frame_inds=None):
+        """ococc_bbox_head.py:433-606 (corner loss is off in the ococcnet config and not built)."""
+        losses = {}
+        cls_score, bbox_pred = results_dict['cls_score'], results_dict['bbox_pred']
+        nonempty = results_dict['nonempty_roi_mask']
+        n_total = cls_score.shape[0]
+        assert n_total > 0 and not self.with_corner_loss
+        label_weights, bbox_weights, reg_mask = label_weights.clone(), bbox_weights.clone(), reg_mask.clone()
+        label_weights[~nonempty] = 0
+        label_weights[nonempty] = 1
+        bbox_weights[...] = 1
+        reg_mask[~nonempty] = 0
+        cls_avg = n_total * 1.0
+        if self.train_cfg.get('sync_cls_avg_factor', False):
+            cls_avg = reduce_mean(bbox_weights.new_tensor([cls_avg]))
+        losses['loss_rcnn_cls'] = self.loss_cls(cls_score.view(-1), labels, label_weights, avg_factor=cls_avg)
+        pos_inds = reg_mask > 0
+        losses['num_pos_rois'] = pos_inds.sum().float()
+        losses['num_neg_rois'] = (reg_mask <= 0).sum().float()
+        reg_avg = pos_inds.sum().item()
+        if self.train_cfg.get('sync_reg_avg_factor', False):
+            reg_avg = reduce_mean(bbox_weights.new_tensor([reg_avg]))
+        if not pos_inds.any():
+            losses['loss_rcnn_bbox'] = bbox_pred.sum() * 0
+        else:
+            pos_pred = bbox_pred[pos_inds]
+            bbox_targets = self.filter_pos_assigned_but_empty_rois(bbox_targets, pos_batch_idx, pos_inds,
+                                                                   rois[:, 0].int())
+            w = bbox_weights[pos_inds].view(-1, 1).repeat(1, pos_pred.shape[-1])
+            code_weights = self.train_cfg.get('rcnn_code_weights', None)
+            if code_weights is not None:
+                w = w * torch.tensor(code_weights, dtype=w.dtype, device=w.device)[None, :]
+            assert pos_pred.size(0) == bbox_targets.size(0)
+            losses['loss_rcnn_bbox'] = self.loss_bbox(pos_pred, bbox_targets, w, avg_factor=reg_avg)
+        losses.update(self.loss_occ(rois, results_dict['fused_roi_feats'], results_dict['ori_roi_feats'],
+                                    occ_pos_batch_idx, pos_gt_bboxes_occ, occ_reg_mask.clone(), nonempty,
+                                    pos_roi_local_xyz, gt_occ, occ_scores, transform_occ=transform_occ,
+                                    roi_frame_inds=roi_frame_inds))
+        return losses
+
+    def loss_occ(self, rois, roi_features, ori_roi_feats, pos_batch_idx, pos_gt_bboxes, reg_mask,
+                 nonempty_roi_mask, gt_smp_local_coords, gt_smp_occ_labels, gt_occ_label_scores,
+                 transform_occ=False, roi_frame_inds=None, do_aug=False):
+        """ococc_bbox_head.py:608-811 (default train_cfg switches of ococcnet.py: no residual /
+        contrastive / outside / observed-feature variants)."""
+        losses = {}
+        decoder = self.occ_ae_head.occ_decoder
+        reg_mask[~nonempty_roi_mask] = 0
+        pos_inds = reg_mask > 0
+        num_occupied = (gt_smp_occ_labels == 1).sum().float()
+        losses['num_occupied'] = num_occupied
+        losses['num_free'] = gt_smp_occ_labels.numel() - num_occupied
+        if not pos_inds.any():
+            idx = torch.arange(roi_features.size(0), device=roi_features.device)
+            losses['loss_rcnn_occ'] = decoder(roi_features, roi_features.new_zeros(roi_features.size(0), 3), idx) * 0
+            for k in ('recall_neg', 'recall_pos', 'precision_neg', 'precision_pos'):
+                losses[k] = roi_features.new_ones(1)
+            return losses
+        pos_roi_features = roi_features[pos_inds]  # [M, D]
+        rb = rois[:, 0].int()
+        occ_targets = self.filter_pos_assigned_but_empty_rois(gt_smp_occ_labels, pos_batch_idx, pos_inds, rb)
+        occ_smp_xyz = self.filter_pos_assigned_but_empty_rois(gt_smp_local_coords, pos_batch_idx, pos_inds, rb)
+        pos_gt_bboxes = self.filter_pos_assigned_but_empty_rois(pos_gt_bboxes, pos_batch_idx, pos_inds, rb)
+        if transform_occ:
+            pr = rois[pos_inds][:, 1:]
+            with torch.no_grad():
+                occ_smp_xyz = rotation_3d_in_axis(occ_smp_xyz, pos_gt_bboxes[:, 6], axis=2)
+                occ_smp_xyz += pos_gt_bboxes[..., None, 0:3]
+                occ_smp_xyz[..., 2] += pos_gt_bboxes[:, None, 5] / 2
+                occ_smp_xyz -= pr[..., None, :3]
+                occ_smp_xyz[..., 2] -= pr[:, None, 5] / 2
+                occ_smp_xyz = rotation_3d_in_axis(occ_smp_xyz, -(pr[:, 6]), axis=2)
+        if do_aug:
+            occ_smp_xyz[..., 2] = -occ_smp_xyz[..., 2]
+        scores = self.filter_pos_assigned_but_empty_rois(gt_occ_label_scores, pos_batch_idx, pos_inds, rb)
+        M, K, _ = occ_targets.shape
+        occ_weights = (scores > self.occ_label_thresh).to(scores.dtype).view(M, 1).repeat(1, K)
+        # decoder with (features, points, RoI index): no [M,K,D] copies (reference :711,:740)
+        idx = torch.arange(M, device=rois.device).repeat_interleave(K)
+        occ_preds = decoder(pos_roi_features, occ_smp_xyz.reshape(M * K, 3), idx)
+        occ_labels = (occ_targets[..., -1] == 1).long()
+        losses['loss_rcnn_occ'] = self.loss_occ_comp(occ_preds.view(-1), occ_labels.view(-1), occ_weights.view(-1))
+        with torch.no_grad():
+            pred_cls = decoder.get_cls_from_pred(occ_preds.view(-1, 1)) if decoder.cls_dim == 1 \
+                else decoder.get_cls_from_pred(occ_preds)
+            lab, valid = occ_labels.view(-1), occ_weights.view(-1) > 0
+            neg_tp = ((lab[valid] == 0) & (pred_cls[valid] == 0)).sum()
+            pos_tp = ((lab[valid] == 1) & (pred_cls[valid] == 1)).sum()
+            losses['recall_neg'] = neg_tp / ((lab[valid] == 0).sum() + 1e-6)
+            losses['recall_pos'] = pos_tp / ((lab[valid] == 1).sum() + 1e-6)
+            losses['precision_neg'] = neg_tp / ((pred_cls[valid] == 0).sum() + 1e-6)
+            losses['precision_pos'] = pos_tp / ((pred_cls[valid] == 1).sum() + 1e-6)
+        return losses

@@ -357,3 +357,46 @@ int64_t oracle_unique_rows(const int32_t* coors, int64_t n, int ndim, int32_t* o
   free(order);
   return u;
 }
+
+/* ------------------------------------------------------------------ A3 ---- */
+/* Points-in-rotated-box pooling with the semantics documented in
+ * objectcentricocccompletion_amd/csrc/point_pool.hip (TorchEx source absent: the contract
+ * comes from mmdet3d/ops/dynamic_point_pool_op.py:63-113 and the assertions of
+ * dynamic_point_roi_extractor.py:222-234; geometry as mmdet3d's check_pt_in_box3d).
+ * Rows sorted by (roi, point).  Returns the number of rows written. */
+int64_t oracle_point_pool(const float* rois, const int32_t* roi_key, int64_t R, const float* pts,
+                          const int32_t* pts_key, int64_t N, const float* extra, int max_inbox,
+                          int64_t max_all, int64_t* out_pts, int64_t* out_roi, float* feats,
+                          int32_t* roi_counts) {
+  int64_t m = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    const float* b = rois + r * 7;
+    const float w = b[3], l = b[4], h = b[5], rz = b[6];
+    const float cx = b[0], cy = b[1], cz = b[2] + h * 0.5f;
+    const float hw = w * 0.5f, hl = l * 0.5f, hh = h * 0.5f;
+    const float ehw = (w + extra[0]) * 0.5f, ehl = (l + extra[1]) * 0.5f, ehh = (h + extra[2]) * 0.5f;
+    const float cosa = cosf(-rz), sina = sinf(-rz);
+    int kept = 0;
+    for (int64_t i = 0; i < N && kept < max_inbox && m < max_all; ++i) {
+      if (pts_key[i] != roi_key[r]) continue;
+      const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+      const float dz = z - cz;
+      if (fabsf(dz) > ehh) continue;
+      const float sx = x - cx, sy = y - cy;
+      const float px = sx * cosa + sy * (-sina);
+      const float py = sx * sina + sy * cosa;
+      if (!(px > -ehl && px < ehl && py > -ehw && py < ehw)) continue;
+      const int inner = fabsf(dz) <= hh && px > -hl && px < hl && py > -hw && py < hw;
+      float* f = feats + m * 13;
+      f[0] = x; f[1] = y; f[2] = z; f[3] = px; f[4] = py; f[5] = dz;
+      f[6] = px + hl; f[7] = py + hw; f[8] = dz + hh; f[9] = hl - px; f[10] = hw - py; f[11] = hh - dz;
+      f[12] = inner ? 0.f : 1.f;
+      out_pts[m] = i;
+      out_roi[m] = r;
+      ++m;
+      ++kept;
+    }
+    if (roi_counts) roi_counts[r] = kept;
+  }
+  return m;
+}

@@ -30,7 +30,7 @@ def _lib():
                        capture_output=True)
     lib = ctypes.CDLL(_SO)
     lib.oracle_hard_voxelize.restype = ctypes.c_int
-    for name in ('oracle_subm_rulebook', 'oracle_conv_rulebook', 'oracle_unique_rows'):
+    for name in ('oracle_subm_rulebook', 'oracle_conv_rulebook', 'oracle_unique_rows', 'oracle_point_pool'):
         getattr(lib, name).restype = ctypes.c_int64
     return lib
 
@@ -174,6 +174,22 @@ def dynamic_scatter(feats, coors, mode):
     outc, inv, counts = unique_rows(coors)
     out, _, _ = segment_reduce(feats, inv, outc.shape[0], mode)
     return out, outc, inv, counts
+
+
+def point_pool(rois, roi_key, pts, pts_key, extra_wlh, max_inbox_point, max_all_pts):
+    """TorchEx dynamic_point_pool_mixed contract (dynamic_point_pool_op.py:63-113), rows sorted by
+    (roi, point) -> (pts_idx [M] i64, roi_idx [M] i64, feats [M,13] f32, roi_counts [R] i32)."""
+    rois, pts = _f(rois), _f(pts)
+    roi_key, pts_key = _i(roi_key), _i(pts_key)
+    R, N = rois.shape[0], pts.shape[0]
+    op = np.full((max_all_pts,), -1, np.int64)
+    orr = np.full((max_all_pts,), -1, np.int64)
+    fe = np.zeros((max_all_pts, 13), np.float32)
+    rc = np.zeros((R,), np.int32)
+    m = L().oracle_point_pool(_p(rois), _p(roi_key), i64(R), _p(pts), _p(pts_key), i64(N),
+                              _p(_f(extra_wlh)), ci(max_inbox_point), i64(max_all_pts), _p(op), _p(orr),
+                              _p(fe), _p(rc))
+    return op[:m].copy(), orr[:m].copy(), fe[:m].copy(), rc
 
 
 # ------------------------------------------------------------------ floating point helpers

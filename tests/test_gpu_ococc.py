@@ -1,0 +1,181 @@
+"""GPU parity, OcOccNet side (A3-A15): HIP-backed modules vs golden vectors captured from the
+imported reference (tests/golden/ococc_head.npz, oracle/gen_golden_ococc.py) and vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+# fp32 network, 66 M parameters, GEMMs through hipBLASLt: accumulation order differs from the CPU
+REL = 2e-3
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'ococc_head.npz'))
+
+
+@pytest.fixture(scope='module')
+def head(dev):
+    from objectcentricocccompletion_amd import heads  # noqa: F401
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import HEADS
+    cfg = ococcnet_model_cfg()
+    hc = dict(cfg['roi_head']['bbox_head'])
+    hc['train_cfg'], hc['test_cfg'] = cfg['train_cfg'], cfg['test_cfg']
+    h = HEADS.build(hc)
+    h.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in h.state_dict().items()}, seed=0))
+    return h.to(dev).eval()
+
+
+def _inputs(gold, dev):
+    T = lambda k: torch.from_numpy(gold['in_' + k]).to(dev)
+    info = dict(local_xyz=T('local_xyz'), boundary_offset=T('boundary_offset'), is_in_margin=T('is_in_margin'))
+    return T('pts_xyz'), T('pts_feats'), info, T('roi_inds'), T('rois'), T('roi_frame_inds')
+
+
+@pytest.mark.parametrize('caps', [(4096, 300000), (7, 300000), (4096, 500)])
+def test_point_pool_vs_oracle(dev, caps):
+    from objectcentricocccompletion_amd.point_pool import dynamic_point_pool_mixed
+    t = synth.synth_tracklets(4, 32, 70, seed=2)
+    rois = t['rois']
+    mf = int(t['roi_frame_inds'].max()) + 1
+    rk = (rois[:, 0].astype(np.int64) * mf + t['roi_frame_inds']).astype(np.int32)
+    pk = (t['pts_batch'] * mf + t['pts_frame']).astype(np.int32)
+    epi, eri, ef, ecnt = O.point_pool(rois[:, 1:], rk, t['pts_xyz'], pk, [0.5, 0.5, 0.5], *caps)
+    pi, ri, f, cnt = dynamic_point_pool_mixed(torch.from_numpy(rois[:, 1:]).to(dev), torch.from_numpy(rk).to(dev),
+                                              torch.from_numpy(t['pts_xyz']).to(dev), torch.from_numpy(pk).to(dev),
+                                              [0.5, 0.5, 0.5], caps[0], caps[1], return_counts=True)
+    assert pi.dtype == torch.long and np.array_equal(pi.cpu().numpy(), epi)   # same rows, same order
+    assert np.array_equal(ri.cpu().numpy(), eri) and np.array_equal(cnt.cpu().numpy(), ecnt)
+    assert np.allclose(f.cpu().numpy(), ef, atol=2e-5)                      # sinf/cosf of device vs libm
+    assert np.array_equal(f[:, 12].cpu().numpy(), ef[:, 12])
+
+
+def test_point_pool_nothing_inside(dev):
+    from objectcentricocccompletion_amd.point_pool import dynamic_point_pool_mixed
+    rois = torch.tensor([[0., 0, 0, 2, 4, 1.5, 0.3]], device=dev)
+    pts = torch.tensor([[50., 50, 0], [60, 60, 0]], device=dev)
+    pi, ri, f = dynamic_point_pool_mixed(rois, torch.zeros(1, dtype=torch.int32, device=dev), pts,
+                                         torch.zeros(2, dtype=torch.int32, device=dev), [0.5] * 3, 16, 100)
+    assert pi.tolist() == [-1] and ri.tolist() == [-1] and f.shape == (1, 13)  # the reference's fake row
+
+
+def test_extractor_on_tracklets(dev):
+    from objectcentricocccompletion_amd.point_pool import TrackletPointRoIExtractor
+    t = synth.synth_tracklets(2, 16, 50, seed=4, first_frame=3)
+    ext = TrackletPointRoIExtractor(extra_wlh=[0.5, 0.5, 0.5], max_inbox_point=4096, max_all_point=(300000, 600000), debug=True)
+    D = lambda a: torch.from_numpy(a).to(dev)
+    inds, roi_inds, info = ext(D(t['pts_xyz']), D(t['pts_batch']), D(t['pts_frame']), D(t['rois']), D(t['roi_frame_inds']))
+    assert set(info) == {'local_xyz', 'boundary_offset', 'is_in_margin'} and len(inds) == len(roi_inds) > 100
+    assert bool((D(t['pts_batch'])[inds] == D(t['rois'])[roi_inds][:, 0].long()).all())
+    assert bool((D(t['pts_frame'])[inds] == D(t['roi_frame_inds'])[roi_inds]).all())
+
+
+def test_small_pieces_vs_reference_golden(dev, gold, head):
+    from objectcentricocccompletion_amd.occ import occ_ops
+    pts_xyz, pts_feats, info, roi_inds, rois, frames = _inputs(gold, dev)
+    with torch.no_grad():
+        blk = head.block_list[1]
+        pf, vf = blk(torch.from_numpy(gold['sir_x']).to(dev), roi_inds, torch.from_numpy(gold['sir_fcluster']).to(dev))
+        assert rel_err(pf.cpu(), gold['sir_point_feats']) < 1e-4 and rel_err(vf.cpu(), gold['sir_voxel_feats']) < 1e-4
+        c = occ_ops.quantize_points(info['local_xyz'], rois, roi_inds, 0.2, to_center=True)
+        assert np.allclose(c.cpu().numpy(), gold['quant_centers'], atol=1e-5)
+        pe = head.occ_ae_head.occ_decoder.pos_encode(torch.from_numpy(gold['posenc_in']).to(dev))
+        assert np.allclose(pe.cpu().numpy(), gold['posenc_out'], atol=2e-4)   # sin(pi 2^9 x): argument up to ~1600
+        tpe = head.pos_enc(frames.view(2, -1).t().float())
+        assert np.allclose(tpe.cpu().numpy(), gold['tpe_out'], atol=2e-5)
+
+
+def test_head_forward_vs_reference_golden(dev, gold, head):
+    pts_xyz, pts_feats, info, roi_inds, rois, frames = _inputs(gold, dev)
+    with torch.no_grad():
+        res = head(pts_xyz, pts_feats, info, roi_inds, rois, frames)
+        fcf, nonempty, _ = head.roi_encode(pts_xyz, pts_feats, info, roi_inds, rois)
+    assert np.array_equal(res['nonempty_roi_mask'].cpu().numpy(), gold['out_nonempty_roi_mask'])
+    assert rel_err(fcf.cpu(), gold['out_final_cluster_feats']) < REL
+    for k in ('ori_roi_feats', 'fused_roi_feats', 'cls_score', 'bbox_pred'):
+        assert rel_err(res[k].cpu(), gold['out_' + k]) < REL, k
+    dec = head.decode_from_rois(rois, torch.from_numpy(gold['out_bbox_pred']).to(dev))
+    assert np.allclose(dec.cpu().numpy(), gold['decoded_boxes'], atol=1e-3)
+
+
+def test_decoder_factorised_first_layer_vs_reference_golden(dev, gold, head):
+    """Reference: K copies of every RoI feature through a 1596-wide Linear (occ_base.py:120-139).
+    Ours: W_roi . LN(f) once per RoI + W_pe . pe per point.  Same logits."""
+    dec = head.occ_ae_head.occ_decoder
+    feats = torch.from_numpy(gold['out_fused_roi_feats']).to(dev)
+    xyz = torch.from_numpy(gold['dec_xyz']).to(dev)
+    R, K, _ = xyz.shape
+    with torch.no_grad():
+        idx = torch.arange(R, device=dev).repeat_interleave(K)
+        fact = dec(feats, xyz.reshape(-1, 3), idx).view(R, K, 1)
+        full = dec.occ_forward(feats[:, None, :].repeat(1, K, 1), xyz)
+    scale = np.abs(gold['dec_logits']).max()
+    assert np.abs(full.cpu().numpy() - gold['dec_logits']).max() < REL * scale
+    assert np.abs(fact.cpu().numpy() - gold['dec_logits']).max() < REL * scale
+    cls_ref = (1 / (1 + np.exp(-gold['dec_logits'])) > 0.5).astype(np.int64).squeeze(-1)
+    agree = (dec.get_cls_from_pred(fact).cpu().numpy() == cls_ref).mean()
+    assert agree > 0.999      # occupancy decisions (what the IoU metric counts) agree
+
+
+def test_targets_vs_reference_golden(dev, gold, head):
+    from objectcentricocccompletion_amd.heads import _Sampling
+    samples = []
+    rois = gold['in_rois']
+    for b in range(2):
+        rb = torch.from_numpy(rois[rois[:, 0] == b][:, 1:]).to(dev)
+        samples.append(_Sampling(rb, torch.from_numpy(gold[f'tgt_in_gt_{b}']).to(dev),
+                                 torch.from_numpy(gold[f'tgt_in_iou_{b}']).to(dev),
+                                 torch.zeros(len(rb), dtype=torch.long, device=dev),
+                                 torch.from_numpy(gold[f'tgt_in_occ_{b}']).to(dev),
+                                 torch.tensor([0.9 - 0.6 * b], device=dev)))
+    tg = head.get_targets(samples, head.train_cfg, transform_occ=True, num_occ_per_tracklet=-1)
+    names = ['label', 'bbox_targets', 'bbox_target_batch_idx', 'pos_gt_bboxes', 'pos_gt_labels', 'reg_mask',
+             'label_weights', 'bbox_weights', 'pos_roi_local_xyz', 'gt_occ', 'occ_score', 'occ_reg_mask',
+             'occ_target_batch_idx', 'pos_gt_bboxes_occ']
+    for n, v in zip(names, tg):
+        assert np.allclose(v.cpu().numpy(), gold['tgt_' + n], atol=2e-4), n
+
+
+def test_head_loss_and_backward_runs(dev, gold, head):
+    """Forward + loss + backward of the whole head on the golden inputs: finite losses with the
+    reference's dictionary keys, gradients reach every trainable parameter group."""
+    from objectcentricocccompletion_amd.heads import _Sampling
+    pts_xyz, pts_feats, info, roi_inds, rois, frames = _inputs(gold, dev)
+    head.train()
+    try:
+        res = head(pts_xyz, pts_feats, info, roi_inds, rois, frames)
+        samples = []
+        for b in range(2):
+            rb = rois[rois[:, 0] == b][:, 1:]
+            samples.append(_Sampling(rb, torch.from_numpy(gold[f'tgt_in_gt_{b}']).to(dev),
+                                     torch.from_numpy(gold[f'tgt_in_iou_{b}']).to(dev),
+                                     torch.zeros(len(rb), dtype=torch.long, device=dev),
+                                     torch.from_numpy(gold[f'tgt_in_occ_{b}']).to(dev),
+                                     torch.tensor([0.9 - 0.6 * b], device=dev)))
+        tg = head.get_targets(samples, head.train_cfg, transform_occ=True)
+        losses = head.loss(res, rois, *tg, transform_occ=False, roi_frame_inds=frames)
+        for k in ('loss_rcnn_cls', 'loss_rcnn_bbox', 'loss_rcnn_occ', 'num_pos_rois', 'num_occupied', 'num_free',
+                  'recall_pos', 'recall_neg', 'precision_pos', 'precision_neg'):
+            assert k in losses and bool(torch.isfinite(losses[k]).all()), k
+        total = losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()
+        total.backward()
+        for name in ('block_list.0.vfe_layers.0.linear.weight', 'occ_ae_head.point_encoder.block_list.5.rel_mlp.0.0.weight',
+                     'occ_ae_head.occ_decoder.conv_occ.0.0.weight', 'trans_enc.layers.2.self_attn.in_proj_weight',
+                     'roi_pos_enc_mlp.0.0.weight', 'conv_latent.0.0.weight', 'conv_fused.2.weight', 'conv_cls.2.bias', 'conv_reg.2.weight'):
+            g = dict(head.named_parameters())[name].grad
+            assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0, name
+    finally:
+        head.eval()
+        head.zero_grad(set_to_none=True)
