@@ -250,6 +250,15 @@ int ococc_dynamic_point_pool_mixed(const float* rois, const int32_t* rois_key, i
                                    float* out_pts_feats, int32_t* roi_counts, int32_t* num_out,
                                    void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * A2  pairwise (i-th with i-th) 3-D IoU of rotated boxes
+ * replaces LiDARInstance3DBoxes.aligned_iou_3d
+ *   (mmdet3d/core/bbox/structures/lidar_box3d.py:404-448 -> TorchEx boxes_overlap_1to1).
+ * boxes [n,7] f32 (x, y, z_bottom, w, l, h, yaw); iou [n] f32.
+ * ------------------------------------------------------------------------ */
+int ococc_aligned_iou3d_f32(const float* boxes1, const float* boxes2, int64_t n, float* iou,
+                            ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

@@ -1,0 +1,258 @@
+"""TrackletRoIHeadOCC / TrackletDetectorOCC -- host mirror of
+mmdet3d/models/roi_heads/tracklet_roi_head_occ.py (forward_train :85-114, simple_test
+:492-610, test_occ :394-486, _bbox_forward(_train) :759-878, _assign_and_sample :880-991,
+_select_one2one_candidates :993-1030, tracklets2rois :1045-1060, get_gt_rois :1065-1075) and
+mmdet3d/models/detectors/tracklet_detector_occ.py (:96-198, :313-345).  Same type strings,
+constructor arguments, loss-dict keys and result-dict keys; tracklets are the plain-tensor
+``Tracklet`` of tracklet.py."""
+import torch
+from torch import nn
+
+from .bbox import rotation_3d_in_axis
+from .registry import BBOX_ASSIGNERS, DETECTORS, HEADS, ROI_EXTRACTORS
+from .tracklet import SamplingResult
+
+
+def bbox3d2roi(bbox_list):
+    """[N_i, 7] per sample -> [sum N_i, 8] with the sample index in column 0."""
+    out = []
+    for i, b in enumerate(bbox_list):
+        out.append(torch.cat([b.new_full((b.size(0), 1), i), b], dim=-1) if b.size(0) > 0
+                   else torch.zeros_like(b[:, :1].expand(0, b.size(1) + 1)))
+    return torch.cat(out, 0)
+
+
+@HEADS.register_module()
+class TrackletRoIHeadOCC(nn.Module):
+
+    def __init__(self, num_classes=3, roi_extractor=None, bbox_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None, general_cfg=dict(), history_only=False):
+        super().__init__()
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.general_cfg, self.num_classes = general_cfg, num_classes
+        self.with_roi_scores = general_cfg.get('with_roi_scores', False)
+        self.with_roi_corners = general_cfg.get('with_roi_corners', False)
+        assert not self.with_roi_corners, 'with_roi_corners is off in ococcnet.py and not built'
+        self.roi_extractor = ROI_EXTRACTORS.build(roi_extractor)
+        bh = dict(bbox_head)
+        bh['train_cfg'], bh['test_cfg'] = train_cfg, test_cfg
+        self.bbox_head = HEADS.build(bh)
+        if train_cfg is not None:
+            self.bbox_assigner = BBOX_ASSIGNERS.build(train_cfg['assigner'])
+        self.history_only = history_only
+
+    # ------------------------------------------------------------------ training
+    def forward_train(self, pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, img_metas, tracklet_list,
+                      gt_candidates_list, gt_occs_list, gt_occ_scores_list):
+        samples = self._assign_and_sample(tracklet_list, gt_candidates_list, gt_occs_list, gt_occ_scores_list,
+                                          pts_batch_idx, pts_frame_inds)
+        return dict(self._bbox_forward_train(pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, samples)['loss_bbox'])
+
+    def _select_one2one_candidates(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list):
+        """Per proposal tracklet: the GT candidate with most frames of IoU > candidate_thresh."""
+        cfg = self.train_cfg if self.train_cfg is not None else self.test_cfg
+        thr = cfg.get('candidate_thresh', 0.5)
+        out_trks, out_occs, out_scores = [], [], []
+        for trk, cands, occs, scores in zip(tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list):
+            if len(cands) == 0:
+                out_trks.append(trk.new_empty())
+                out_occs.append(None)
+                out_scores.append(None)
+                continue
+            aff = torch.tensor([int((trk.intersection_ious(c) > thr).sum()) for c in cands])
+            k = int(torch.argmax(aff))
+            out_trks.append(cands[k])
+            out_occs.append(occs[k])
+            out_scores.append(scores[k])
+        return out_trks, out_occs, out_scores
+
+    def _assign_and_sample(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list, pts_batch_idx,
+                           pts_frame_inds):
+        gts, occs, occ_scores = self._select_one2one_candidates(tracklet_list, candidates_list, gt_occs_list,
+                                                                gt_occ_scores_list)
+        results = []
+        for tid, (trk, gt) in enumerate(zip(tracklet_list, gts)):
+            cur = trk.concated_boxes()
+            assign = self.bbox_assigner.assign(trk, gt)
+            s = SamplingResult(assign, cur, gt.concated_boxes())
+            order = torch.cat([s.pos_inds, s.neg_inds])
+            s.iou = assign.max_overlaps[order].detach()
+            n = len(cur)
+            base = torch.arange(n, device=trk.device, dtype=torch.long)
+            if self.train_cfg.get('keep_frame_inds', True):
+                fr = torch.unique(pts_frame_inds[pts_batch_idx == tid])
+                if len(fr) < n:
+                    fr = torch.cat([fr, fr[-1:].repeat(n - len(fr))])
+                s.bboxes_frame_inds = fr[order]
+            elif self.train_cfg.get('random_shift_frame_inds', False):
+                shift = int(torch.randint(0, 200 - n + 1, (1,)).item())
+                pts_frame_inds[pts_batch_idx == tid] += shift
+                s.bboxes_frame_inds = base[order] + shift
+            else:
+                s.bboxes_frame_inds = base[order]
+            s.scores = assign.scores[order]
+            s.occ_labels, s.occ_scores = occs[tid], occ_scores[tid]
+            results.append(s)
+        return results
+
+    def _bbox_forward_train(self, pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, sampling_results):
+        rois = bbox3d2roi([r.bboxes for r in sampling_results])
+        roi_frame_inds = torch.cat([r.bboxes_frame_inds for r in sampling_results])
+        roi_scores = torch.cat([r.scores for r in sampling_results])
+        res = self._bbox_forward(pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, rois, roi_scores, roi_frame_inds)
+        pre = self.train_cfg.get('transform_occ_pre', False)
+        targets = self.bbox_head.get_targets(sampling_results, self.train_cfg, transform_occ=pre,
+                                             num_occ_per_tracklet=self.train_cfg.get('num_occ_per_tracklet', -1))
+        loss = self.bbox_head.loss(res, rois, *targets, transform_occ=not pre, roi_frame_inds=roi_frame_inds)
+        labels = targets[0].view(-1) > 0.5
+        preds = res['cls_score'].view(-1).sigmoid().detach() > 0.5
+        f = lambda m: m.float().sum()
+        loss['acc'] = (preds == labels).float().mean().detach()
+        loss['precision_posbox'] = f(preds & labels) / (f(preds).detach() + 1e-6)
+        loss['recall_posbox'] = f(preds & labels) / (f(labels).detach() + 1e-6)
+        loss['precision_negbox'] = f(~preds & ~labels) / (f(~preds).detach() + 1e-6)
+        loss['recall_negbox'] = f(~preds & ~labels) / (f(~labels).detach() + 1e-6)
+        res.update(loss_bbox=loss)
+        return res
+
+    def _bbox_forward(self, pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, rois, roi_scores, roi_frame_inds):
+        """Pool the points of every RoI, append the RoI score, run the head (:828-878)."""
+        assert pts_xyz.size(0) == pts_feats.size(0) == pts_batch_idx.size(0) == pts_frame_inds.size(0)
+        inds, roi_inds, info = self.roi_extractor(pts_xyz[:, :3], pts_batch_idx, pts_frame_inds, rois[:, :8],
+                                                  roi_frame_inds)
+        new_feats, new_xyz = pts_feats[inds], pts_xyz[inds]
+        if self.with_roi_scores:
+            new_feats = torch.cat([new_feats, roi_scores[roi_inds].unsqueeze(1)], 1)
+        return self.bbox_head(new_xyz, new_feats, info, roi_inds, rois, roi_frame_inds)
+
+    # ------------------------------------------------------------------ inference
+    def tracklets2rois(self, tracklets):
+        rois = bbox3d2roi([t.concated_boxes()[:, :7] for t in tracklets])
+        frames = torch.cat([torch.arange(len(t), device=rois.device, dtype=torch.long) for t in tracklets])
+        return rois, frames, torch.cat([t.concated_scores() for t in tracklets]), \
+            torch.cat([t.concated_labels() for t in tracklets])
+
+    def get_gt_rois(self, tracklets, gt_tracklets):
+        boxes, masks = zip(*[gt.concated_boxes_from_ts(trk.ts_list) for trk, gt in zip(tracklets, gt_tracklets)])
+        return torch.cat([torch.cat(masks, 0)[:, None].float(), torch.cat(boxes, 0)], 1)
+
+    def simple_test(self, pts_xyz, pts_feats, pts_batch_inds, pts_frame_inds, img_metas, tracklet_list,
+                    gt_tracklet_candidates=None, gt_occ_list=None, gt_occ_scores_list=None, **kwargs):
+        """One tracklet at a time (batch size 1, as the reference asserts :547): refined boxes and,
+        with test_occ_iou, per-RoI occupancy intersection / union counts."""
+        assert len(tracklet_list) == 1
+        rois, roi_frame_inds, cls_preds, labels_3d = self.tracklets2rois(tracklet_list)
+        res = self._bbox_forward(pts_xyz, pts_feats, pts_batch_inds, pts_frame_inds, rois, cls_preds, roi_frame_inds)
+        boxes = self.bbox_head.decode_from_rois(rois, res['bbox_pred'])
+        out = dict(boxes_3d=boxes, scores_3d=res['cls_score'].sigmoid().view(-1), labels_3d=labels_3d,
+                   valid_roi_mask=res['nonempty_roi_mask'])
+        if self.test_cfg.get('test_occ_iou', False) and gt_tracklet_candidates is not None:
+            gts, occs, _ = self._select_one2one_candidates(tracklet_list, gt_tracklet_candidates, gt_occ_list,
+                                                           gt_occ_scores_list)
+            if occs[0] is not None and len(gts[0]) > 0:
+                gt_rois = self.get_gt_rois(tracklet_list, gts)
+                out.update(self.test_occ(rois, gt_rois, res['fused_roi_feats'], [occs[0]]))
+        return [out]
+
+    @torch.no_grad()
+    def test_occ(self, occ_rois, gt_rois, fused_roi_feats, gt_occ_list):
+        """Chunked decoding of all GT voxels in every matched RoI frame; integer inter / union per
+        RoI (:394-486).  The decoder is called with (features, points, RoI index) -- no
+        [chunk,K,1536] copies."""
+        match = gt_rois[:, 0].bool() if gt_rois[:, 0].dtype != torch.bool else gt_rois[:, 0]
+        chunk = self.test_cfg.get('iou_chunk_size', -1)
+        chunk = int(match.sum()) if chunk == -1 else chunk
+        pred_boxes, gt_boxes_all, feats = occ_rois[match][:, 1:], gt_rois[match][:, 1:], fused_roi_feats[match]
+        occ_xyz, occ_label = gt_occ_list[0][..., :3], (gt_occ_list[0][..., 3] == 1).long()
+        K = occ_xyz.size(0)
+        decoder = self.bbox_head.occ_ae_head.occ_decoder
+        inters, unions, gt_boxes = [], [], []
+        for f, pb, gb in zip(torch.split(feats, chunk), torch.split(pred_boxes, chunk), torch.split(gt_boxes_all, chunk)):
+            n = gb.size(0)
+            xyz = occ_xyz[None].repeat(n, 1, 1)
+            lab = occ_label[None].repeat(n, 1)
+            if self.test_cfg.get('transform_to_gt', True):
+                xyz = rotation_3d_in_axis(xyz, gb[:, 6], axis=2)
+                xyz += gb[..., None, 0:3]
+                xyz[..., 2] += gb[:, None, 5] / 2
+                xyz -= pb[..., None, :3]
+                xyz[..., 2] -= pb[:, None, 5] / 2
+                xyz = rotation_3d_in_axis(xyz, -(pb[:, 6]), axis=2)
+            if self.test_cfg.get('ignore_outside_occ', False):
+                half = pb[:, None, 3:6] / 2
+                inside = (xyz >= -half).all(-1) & (xyz <= half).all(-1)
+            else:
+                inside = torch.ones((n, K), dtype=torch.bool, device=xyz.device)
+            idx = torch.arange(n, device=xyz.device).repeat_interleave(K)
+            cls = decoder.get_cls_from_pred(decoder(f, xyz.reshape(n * K, 3), idx)).view(n, K) * inside
+            inters.append(((cls == 1) & (lab == 1)).sum(1).cpu())
+            unions.append(((cls == 1) | (lab == 1)).sum(1).cpu())
+            gt_boxes.append(gb.cpu())
+        return dict(inters=inters, unions=unions, gt_boxes=gt_boxes)
+
+
+@DETECTORS.register_module()
+class TrackletDetectorOCC(nn.Module):
+    """Concatenate the per-sample point lists, build batch / frame indices, call the RoI head
+    (tracklet_detector_occ.py:96-198).  Points: [n_i, 3 + C] with xyz first; the decorated
+    features (intensity, elongation, yaw/pi, size/10 x3, score) follow."""
+
+    def __init__(self, roi_head, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__()
+        rh = dict(roi_head)
+        rh['train_cfg'], rh['test_cfg'] = train_cfg, test_cfg
+        self.roi_head = HEADS.build(rh)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    @staticmethod
+    def _cat_points(points, pts_frame_inds):
+        xyz = torch.cat([p[:, :3] for p in points], 0)
+        feats = torch.cat([p[:, 3:] for p in points], 0)
+        batch = torch.cat([torch.full((p.size(0),), i, dtype=torch.long, device=p.device) for i, p in enumerate(points)])
+        return xyz.contiguous(), feats.contiguous(), batch, torch.cat(pts_frame_inds, 0).long()
+
+    def forward_train(self, points, pts_frame_inds, img_metas, tracklet, gt_tracklet_candidates, gt_occs=None,
+                      gt_occ_scores=None, **kwargs):
+        xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
+        return self.roi_head.forward_train(xyz, feats, batch, frames, img_metas, tracklet, gt_tracklet_candidates,
+                                           gt_occs, gt_occ_scores)
+
+    def simple_test(self, points, pts_frame_inds, img_metas, tracklet, gt_tracklet_candidates=None, gt_occs=None,
+                    gt_occ_scores=None, **kwargs):
+        xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
+        return self.roi_head.simple_test(xyz, feats, batch, frames, img_metas, tracklet, gt_tracklet_candidates,
+                                         gt_occs, gt_occ_scores)
+
+    def forward(self, return_loss=True, **kwargs):
+        return self.forward_train(**kwargs) if return_loss else self.simple_test(**kwargs)
+
+
+def occupancy_iou_metrics(results):
+    """Aggregate per-RoI (inter, union, gt box) lists exactly as WaymoTrackletDatasetWithOcc.evaluate
+    does for metric 'iou' (mmdet3d/datasets/waymo_tracklet_dataset.py:629-672): overall IoU =
+    sum inter / sum union, mIoU over tracklets, mIoU over boxes, and the mean box IoU by GT
+    volume (<30, [30,150), >=150 m^3)."""
+    total_inter = total_union = 0.0
+    track, box, small, medium, large = [], [], [], [], []
+    for r in results:
+        if 'inters' not in r or (len(r['inters']) == 0 and len(r['unions']) == 0):
+            continue
+        inters = torch.cat(r['inters'], 0)
+        unions = torch.cat(r['unions'], 0)
+        box_ious = inters / unions
+        box.extend(box_ious.tolist())
+        if 'gt_boxes' in r:
+            vol = torch.cat(r['gt_boxes'], 0)[:, 3:6].prod(1)
+            small.extend(box_ious[vol < 30].tolist())
+            medium.extend(box_ious[(vol >= 30) & (vol < 150)].tolist())
+            large.extend(box_ious[vol >= 150].tolist())
+        total_inter += float(inters.sum())
+        total_union += float(unions.sum())
+        track.append(float(inters.sum() / unions.sum()))
+    if not track:
+        return {}
+    out = dict(iou=total_inter / total_union, miou_track=sum(track) / len(track), miou_box=sum(box) / len(box))
+    for name, lst in (('small', small), ('medium', medium), ('large', large)):
+        if lst:
+            out['iou_' + name] = sum(lst) / len(lst)
+    return out

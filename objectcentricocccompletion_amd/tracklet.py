@@ -1,0 +1,145 @@
+"""Tracklet container and assignment -- the parts of LiDARTracklet
+(mmdet3d/core/bbox/structures/lidar_tracklet.py:278-339) and TrackletAssigner
+(mmdet3d/core/bbox/assigners/tracklet_assigner.py:14-57) the RoI head touches, on plain
+tensors: boxes [L,7] (x,y,z_bottom,w,l,h,yaw), timestamps, per-box scores, a class id."""
+import torch
+
+from . import _lib as L
+from .registry import BBOX_ASSIGNERS
+
+
+def aligned_iou_3d(boxes1, boxes2):
+    """i-th box of boxes1 with i-th box of boxes2 (lidar_box3d.py:404-448), HIP kernel."""
+    L.require_device(boxes1, boxes2)
+    b1, b2 = boxes1[:, :7].contiguous().float(), boxes2[:, :7].contiguous().float()
+    assert b1.shape == b2.shape
+    out = torch.empty((b1.size(0),), dtype=torch.float32, device=b1.device)
+    L.check(L.lib.ococc_aligned_iou3d_f32(L.ptr(b1), L.ptr(b2), b1.size(0), L.ptr(out), L.stream()),
+            'aligned_iou3d')
+    return out
+
+
+class Tracklet(object):
+    """Boxes of one object over time.  ``type`` is the class id (0 = vehicle in the ococcnet
+    config)."""
+
+    def __init__(self, boxes, ts_list, scores=None, type=0, segment_name=None, id=None):
+        self.boxes = boxes
+        self.ts_list = list(ts_list)
+        assert len(self.ts_list) == boxes.size(0)
+        self.scores = scores if scores is not None else boxes.new_ones((boxes.size(0),))
+        self.type = type
+        self.segment_name, self.id = segment_name, id
+        self.ts2index = {ts: i for i, ts in enumerate(self.ts_list)}
+
+    def __len__(self):
+        return self.boxes.size(0)
+
+    @property
+    def device(self):
+        return self.boxes.device
+
+    def new_empty(self):
+        return Tracklet(self.boxes.new_zeros((0, self.boxes.size(1))), [], self.scores.new_zeros((0,)), self.type)
+
+    def concated_boxes(self):
+        return self.boxes
+
+    def concated_scores(self):
+        return self.scores
+
+    def concated_labels(self):
+        return torch.full((len(self),), self.type, device=self.device, dtype=torch.long)
+
+    def get_index_from_ts(self, ts):
+        return self.ts2index.get(ts, -1)
+
+    def ts_intersection(self, trk):
+        other = set(trk.ts_list)
+        return [ts for ts in self.ts_list if ts in other]
+
+    def intersection_ious(self, trk):
+        """IoU of the boxes the two tracklets have at common timestamps (lidar_tracklet.py:290-299)."""
+        inter = self.ts_intersection(trk)
+        if len(inter) == 0:
+            return self.boxes.new_zeros(0)
+        i1 = torch.tensor([self.ts2index[t] for t in inter], device=self.device)
+        i2 = torch.tensor([trk.ts2index[t] for t in inter], device=self.device)
+        return aligned_iou_3d(self.boxes[i1], trk.boxes[i2])
+
+    def self_ious(self, trk):
+        """Per own box: IoU with the other tracklet's box of the same timestamp, 0 if none (:278-288)."""
+        out = self.boxes.new_zeros(len(self))
+        inter = self.ts_intersection(trk)
+        if len(inter) == 0:
+            return out
+        idx = torch.tensor([self.ts2index[t] for t in inter], device=self.device, dtype=torch.long)
+        out[idx] = self.intersection_ious(trk)
+        return out
+
+    def concated_boxes_from_ts(self, ts_list):
+        """Boxes at the given timestamps (zeros + False where this tracklet has none) (:318-339)."""
+        boxes = self.boxes.new_zeros((len(ts_list), 7))
+        mask = torch.zeros((len(ts_list),), dtype=torch.bool, device=self.device)
+        for i, ts in enumerate(ts_list):
+            j = self.ts2index.get(ts, None)
+            if j is not None:
+                boxes[i] = self.boxes[j, :7]
+                mask[i] = True
+        return boxes, mask
+
+
+class AssignResult(object):
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class SamplingResult(object):
+    """PseudoSampler output (every box kept): positives first, then negatives."""
+
+    def __init__(self, assign_result, bboxes, gt_bboxes):
+        self.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        self.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        self.pos_bboxes, self.neg_bboxes = bboxes[self.pos_inds], bboxes[self.neg_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[self.pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            self.pos_gt_bboxes = gt_bboxes.new_zeros((0, 7))
+        else:
+            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[self.pos_inds] if assign_result.labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+@BBOX_ASSIGNERS.register_module()
+class TrackletAssigner(object):
+    """Frame-by-frame assignment by timestamp (tracklet_assigner.py:14-57)."""
+
+    def __init__(self, object_centric=False, iou_thr=0.5):
+        self.object_centric, self.iou_thr = object_centric, iou_thr
+
+    def assign(self, trk_pd, trk_gt):
+        device = trk_pd.device
+        num_gts, num_bboxes = len(trk_gt), len(trk_pd)
+        assigned_labels = torch.full((num_bboxes,), -1, dtype=torch.long, device=device)
+        scores = trk_pd.concated_scores().detach()
+        if num_gts == 0 or num_bboxes == 0:
+            gt_inds = torch.full((num_bboxes,), -1, dtype=torch.long, device=device)
+            if num_gts == 0:
+                gt_inds[:] = 0
+            res = AssignResult(num_gts, gt_inds, torch.zeros((num_bboxes,), device=device), assigned_labels)
+            res.scores = scores
+            return res
+        overlaps = trk_pd.self_ious(trk_gt)
+        idx = [trk_gt.get_index_from_ts(ts) + 1 for ts in trk_pd.ts_list]
+        if self.object_centric:
+            ov = overlaps.tolist()
+            idx = [j if ov[i] > self.iou_thr else 0 for i, j in enumerate(idx)]
+        gt_inds = torch.tensor(idx, dtype=torch.long, device=device)
+        assigned_labels[gt_inds > 0] = trk_gt.type
+        res = AssignResult(num_gts, gt_inds, overlaps, assigned_labels)
+        res.scores = scores
+        return res

@@ -400,3 +400,68 @@ int64_t oracle_point_pool(const float* rois, const int32_t* roi_key, int64_t R, 
   }
   return m;
 }
+
+/* ------------------------------------------------------------------ A2 ---- */
+/* aligned_iou_3d (mmdet3d/core/bbox/structures/lidar_box3d.py:404-448): BEV overlap of two
+ * rotated rectangles (w along x at yaw 0, clockwise yaw -- the iou3d convention, the TorchEx
+ * source being absent) times the height overlap, over the union volume (clamp 1e-8).
+ * Independent formulation from the HIP kernel: the intersection polygon is collected as the
+ * vertices of either rectangle inside the other plus all edge-edge intersection points,
+ * sorted by angle around their centroid. */
+static void box_corners(const float* b, double* cx, double* cy) {
+  const double hw = b[3] * 0.5, hl = b[4] * 0.5, ca = cos((double)b[6]), sa = sin((double)b[6]);
+  const double dx[4] = {-hw, hw, hw, -hw}, dy[4] = {-hl, -hl, hl, hl};
+  for (int k = 0; k < 4; ++k) {
+    cx[k] = dx[k] * ca + dy[k] * sa + b[0];
+    cy[k] = -dx[k] * sa + dy[k] * ca + b[1];
+  }
+}
+static int inside_quad(const double* qx, const double* qy, double px, double py) {
+  int pos = 0, neg = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) & 3;
+    const double c = (qx[j] - qx[i]) * (py - qy[i]) - (qy[j] - qy[i]) * (px - qx[i]);
+    if (c > 1e-12) pos = 1;
+    if (c < -1e-12) neg = 1;
+  }
+  return !(pos && neg);
+}
+void oracle_aligned_iou3d(const float* b1, const float* b2, int64_t n, float* iou) {
+  for (int64_t t = 0; t < n; ++t) {
+    const float* a = b1 + t * 7;
+    const float* b = b2 + t * 7;
+    double ax[4], ay[4], bx[4], by[4], px[24], py[24];
+    int m = 0;
+    box_corners(a, ax, ay);
+    box_corners(b, bx, by);
+    for (int i = 0; i < 4; ++i) if (inside_quad(bx, by, ax[i], ay[i])) { px[m] = ax[i]; py[m++] = ay[i]; }
+    for (int i = 0; i < 4; ++i) if (inside_quad(ax, ay, bx[i], by[i])) { px[m] = bx[i]; py[m++] = by[i]; }
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        const int i2 = (i + 1) & 3, j2 = (j + 1) & 3;
+        const double rx = ax[i2] - ax[i], ry = ay[i2] - ay[i], sx = bx[j2] - bx[j], sy = by[j2] - by[j];
+        const double den = rx * sy - ry * sx;
+        if (fabs(den) < 1e-14) continue;
+        const double u = ((bx[j] - ax[i]) * sy - (by[j] - ay[i]) * sx) / den;
+        const double v = ((bx[j] - ax[i]) * ry - (by[j] - ay[i]) * rx) / den;
+        if (u >= 0 && u <= 1 && v >= 0 && v <= 1) { px[m] = ax[i] + u * rx; py[m++] = ay[i] + u * ry; }
+      }
+    double area = 0.0;
+    if (m >= 3) {
+      double gx = 0, gy = 0;
+      for (int i = 0; i < m; ++i) { gx += px[i]; gy += py[i]; }
+      gx /= m; gy /= m;
+      for (int i = 1; i < m; ++i)  /* insertion sort by angle */
+        for (int j = i; j > 0 && atan2(py[j] - gy, px[j] - gx) < atan2(py[j - 1] - gy, px[j - 1] - gx); --j) {
+          double tx = px[j], ty = py[j]; px[j] = px[j - 1]; py[j] = py[j - 1]; px[j - 1] = tx; py[j - 1] = ty;
+        }
+      for (int i = 0; i < m; ++i) { const int j = (i + 1) % m; area += px[i] * py[j] - px[j] * py[i]; }
+      area = fabs(area) * 0.5;
+    }
+    double top = fmin((double)a[2] + a[5], (double)b[2] + b[5]), bot = fmax((double)a[2], (double)b[2]);
+    double oh = top - bot; if (oh < 0) oh = 0;
+    const double inter = area * oh, v1 = (double)a[3] * a[4] * a[5], v2 = (double)b[3] * b[4] * b[5];
+    double den = v1 + v2 - inter; if (den < 1e-8) den = 1e-8;
+    iou[t] = (float)(inter / den);
+  }
+}

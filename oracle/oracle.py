@@ -192,6 +192,14 @@ def point_pool(rois, roi_key, pts, pts_key, extra_wlh, max_inbox_point, max_all_
     return op[:m].copy(), orr[:m].copy(), fe[:m].copy(), rc
 
 
+def aligned_iou3d(boxes1, boxes2):
+    """lidar_box3d.py:404-448 -> iou [n] f32 (i-th box with i-th box)."""
+    b1, b2 = _f(boxes1), _f(boxes2)
+    out = np.zeros((b1.shape[0],), np.float32)
+    L().oracle_aligned_iou3d(_p(b1), _p(b2), i64(b1.shape[0]), _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ floating point helpers
 def bf16_round(a):
     """round-to-nearest-even float32 -> bfloat16 -> float32 (numpy)."""

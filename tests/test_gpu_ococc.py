@@ -179,3 +179,78 @@ def test_head_loss_and_backward_runs(dev, gold, head):
     finally:
         head.eval()
         head.zero_grad(set_to_none=True)
+
+
+def test_aligned_iou3d_vs_oracle(dev):
+    from objectcentricocccompletion_amd.tracklet import aligned_iou_3d
+    rng = np.random.default_rng(8)
+    n = 4000
+    b1 = np.concatenate([rng.uniform(-5, 5, (n, 3)), rng.uniform(1, 5, (n, 3)), rng.uniform(-4, 4, (n, 1))], 1).astype(np.float32)
+    b2 = b1 + rng.normal(0, [0.6, 0.6, 0.3, 0.2, 0.2, 0.2, 0.3], (n, 7)).astype(np.float32)
+    b2[:50] = b1[:50]                      # identical boxes -> 1
+    b2[50:100, :2] += 100                  # disjoint -> 0
+    got = aligned_iou_3d(torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev)).cpu().numpy()
+    exp = O.aligned_iou3d(b1, b2)
+    assert np.allclose(got, exp, atol=2e-4) and np.allclose(got[:50], 1, atol=1e-5) and (got[50:100] == 0).all()
+
+
+def _synthetic_batch(dev, B=2, L=8, seed=6):
+    from objectcentricocccompletion_amd.tracklet import Tracklet
+    t = synth.synth_tracklets(B, L, 90, seed=seed)
+    rng = np.random.default_rng(seed)
+    points, frames, trks, cands, occs, occ_scores = [], [], [], [], [], []
+    for b in range(B):
+        rb = t['rois'][t['rois'][:, 0] == b][:, 1:]
+        m = t['pts_batch'] == b
+        score = rng.uniform(0.3, 1.0, size=L).astype(np.float32)
+        fr = t['pts_frame'][m]
+        deco = np.concatenate([t['pts_attr'][m], rb[fr][:, 6:7] / np.pi, rb[fr][:, 3:6] / 10, score[fr][:, None]], 1)
+        points.append(torch.from_numpy(np.concatenate([t['pts_xyz'][m], deco], 1).astype(np.float32)).to(dev))
+        frames.append(torch.from_numpy(fr).to(dev))
+        ts = list(range(1000 + b * 100, 1000 + b * 100 + L))
+        trks.append(Tracklet(torch.from_numpy(rb).to(dev), ts, torch.from_numpy(score).to(dev), type=0))
+        gt = rb + rng.normal(0, [0.1, 0.1, 0.05, 0.05, 0.05, 0.05, 0.02], rb.shape).astype(np.float32)
+        far = gt.copy()
+        far[:, :2] += 30
+        cands.append([Tracklet(torch.from_numpy(far).to(dev), ts, type=0), Tracklet(torch.from_numpy(gt).to(dev), ts, type=0)])
+        occ = np.concatenate([(rng.random((64, 3)) - 0.5) * [4.5, 2.0, 1.6], rng.integers(0, 3, (64, 1))], 1).astype(np.float32)
+        occs.append([torch.from_numpy(occ).to(dev)] * 2)
+        occ_scores.append([torch.tensor([0.9], device=dev)] * 2)
+    return points, frames, trks, cands, occs, occ_scores
+
+
+def test_detector_train_and_test_end_to_end(dev):
+    """configs/ococc/ococcnet.py model dict -> TrackletDetectorOCC -> losses with the reference's
+    keys, backward, then inference with occupancy IoU counts and the dataset's IoU aggregation."""
+    from objectcentricocccompletion_amd import heads, point_pool, roi_head  # noqa: F401 (register)
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    torch.manual_seed(0)
+    cfg = ococcnet_model_cfg()
+    model = DETECTORS.build(cfg).to(dev)
+    sd = model.state_dict()
+    assert 'roi_head.bbox_head.block_list.0.rel_mlp.0.0.weight' in sd          # reference checkpoint prefix
+    assert 'roi_head.bbox_head.occ_ae_head.occ_decoder.conv_occ.3.weight' in sd
+    points, frames, trks, cands, occs, occ_scores = _synthetic_batch(dev)
+    model.train()
+    losses = model(return_loss=True, points=points, pts_frame_inds=[f.clone() for f in frames], img_metas=None,
+                   tracklet=trks, gt_tracklet_candidates=cands, gt_occs=occs, gt_occ_scores=occ_scores)
+    for k in ('loss_rcnn_cls', 'loss_rcnn_bbox', 'loss_rcnn_occ', 'acc', 'precision_posbox', 'recall_posbox',
+              'num_pos_rois', 'num_occupied', 'recall_pos', 'precision_neg'):
+        assert k in losses and bool(torch.isfinite(losses[k]).all()), k
+    assert float(losses['num_pos_rois']) > 0      # the near candidate, not the far one, was selected
+    (losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()).backward()
+    assert all(p.grad is not None for n, p in model.named_parameters() if 'conv_cls' in n or 'occ_decoder' in n)
+    model.eval()
+    results = []
+    with torch.no_grad():
+        for b in range(len(points)):
+            r = model(return_loss=False, points=[points[b]], pts_frame_inds=[frames[b]], img_metas=None,
+                      tracklet=[trks[b]], gt_tracklet_candidates=[cands[b]], gt_occs=[occs[b]],
+                      gt_occ_scores=[occ_scores[b]])
+            assert r[0]['boxes_3d'].shape == (len(trks[b]), 7) and 'inters' in r[0]
+            i, u = torch.cat(r[0]['inters']), torch.cat(r[0]['unions'])
+            assert i.dtype == torch.long and bool((i <= u).all()) and bool((u > 0).all())
+            results.append(r[0])
+    m = roi_head.occupancy_iou_metrics(results)
+    assert 0.0 <= m['iou'] <= 1.0 and 'miou_track' in m and 'miou_box' in m and 'iou_small' in m

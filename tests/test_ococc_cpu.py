@@ -92,3 +92,23 @@ def test_oracle_point_pool_contract():
     assert len(pi2) == 37 and cnt2.max() <= 5
     for q in np.unique(ri2)[:-1]:
         assert np.array_equal(pi2[ri2 == q], pi[ri == q][:5])
+
+
+def test_occupancy_iou_aggregation_formula():
+    """waymo_tracklet_dataset.py:629-672 restated in numpy."""
+    from objectcentricocccompletion_amd.roi_head import occupancy_iou_metrics
+    rng = np.random.default_rng(0)
+    results, I, U, V, T = [], [], [], [], []
+    for _ in range(5):
+        u = rng.integers(10, 200, size=12)
+        i = (u * rng.random(12)).astype(np.int64)
+        g = np.concatenate([rng.random((12, 3)), rng.uniform(1, 8, (12, 3)), rng.random((12, 1))], 1)
+        results.append(dict(inters=[torch.from_numpy(i[:7]), torch.from_numpy(i[7:])],
+                            unions=[torch.from_numpy(u[:7]), torch.from_numpy(u[7:])],
+                            gt_boxes=[torch.from_numpy(g[:7]), torch.from_numpy(g[7:])]))
+        I.append(i); U.append(u); V.append(g[:, 3:6].prod(1)); T.append(i.sum() / u.sum())
+    I, U, V = np.concatenate(I), np.concatenate(U), np.concatenate(V)
+    m = occupancy_iou_metrics(results + [dict(boxes_3d=None)])
+    assert np.isclose(m['iou'], I.sum() / U.sum()) and np.isclose(m['miou_track'], np.mean(T))
+    assert np.isclose(m['miou_box'], np.mean(I / U)) and np.isclose(m['iou_small'], np.mean((I / U)[V < 30]))
+    assert np.isclose(m['iou_medium'], np.mean((I / U)[(V >= 30) & (V < 150)]))
