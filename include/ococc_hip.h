@@ -155,6 +155,24 @@ int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_s
                               int32_t* indice_pairs, int32_t* indice_num, void* workspace,
                               int64_t workspace_bytes, ococc_stream_t stream);
 
+/* Regular (strided) / transposed sparse conv rulebook: the non sub-manifold branch of
+ * spconv::getIndicePair (spconv_ops.h:105-141; geometry.h:144-245, indice.cu.h:22-145).
+ * Active outputs are numbered in sorted order of their flat grid index (the reference's GPU
+ * path; its CPU functor numbers by first appearance); pairs of an offset are in ascending
+ * input row.  out_indices [out_capacity,4] (use n*kvol as the safe bound or
+ * min(n*kvol, batch*D*H*W)), indice_pairs [kvol,2,n] (-1 filled), indice_num [kvol],
+ * num_out: device int32.  kvol <= 255. */
+int64_t ococc_conv_rulebook_workspace_bytes(int64_t n, int32_t batch_size,
+                                            const int32_t host_out_shape[3],
+                                            const int32_t host_ksize[3]);
+int ococc_conv_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
+                              const int32_t host_out_shape[3], const int32_t host_ksize[3],
+                              const int32_t host_stride[3], const int32_t host_padding[3],
+                              const int32_t host_dilation[3], int32_t transpose,
+                              int32_t* out_indices, int64_t out_capacity, int32_t* indice_pairs,
+                              int32_t* indice_num, int32_t* num_out, void* workspace,
+                              int64_t workspace_bytes, ococc_stream_t stream);
+
 /* Rebuild the gather tables from a reference-format rulebook (any conv type:
  * regular / inverse / user supplied).  Each (row, offset) may appear at most
  * once on the chosen side (true for every spconv rulebook).

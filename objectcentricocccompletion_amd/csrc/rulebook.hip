@@ -144,6 +144,136 @@ pairs_to_table_kernel(const int32_t* __restrict__ pairs, const int32_t* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Regular (strided) and transposed sparse conv rulebook: spconv::getIndicePair non-subM branch
+// (spconv_ops.h:105-141; CPU functors geometry.h:144-245, GPU kernels indice.cu.h:22-145).
+// Output rows are numbered in SORTED order of their flat grid index -- what the reference's
+// GPU path produces through torch::_unique (spconv_ops.h:130); its CPU functor numbers them
+// by first appearance instead.  Pairs inside an offset are in ascending input row, as on the
+// CPU.  Same bitmap + popcount machinery as the sub-manifold case.
+struct ConvGeom {
+  int32_t batch, oD, oH, oW;
+  int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int32_t transpose;
+};
+
+__device__ __forceinline__ bool conv_out_coord(int in, int c, int s, int p, int d, int osz, int transpose,
+                                               int* out) {
+  int o;
+  if (transpose) {
+    o = in * s - p + c * d;  // getValidOutPosTranspose, geometry.h:87-142
+  } else {
+    const int t = in + p - c * d;  // out * s - p + c * d = in, geometry.h:24-85
+    if (t < 0 || t % s != 0) return false;
+    o = t / s;
+  }
+  if (o < 0 || o >= osz) return false;
+  *out = o;
+  return true;
+}
+
+// grid (ceil(n/256), kvol): cand[k][j] = flat output cell reached from input j through offset k
+__global__ void __launch_bounds__(256)
+conv_mark_kernel(const int32_t* __restrict__ indices, int64_t n, ConvGeom g, int32_t* __restrict__ cand,
+                 uint32_t* __restrict__ bitmap) {
+  const int k = blockIdx.y;
+  const int cx = k % g.kw, cy = (k / g.kw) % g.kh, cz = k / (g.kw * g.kh);
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int32_t b = indices[j * 4];
+  int oz, oy, ox;
+  int32_t cell = -1;
+  if ((unsigned)b < (unsigned)g.batch &&
+      conv_out_coord(indices[j * 4 + 1], cz, g.sd, g.pd, g.dd, g.oD, g.transpose, &oz) &&
+      conv_out_coord(indices[j * 4 + 2], cy, g.sh, g.ph, g.dh, g.oH, g.transpose, &oy) &&
+      conv_out_coord(indices[j * 4 + 3], cx, g.sw, g.pw, g.dw, g.oW, g.transpose, &ox)) {
+    cell = (int32_t)((((int64_t)b * g.oD + oz) * g.oH + oy) * g.oW + ox);
+    atomicOr(bitmap + (cell >> 5), 1u << (cell & 31));
+  }
+  cand[(int64_t)k * n + j] = cell;
+}
+
+__global__ void __launch_bounds__(256)
+conv_emit_out_kernel(int64_t words, const uint32_t* __restrict__ bitmap,
+                     const uint32_t* __restrict__ prefix, ConvGeom g, int32_t* __restrict__ out_indices,
+                     int64_t capacity) {
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words;
+       w += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t bits = bitmap[w];
+    int64_t r = prefix[w];
+    while (bits) {
+      const int bb = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (r < capacity) {
+        int64_t cell = w * 32 + bb;
+        int32_t* o = out_indices + r * 4;
+        o[3] = (int32_t)(cell % g.oW); cell /= g.oW;
+        o[2] = (int32_t)(cell % g.oH); cell /= g.oH;
+        o[1] = (int32_t)(cell % g.oD); cell /= g.oD;
+        o[0] = (int32_t)cell;
+      }
+      ++r;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+conv_cell_to_rank_kernel(int64_t total, const uint32_t* __restrict__ bitmap,
+                         const uint32_t* __restrict__ prefix, int32_t* __restrict__ cand) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t cell = cand[i];
+    if (cell >= 0) cand[i] = rank_of(bitmap, prefix, cell);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+conv_compact_pairs_kernel(const int32_t* __restrict__ cand, const uint32_t* __restrict__ pos, int64_t n,
+                          int32_t* __restrict__ pairs) {
+  const int k = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t o = cand[(int64_t)k * n + j];
+    if (o < 0) continue;
+    const int64_t p = pos[(int64_t)k * n + j];
+    pairs[((int64_t)k * 2 + 0) * n + p] = (int32_t)j;
+    pairs[((int64_t)k * 2 + 1) * n + p] = o;
+  }
+}
+
+__global__ void copy_totals_kernel(const uint32_t* __restrict__ totals, int kvol,
+                                   int32_t* __restrict__ indice_num) {
+  if ((int)threadIdx.x < kvol) indice_num[threadIdx.x] = (int32_t)totals[threadIdx.x];
+}
+
+struct ConvLayout {
+  int64_t words, off_bitmap, off_prefix, off_cand, off_pos, off_scratch, off_totals, total;
+};
+inline bool make_conv_layout(int64_t n, int32_t batch, const int32_t* oshape, const int32_t* ksize,
+                             ConvLayout* L) {
+  if (batch < 1 || !oshape || !ksize || n < 0) return false;
+  int64_t cells = batch;
+  for (int i = 0; i < 3; ++i) {
+    if (oshape[i] < 1 || ksize[i] < 1) return false;
+    cells *= oshape[i];
+    if (cells > 0x7fffffffLL) return false;
+  }
+  const int64_t kvol = (int64_t)ksize[0] * ksize[1] * ksize[2];
+  L->words = (cells + 31) / 32;
+  int64_t off = 0;
+  auto take = [&](int64_t b) { int64_t o = off; off += ococc_align_up(b > 0 ? b : 4, 256); return o; };
+  L->off_bitmap = take(L->words * 4);
+  L->off_prefix = take(L->words * 4);
+  L->off_cand = take(kvol * n * 4);
+  L->off_pos = take(kvol * n * 4);
+  const int64_t s1 = ococc_scan::scratch_words(L->words, 1);
+  const int64_t s2 = ococc_scan::scratch_words(n > 0 ? n : 1, (int)kvol);
+  L->off_scratch = take((s1 > s2 ? s1 : s2) * 4);
+  L->off_totals = take((kvol + 1) * 4);
+  L->total = off;
+  return true;
+}
+
 struct Layout {
   int64_t words, off_bitmap, off_prefix, off_perm, off_pos, off_scratch, off_totals, total;
 };
@@ -261,6 +391,70 @@ extern "C" int ococc_rulebook_pairs_to_table(const int32_t* indice_pairs,
   hipLaunchKernelGGL(pairs_to_table_kernel, dim3(ococc_grid_1d(pair_capacity, 256, 1024), kvol),
                      dim3(256), 0, stream, indice_pairs, indice_num, pair_capacity, (int)side,
                      num_rows, table, blockmask);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int64_t ococc_conv_rulebook_workspace_bytes(int64_t n, int32_t batch_size,
+                                                       const int32_t host_out_shape[3],
+                                                       const int32_t host_ksize[3]) {
+  ConvLayout L;
+  if (!make_conv_layout(n, batch_size, host_out_shape, host_ksize, &L)) return -1;
+  return L.total;
+}
+
+extern "C" int ococc_conv_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
+                                         const int32_t host_out_shape[3], const int32_t host_ksize[3],
+                                         const int32_t host_stride[3], const int32_t host_padding[3],
+                                         const int32_t host_dilation[3], int32_t transpose,
+                                         int32_t* out_indices, int64_t out_capacity,
+                                         int32_t* indice_pairs, int32_t* indice_num, int32_t* num_out,
+                                         void* workspace, int64_t workspace_bytes,
+                                         ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ConvLayout L;
+  OCOCC_REQUIRE(make_conv_layout(n, batch_size, host_out_shape, host_ksize, &L),
+                "need batch>=1, out_shape>=1, batch*D*H*W < 2^31");
+  OCOCC_REQUIRE(host_stride && host_padding && host_dilation, "null geometry");
+  OCOCC_REQUIRE(indice_num && num_out, "null indice_num / num_out");
+  const int kvol = host_ksize[0] * host_ksize[1] * host_ksize[2];
+  for (int i = 0; i < 3; ++i)
+    OCOCC_REQUIRE(host_stride[i] >= 1 && host_dilation[i] >= 1 && host_padding[i] >= 0, "bad geometry");
+  OCOCC_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), stream));
+  OCOCC_HIP(hipMemsetAsync(num_out, 0, sizeof(int32_t), stream));
+  if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(indices && out_indices && indice_pairs, "null pointer");
+  OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
+  char* ws = (char*)workspace;
+  uint32_t* bitmap = (uint32_t*)(ws + L.off_bitmap);
+  uint32_t* prefix = (uint32_t*)(ws + L.off_prefix);
+  int32_t* cand = (int32_t*)(ws + L.off_cand);
+  uint32_t* pos = (uint32_t*)(ws + L.off_pos);
+  uint32_t* scratch = (uint32_t*)(ws + L.off_scratch);
+  uint32_t* totals = (uint32_t*)(ws + L.off_totals);
+  ConvGeom g{batch_size, host_out_shape[0], host_out_shape[1], host_out_shape[2],
+             host_ksize[0], host_ksize[1], host_ksize[2], host_stride[0], host_stride[1], host_stride[2],
+             host_padding[0], host_padding[1], host_padding[2], host_dilation[0], host_dilation[1],
+             host_dilation[2], transpose ? 1 : 0};
+  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.words * 4, stream));
+  OCOCC_HIP(hipMemsetAsync(indice_pairs, 0xff, (int64_t)kvol * 2 * n * 4, stream));
+  hipLaunchKernelGGL(conv_mark_kernel, dim3((unsigned)ococc_cdiv(n, 256), kvol), dim3(256), 0, stream,
+                     indices, n, g, cand, bitmap);
+  OCOCC_CHECK_LAUNCH();
+  OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bitmap, L.words, L.words, 1, prefix, L.words,
+                                                         scratch, (uint32_t*)num_out, stream));
+  hipLaunchKernelGGL(conv_emit_out_kernel, dim3(ococc_grid_1d(L.words, 256)), dim3(256), 0, stream,
+                     L.words, bitmap, prefix, g, out_indices, out_capacity);
+  OCOCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv_cell_to_rank_kernel, dim3(ococc_grid_1d((int64_t)kvol * n, 256)), dim3(256), 0,
+                     stream, (int64_t)kvol * n, bitmap, prefix, cand);
+  OCOCC_CHECK_LAUNCH();
+  OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::NONNEG>((const uint32_t*)cand, n, n, kvol, pos, n,
+                                                           scratch, totals, stream));
+  hipLaunchKernelGGL(conv_compact_pairs_kernel, dim3(ococc_grid_1d(n, 256, 1024), kvol), dim3(256), 0,
+                     stream, cand, pos, n, indice_pairs);
+  OCOCC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(copy_totals_kernel, dim3(1), dim3(256), 0, stream, totals, kvol, indice_num);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -185,6 +185,55 @@ int64_t oracle_conv_rulebook(const int32_t* indices, int64_t n, int batch, const
   return nact;
 }
 
+/* geometry.h:87-142 (getValidOutPosTranspose) + :195-245 (getIndicePairsDeConv): transposed
+ * sparse conv, outputs numbered by first appearance. */
+int64_t oracle_deconv_rulebook(const int32_t* indices, int64_t n, int batch, const int32_t* oshape,
+                               const int32_t* ks, const int32_t* stride, const int32_t* pad,
+                               const int32_t* dil, int32_t* out_indices, int32_t* pairs, int32_t* num) {
+  const int64_t vol = (int64_t)oshape[0] * oshape[1] * oshape[2];
+  int32_t* grid = (int32_t*)malloc(vol * batch * sizeof(int32_t));
+  for (int64_t c = 0; c < vol * batch; ++c) grid[c] = -1;
+  int64_t nact = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    const int32_t* p = indices + j * 4;
+    int32_t lo[3], cs[3], cnt[3] = {0, 0, 0};
+    int npts = 1;
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = p[1 + d] * stride[d] - pad[d];
+      cs[d] = ks[d];  /* (uppers - lowers) / dil + 1 with uppers = lowers + (k-1)*dil */
+      npts *= cs[d];
+    }
+    for (int i = 0; i < npts; ++i) {
+      int valid = 1, m = 1, off = 0;
+      int32_t q[3];
+      for (int d = 2; d >= 0; --d) {
+        const int32_t up = lo[d] + (ks[d] - 1) * dil[d];
+        const int32_t v = up - cnt[d] * dil[d];
+        q[d] = v;
+        if (v < 0 || v > oshape[d] - 1) valid = 0;
+        off += m * (v - lo[d]) / dil[d];
+        m *= ks[d];
+      }
+      if (valid) {
+        const int64_t cell = (((int64_t)p[0] * oshape[0] + q[0]) * oshape[1] + q[1]) * oshape[2] + q[2];
+        if (grid[cell] == -1) {
+          out_indices[nact * 4] = p[0];
+          for (int k = 0; k < 3; ++k) out_indices[nact * 4 + 1 + k] = q[k];
+          grid[cell] = (int32_t)nact++;
+        }
+        pairs[((int64_t)off * 2 + 0) * n + num[off]] = (int32_t)j;
+        pairs[((int64_t)off * 2 + 1) * n + num[off]] = grid[cell];
+        num[off] += 1;
+      }
+      cnt[2] += 1;
+      for (int d = 2; d > 0; --d)
+        if (cnt[d] == cs[d]) { cnt[d - 1] += 1; cnt[d] = 0; }
+    }
+  }
+  free(grid);
+  return nact;
+}
+
 /* ------------------------------------------------------------------ B4 ---- */
 static int argmax_first(const int32_t* num, int kvol) {
   int best = 0;

@@ -30,7 +30,8 @@ def _lib():
                        capture_output=True)
     lib = ctypes.CDLL(_SO)
     lib.oracle_hard_voxelize.restype = ctypes.c_int
-    for name in ('oracle_subm_rulebook', 'oracle_conv_rulebook', 'oracle_unique_rows', 'oracle_point_pool'):
+    for name in ('oracle_subm_rulebook', 'oracle_conv_rulebook', 'oracle_unique_rows', 'oracle_point_pool',
+                 'oracle_deconv_rulebook'):
         getattr(lib, name).restype = ctypes.c_int64
     return lib
 
@@ -95,15 +96,16 @@ def subm_rulebook(indices, batch_size, spatial_shape, ksize=(3, 3, 3), dilation=
     return pairs, num
 
 
-def conv_rulebook(indices, batch_size, out_shape, ksize, stride, padding, dilation):
-    """geometry.h:144-193 -> (out_indices [M,4], indice_pairs [K,2,N], indice_num [K])."""
+def conv_rulebook(indices, batch_size, out_shape, ksize, stride, padding, dilation, transpose=False):
+    """geometry.h:144-193 (or :195-245 transposed) -> (out_indices [M,4], indice_pairs [K,2,N], indice_num [K])."""
     indices = _i(indices)
     n = indices.shape[0]
     kvol = int(np.prod(ksize))
     pairs = np.full((kvol, 2, n), -1, np.int32)
     num = np.zeros((kvol,), np.int32)
     outi = np.zeros((max(n * kvol, 1), 4), np.int32)
-    m = L().oracle_conv_rulebook(_p(indices), i64(n), ci(batch_size), _p(_i(out_shape)),
+    fn = L().oracle_deconv_rulebook if transpose else L().oracle_conv_rulebook
+    m = fn(_p(indices), i64(n), ci(batch_size), _p(_i(out_shape)),
                                  _p(_i(ksize)), _p(_i(stride)), _p(_i(padding)), _p(_i(dilation)),
                                  _p(outi), _p(pairs), _p(num))
     return outi[:m].copy(), pairs, num

@@ -235,3 +235,93 @@ def test_conv_properties_at_benchmark_scale(dev):
     # <dW, W> == <conv(x), dy>
     rhs2 = float((dw.double() * w.double()).sum())
     assert abs(lhs - rhs2) < 1e-3 * max(abs(lhs), 1.0)
+
+
+def _match_sorted(outids_oracle):
+    """permutation: oracle output row (first-appearance order) -> row in sorted order."""
+    o = outids_oracle.astype(np.int64)
+    key = ((o[:, 0] * 10000 + o[:, 1]) * 10000 + o[:, 2]) * 10000 + o[:, 3]
+    order = np.argsort(key, kind='stable')
+    perm = np.empty(len(o), np.int64)
+    perm[order] = np.arange(len(o))
+    return order, perm
+
+
+@pytest.mark.parametrize('case', [
+    dict(ks=(3, 3, 3), stride=(2, 2, 2), pad=(1, 1, 1), transpose=False),
+    dict(ks=(3, 3, 3), stride=(1, 1, 1), pad=(0, 0, 0), transpose=False),
+    dict(ks=(3, 1, 1), stride=(2, 1, 1), pad=(0, 0, 0), transpose=False),
+    dict(ks=(2, 2, 2), stride=(2, 2, 2), pad=(0, 0, 0), transpose=False),
+    dict(ks=(3, 3, 3), stride=(2, 2, 2), pad=(1, 1, 1), transpose=True),
+])
+def test_regular_and_transposed_rulebook_vs_oracle(dev, case):
+    """SparseConv3d / transposed rulebooks: same active outputs, same pairs per offset in the same
+    (ascending input) order; output rows are numbered sorted instead of by first appearance."""
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(17)
+    B, shape = 3, (9, 10, 11)
+    idx = _voxels(rng, B, shape, 0.15, True)
+    ks, st, pd = case['ks'], case['stride'], case['pad']
+    if case['transpose']:
+        oshape = ops.get_deconv_output_size(list(shape), list(ks), list(st), list(pd), [1, 1, 1], [0, 0, 0])
+    else:
+        oshape = ops.get_conv_output_size(list(shape), list(ks), list(st), list(pd), [1, 1, 1])
+    eo, ep, en = O.conv_rulebook(idx, B, oshape, ks, st, pd, (1, 1, 1), transpose=case['transpose'])
+    outids, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), list(ks), list(st),
+                                              list(pd), 1, 0, subm=False, transpose=case['transpose'])
+    order, perm = _match_sorted(eo)
+    assert np.array_equal(outids.cpu().numpy(), eo[order])
+    assert np.array_equal(num.cpu().numpy(), en)
+    p = pairs.cpu().numpy()
+    for k in range(len(en)):
+        assert np.array_equal(p[k, 0, :en[k]], ep[k, 0, :en[k]])
+        assert np.array_equal(p[k, 1, :en[k]], perm[ep[k, 1, :en[k]]])
+        assert (p[k, :, en[k]:] == -1).all()
+
+
+def test_sparse_conv3d_and_inverse_modules_vs_dense(dev):
+    """SparseConv3d (stride 2) followed by its SparseInverseConv3d partner, forward and backward,
+    against dense conv3d / the oracle's inverse formulation."""
+    from objectcentricocccompletion_amd.spconv import SparseConv3d, SparseConvTensor, SparseInverseConv3d
+    rng = np.random.default_rng(23)
+    B, shape, cin, cmid = 2, (8, 10, 12), 16, 32
+    idx = _voxels(rng, B, shape, 0.2, True)
+    n = len(idx)
+    torch.manual_seed(1)
+    down = SparseConv3d(cin, cmid, 3, stride=2, padding=1, bias=False, indice_key='d1').to(dev)
+    up = SparseInverseConv3d(cmid, cin, 3, indice_key='d1', bias=False).to(dev)
+    x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    st = SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B)
+    mid = down(st)
+    out = up(mid)
+    assert out.features.shape == (n, cin) and torch.equal(out.indices.cpu(), torch.from_numpy(idx))
+    (out.features ** 2).sum().backward()
+    # reference math from the oracle rulebook (first-appearance numbering) in float64
+    oshape = [(s + 2 - 3) // 2 + 1 for s in shape]
+    eo, ep, en = O.conv_rulebook(idx, B, oshape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    order, perm = _match_sorted(eo)
+    w1 = O.bf16_round(down.weight.detach().cpu().numpy())
+    w2 = O.bf16_round(up.weight.detach().cpu().numpy())
+    ymid = O.indice_conv(x, w1, ep, en, len(eo))
+    assert np.allclose(mid.features.detach().cpu().numpy(), ymid[order], rtol=1e-3, atol=2e-3)
+    yout = O.indice_conv(O.bf16_round(ymid), w2, ep, en, n, inverse=True)
+    assert np.allclose(out.features.detach().cpu().numpy(), yout, rtol=2e-2, atol=3e-2)  # bf16 hop in between
+    # dense cross-check of the strided conv
+    dense = torch.zeros((B,) + shape + (cin,))
+    dense[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = torch.from_numpy(x)
+    yd = torch.nn.functional.conv3d(dense.permute(0, 4, 1, 2, 3), torch.from_numpy(w1).permute(4, 3, 0, 1, 2),
+                                    padding=1, stride=2).permute(0, 2, 3, 4, 1)
+    oi = mid.indices.cpu().numpy()
+    assert np.allclose(mid.features.detach().cpu().numpy(), yd[oi[:, 0], oi[:, 1], oi[:, 2], oi[:, 3]].numpy(),
+                       rtol=1e-3, atol=2e-3)
+    # gradients: adjoint identity through both layers
+    g = xt.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+    assert down.weight.grad is not None and up.weight.grad is not None
+    din, dw2 = O.indice_conv_backward(O.bf16_round(ymid), w2, O.bf16_round(2 * yout), ep, en, inverse=True)
+    assert rel_close(up.weight.grad.cpu().numpy(), dw2, 5e-2)
+
+
+def rel_close(a, b, tol):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12)) < tol
