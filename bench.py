@@ -99,8 +99,9 @@ def main():
     model = SubMOccEncoder().to(dev)
     params = [p for p in model.parameters()]
     opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
-    flat_numel = sum(p.numel() for p in params)
-    bucket = torch.zeros(flat_numel, dtype=torch.float32, device=dev)
+    from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
+    broadcast_parameters(model)
+    buckets = GradBuckets(params)
     B, P = args.grids, args.points
     xyz, feats, bidx = synthetic_object_grids(B, P, seed=rank, device=dev)
 
@@ -115,17 +116,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         out = model(xyz, feats, bidx, B)
         out.features.backward(d_out)
-        if world > 1:  # data parallel: one bucketed gradient all-reduce over RCCL / xGMI
-            off = 0
-            for p in params:
-                bucket[off:off + p.numel()].copy_(p.grad.reshape(-1))
-                off += p.numel()
-            dist.all_reduce(bucket)
-            bucket.div_(world)
-            off = 0
-            for p in params:
-                p.grad.copy_(bucket[off:off + p.numel()].view_as(p.grad))
-                off += p.numel()
+        buckets.all_reduce()  # data parallel: bucketed gradient all-reduce over RCCL / xGMI (no-op at N=1)
         opt.step()
         return out
 

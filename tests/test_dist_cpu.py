@@ -1,0 +1,83 @@
+"""CPU suite, part 4: the N>1 path on gloo with world_size 2 -- shard ranges, bucketed
+gradient all-reduce (== gradient of the concatenated batch), parameter broadcast and the
+avg-factor reduce_mean of the loss.  A small torch module stands in for the HIP model (the
+product ops refuse CPU tensors); the collective plumbing under test is the shipped code."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from objectcentricocccompletion_amd import dist as od
+    from objectcentricocccompletion_amd.losses import reduce_mean
+    r, w, _ = od.init_dist('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)               # different init per rank ...
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+    od.broadcast_parameters(model)              # ... made identical here
+    torch.manual_seed(0)
+    x_all, y_all = torch.randn(8, 6), torch.randn(8, 3)
+    lo, hi = od.shard_range(8, rank, world)     # tracklets are sharded, no data-path collective
+    loss = ((model(x_all[lo:hi]) - y_all[lo:hi]) ** 2).sum() / 8 * world
+    loss.backward()
+    buckets = od.GradBuckets(model.parameters(), bucket_bytes=256)   # forces several buckets
+    assert len(buckets.buckets) > 1
+    buckets.all_reduce()
+    avg = reduce_mean(torch.tensor([float(rank + 1)]))
+    q.put((rank, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()],
+           float(avg), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_bucketed_allreduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, w0, a0, s0), (_, g1, w1, a1, s1) = out
+    assert s0 == (0, 4) and s1 == (4, 8) and a0 == a1 == 1.5
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)                 # broadcast made the replicas identical
+    for a, b in zip(g0, g1):
+        assert torch.allclose(a, b)              # both ranks hold the same averaged gradient
+    # single-process reference on the whole batch
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+    with torch.no_grad():
+        for p, w in zip(model.parameters(), w0):
+            p.copy_(w)
+    torch.manual_seed(0)
+    x_all, y_all = torch.randn(8, 6), torch.randn(8, 3)
+    (((model(x_all) - y_all) ** 2).sum() / 8).backward()
+    for p, g in zip(model.parameters(), g0):
+        assert torch.allclose(p.grad, g, atol=1e-6)
+
+
+def test_shard_range_covers_everything():
+    from objectcentricocccompletion_amd.dist import shard_range
+    for n in (0, 1, 7, 64, 257):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
