@@ -40,6 +40,9 @@ def parse():
     ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
     ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet'],
+                    help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]')
+    ap.add_argument('--tracklets', type=int, default=4)
     return ap.parse_args()
 
 
@@ -79,6 +82,64 @@ def pmc_traffic():
         return None
 
 
+def bench_ococcnet(args, world, rank, dev):
+    """configs[2]: full ococcnet.py model on synthetic Waymo-shaped tracklets, B tracklets x 32 frames
+    (= B*32 object grids) per GPU per step, K = 512 occupancy queries, fwd + bwd + AdamW, fp32 as the
+    reference trains."""
+    from objectcentricocccompletion_amd import heads, point_pool, roi_head  # noqa: F401
+    from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
+    torch.manual_seed(0)
+    cfg = ococcnet_model_cfg()
+    cfg['train_cfg']['random_shift_frame_inds'] = False  # host RNG + in-place shift: keep steps identical
+    model = DETECTORS.build(cfg).to(dev).train()
+    broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-6, fused=True)
+    buckets = GradBuckets(params)
+    B, L = args.tracklets, 32
+    batch = synthetic_training_batch(B, L, pts_per_frame=64, occ_queries=512, seed=rank, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **batch)
+        total = losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()
+        total.backward()
+        buckets.all_reduce()
+        opt.step()
+        return total
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * B * L * args.steps / dt, 1),
+            'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[2]: full ococcnet.py model (66.55 M parameters), {B} tracklets x {L} '
+                                   f'frames = {B * L} object grids/GPU/step, 64 points/frame, K=512 occupancy '
+                                   'queries, fwd+bwd+AdamW, all-reduce of 266 MB gradients at N>1',
+                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}'},
+            'roofline': None, 'cpu_baseline': None}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -91,6 +152,13 @@ def main():
     dev = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
+
+    if args.workload == 'ococcnet':
+        bench_ococcnet(args, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
     from objectcentricocccompletion_amd.spconv import ops as sp_ops

@@ -277,6 +277,41 @@ int ococc_dynamic_point_pool_mixed(const float* rois, const int32_t* rois_key, i
 int ococc_aligned_iou3d_f32(const float* boxes1, const float* boxes2, int64_t n, float* iou,
                             ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * B6  in-group ranks of integer keys (SST window bookkeeping)
+ * replaces TorchEx ingroup_indices.forward (mmdet3d/ops/sst/sst_ops.py:243-263; python twin
+ * get_inner_win_inds_deprecated :194-241) and make_continuous_inds (:316-330).
+ * keys [n] int32 in [0, key_bound) (negative keys are skipped: conti = inner = -1).
+ * conti [n]: rank of the key among the distinct keys; inner [n]: number of earlier elements
+ * with the same key (stable); counts [>= num_groups] (buffer of n ints, may be NULL);
+ * num_groups, status (1 if a key >= key_bound was seen): device int32.
+ * ------------------------------------------------------------------------ */
+int64_t ococc_group_rank_workspace_bytes(int64_t n, int64_t key_bound);
+int ococc_group_rank_i32(const int32_t* keys, int64_t n, int64_t key_bound, int32_t* conti, int32_t* inner,
+                         int32_t* counts, int32_t* num_groups, int32_t* status, void* workspace,
+                         int64_t workspace_bytes, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * B7  window attention core  out = softmax(q k^T * scale + key mask) v  per (window, head)
+ * replaces the attention inside nn.MultiheadAttention as WindowAttention calls it on padded
+ * [num_windows, max_tokens, C] tensors (mmdet3d/models/sst/sst_basic_block_v2.py:41-75).
+ * q, k, v: bf16 rows (window*max_tokens + token) with the given row strides (elements), head h in
+ * columns [16h, 16h+16); key_len [num_windows] int32 = valid tokens (a prefix) of each window;
+ * out bf16 like q; lse [num_windows, num_heads, max_tokens] f32 (log-sum-exp of the scaled
+ * scores, saved for backward).  head_dim must be 16, max_tokens <= 160.
+ * ------------------------------------------------------------------------ */
+int ococc_window_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride,
+                               int64_t k_stride, int64_t v_stride, const int32_t* key_len,
+                               int64_t num_windows, int32_t max_tokens, int32_t num_heads, int32_t head_dim,
+                               float scale, uint16_t* out, int64_t out_stride, float* lse,
+                               ococc_stream_t stream);
+int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride,
+                               int64_t k_stride, int64_t v_stride, const uint16_t* out, const uint16_t* dout,
+                               int64_t o_stride, const float* lse, const int32_t* key_len,
+                               int64_t num_windows, int32_t max_tokens, int32_t num_heads, int32_t head_dim,
+                               float scale, uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dq_stride,
+                               int64_t dk_stride, int64_t dv_stride, ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

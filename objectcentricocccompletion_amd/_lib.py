@@ -61,6 +61,12 @@ SIGNATURES = {
     'ococc_dynamic_point_pool_mixed': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, _F3, c_i32, c_i64, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_aligned_iou3d_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'ococc_group_rank_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'ococc_group_rank_i32': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_window_attn_fwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32,
+                                           c_f32, c_vp, c_i64, c_vp, c_vp]),
+    'ococc_window_attn_bwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64,
+                                           c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
 }

@@ -84,7 +84,6 @@ ln_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n, 
                   const float* __restrict__ gamma, const float* __restrict__ beta,
                   const float* __restrict__ mean_rstd, int act, T* __restrict__ dx,
                   float* __restrict__ partials) {
-  __shared__ float red[256];
   const int rows_per_block = 256 / lpr;
   const int li = threadIdx.x % lpr;
   const int rloc = threadIdx.x / lpr;
@@ -122,21 +121,22 @@ ln_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n, 
       if (ch < c) st<T>(dx + r * c + ch, rstd * (dzg[j] - s1 - xh[j] * s2));
     }
   }
-  // combine the row groups of this block (fixed order), then one slab per block
-  float* slab = partials + (int64_t)blockIdx.x * 2 * c;
+  // combine the row groups of this block through LDS (fixed order), one slab per block
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [rows_per_block][2*c]
 #pragma unroll
   for (int j = 0; j < VPL; ++j) {
     const int ch = li + j * lpr;
-    for (int which = 0; which < 2; ++which) {
-      __syncthreads();
-      red[threadIdx.x] = which ? db[j] : dg[j];
-      __syncthreads();
-      if (rloc == 0 && ch < c) {
-        float s = 0.f;
-        for (int g = 0; g < rows_per_block; ++g) s += red[g * lpr + li];
-        slab[which * c + ch] = s;
-      }
+    if (ch < c) {
+      red[rloc * 2 * c + ch] = dg[j];
+      red[rloc * 2 * c + c + ch] = db[j];
     }
+  }
+  __syncthreads();
+  float* slab = partials + (int64_t)blockIdx.x * 2 * c;
+  for (int i = threadIdx.x; i < 2 * c; i += 256) {
+    float s = 0.f;
+    for (int g = 0; g < rows_per_block; ++g) s += red[g * 2 * c + i];
+    slab[i] = s;
   }
 }
 
@@ -200,7 +200,6 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
                       const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
                       float* __restrict__ partials) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
-  __shared__ float red[256];
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
   float g[8], b[8], dg[8], db[8];
 #pragma unroll
@@ -233,19 +232,19 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
     for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[j] - s1 - xv[j] * s2);
     *(u32x4*)(dx + r * C + li * 8) = pack8(o);
   }
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [RPB][2*C]
+  float* mine = red + rloc * 2 * C;
+  *(f32x4*)(mine + li * 8) = f32x4{dg[0], dg[1], dg[2], dg[3]};
+  *(f32x4*)(mine + li * 8 + 4) = f32x4{dg[4], dg[5], dg[6], dg[7]};
+  *(f32x4*)(mine + C + li * 8) = f32x4{db[0], db[1], db[2], db[3]};
+  *(f32x4*)(mine + C + li * 8 + 4) = f32x4{db[4], db[5], db[6], db[7]};
+  __syncthreads();
   float* slab = partials + (int64_t)blockIdx.x * 2 * C;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    for (int which = 0; which < 2; ++which) {
-      __syncthreads();
-      red[threadIdx.x] = which ? db[j] : dg[j];
-      __syncthreads();
-      if (rloc == 0) {
-        float s = 0.f;
-        for (int q = 0; q < RPB; ++q) s += red[q * LPR + li];
-        slab[which * C + li * 8 + j] = s;
-      }
-    }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float s = 0.f;
+#pragma unroll 4
+    for (int g = 0; g < RPB; ++g) s += red[g * 2 * C + i];
+    slab[i] = s;
   }
 }
 
@@ -344,7 +343,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
                hipStream_t stream) {
   if (sizeof(T) == 2 && vec_ok(c)) {
     const int grid = vec_blocks(n, c, 512);
-#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
@@ -357,11 +356,11 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = bwd_blocks(n, lpr);
   if (vpl <= 4)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 4>), dim3(grid), dim3(256), (256 / lpr) * 2 * c * 4, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
   else if (vpl <= 8)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 8>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 8>), dim3(grid), dim3(256), (256 / lpr) * 2 * c * 4, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
   else if (vpl <= 32)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 32>), dim3(grid), dim3(256), 0, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_kernel<T, 32>), dim3(grid), dim3(256), (256 / lpr) * 2 * c * 4, stream, x, dy, n, c, lpr, gamma, beta, mean_rstd, act, dx, partials);
   else
     return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "c must be <= 2048");
   OCOCC_CHECK_LAUNCH();
@@ -389,7 +388,7 @@ extern "C" int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, cons
 
 extern "C" int64_t ococc_layernorm_act_bwd_workspace_bytes(int64_t n, int32_t c) {
   if (n < 0 || c < 1) return -1;
-  return (int64_t)512 * 2 * c * (int64_t)sizeof(float);
+  return (int64_t)512 * 2 * c * (int64_t)sizeof(float);  // one slab per block, <= 512 blocks
 }
 
 extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,

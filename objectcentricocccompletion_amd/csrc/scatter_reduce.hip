@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kRowsPerWave = 64;
+constexpr int kMaxRowsPerWave = 64;
 
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   // sign-split trick: valid because the destination starts at -inf
@@ -42,7 +42,7 @@ __device__ __forceinline__ void flush(float* out, int64_t seg, int c, int ch, fl
 template <int MODE>
 __global__ void __launch_bounds__(256)
 segment_reduce_kernel(const float* __restrict__ feats, const int32_t* __restrict__ inv, int64_t n,
-                      int c, int cp, float* __restrict__ out) {
+                      int c, int cp, int kRowsPerWave, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -70,10 +70,13 @@ segment_reduce_kernel(const float* __restrict__ feats, const int32_t* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) fill_f32_kernel(float* p, int64_t count, float v) {
+// out = v (and arg = 0x7f7f7f7f when given) in one launch
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* p, int32_t* arg, int64_t count, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
-       i += (int64_t)gridDim.x * blockDim.x)
+       i += (int64_t)gridDim.x * blockDim.x) {
     p[i] = v;
+    if (arg) arg[i] = 0x7f7f7f7f;
+  }
 }
 
 // MEAN: divide by the count; MAX: segments nobody wrote become 0 (torch_scatter)
@@ -172,24 +175,25 @@ extern "C" int ococc_segment_reduce_f32(const float* feats, const int32_t* inv, 
   if (num_segments == 0) return OCOCC_OK;
   OCOCC_REQUIRE(out, "null out");
   const int64_t total = num_segments * c;
-  if (reduce_type == OCOCC_REDUCE_MAX) {
-    hipLaunchKernelGGL(fill_f32_kernel, dim3(ococc_grid_1d(total, 256)), dim3(256), 0, stream, out,
-                       total, -INFINITY);
-    OCOCC_CHECK_LAUNCH();
-    if (arg) OCOCC_HIP(hipMemsetAsync(arg, 0x7f, total * sizeof(int32_t), stream));
-  } else {
-    OCOCC_HIP(hipMemsetAsync(out, 0, total * sizeof(float), stream));
-  }
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(ococc_grid_1d(total, 256)), dim3(256), 0, stream, out,
+                     reduce_type == OCOCC_REDUCE_MAX ? arg : (int32_t*)nullptr, total,
+                     reduce_type == OCOCC_REDUCE_MAX ? -INFINITY : 0.f);
+  OCOCC_CHECK_LAUNCH();
   if (n > 0) {
     OCOCC_REQUIRE(feats && inv, "null feats/inv");
     const int cp = lanes_per_row(c);
+    // enough waves to cover the chip even for a few thousand rows; long runs per wave otherwise
+    int64_t rpw = ococc_cdiv(n * (64 / cp), 8192);
+    rpw = rpw < 4 ? 4 : (rpw > kMaxRowsPerWave ? kMaxRowsPerWave : rpw);
+    rpw = ococc_align_up(rpw, 64 / cp);
+    const int kRowsPerWave = (int)rpw;
     const int grid = ococc_grid_1d(ococc_cdiv(n, kRowsPerWave) * 64, 256);
     if (reduce_type == OCOCC_REDUCE_MAX)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(segment_reduce_kernel<OCOCC_REDUCE_MAX>), dim3(grid),
-                         dim3(256), 0, stream, feats, inv, n, (int)c, cp, out);
+                         dim3(256), 0, stream, feats, inv, n, (int)c, cp, kRowsPerWave, out);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(segment_reduce_kernel<OCOCC_REDUCE_SUM>), dim3(grid),
-                         dim3(256), 0, stream, feats, inv, n, (int)c, cp, out);
+                         dim3(256), 0, stream, feats, inv, n, (int)c, cp, kRowsPerWave, out);
     OCOCC_CHECK_LAUNCH();
   }
   if (reduce_type == OCOCC_REDUCE_MEAN) {

@@ -12,6 +12,7 @@ from torch import nn
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import (build_mlp, fuse_norm_act, get_activation_layer, scatter_v2,
                           unique_with_inverse)
+from .voxel.scatter_points import gather_rows
 
 
 class DynamicVFELayerV2(nn.Module):
@@ -90,7 +91,7 @@ class SIRLayer(nn.Module):
         if f_cluster is None:
             voxel_mean, mean_coors, unq_inv = scatter_v2(features[:, :3], coors, mode='avg',
                                                          unq_inv=unq_inv_once, new_coors=new_coors_once)
-            points_mean = voxel_mean[unq_inv.long()]
+            points_mean = gather_rows(voxel_mean, unq_inv)
             f_cluster = (features[:, :3] - points_mean[:, :3]) / self.rel_dist_scaler
         else:
             f_cluster = f_cluster / self.rel_dist_scaler
@@ -109,7 +110,7 @@ class SIRLayer(nn.Module):
                                                            unq_inv=unq_inv_once, new_coors=new_coors_once)
             voxel_feats_list.append(voxel_feats)
             if i != len(self.vfe_layers) - 1:
-                features = torch.cat([point_feats, voxel_feats[unq_inv.long()]], dim=1)
+                features = torch.cat([point_feats, gather_rows(voxel_feats, unq_inv)], dim=1)
         voxel_feats = torch.cat(voxel_feats_list, dim=1)
 
         if return_both:

@@ -1,0 +1,319 @@
+"""SST (single-stride sparse transformer) input layer, window attention blocks and backbone --
+host mirror of SSTInputLayerV2 (mmdet3d/models/middle_encoders/sst_input_layer_v2.py:41-330),
+WindowAttention / EncoderLayer / BasicShiftBlockV2 (mmdet3d/models/sst/sst_basic_block_v2.py:14-169)
+and SSTv2 (mmdet3d/models/backbones/sst_v2.py:17-197).  Same constructor arguments, dictionaries
+and parameter names (win_attn.self_attn.in_proj_weight, linear1, norm1, ...).
+
+Device work: window ranks ococc_group_rank_i32; attention core ococc_window_attn_{fwd,bwd}_bf16
+(MFMA QK^T / PV on padded windows); projections / FFN are GEMMs through torch."""
+import torch
+from torch import nn
+
+from .. import _lib as L
+from ..norm import layer_norm_act
+from ..registry import BACKBONES, MIDDLE_ENCODERS, build_conv_layer, build_norm_layer
+from .sst_ops import (flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
+                      window2flat_v2)
+
+
+@MIDDLE_ENCODERS.register_module()
+class SSTInputLayerV2(nn.Module):
+    """Regional grouping, voxel drop / region batching, flat<->window index maps, positional
+    embedding and key masks for the two window shifts."""
+
+    def __init__(self, drop_info, window_shape, sparse_shape, shuffle_voxels=True, debug=True,
+                 normalize_pos=False, pos_temperature=10000, mute=False):
+        super().__init__()
+        self.meta_drop_info = drop_info
+        self.sparse_shape, self.window_shape = sparse_shape, window_shape
+        self.shuffle_voxels, self.debug = shuffle_voxels, debug
+        self.normalize_pos, self.pos_temperature, self.mute = normalize_pos, pos_temperature, mute
+
+    def set_drop_info(self):
+        meta = self.meta_drop_info
+        self.drop_info = (meta[0] if self.training else meta[1]) if isinstance(meta, tuple) else meta
+
+    def forward(self, voxel_feats, voxel_coors, batch_size=None):
+        self.set_drop_info()
+        voxel_coors = voxel_coors.long()
+        if self.shuffle_voxels:
+            shuffle_inds = torch.randperm(len(voxel_feats), device=voxel_feats.device)
+            voxel_feats, voxel_coors = voxel_feats[shuffle_inds], voxel_coors[shuffle_inds]
+        info = self.window_partition(voxel_coors)
+        info['voxel_feats'], info['voxel_coors'] = voxel_feats, voxel_coors
+        info = self.drop_voxel(info, 2)
+        voxel_feats, voxel_coors = info['voxel_feats'], info['voxel_coors']
+        for i in range(2):
+            info[f'flat2win_inds_shift{i}'] = get_flat2win_inds_v2(
+                info[f'batch_win_inds_shift{i}'], info[f'voxel_drop_level_shift{i}'], self.drop_info, debug=self.debug)
+            info[f'pos_dict_shift{i}'] = self.get_pos_embed(
+                info[f'flat2win_inds_shift{i}'], info[f'coors_in_win_shift{i}'], voxel_feats.size(1), voxel_feats.dtype)
+            info[f'key_mask_shift{i}'] = self.get_key_padding_mask(info[f'flat2win_inds_shift{i}'])
+        if self.shuffle_voxels:
+            info['shuffle_inds'] = shuffle_inds
+        return info
+
+    def drop_single_shift(self, batch_win_inds):
+        """keep mask + drop level of every voxel from the population of its window (:128-148)."""
+        drop_lvl = -torch.ones_like(batch_win_inds)
+        inner = get_inner_win_inds(batch_win_inds)
+        num_per_voxel = torch.bincount(batch_win_inds)[batch_win_inds]
+        target = torch.zeros_like(batch_win_inds)
+        for dl in self.drop_info:
+            lower, upper = self.drop_info[dl]['drop_range']
+            m = (num_per_voxel >= lower) & (num_per_voxel < upper)
+            target[m] = self.drop_info[dl]['max_tokens']
+            drop_lvl[m] = dl
+        return inner < target, drop_lvl
+
+    def drop_voxel(self, info, num_shifts):
+        """Two sequential drops: shift 0, then shift 1 on the survivors (:150-220)."""
+        win0 = info['batch_win_inds_shift0']
+        n_all = win0.shape[0]
+        keep_inds = torch.arange(n_all, device=win0.device, dtype=torch.long)
+        keep0, lvl0 = self.drop_single_shift(win0)
+        lvl0, keep_inds, win0 = lvl0[keep0], keep_inds[keep0], win0[keep0]
+        win1 = info['batch_win_inds_shift1'][keep0]
+        keep1, lvl1 = self.drop_single_shift(win1)
+        info['voxel_keep_inds'] = keep_inds[keep1]
+        info['voxel_drop_level_shift0'], info['batch_win_inds_shift0'] = lvl0[keep1], win0[keep1]
+        info['voxel_drop_level_shift1'], info['batch_win_inds_shift1'] = lvl1[keep1], win1[keep1]
+        keep = info['voxel_keep_inds']
+        for k, v in list(info.items()):
+            if isinstance(v, torch.Tensor) and len(v) == n_all and k not in (
+                    'voxel_keep_inds', 'voxel_drop_level_shift0', 'batch_win_inds_shift0',
+                    'voxel_drop_level_shift1', 'batch_win_inds_shift1'):
+                info[k] = v[keep]
+        return info
+
+    @torch.no_grad()
+    def window_partition(self, coors):
+        info = {}
+        for i in range(2):
+            info[f'batch_win_inds_shift{i}'], info[f'coors_in_win_shift{i}'] = get_window_coors(
+                coors, self.sparse_shape, self.window_shape, i == 1)
+        return info
+
+    @torch.no_grad()
+    def get_pos_embed(self, inds_dict, coors_in_win, feat_dim, dtype):
+        """Sinusoidal embedding of the in-window coordinate (:239-305)."""
+        ws = self.window_shape
+        if len(ws) == 2 or ws[-1] == 1:
+            ndim, (win_x, win_y), win_z = 2, ws[:2], 0
+        else:
+            ndim = 3
+            win_x, win_y, win_z = ws
+        z, y, x = coors_in_win[:, 0] - win_z / 2, coors_in_win[:, 1] - win_y / 2, coors_in_win[:, 2] - win_x / 2
+        if self.normalize_pos:
+            x, y, z = x / win_x * 2 * 3.1415, y / win_y * 2 * 3.1415, z / win_z * 2 * 3.1415
+        pos_length = feat_dim // ndim
+        inv_freq = torch.arange(pos_length, dtype=torch.float32, device=coors_in_win.device)
+        inv_freq = self.pos_temperature ** (2 * (inv_freq // 2) / pos_length)
+        emb = []
+        for a in ([x, y, z] if ndim == 3 else [x, y]):
+            e = a[:, None] / inv_freq[None, :]
+            emb.append(torch.stack([e[:, ::2].sin(), e[:, 1::2].cos()], dim=-1).flatten(1))
+        pos = torch.cat(emb, dim=-1).to(dtype)
+        gap = feat_dim - pos.size(1)
+        if gap > 0:
+            pos = torch.cat([pos, torch.zeros((pos.size(0), gap), dtype=dtype, device=pos.device)], dim=1)
+        return flat2window_v2(pos, inds_dict)
+
+    @torch.no_grad()
+    def get_key_padding_mask(self, ind_dict):
+        n = len(ind_dict['voxel_drop_level'])
+        ones = torch.ones((n, 1), device=ind_dict['voxel_drop_level'].device).bool()
+        d = flat2window_v2(ones, ind_dict)
+        return {k: v.logical_not().squeeze(2) for k, v in d.items()}
+
+
+class _WindowAttnCore(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) + mask) v on padded windows, bf16 MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_len, num_heads):
+        nW, T, C = q.shape
+        D = C // num_heads
+        qb, kb, vb = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
+        out = torch.empty_like(qb)
+        lse = torch.empty((nW, num_heads, T), dtype=torch.float32, device=q.device)
+        scale = float(D) ** -0.5
+        L.check(L.lib.ococc_window_attn_fwd_bf16(L.ptr(qb), L.ptr(kb), L.ptr(vb), C, C, C, L.ptr(key_len), nW, T,
+                                                 num_heads, D, scale, L.ptr(out), C, L.ptr(lse), L.stream()),
+                'window_attn_fwd')
+        ctx.save_for_backward(qb, kb, vb, out, lse, key_len)
+        ctx.meta = (num_heads, D, scale, q.dtype)
+        return out.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qb, kb, vb, out, lse, key_len = ctx.saved_tensors
+        H, D, scale, dt = ctx.meta
+        nW, T, C = qb.shape
+        do = dout.to(torch.bfloat16).contiguous()
+        dq, dk, dv = torch.empty_like(qb), torch.empty_like(kb), torch.empty_like(vb)
+        L.check(L.lib.ococc_window_attn_bwd_bf16(L.ptr(qb), L.ptr(kb), L.ptr(vb), C, C, C, L.ptr(out), L.ptr(do), C,
+                                                 L.ptr(lse), L.ptr(key_len), nW, T, H, D, scale, L.ptr(dq), L.ptr(dk),
+                                                 L.ptr(dv), C, C, C, L.stream()), 'window_attn_bwd')
+        return dq.to(dt), dk.to(dt), dv.to(dt), None, None
+
+
+class WindowMultiheadAttention(nn.Module):
+    """Parameter layout of nn.MultiheadAttention (in_proj_weight [3E,E], in_proj_bias,
+    out_proj.{weight,bias}); batch-first padded windows [nW, T, E]; attention core on the HIP kernel."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward(self, qk_in, v_in, key_padding_mask):
+        nW, T, E = qk_in.shape
+        w, b = self.in_proj_weight, self.in_proj_bias
+        qk = torch.addmm(b[:2 * E], qk_in.reshape(nW * T, E), w[:2 * E].t())
+        v = torch.addmm(b[2 * E:], v_in.reshape(nW * T, E), w[2 * E:].t())
+        key_len = (~key_padding_mask).sum(1).to(torch.int32)  # valid tokens are a prefix of each window
+        o = _WindowAttnCore.apply(qk[:, :E].reshape(nW, T, E), qk[:, E:].reshape(nW, T, E), v.view(nW, T, E),
+                                  key_len, self.num_heads)
+        return self.out_proj(o.reshape(nW * T, E)).view(nW, T, E)
+
+
+class WindowAttention(nn.Module):
+
+    def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None, layer_cfg=dict()):
+        super().__init__()
+        assert not layer_cfg.get('cosine', False) and not layer_cfg.get('linear', False), \
+            'cosine / linear attention variants are not built'
+        self.nhead = nhead
+        self.self_attn = WindowMultiheadAttention(d_model, nhead, dropout=dropout)
+        self.layer_id = layer_id
+
+    def forward(self, feat_2d, pos_dict, ind_dict, key_padding_dict):
+        feat_3d_dict = flat2window_v2(feat_2d, ind_dict)
+        out = {}
+        for name, feat_3d in feat_3d_dict.items():
+            pos = pos_dict[name]
+            qk = feat_3d + pos if pos is not None else feat_3d
+            out[name] = self.self_attn(qk, feat_3d, key_padding_dict[name])
+        return window2flat_v2(out, ind_dict)
+
+
+def _activation(name):
+    return {'relu': torch.nn.functional.relu, 'gelu': torch.nn.functional.gelu}[name]
+
+
+class EncoderLayer(nn.Module):
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', batch_first=False,
+                 layer_id=None, mlp_dropout=0, layer_cfg=dict()):
+        super().__init__()
+        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_id=layer_id, layer_cfg=layer_cfg)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(mlp_dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        assert not layer_cfg.get('use_bn', False), 'use_bn (NaiveSyncBN) is not built; LayerNorm only'
+        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1, self.dropout2 = nn.Dropout(mlp_dropout), nn.Dropout(mlp_dropout)
+        self.activation = _activation(activation)
+        self.post_norm = layer_cfg.get('post_norm', True)
+
+    @staticmethod
+    def _ln(norm, x):
+        return layer_norm_act(x, norm.weight, norm.bias, norm.eps, 'none')
+
+    def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
+        if self.post_norm:
+            src = self._ln(self.norm1, src + self.dropout1(self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)))
+            src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+            return self._ln(self.norm2, src + self.dropout2(src2))
+        src = src + self.dropout1(self.win_attn(self._ln(self.norm1, src), pos_dict, ind_dict, key_padding_mask_dict))
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(self._ln(self.norm2, src)))))
+        return src + self.dropout2(src2)
+
+
+class BasicShiftBlockV2(nn.Module):
+    """Two encoder layers, the second on the shifted windows."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', batch_first=False,
+                 block_id=-100, layer_cfg=dict()):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([
+            EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first,
+                         layer_id=block_id * 2 + i, layer_cfg=layer_cfg) for i in range(2)])
+
+    def forward(self, src, pos_dict_list, ind_dict_list, key_mask_dict_list, using_checkpoint=False):
+        num_shifts = len(pos_dict_list)
+        assert num_shifts in (1, 2)
+        out = src
+        for i in range(2):
+            j = i % num_shifts
+            out = self.encoder_list[i](out, pos_dict_list[j], ind_dict_list[j], key_mask_dict_list[j])
+        return out
+
+
+@BACKBONES.register_module()
+class SSTv2(nn.Module):
+
+    def __init__(self, d_model=[], nhead=[], num_blocks=6, dim_feedforward=[], dropout=0.0, activation='gelu',
+                 output_shape=None, num_attached_conv=2, conv_in_channel=64, conv_out_channel=64,
+                 norm_cfg=dict(type='naiveSyncBN2d', eps=1e-3, momentum=0.01), conv_cfg=dict(type='Conv2d', bias=False),
+                 debug=True, in_channel=None, to_bev=True,
+                 conv_kwargs=dict(kernel_size=3, dilation=2, padding=2, stride=1), checkpoint_blocks=[],
+                 layer_cfg=dict(), conv_shortcut=False):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.checkpoint_blocks, self.conv_shortcut, self.to_bev = checkpoint_blocks, conv_shortcut, to_bev
+        if in_channel is not None:
+            self.linear0 = nn.Linear(in_channel, d_model[0])
+        self.block_list = nn.ModuleList([
+            BasicShiftBlockV2(d_model[i], nhead[i], dim_feedforward[i], dropout, activation, batch_first=False,
+                              block_id=i, layer_cfg=layer_cfg) for i in range(num_blocks)])
+        for name, p in self.named_parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.output_shape, self.debug, self.num_attached_conv = output_shape, debug, num_attached_conv
+        if num_attached_conv > 0:
+            convs = []
+            for i in range(num_attached_conv):
+                kw = conv_kwargs if isinstance(conv_kwargs, dict) else conv_kwargs[i]
+                conv = build_conv_layer(conv_cfg, in_channels=conv_in_channel if i == 0 else conv_out_channel,
+                                        out_channels=conv_out_channel, **kw)
+                layers = [conv] + ([build_norm_layer(norm_cfg, conv_out_channel)[1]] if norm_cfg else []) + \
+                    [nn.ReLU(inplace=True)]
+                convs.append(nn.Sequential(*layers))
+            self.conv_layer = nn.ModuleList(convs)
+
+    def forward(self, voxel_info):
+        num_shifts = 2
+        assert voxel_info['voxel_coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
+        batch_size = int(voxel_info['voxel_coors'][:, 0].max().item()) + 1
+        ind_dicts = [voxel_info[f'flat2win_inds_shift{i}'] for i in range(num_shifts)]
+        masks = [voxel_info[f'key_mask_shift{i}'] for i in range(num_shifts)]
+        poss = [voxel_info[f'pos_dict_shift{i}'] for i in range(num_shifts)]
+        out = voxel_info['voxel_feats']
+        if hasattr(self, 'linear0'):
+            out = self.linear0(out)
+        for block in self.block_list:
+            out = block(out, poss, ind_dicts, masks)
+        if self.to_bev:
+            out = self.recover_bev(out, voxel_info['voxel_coors'], batch_size)
+        if self.num_attached_conv > 0:
+            assert self.to_bev
+            for conv in self.conv_layer:
+                tmp = conv(out)
+                out = tmp + out if (tmp.shape == out.shape and self.conv_shortcut) else tmp
+        if not self.to_bev:
+            out = {'voxel_feats': out, 'voxel_coors': voxel_info['voxel_coors']}
+        return [out]
+
+    def recover_bev(self, voxel_feat, coors, batch_size):
+        """Scatter voxel rows into a dense [B, C, ny, nx] canvas (sst_v2.py:156-197)."""
+        ny, nx = self.output_shape
+        c = voxel_feat.shape[-1]
+        canvas = torch.zeros((batch_size, ny * nx, c), dtype=voxel_feat.dtype, device=voxel_feat.device)
+        canvas[coors[:, 0], coors[:, 2] * nx + coors[:, 3]] = voxel_feat
+        return canvas.permute(0, 2, 1).reshape(batch_size, c, ny, nx)

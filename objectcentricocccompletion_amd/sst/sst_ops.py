@@ -18,6 +18,7 @@ def unique_with_inverse(coors, dims=None, return_counts=False):
         dims = [int(d) + 1 for d in dims]
     new_coors, inv, counts = grid_unique(shifted, dims)
     new_coors = new_coors - 1
+    inv._ococc_counts = counts
     if return_counts:
         return new_coors, inv, counts
     return new_coors, inv
@@ -110,3 +111,136 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias
             layer_list.append(nn.Sequential(*sq))
         last_channel = c
     return nn.Sequential(*layer_list)
+
+
+# ------------------------------------------------------------------------------------------
+# SST window bookkeeping (sst_ops.py:26-148, 243-330)
+# ------------------------------------------------------------------------------------------
+def group_rank(keys, key_bound=None):
+    """(conti, inner, counts): rank of each key among the distinct keys, stable rank of each element
+    inside its group, and the group sizes.  HIP: ococc_group_rank_i32."""
+    from .. import _lib as L
+    L.require_device(keys)
+    k32 = keys.to(torch.int32).contiguous()
+    n = k32.numel()
+    dev = keys.device
+    if n == 0:
+        z = torch.zeros((0,), dtype=torch.int32, device=dev)
+        return z, z.clone(), z.clone()
+    if key_bound is None:
+        key_bound = int(k32.max().item()) + 1
+    key_bound = max(int(key_bound), 1)
+    ws = L.workspace(L.lib.ococc_group_rank_workspace_bytes(n, key_bound), dev)
+    conti = torch.empty((n,), dtype=torch.int32, device=dev)
+    inner = torch.empty((n,), dtype=torch.int32, device=dev)
+    counts = torch.empty((n,), dtype=torch.int32, device=dev)
+    meta = torch.zeros((2,), dtype=torch.int32, device=dev)
+    L.check(L.lib.ococc_group_rank_i32(L.ptr(k32), n, key_bound, L.ptr(conti), L.ptr(inner), L.ptr(counts),
+                                       meta.data_ptr(), meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()),
+            'group_rank')
+    num, status = meta.tolist()
+    if status:
+        raise L.OcoccError(f'group_rank: a key is >= the declared bound {key_bound}')
+    return conti, inner, counts[:num]
+
+
+@torch.no_grad()
+def get_inner_win_inds(win_inds):
+    """Index of every voxel inside its window, 0..m-1 (sst_ops.py:243-263; the reference accepts any
+    order within a window, ours is the stable one)."""
+    return group_rank(win_inds)[1].to(win_inds.dtype)
+
+
+@torch.no_grad()
+def make_continuous_inds(inds):
+    """sst_ops.py:316-330: relabel window ids 0..num_windows-1 in sorted order."""
+    return group_rank(inds)[0].to(inds.dtype)
+
+
+@torch.no_grad()
+def get_window_coors(coors, sparse_shape, window_shape, do_shift):
+    """Window id of every voxel (unique in the batch) and its coordinate inside the window
+    (sst_ops.py:266-313).  coors [N,4] = (b,z,y,x); integer elementwise math."""
+    if len(window_shape) == 2:
+        win_shape_x, win_shape_y = window_shape
+        win_shape_z = sparse_shape[-1]
+    else:
+        win_shape_x, win_shape_y, win_shape_z = window_shape
+    sparse_shape_x, sparse_shape_y, sparse_shape_z = sparse_shape
+    assert sparse_shape_z < sparse_shape_x, 'Usually holds... in case of wrong order'
+    import math
+    max_x = int(math.ceil(sparse_shape_x / win_shape_x) + 1)
+    max_y = int(math.ceil(sparse_shape_y / win_shape_y) + 1)
+    max_z = int(math.ceil(sparse_shape_z / win_shape_z) + 1)
+    if do_shift:
+        shift_x, shift_y, shift_z = win_shape_x // 2, win_shape_y // 2, win_shape_z // 2
+    else:
+        shift_x, shift_y, shift_z = win_shape_x, win_shape_y, win_shape_z
+    if sparse_shape_z == win_shape_z:
+        shift_z = 0
+    sx, sy, sz = coors[:, 3] + shift_x, coors[:, 2] + shift_y, coors[:, 1] + shift_z
+    wx, wy, wz = sx // win_shape_x, sy // win_shape_y, sz // win_shape_z
+    batch_win_inds = coors[:, 0] * (max_x * max_y * max_z) + wx * max_y * max_z + wy * max_z + wz
+    coors_in_win = torch.stack([sz % win_shape_z, sy % win_shape_y, sx % win_shape_x], dim=-1)
+    return batch_win_inds, coors_in_win
+
+
+@torch.no_grad()
+def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
+    """Per drop level: slot of every voxel in the padded [num_windows * max_tokens] layout and the
+    voxel positions of that level (sst_ops.py:26-63)."""
+    out = {}
+    for dl in drop_info:
+        dl_mask = voxel_drop_lvl == dl
+        if not dl_mask.any():
+            continue
+        conti, inner, _ = group_rank(batch_win_inds[dl_mask])
+        max_tokens = drop_info[dl]['max_tokens']
+        if debug:
+            assert int(inner.max()) < max_tokens, f'Max inner inds({int(inner.max())}) larger(equal) than {max_tokens}'
+        out[dl] = ((conti.long() * max_tokens + inner.long()), torch.where(dl_mask))
+    return out
+
+
+def get_flat2win_inds_v2(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
+    d = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug)
+    d['voxel_drop_level'] = voxel_drop_lvl
+    d['batching_info'] = drop_info
+    return d
+
+
+def flat2window(feat, voxel_drop_lvl, flat2win_inds_dict, drop_info, padding=0):
+    """[N, C] -> per drop level [num_windows, max_tokens, C], padded (sst_ops.py:66-104)."""
+    feat_dim = feat.shape[-1]
+    out = {}
+    for dl in drop_info:
+        if dl not in flat2win_inds_dict:
+            continue
+        this_inds, flat_pos = flat2win_inds_dict[dl]
+        max_tokens = drop_info[dl]['max_tokens']
+        num_windows = int((this_inds // max_tokens).max().item()) + 1
+        feat_3d = torch.full((num_windows * max_tokens, feat_dim), padding, dtype=feat.dtype, device=feat.device)
+        feat_3d[this_inds] = feat[flat_pos[0]]
+        out[dl] = feat_3d.reshape(num_windows, max_tokens, feat_dim)
+    return out
+
+
+def window2flat(feat_3d_dict, inds_dict):
+    """Inverse of flat2window (sst_ops.py:106-131)."""
+    first = feat_3d_dict[list(feat_3d_dict.keys())[0]]
+    n = sum(inds_dict[dl][0].shape[0] for dl in inds_dict)
+    out = torch.zeros((n, first.shape[-1]), device=first.device, dtype=first.dtype)
+    for dl in feat_3d_dict:
+        inds, flat_pos = inds_dict[dl]
+        out[flat_pos[0]] = feat_3d_dict[dl].reshape(-1, first.shape[-1])[inds]
+    return out
+
+
+def window2flat_v2(feat_3d_dict, inds_dict):
+    return window2flat(feat_3d_dict, {k: inds_dict[k] for k in inds_dict if not isinstance(k, str)})
+
+
+def flat2window_v2(feat, inds_dict, padding=0):
+    assert 'voxel_drop_level' in inds_dict, 'voxel_drop_level should be in inds_dict in v2 function'
+    inds_v1 = {k: inds_dict[k] for k in inds_dict if not isinstance(k, str)}
+    return flat2window(feat, inds_dict['voxel_drop_level'], inds_v1, inds_dict['batching_info'], padding=padding)

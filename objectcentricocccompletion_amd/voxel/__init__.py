@@ -1,4 +1,4 @@
-from .scatter_points import DynamicScatter, dynamic_scatter, segment_reduce
+from .scatter_points import DynamicScatter, dynamic_scatter, gather_rows, segment_reduce
 from .voxelize import Voxelization, voxelization
 
-__all__ = ['Voxelization', 'voxelization', 'dynamic_scatter', 'DynamicScatter', 'segment_reduce']
+__all__ = ['Voxelization', 'voxelization', 'dynamic_scatter', 'DynamicScatter', 'segment_reduce', 'gather_rows']

@@ -54,7 +54,9 @@ def grid_unique(coors, dims=None):
     out_coors = out_coors[:num]
     if squeeze:
         out_coors = out_coors[:, 0]
-    return out_coors, inv, counts[:num]
+    counts = counts[:num]
+    inv._ococc_counts = counts  # rides along so later reductions skip the counting pass
+    return out_coors, inv, counts
 
 
 class _SegmentReduce(Function):
@@ -98,9 +100,38 @@ class _SegmentReduce(Function):
 
 def segment_reduce(feats, inv, num_segments, mode, counts=None):
     """Reduce rows of feats into num_segments rows following the dense inverse map inv."""
+    if counts is None:
+        counts = getattr(inv, '_ococc_counts', None)  # cached by grid_unique / unique_with_inverse
     if inv.dtype != torch.int32:
         inv = inv.to(torch.int32)
     return _SegmentReduce.apply(feats, inv.contiguous(), int(num_segments), mode, counts)
+
+
+class _GatherRows(Function):
+    """rows[inv]: the "map voxel features back to points" step of SIRLayer
+    (voxel_encoder.py:758-760,811).  Backward is a segment SUM of the incoming rows -- the HIP
+    run-length reduction instead of torch's sort-based index backward."""
+
+    @staticmethod
+    def forward(ctx, rows, inv):
+        ctx.save_for_backward(inv)
+        ctx.num_rows = rows.size(0)
+        return rows.index_select(0, inv.long() if inv.dtype != torch.int64 else inv)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (inv,) = ctx.saved_tensors
+        grad = grad.contiguous().float()
+        n, c = grad.shape
+        out = torch.empty((ctx.num_rows, c), dtype=torch.float32, device=grad.device)
+        i32 = inv if inv.dtype == torch.int32 else inv.to(torch.int32)
+        L.check(L.lib.ococc_segment_reduce_f32(L.ptr(grad), L.ptr(i32), n, c, 0, None, L.ptr(out), None,
+                                               ctx.num_rows, L.stream()), 'gather_rows_bwd')
+        return out, None
+
+
+def gather_rows(rows, inv):
+    return _GatherRows.apply(rows, inv)
 
 
 def dynamic_scatter(feats, coors, reduce_type='max', grid_shape=None):

@@ -1,0 +1,127 @@
+"""GPU parity, SST side (B6, B7): window bookkeeping and window attention vs golden vectors from
+the imported reference (tests/golden/sst.npz, oracle/gen_golden_sst.py) and vs torch math."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+DROP = {0: dict(max_tokens=30, drop_range=(0, 30)), 1: dict(max_tokens=60, drop_range=(30, 60)),
+        2: dict(max_tokens=100, drop_range=(60, 100000))}
+SPARSE, WINDOW = (40, 40, 32), (8, 8, 8)
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'sst.npz'))
+
+
+def test_group_rank_vs_numpy(dev):
+    from objectcentricocccompletion_amd.sst import get_inner_win_inds, group_rank, make_continuous_inds
+    rng = np.random.default_rng(0)
+    keys = rng.integers(0, 5000, size=200_000).astype(np.int64) * 7   # sparse key space
+    kt = torch.from_numpy(keys).to(dev)
+    conti, inner, counts = group_rank(kt)
+    uniq, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
+    assert np.array_equal(conti.cpu().numpy(), inv) and np.array_equal(counts.cpu().numpy(), cnt)
+    order = np.argsort(keys, kind='stable')
+    exp = np.empty(len(keys), np.int64)
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    exp[order] = np.arange(len(keys)) - np.repeat(start, cnt)
+    assert np.array_equal(inner.cpu().numpy(), exp)                  # stable rank inside the group
+    assert torch.equal(get_inner_win_inds(kt), inner.long()) and torch.equal(make_continuous_inds(kt), conti.long())
+    c2, i2, n2 = group_rank(torch.zeros(0, dtype=torch.long, device=dev))
+    assert c2.numel() == i2.numel() == n2.numel() == 0
+
+
+def test_input_layer_vs_reference_golden(dev, gold):
+    from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2
+    from objectcentricocccompletion_amd.sst import window2flat_v2, flat2window_v2
+    layer = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=True, mute=True).eval()
+    feats, coors = torch.from_numpy(gold['feats']).to(dev), torch.from_numpy(gold['coors']).to(dev)
+    info = layer(feats, coors)
+    assert len(info['voxel_feats']) == len(feats)
+    for i in range(2):
+        assert np.array_equal(info[f'batch_win_inds_shift{i}'].cpu().numpy(), gold[f'batch_win_inds_shift{i}'])
+        assert np.array_equal(info[f'coors_in_win_shift{i}'].cpu().numpy(), gold[f'coors_in_win_shift{i}'])
+        assert np.array_equal(info[f'voxel_drop_level_shift{i}'].cpu().numpy(), gold[f'drop_level_shift{i}'])
+        ind = info[f'flat2win_inds_shift{i}']
+        pos_flat = window2flat_v2(info[f'pos_dict_shift{i}'], ind)
+        assert np.allclose(pos_flat[::4].cpu().numpy(), gold[f'pos_flat_shift{i}'], atol=1e-5)
+        tokens = np.array([int((~m).sum()) for m in info[f'key_mask_shift{i}'].values()])
+        assert np.array_equal(tokens, gold[f'tokens_per_level_shift{i}'])
+        # round trip of the padded layout and "valid tokens are a prefix of every window"
+        back = window2flat_v2(flat2window_v2(feats, ind), ind)
+        assert torch.equal(back, feats)
+        for m in info[f'key_mask_shift{i}'].values():
+            valid = (~m).long()
+            assert bool((valid[:, 1:] <= valid[:, :-1]).all())
+
+
+def test_window_attention_core_vs_torch(dev):
+    from objectcentricocccompletion_amd.sst.sst_modules import _WindowAttnCore
+    g = torch.Generator().manual_seed(1)
+    for T in (30, 60, 100, 144, 7):
+        nW, H, D = 37, 8, 16
+        q, k, v = (torch.randn(nW, T, H * D, generator=g).to(dev).bfloat16().float().requires_grad_(True) for _ in range(3))
+        key_len = torch.randint(1, T + 1, (nW,), generator=g).to(dev).int()
+        dout = torch.randn(nW, T, H * D, generator=g).to(dev).bfloat16().float()
+        out = _WindowAttnCore.apply(q, k, v, key_len, H)
+        out.backward(dout)
+        qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+        s = torch.einsum('wthd,wshd->whts', qr.view(nW, T, H, D), kr.view(nW, T, H, D)) * D ** -0.5
+        mask = torch.arange(T, device=dev)[None, :] >= key_len[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float('-inf'))
+        ref = torch.einsum('whts,wshd->wthd', torch.softmax(s, -1), vr.view(nW, T, H, D)).reshape(nW, T, H * D)
+        ref.backward(dout.double())
+        qmask = (~mask)[:, :, None]           # padded query rows are discarded by window2flat
+        assert float(((out.detach().double() - ref.detach()) * qmask).abs().max()) < 3e-2
+        for got, exp in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+            # padded queries receive no gradient in the real flow (their dout is zero); mimic that
+            pass
+        # gradient check with dout zeroed on padded queries (the real flow)
+        for t in (q, k, v):
+            t.grad = None
+        out2 = _WindowAttnCore.apply(q, k, v, key_len, H)
+        out2.backward(dout * qmask)
+        qr.grad = kr.grad = vr.grad = None
+        ref2 = torch.einsum('whts,wshd->wthd', torch.softmax(
+            (torch.einsum('wthd,wshd->whts', qr.view(nW, T, H, D), kr.view(nW, T, H, D)) * D ** -0.5)
+            .masked_fill(mask[:, None, None, :], float('-inf')), -1), vr.view(nW, T, H, D)).reshape(nW, T, H * D)
+        ref2.backward((dout * qmask).double())
+        for got, exp in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+            scale = float(exp.abs().max())
+            assert float((got.double() - exp).abs().max()) < 3e-2 * scale, T
+
+
+def test_sst_backbone_vs_reference_golden(dev, gold):
+    from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2, SSTv2
+    layer = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=False, mute=True).eval()
+    model = SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, dropout=0.0,
+                  activation='gelu', num_attached_conv=0, to_bev=False)
+    sd = model.state_dict()
+    ref = dict(zip(gold['param_names'].tolist(), gold['param_shapes'].tolist()))
+    assert set(sd) == set(ref) and all(','.join(map(str, v.shape)) == ref[k] for k, v in sd.items())
+    model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=7))
+    model = model.to(dev).eval()
+    feats, coors = torch.from_numpy(gold['feats']).to(dev), torch.from_numpy(gold['coors']).to(dev)
+    info = layer(feats, coors)
+    with torch.no_grad():
+        one = model.block_list[0].encoder_list[0](feats, info['pos_dict_shift0'], info['flat2win_inds_shift0'],
+                                                  info['key_mask_shift0'])
+        out = model(info)[0]['voxel_feats']
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(one.cpu().numpy(), gold['one_layer']) < 2e-2      # bf16 attention core inside an fp32 block
+    assert rel(out.cpu().numpy(), gold['out']) < 3e-2
+    # training step runs
+    model.train()
+    x = feats.clone().requires_grad_(True)
+    info2 = layer(x, coors)
+    y = model(info2)[0]['voxel_feats']
+    y.pow(2).mean().backward()
+    assert x.grad is not None and bool(torch.isfinite(x.grad).all())
+    assert all(p.grad is not None for p in model.parameters())
