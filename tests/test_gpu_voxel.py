@@ -82,7 +82,8 @@ def test_segment_reduce_fwd_bwd_vs_oracle(dev, mode, c):
     if mode == 'max':
         assert np.array_equal(out.detach().cpu().numpy(), eo)  # exact: integer atomics on bit patterns
     else:
-        assert np.allclose(out.detach().cpu().numpy(), eo, rtol=1e-5, atol=1e-5)
+        # float atomics add run partials in arrival order: fp32 rounding differs from the sequential oracle
+        assert np.allclose(out.detach().cpu().numpy(), eo, rtol=1e-5, atol=5e-5)
     go = rng.standard_normal((segs, c)).astype(np.float32)
     out.backward(torch.from_numpy(go).to(dev))
     exp = np.zeros_like(feats)
