@@ -21,8 +21,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# ROCm 7.2's graph "packet capture" fast path faults when device memory is allocated between two
+# replays of a large graph (tools/graph_bisect.py); must be off before the HIP runtime loads.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -43,6 +47,10 @@ def parse():
     ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet'],
                     help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]')
     ap.add_argument('--tracklets', type=int, default=4)
+    ap.add_argument('--split-graph', action='store_true',
+                    help='use the N>1 launch plan (fwd+bwd graph, eager all-reduce, optimizer graph) at N=1 too')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='launch every kernel eagerly from Python instead of replaying the captured HIP graph')
     return ap.parse_args()
 
 
@@ -166,8 +174,10 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     model = SubMOccEncoder().to(dev)
     params = [p for p in model.parameters()]
-    opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
+    use_graph = not args.no_graph
+    opt = torch.optim.AdamW(params, lr=1e-4, fused=True, capturable=use_graph)
     from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
+    from objectcentricocccompletion_amd.graph import GraphedStep
     broadcast_parameters(model)
     buckets = GradBuckets(params)
     B, P = args.grids, args.points
@@ -176,23 +186,73 @@ def main():
     # Upstream gradient of the encoder output, as a downstream head would hand it back
     # (fixed synthetic bf16 tensor; the voxel count of the fixed synthetic input is fixed).
     with torch.no_grad():
-        n_act = model(xyz, feats, bidx, B).features.shape[0]
+        ref_out = model(xyz, feats, bidx, B)
+        n_act = ref_out.features.shape[0]
+        n_pairs = int(ref_out.indice_dict['subm1'][3].sum().item())
+        del ref_out
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    d_out = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
+    d_act = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
 
-    def step():
+    def eager_step():
         opt.zero_grad(set_to_none=True)
         out = model(xyz, feats, bidx, B)
-        out.features.backward(d_out)
+        out.features.backward(d_act)
         buckets.all_reduce()  # data parallel: bucketed gradient all-reduce over RCCL / xGMI (no-op at N=1)
         opt.step()
         return out
 
+    # Fixed-capacity form for graph capture: one voxel row per point, rows past the active count are
+    # inert (-1 coordinates, no rulebook pair) and receive a zero upstream gradient.
+    d_cap = torch.zeros(B * P, 128, dtype=torch.bfloat16, device=dev)
+    d_cap[:n_act] = d_act
+
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
+        out = model(xyz, feats, bidx, B, static=True)
+        out.features.backward(d_cap)
+        return out
+
+    def whole_step():
+        out = fwd_bwd()
+        opt.step()
+        return out
+
+    # dominant kernel: the 64->128 forward gather-GEMM, HIP events on the launch stream.  Event-record
+    # nodes inside a captured graph are rejected by this ROCm (hipEventRecordExternal: invalid argument),
+    # so in graph mode the events go around the same kernel in eager steps run right after the timed
+    # replays (same process, same inputs); the rocprofv3 trace of the replays is the cross-check.
+    probe = sp_ops.KernelProbe(kd=64, ncols=128)
+
+    graph_note = 'eager launches'
+    if use_graph:
+        try:
+            if world == 1 and not args.split_graph:
+                g_all = GraphedStep(whole_step, warmup=3)
+
+                def step():
+                    return g_all.replay()
+            else:
+                # the gradient all-reduce stays an eager RCCL call between two graphs
+                g_fb = GraphedStep(fwd_bwd, warmup=3)
+                g_opt = GraphedStep(opt.step, warmup=0, pool=g_fb.pool())
+
+                def step():
+                    out = g_fb.replay()
+                    buckets.all_reduce()
+                    g_opt.replay()
+                    return out
+            graph_note = 'one hipGraphLaunch per step' if world == 1 and not args.split_graph else 'two HIP graphs + eager RCCL all-reduce'
+        except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, never to another device
+            print(f'[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
+            use_graph = False
+            opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
+    if not use_graph:
+        step = eager_step
+
     for _ in range(args.warmup):
         out = step()
-    # dominant kernel: the 64->128 forward gather-GEMM; events on the launch stream
-    probe = sp_ops.KernelProbe(kd=64, ncols=128)
-    sp_ops.set_probe(probe)
+    if not use_graph:
+        sp_ops.set_probe(probe)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -204,15 +264,19 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     sp_ops.set_probe(None)
+    if use_graph:
+        sp_ops.set_probe(probe)
+        for _ in range(min(args.steps, 20)):
+            eager_step()
+        torch.cuda.synchronize()
+        sp_ops.set_probe(None)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
     if rank == 0:
-        n_vox = int(out.features.shape[0])
-        rb = out.indice_dict['subm1']
-        n_pairs = int(rb[3].sum().item())
+        n_vox = int(n_act)
         kern_ms = probe.mean_ms()
         # algorithmic (compulsory) bytes of one 64->128 forward launch, SURVEY.md 8d:
         # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
@@ -236,10 +300,10 @@ def main():
                             f'{B} object grids/GPU x {P} random points, 0.2 m voxels, 40^3 grid, '
                             'channels 16-32-64-128, LN+GELU, bf16 features',
                 'grids_per_gpu': B, 'points_per_grid': P, 'active_voxels': n_vox,
-                'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}',
+                'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}', 'launch': graph_note,
             },
             'roofline': {
-                'kernel': 'gather_gemm_kernel<64,32,4,bf16> (SubMConv3d 64->128 forward)',
+                'kernel': 'gather_gemm_kernel<64,32,4,4,true> (SubMConv3d 64->128 forward)',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,
@@ -249,6 +313,7 @@ def main():
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
+                'timed_in': 'timed region' if not use_graph else 'eager steps after the timed graph replays',
             },
         }
         if not args.no_cpu_baseline:

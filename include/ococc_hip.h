@@ -316,6 +316,17 @@ int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint1
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Stream timers (HIP events) for the measurement harness (bench.py roofline line).  No reference
+ * counterpart.  in_graph != 0 records with hipEventRecordExternal, i.e. as an event-record node
+ * of the HIP graph being captured on `stream`, so that a kernel inside a replayed graph can be
+ * timed; the elapsed time is read after the stream has been synchronised.
+ * ------------------------------------------------------------------------------------------- */
+int ococc_timer_create(void** timer);
+int ococc_timer_record(void* timer, int32_t in_graph, ococc_stream_t stream);
+int ococc_timer_elapsed_ms(void* start, void* stop, float* ms);
+int ococc_timer_destroy(void* timer);
+
 #ifdef __cplusplus
 }
 #endif

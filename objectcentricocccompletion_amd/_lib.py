@@ -69,7 +69,34 @@ SIGNATURES = {
                                            c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    'ococc_timer_create': (c_i32, [ctypes.POINTER(c_vp)]),
+    'ococc_timer_record': (c_i32, [c_vp, c_i32, c_vp]),
+    'ococc_timer_elapsed_ms': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_f32)]),
+    'ococc_timer_destroy': (c_i32, [c_vp]),
 }
+
+
+class Timer(object):
+    """One HIP event behind the C ABI (ococc_timer_*), recorded on torch's current stream."""
+
+    def __init__(self):
+        h = c_vp()
+        check(lib.ococc_timer_create(ctypes.byref(h)), 'timer_create')
+        self.h = h
+
+    def record(self, in_graph=False):
+        check(lib.ococc_timer_record(self.h, int(in_graph), stream()), 'timer_record')
+
+    def elapsed_ms(self, stop):
+        ms = c_f32()
+        check(lib.ococc_timer_elapsed_ms(self.h, stop.h, ctypes.byref(ms)), 'timer_elapsed')
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            lib.ococc_timer_destroy(self.h)
+        except Exception:  # interpreter shutdown
+            pass
 
 
 class OcoccError(RuntimeError):

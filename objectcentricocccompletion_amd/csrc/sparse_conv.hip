@@ -40,6 +40,10 @@ constexpr int kConvThreads = 512;  // 8 waves, 2 per SIMD
 constexpr int kConvWaves = kConvThreads / 64;
 constexpr int kLdsBudget = 144 * 1024;
 
+// A row of zeros in device memory: rows without a neighbour gather from here, so no per-element
+// zero-select is needed after the loads (it stays L1 resident).
+__device__ __attribute__((aligned(256))) uint16_t g_zero_row[256];
+
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
   u32x4 z = {0u, 0u, 0u, 0u};
   return __builtin_bit_cast(bf16x8, z);
@@ -60,15 +64,31 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
 
   const int cs0 = blockIdx.y * CS;
   // ---- stage this column slice of all kvol weight matrices into LDS ----
+  // Loads are issued in groups of 8 per thread before any of them is consumed: one memory
+  // latency per 64 KB instead of one per 8 KB.
   {
     constexpr int PPR = KD / 8;  // 16-byte pieces per row
+    constexpr int UN = 8;
     const int total = kvol * CS * PPR;
-    for (int idx = threadIdx.x; idx < total; idx += kConvThreads) {
-      const int piece = idx % PPR;
-      const int row = (idx / PPR) % CS;
-      const int k = idx / (PPR * CS);
-      const u32x4 v = *(const u32x4*)(wn + ((int64_t)(k * ncols + cs0 + row)) * KD + piece * 8);
-      *(u32x4*)(wl + (k * CS + row) * LDW + piece * 8) = v;
+    for (int base = 0; base < total; base += kConvThreads * UN) {
+      u32x4 tmp[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * kConvThreads + threadIdx.x;
+        tmp[u] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < total) {
+          const int piece = idx % PPR, row = (idx / PPR) % CS, k = idx / (PPR * CS);
+          tmp[u] = *(const u32x4*)(wn + ((int64_t)(k * ncols + cs0 + row)) * KD + piece * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int idx = base + u * kConvThreads + threadIdx.x;
+        if (idx < total) {
+          const int piece = idx % PPR, row = (idx / PPR) % CS, k = idx / (PPR * CS);
+          *(u32x4*)(wl + (k * CS + row) * LDW + piece * 8) = tmp[u];
+        }
+      }
     }
   }
   __syncthreads();
@@ -116,14 +136,6 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
       icur[s] = v;
     }
     while (kcur[0] >= 0) {
-#pragma unroll
-      for (int s = 0; s < G; ++s) {
-        knxt[s] = -1;
-        if (um) { knxt[s] = __builtin_ctz(um); um &= um - 1; }
-        int32_t v = -1;
-        if (knxt[s] >= 0 && row_ok) v = table[(int64_t)knxt[s] * n_out + row_l];
-        inxt[s] = v;
-      }
       // x[s][rb][*] is written and read only under the same wave-uniform predicate
       // on(s, rb), so inactive (offset, block) pairs cost no instruction at all.
       bf16x8 x[G][RB][KSTEPS];
@@ -135,22 +147,48 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
           if (kcur[s] >= 0 && ((m[rb] >> (kcur[s] & 31)) & 1u)) onmask |= 1u << (s * RB + rb);
         }
       }
+      // Pass 1: issue every gather of the batch.  Loads are unconditional inside an active
+      // (offset, block) pair -- rows without a neighbour read row 0 and are zeroed later -- so no
+      // select or exec-masked move touches a register with a load in flight and the compiler
+      // places ONE wait for the whole batch instead of one per load.
+      // The index shuffles run unconditionally and first: they are the only consumers of the
+      // (possibly still loading) index registers, so the single wait for them sits here, in
+      // straight-line code, and not in front of every gather.
+      int32_t ibv[G][RB];
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          ibv[s][rb] = __shfl(icur[s], rb * 16 + lrow, 64);
+        }
+      }
 #pragma unroll
       for (int s = 0; s < G; ++s) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           if (onmask & (1u << (s * RB + rb))) {
-            const int32_t ib = __shfl(icur[s], rb * 16 + lrow, 64);
-            const uint16_t* src = feat + (int64_t)(ib < 0 ? 0 : ib) * KD + kg * 8;
+            const int32_t ib = ibv[s][rb];
+            const int kq = (KD % 32 == 0) ? kg * 8 : ((kg * 8 < KD) ? kg * 8 : 0);
+            const uint16_t* src = (ib >= 0 ? feat + (int64_t)ib * KD : g_zero_row) + kq;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
-              bf16x8 v = zero_bf16x8();
-              if (ib >= 0 && ks * 32 + kg * 8 < KD) v = *(const bf16x8*)(src + ks * 32);
-              x[s][rb][ks] = v;
+              const int off = (KD % 32 == 0 || ks * 32 + kg * 8 < KD) ? ks * 32 : 0;
+              x[s][rb][ks] = *(const bf16x8*)(src + off);
             }
           }
         }
       }
+      // Next batch's indices: issued behind this batch's gathers so both are in flight together
+      // (one memory latency per batch).
+#pragma unroll
+      for (int s = 0; s < G; ++s) {
+        knxt[s] = -1;
+        if (um) { knxt[s] = __builtin_ctz(um); um &= um - 1; }
+        int32_t v = -1;
+        if (knxt[s] >= 0 && row_ok) v = table[(int64_t)knxt[s] * n_out + row_l];
+        inxt[s] = v;
+      }
+      // Pass 2: weights from LDS, zero-select, MFMA.
 #pragma unroll
       for (int s = 0; s < G; ++s) {
         if (!((onmask >> (s * RB)) & ((1u << RB) - 1u))) continue;
@@ -161,18 +199,25 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
           const int koff = ks * 32 + kg * 8;
 #pragma unroll
           for (int cb = 0; cb < NB; ++cb) {
-            w[ks][cb] = zero_bf16x8();
-            if (koff < KD) w[ks][cb] = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + koff);
+            if (KD % 32 == 0) {
+              w[ks][cb] = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + koff);
+            } else {
+              const bf16x8 t = *(const bf16x8*)(wl + (k * CS + cb * 16 + lrow) * LDW + (koff < KD ? koff : 0));
+              w[ks][cb] = koff < KD ? t : zero_bf16x8();
+            }
           }
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
           if (onmask & (1u << (s * RB + rb))) {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks)
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+              // k positions beyond KD (KD = 16 only) multiply zero weights: no select on x needed
+              const bf16x8 xv = x[s][rb][ks];
 #pragma unroll
               for (int cb = 0; cb < NB; ++cb)
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cb], x[s][rb][ks], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ks][cb], xv, acc[rb][cb], 0, 0, 0);
+            }
           }
         }
       }
@@ -298,32 +343,39 @@ weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int 
 
 // ---------------------------------------------------------------- wgrad
 constexpr int kWgThreads = 256;
-constexpr int kWgSteps = 16;  // 32-pair MFMA k-steps per workgroup
+constexpr int kWgSteps = 8;  // 32-pair MFMA k-steps per workgroup
 
-// Work item g of the flattened (offset, part) list: offset k owns
-// ceil(ceil(num[k]/32) / kWgSteps) consecutive items.  Returns false past the end.
-__device__ __forceinline__ bool wg_locate(const int32_t* __restrict__ num, int kvol, int g, int* k_out,
-                                          int* part_out, int* base_out) {
-  int base = 0;
-  for (int k = 0; k < kvol; ++k) {
-    const int ksteps = (num[k] + 31) >> 5;
-    const int groups = (ksteps + kWgSteps - 1) / kWgSteps;
-    if (g < base + groups) {
-      *k_out = k;
-      *part_out = g - base;
-      *base_out = base;
-      return true;
+// Flattened (offset, part) work list: offset k owns ceil(ceil(num[k]/32) / kWgSteps) consecutive
+// items.  A one-wave kernel writes the exclusive prefix (kvol+1 ints) so that the thousands of
+// surplus workgroups of the worst-case grid leave after a single load.
+__global__ void wgrad_prefix_kernel(const int32_t* __restrict__ num, int kvol, int32_t* __restrict__ prefix) {
+  if (threadIdx.x == 0) {
+    int base = 0;
+    for (int k = 0; k < kvol; ++k) {
+      prefix[k] = base;
+      const int ksteps = (num[k] + 31) >> 5;
+      base += (ksteps + kWgSteps - 1) / kWgSteps;
     }
-    base += groups;
+    prefix[kvol] = base;
   }
-  return false;
+}
+
+__device__ __forceinline__ bool wg_locate(const int32_t* __restrict__ prefix, int kvol, int g, int* k_out,
+                                          int* part_out, int* base_out) {
+  if (g >= prefix[kvol]) return false;
+  int k = 0;
+  while (k + 1 < kvol && prefix[k + 1] <= g) ++k;
+  *k_out = k;
+  *part_out = g - prefix[k];
+  *base_out = prefix[k];
+  return true;
 }
 
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(kWgThreads)
 wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
-             int64_t cap, float* __restrict__ slabs) {
+             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num,
+             const int32_t* __restrict__ prefix, int kvol, int64_t cap, float* __restrict__ slabs) {
   constexpr int MB = CIN / 16, NB = COUT / 16;
   constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
   constexpr int WM = 4 / WN;            // waves along the cin blocks
@@ -334,7 +386,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
 
   int k, part, base;
-  if (!wg_locate(num, kvol, blockIdx.x, &k, &part, &base)) return;
+  if (!wg_locate(prefix, kvol, blockIdx.x, &k, &part, &base)) return;
   const int nk = num[k];
   const int ksteps = (nk + 31) >> 5;
   const int first = part * kWgSteps;
@@ -469,13 +521,12 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
 // block; lane p adds slabs p, p+16, ...; a fixed tree joins the 16 lanes.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
+wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ prefix, int kvol,
                     int64_t elems, float* __restrict__ dw) {
   __shared__ float red[4][16];
   const int k = blockIdx.y;
-  int base = 0;
-  for (int j = 0; j < k; ++j) base += (((num[j] + 31) >> 5) + kWgSteps - 1) / kWgSteps;
-  const int nslabs = (((num[k] + 31) >> 5) + kWgSteps - 1) / kWgSteps;
+  const int base = prefix[k];
+  const int nslabs = prefix[k + 1] - base;
   const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
   float s = 0.f;
@@ -496,14 +547,14 @@ inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
 
 template <int CIN>
 int dispatch_wgrad_cout(const uint16_t* x, const uint16_t* dy, int cout, const int32_t* pairs,
-                        const int32_t* num, int kvol, int64_t cap, float* slabs,
+                        const int32_t* num, const int32_t* prefix, int kvol, int64_t cap, float* slabs,
                         hipStream_t stream) {
   dim3 grid((unsigned)wgrad_max_groups(kvol, cap)), block(kWgThreads);
   switch (cout) {
-    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
-    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
-    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
+    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cout must be 16/32/64/128");
   }
   OCOCC_CHECK_LAUNCH();
@@ -557,7 +608,7 @@ extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t
 extern "C" int64_t ococc_sparse_conv_wgrad_workspace_bytes(int32_t kvol, int64_t pair_capacity,
                                                            int32_t cin, int32_t cout) {
   if (kvol < 1 || cin < 1 || cout < 1 || pair_capacity < 0) return -1;
-  return wgrad_max_groups(kvol, pair_capacity) * cin * cout * (int64_t)sizeof(float);
+  return 1024 + wgrad_max_groups(kvol, pair_capacity) * cin * cout * (int64_t)sizeof(float);
 }
 
 extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin,
@@ -579,17 +630,20 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
   }
   OCOCC_REQUIRE(x && dy && indice_pairs && indice_num, "null pointer");
   int rc;
-  float* slabs = (float*)workspace;
+  int32_t* prefix = (int32_t*)workspace;  // kvol + 1 ints, then the slabs (256-byte aligned)
+  float* slabs = (float*)((char*)workspace + 1024);
+  hipLaunchKernelGGL(wgrad_prefix_kernel, dim3(1), dim3(64), 0, stream, indice_num, (int)kvol, prefix);
+  OCOCC_CHECK_LAUNCH();
   switch (cin) {
-    case 16: rc = dispatch_wgrad_cout<16>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
-    case 32: rc = dispatch_wgrad_cout<32>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
-    case 64: rc = dispatch_wgrad_cout<64>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
-    case 128: rc = dispatch_wgrad_cout<128>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 16: rc = dispatch_wgrad_cout<16>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
+    case 32: rc = dispatch_wgrad_cout<32>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
+    case 64: rc = dispatch_wgrad_cout<64>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
+    case 128: rc = dispatch_wgrad_cout<128>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cin must be 16/32/64/128");
   }
   if (rc != OCOCC_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ococc_cdiv(elems, 16), kvol), dim3(256), 0,
-                     stream, slabs, indice_num, (int)kvol, elems, dw);
+                     stream, slabs, prefix, (int)kvol, elems, dw);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -1,0 +1,60 @@
+"""HIP-graph capture of a launch-bound step.
+
+The SubMConv3d encoder step is ~80 short kernels (2-90 us each); launched one by one from
+Python the host cannot keep the queue full and a quarter of the step is idle gaps
+(profiles/r01_g_kernel_trace).  With the fixed-capacity ("static") form of the geometry ops
+(voxel.grid_unique(static=True): no device read-back, unused rows are inert) the whole
+forward + backward + optimizer step has no host dependency and is recorded once into a HIP
+graph; each step is then a single hipGraphLaunch.
+
+PyTorch is used here only as the stream / graph / allocator plumbing (torch.cuda.CUDAGraph is
+hipGraph on ROCm); every kernel in the graph comes in through the C ABI on the capturing
+stream.  The reference has no counterpart (it launches eagerly).
+"""
+import os
+
+import torch
+
+
+class GraphedStep(object):
+    """Record ``fn()`` (no arguments; reads its inputs from fixed device tensors) after
+    ``warmup`` eager runs on a side stream, then ``replay()`` it.
+
+    ``fn`` must be free of host synchronisation (no .item(), no shape that depends on device
+    data) and must not allocate outside torch's caching allocator.  Its return value (any
+    structure of tensors) is kept and refers to graph-owned memory that each replay
+    overwrites.  ``capture_ctx`` is entered around the recording only.
+
+    No backward pass may have run on another stream before the capture: autograd pins each
+    parameter's AccumulateGrad node to the stream of its first backward and would pull that
+    stream into the capture (hipStreamEndCapture then crashes)."""
+
+    def __init__(self, fn, warmup=3, pool=None, capture_ctx=None):
+        import contextlib
+        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '') != '0':
+            # ROCm 7.2: with the graph packet-capture fast path on, replaying a graph of this size after
+            # any new device allocation faults ("write access to a read-only page", tools/graph_bisect.py).
+            raise RuntimeError('set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP '
+                               'runtime is loaded (before `import torch`) to use GraphedStep')
+        self.fn = fn
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with (capture_ctx if capture_ctx is not None else contextlib.nullcontext()):
+            with torch.cuda.graph(self.graph, pool=pool, stream=self.stream):
+                self.out = fn()
+        torch.cuda.synchronize()
+
+    def pool(self):
+        return self.graph.pool()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    __call__ = replay

@@ -43,10 +43,14 @@ class SubMOccEncoder(nn.Module):
         coors = torch.cat([batch_idx.view(-1, 1).to(torch.int32), zyx], 1)
         return coors
 
-    def forward(self, points, feats, batch_idx, batch_size):
+    def forward(self, points, feats, batch_idx, batch_size, static=False):
+        """``static=True`` keeps every tensor at its fixed capacity (one row per point; unused
+        voxel rows carry -1 coordinates, take part in no rulebook pair and must get a zero
+        upstream gradient), so that the whole step has no device read-back and can be captured
+        in a HIP graph (graph.GraphedStep)."""
         coors = self.voxelize(points, batch_idx, batch_size)
         vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
-                                         grid_shape=[batch_size] + self.sparse_shape)
+                                         grid_shape=[batch_size] + self.sparse_shape, static=static)
         x = SparseConvTensor(vfeats.to(self.feature_dtype), vcoors, self.sparse_shape, batch_size)
         for layer in self.conv_layers:
             x = layer(x)

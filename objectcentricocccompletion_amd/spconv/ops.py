@@ -19,27 +19,36 @@ class KernelProbe(object):
     recorded on the stream the kernel is launched on, around every matching forward launch
     inside the timed region, and read back after the final synchronize."""
 
-    def __init__(self, kd, ncols, max_events=4096):
+    def __init__(self, kd, ncols, max_events=4096, external=False):
         self.kd, self.ncols, self.max_events = kd, ncols, max_events
+        self.external = external  # events recorded while a HIP graph is being captured
         self.pairs = []
+        self.samples = []
 
     def wrap(self, kd, ncols, launch):
         if kd != self.kd or ncols != self.ncols or len(self.pairs) >= self.max_events:
             return launch()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()  # torch's current stream == the stream handed to the C ABI (_lib.stream())
+        a, b = L.Timer(), L.Timer()  # HIP events behind the C ABI (ococc_timer_*)
+        a.record(self.external)  # torch's current stream == the stream handed to the C ABI (_lib.stream())
         out = launch()
-        b.record()
+        b.record(self.external)
         self.pairs.append((a, b))
         return out
 
+    def sample(self):
+        """Graph mode: read the in-graph event pair after a (synchronised) replay."""
+        for a, b in self.pairs:
+            self.samples.append(a.elapsed_ms(b))
+
     def count(self):
-        return len(self.pairs)
+        return len(self.samples) if self.external else len(self.pairs)
 
     def mean_ms(self):
+        if self.external:
+            return sum(self.samples) / len(self.samples) if self.samples else None
         if not self.pairs:
             return None
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+        return sum(a.elapsed_ms(b) for a, b in self.pairs) / len(self.pairs)
 
 
 _probe = None

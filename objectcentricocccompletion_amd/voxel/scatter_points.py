@@ -12,12 +12,17 @@ from torch.autograd import Function
 from .. import _lib as L
 
 
-def grid_unique(coors, dims=None):
+def grid_unique(coors, dims=None, static=False):
     """Sorted unique rows of non-negative int coordinates.
 
     Returns (out_coors [U,ndim] int32, inv [N] int32 (-1 for dropped rows), counts [U] int32).
     ``dims`` (exclusive upper bound per column) avoids a device read-back; without it the
-    bounds come from coors.amax (one sync, as torch.unique has anyway)."""
+    bounds come from coors.amax (one sync, as torch.unique has anyway).
+
+    ``static=True`` is the fixed-capacity form for HIP-graph capture: nothing is read back, the
+    outputs keep their full capacity U = min(N, prod(dims)), rows past the device-side count are
+    -1 in out_coors / 0 in counts, and a fourth value ``meta`` (int32 [2] on the device:
+    [num_unique, out_of_bounds flag]) is returned for the caller to inspect when it likes."""
     L.require_device(coors)
     squeeze = coors.dim() == 1
     if coors.size(0) == 0:
@@ -29,6 +34,8 @@ def grid_unique(coors, dims=None):
     c = c.contiguous()
     n, ndim = c.shape
     if dims is None:
+        if static:
+            raise L.OcoccError('grid_unique(static=True) needs dims (no device read-back)')
         dims = [int(v) + 1 for v in c.amax(0).clamp_min(0).tolist()]
     dims = [int(d) for d in dims]
     assert len(dims) == ndim
@@ -40,7 +47,10 @@ def grid_unique(coors, dims=None):
     if nbytes < 0:
         raise L.OcoccError(f'grid_unique: coordinate space {dims} too large for the bitmap plan')
     ws = L.workspace(nbytes, c.device)
-    out_coors = torch.empty((cap, ndim), dtype=torch.int32, device=c.device)
+    if static:
+        out_coors = torch.full((cap, ndim), -1, dtype=torch.int32, device=c.device)
+    else:
+        out_coors = torch.empty((cap, ndim), dtype=torch.int32, device=c.device)
     inv = torch.empty((n,), dtype=torch.int32, device=c.device)
     counts = torch.empty((cap,), dtype=torch.int32, device=c.device)
     meta = torch.zeros(2, dtype=torch.int32, device=c.device)  # [num_unique, status]
@@ -48,6 +58,9 @@ def grid_unique(coors, dims=None):
                                         L.ptr(inv), L.ptr(counts), meta.data_ptr(),
                                         meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()),
             'grid_unique')
+    if static:
+        inv._ococc_counts = counts
+        return (out_coors[:, 0] if squeeze else out_coors), inv, counts, meta
     num, status = meta.tolist()
     if status:
         raise L.OcoccError(f'grid_unique: a coordinate is outside the declared bounds {dims}')
@@ -134,10 +147,15 @@ def gather_rows(rows, inv):
     return _GatherRows.apply(rows, inv)
 
 
-def dynamic_scatter(feats, coors, reduce_type='max', grid_shape=None):
+def dynamic_scatter(feats, coors, reduce_type='max', grid_shape=None, static=False):
     """mmdet3d/ops/voxel/scatter_points.py:9-50: (voxel_feats [M,C], voxel_coors [M,ndim]).
-    Rows of coors with a negative entry are dropped; output rows are in sorted order."""
-    voxel_coors, inv, counts = grid_unique(coors, grid_shape)
+    Rows of coors with a negative entry are dropped; output rows are in sorted order.
+    ``static=True``: fixed-capacity outputs (M = number of points; unused rows have -1 coordinates
+    and zero features), no device read-back -- see grid_unique."""
+    if static:
+        voxel_coors, inv, counts, _ = grid_unique(coors, grid_shape, static=True)
+    else:
+        voxel_coors, inv, counts = grid_unique(coors, grid_shape)
     voxel_feats = segment_reduce(feats, inv, voxel_coors.size(0), reduce_type, counts)
     return voxel_feats, voxel_coors.to(coors.dtype)
 

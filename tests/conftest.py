@@ -1,4 +1,8 @@
 import os
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # see objectcentricocccompletion_amd/graph.py
+
+import os
 import sys
 
 import pytest

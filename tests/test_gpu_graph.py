@@ -1,0 +1,89 @@
+"""Fixed-capacity ("static") geometry + HIP-graph replay of the SubMConv3d encoder step must give
+what the eager, exactly-sized path gives (which tests/test_gpu_spconv.py pins to the oracle)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, grids=4, points=500):
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    torch.manual_seed(0)
+    model = SubMOccEncoder().to(dev)
+    xyz, feats, bidx = synthetic_object_grids(grids, points, seed=3, device=dev)
+    return model, xyz, feats, bidx, grids
+
+
+def test_static_grid_unique_matches_dynamic(dev):
+    from objectcentricocccompletion_amd.voxel.scatter_points import grid_unique
+    g = torch.Generator().manual_seed(1)
+    coors = torch.randint(-1, 6, (3000, 4), generator=g, dtype=torch.int32).to(dev)
+    dims = [6, 6, 6, 6]
+    oc, inv, cnt = grid_unique(coors, dims)
+    oc_s, inv_s, cnt_s, meta = grid_unique(coors, dims, static=True)
+    num, status = meta.tolist()
+    assert status == 0 and num == oc.shape[0]
+    assert oc_s.shape[0] == min(coors.shape[0], 6 ** 4)
+    assert torch.equal(oc_s[:num], oc) and bool((oc_s[num:] == -1).all())
+    assert torch.equal(inv_s, inv)
+    assert torch.equal(cnt_s[:num], cnt) and bool((cnt_s[num:] == 0).all())
+
+
+def test_static_encoder_matches_dynamic(dev):
+    model, xyz, feats, bidx, B = _setup(dev)
+    out = model(xyz, feats, bidx, B)
+    n = out.features.shape[0]
+    d = (torch.randn(n, 128, device=dev) / n).to(torch.bfloat16)
+    out.features.backward(d)
+    g_dyn = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+
+    out_s = model(xyz, feats, bidx, B, static=True)
+    cap = xyz.shape[0]
+    assert out_s.features.shape[0] == cap
+    assert torch.equal(out_s.indices[:n], out.indices) and bool((out_s.indices[n:] == -1).all())
+    assert torch.equal(out_s.features[:n], out.features)  # same kernels, same row order: bit-exact
+    d_s = torch.zeros(cap, 128, dtype=torch.bfloat16, device=dev)
+    d_s[:n] = d
+    out_s.features.backward(d_s)
+    for a, p in zip(g_dyn, model.parameters()):
+        # wgrad / LN parameter reductions split the rows differently at a different capacity
+        torch.testing.assert_close(p.grad, a, rtol=2e-3, atol=1e-6)
+
+
+def test_graph_replay_matches_eager(dev):
+    from objectcentricocccompletion_amd.graph import GraphedStep
+    model, xyz, feats, bidx, B = _setup(dev)
+    with torch.no_grad():
+        n = model(xyz, feats, bidx, B).features.shape[0]
+    cap = xyz.shape[0]
+    d_s = torch.zeros(cap, 128, dtype=torch.bfloat16, device=dev)
+    d_s[:n] = (torch.randn(n, 128, device=dev) / n).to(torch.bfloat16)
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        out = model(xyz, feats, bidx, B, static=True)
+        out.features.backward(d_s)
+        return out
+
+    # (capture first: a backward run on another stream beforehand would pin the parameters'
+    # AccumulateGrad nodes to that stream and drag it into the capture)
+    g = GraphedStep(fwd_bwd, warmup=2)
+    for _ in range(3):
+        out_g = g.replay()
+    torch.cuda.synchronize()
+    feat_g = out_g.features.clone()
+    g_g = [p.grad.clone() for p in model.parameters()]
+    out_e = fwd_bwd()
+    torch.cuda.synchronize()
+    assert torch.equal(feat_g, out_e.features)
+    for a, p in zip(g_g, model.parameters()):
+        assert torch.equal(p.grad, a)  # identical launch sequence: deterministic, bit-exact
+
+    # new input through the same graph: overwrite the fixed input tensors in place
+    xyz2 = xyz.roll(17, 0).contiguous()
+    want = model(xyz2, feats, bidx, B, static=True).features.clone()
+    xyz.copy_(xyz2)
+    out_g = g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g.features, want)
