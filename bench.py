@@ -175,7 +175,9 @@ def main():
     model = SubMOccEncoder().to(dev)
     params = [p for p in model.parameters()]
     use_graph = not args.no_graph
-    opt = torch.optim.AdamW(params, lr=1e-4, fused=True, capturable=use_graph)
+    from objectcentricocccompletion_amd.optim import AdamW
+    opt = AdamW(params, lr=1e-4)  # fused multi-tensor HIP kernel, device-side step counter
+    opt.init_state()
     from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
     from objectcentricocccompletion_amd.graph import GraphedStep
     broadcast_parameters(model)
@@ -245,7 +247,6 @@ def main():
         except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, never to another device
             print(f'[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             use_graph = False
-            opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
     if not use_graph:
         step = eager_step
 

@@ -233,8 +233,8 @@ int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, c
  * x, y [n, c] in `dtype` (f32 or bf16); gamma, beta [c] f32.
  * act: 0 = none (plain LayerNorm), 1 = GELU(erf).
  * mean_rstd [n, 2] f32 is written by forward and read by backward.
- * Backward: dx [n,c] in dtype; dgamma, dbeta [c] f32 are ACCUMULATED into
- * (caller zero-fills) from per-workgroup partials in a fixed order.
+ * Backward: dx [n,c] in dtype; dgamma, dbeta [c] f32 are OVERWRITTEN with the sum
+ * of per-workgroup partials taken in a fixed order (deterministic).
  * ------------------------------------------------------------------------ */
 int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, const float* gamma,
                             const float* beta, float eps, int32_t act, void* y, float* mean_rstd,
@@ -315,6 +315,20 @@ int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint1
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW step, torch.optim.AdamW semantics (amsgrad / maximize off) -- the
+ * optimizer the reference configures at configs/_base_/schedules/cosine_2x.py:2-8 (lr override
+ * configs/ococc/ococcnet.py:468-470).  params / grads / exp_avg / exp_avg_sq are HOST arrays of
+ * num_tensors (<= 48) device pointers to contiguous f32 tensors of numel[i] elements.  `step` is a
+ * DEVICE float holding the number of steps taken so far: the kernel uses step + 1 for the bias
+ * corrections and stores it back, so the call can be replayed from a captured HIP graph.
+ * `ticket` is a DEVICE uint32 scratch word, zero before the first call.
+ * ------------------------------------------------------------------------------------------- */
+int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
+                    void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float* step,
+                    uint32_t* ticket, ococc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stream timers (HIP events) for the measurement harness (bench.py roofline line).  No reference

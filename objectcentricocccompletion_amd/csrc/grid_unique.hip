@@ -128,8 +128,13 @@ extern "C" int ococc_grid_unique_i32(const int32_t* coors, int64_t n, int32_t nd
   OCOCC_REQUIRE(n >= 0 && out_capacity >= 0, "negative size");
   OCOCC_REQUIRE(num_unique && status, "num_unique/status must be device pointers");
   OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
-  OCOCC_HIP(hipMemsetAsync(num_unique, 0, sizeof(int32_t), stream));
-  OCOCC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+  // status is a flag the kernels only ever set; num_unique is overwritten by the scan below
+  if (status == num_unique + 1) {
+    OCOCC_HIP(hipMemsetAsync(num_unique, 0, 2 * sizeof(int32_t), stream));
+  } else {
+    OCOCC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
+    if (n == 0) OCOCC_HIP(hipMemsetAsync(num_unique, 0, sizeof(int32_t), stream));
+  }
   if (n == 0) return OCOCC_OK;
   OCOCC_REQUIRE(coors && inv, "null coors/inv");
   char* ws = (char*)workspace;

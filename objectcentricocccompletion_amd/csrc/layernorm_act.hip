@@ -262,9 +262,9 @@ ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
   for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
   if (l == 0 && i < 2 * c) {
     if (i < c) {
-      if (dgamma) dgamma[i] += s;
+      if (dgamma) dgamma[i] = s;
     } else {
-      if (dbeta) dbeta[i - c] += s;
+      if (dbeta) dbeta[i - c] = s;
     }
   }
 }
@@ -400,7 +400,11 @@ extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n,
   OCOCC_REQUIRE(n >= 0 && c >= 1, "bad sizes");
   OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
   OCOCC_REQUIRE(dtype == OCOCC_F32 || dtype == OCOCC_BF16, "dtype must be f32/bf16");
-  if (n == 0) return OCOCC_OK;
+  if (n == 0) {
+    if (dgamma) OCOCC_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), stream));
+    if (dbeta) OCOCC_HIP(hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), stream));
+    return OCOCC_OK;
+  }
   OCOCC_REQUIRE(x && dy && dx && gamma && beta && mean_rstd, "null pointer");
   OCOCC_REQUIRE(workspace && workspace_bytes >= ococc_layernorm_act_bwd_workspace_bytes(n, c),
                 "workspace too small");

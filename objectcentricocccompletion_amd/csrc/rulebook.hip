@@ -53,7 +53,7 @@ mark_voxels_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
   }
 }
 
-// perm[rank(cell of row j)] = j  (largest j wins if a cell is listed twice)
+// perm[rank(cell of row j)] = j + 1  (largest j wins if a cell is listed twice; 0 = empty)
 __global__ void __launch_bounds__(256)
 fill_perm_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
                  const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
@@ -67,40 +67,53 @@ fill_perm_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
       continue;
     const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
     const int32_t r = rank_of(bitmap, prefix, cell);
-    if (r >= 0) atomicMax(perm + r, (int32_t)i);
+    if (r >= 0) atomicMax(perm + r, (int32_t)i + 1);  // row + 1, so that a zero fill means empty
   }
 }
 
-// grid (ceil(n/256), kvol): thread = (output row o, offset k)
+// thread = output row o, looping over the kvol offsets; the 16-row block masks come out of wave
+// ballots and are written once per block (no atomics, so blockmask needs no zero fill)
+template <int KS>  // compile-time kernel size (3x3x3 fast path) or 0 = sizes from g
 __global__ void __launch_bounds__(256)
 neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
                        const int32_t* __restrict__ perm, int32_t* __restrict__ nbr_t,
                        uint32_t* __restrict__ blockmask) {
-  const int k = blockIdx.y;
-  const int kx = k % g.kw, ky = (k / g.kw) % g.kh, kz = k / (g.kw * g.kh);
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t v = -1;
+  const int kd = KS ? KS : g.kd, kh = KS ? KS : g.kh, kw = KS ? KS : g.kw;
+  const int lane = threadIdx.x & 63;
+  int32_t b = -1, z0 = 0, y0 = 0, x0 = 0;
   if (o < n) {
-    const int32_t b = indices[o * 4];
-    const int32_t z = indices[o * 4 + 1] + kz - g.kd / 2;
-    const int32_t y = indices[o * 4 + 2] + ky - g.kh / 2;
-    const int32_t x = indices[o * 4 + 3] + kx - g.kw / 2;
-    if ((unsigned)b < (unsigned)g.batch && (unsigned)z < (unsigned)g.D &&
-        (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) {
+    b = indices[o * 4];
+    z0 = indices[o * 4 + 1] - kd / 2;
+    y0 = indices[o * 4 + 2] - kh / 2;
+    x0 = indices[o * 4 + 3] - kw / 2;
+  }
+  const bool row_ok = (unsigned)b < (unsigned)g.batch;
+  uint32_t mask = 0;
+  auto visit = [&](int kz, int ky, int kx, int k) {
+    const int32_t z = z0 + kz, y = y0 + ky, x = x0 + kx;
+    int32_t v = -1;
+    if (row_ok && (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H &&
+        (unsigned)x < (unsigned)g.W) {
       const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
       const int32_t r = rank_of(bitmap, prefix, cell);
-      if (r >= 0) v = perm[r];
+      if (r >= 0) v = perm[r] - 1;  // perm holds row + 1 (0 = empty)
     }
-    nbr_t[(int64_t)k * n + o] = v;
-  }
-  if (blockmask) {
+    if (o < n) nbr_t[(int64_t)k * n + o] = v;
     const unsigned long long m = __ballot(v >= 0);
-    const int lane = threadIdx.x & 63;
-    if ((lane & 15) == 0 && o < n) {
-      if ((m >> lane) & 0xffffull) atomicOr(blockmask + (o >> 4), 1u << k);
-    }
+    if (k < 32 && ((m >> (lane & 48)) & 0xffffull)) mask |= 1u << k;
+  };
+  if constexpr (KS != 0) {
+#pragma unroll
+    for (int k = 0; k < KS * KS * KS; ++k) visit(k / (KS * KS), (k / KS) % KS, k % KS, k);
+  } else {
+    int k = 0;
+    for (int kz = 0; kz < kd; ++kz)
+      for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx, ++k) visit(kz, ky, kx, k);
   }
+  if (blockmask && (lane & 15) == 0 && o < n) blockmask[o >> 4] = mask;
 }
 
 // pairs[k][0][pos] = j, pairs[k][1][pos] = nbr_t[K-1-k][j]  for valid entries
@@ -291,8 +304,8 @@ inline bool make_layout(int64_t n, int32_t batch, const int32_t* shape, const in
   L->words = (cells + 31) / 32;
   int64_t off = 0;
   L->off_bitmap = off;  off += ococc_align_up(L->words * 4, 256);
+  L->off_perm = off;    off += ococc_align_up(n * 4, 256);  // directly behind the bitmap: one zero fill
   L->off_prefix = off;  off += ococc_align_up(L->words * 4, 256);
-  L->off_perm = off;    off += ococc_align_up(n * 4, 256);
   L->off_pos = off;     off += ococc_align_up(kvol * n * 4, 256);
   int64_t sw = ococc_scan::scratch_words(L->words, 1);
   int64_t sw2 = ococc_scan::scratch_words(n, (int)kvol);
@@ -328,8 +341,10 @@ extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int3
                   "sub-manifold dilation != 1 is not supported");
   const int kvol = host_ksize[0] * host_ksize[1] * host_ksize[2];
   OCOCC_REQUIRE(!blockmask || kvol <= 32, "blockmask needs kernel volume <= 32");
-  if (indice_num) OCOCC_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), stream));
-  if (n == 0) return OCOCC_OK;
+  if (n == 0) {
+    if (indice_num) OCOCC_HIP(hipMemsetAsync(indice_num, 0, kvol * sizeof(int32_t), stream));
+    return OCOCC_OK;
+  }
   OCOCC_REQUIRE((indice_pairs == nullptr) == (indice_num == nullptr),
                 "indice_pairs and indice_num go together");
   OCOCC_REQUIRE(indices && nbr_t, "null indices/nbr_t");
@@ -344,9 +359,8 @@ extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int3
   Geom g{batch_size, host_shape[0], host_shape[1], host_shape[2],
          host_ksize[0], host_ksize[1], host_ksize[2]};
 
-  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.words * 4, stream));
-  OCOCC_HIP(hipMemsetAsync(perm, 0xff, n * 4, stream));
-  if (blockmask) OCOCC_HIP(hipMemsetAsync(blockmask, 0, ococc_cdiv(n, 16) * 4, stream));
+  // bitmap and perm (row + 1, 0 = empty) in one fill; blockmask and indice_num are fully written
+  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.off_prefix - L.off_bitmap, stream));
   const int g1 = ococc_grid_1d(n, 256);
   hipLaunchKernelGGL(mark_voxels_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
                      (int32_t*)nullptr);
@@ -356,8 +370,12 @@ extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int3
   hipLaunchKernelGGL(fill_perm_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
                      prefix, perm);
   OCOCC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(neighbour_table_kernel, dim3((unsigned)ococc_cdiv(n, 256), kvol), dim3(256), 0,
-                     stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
+  if (g.kd == 3 && g.kh == 3 && g.kw == 3)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<3>), dim3((unsigned)ococc_cdiv(n, 256)), dim3(256), 0,
+                       stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<0>), dim3((unsigned)ococc_cdiv(n, 256)), dim3(256), 0,
+                       stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
   OCOCC_CHECK_LAUNCH();
   if (indice_pairs) {
     OCOCC_HIP(hipMemsetAsync(indice_pairs, 0xff, (int64_t)kvol * 2 * n * 4, stream));

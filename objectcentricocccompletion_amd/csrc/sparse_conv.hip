@@ -285,6 +285,239 @@ int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int n
   return OCOCC_OK;
 }
 
+// ---------------------------------------------------------------- full-width variant
+// When the kvol weight matrices of ALL output columns do not fit LDS the kernel above has to cut
+// the columns into slices and every slice re-reads the gather indices and re-gathers the input
+// rows: on the 64->128 layer that is 4x the vector-memory instructions, which is what bounds it
+// (each 64-lane 16-byte gather occupies the CU's address/data path for 16 cycles).
+// Here a workgroup of 4 waves owns 256 consecutive output rows at full width and the weights
+// stream through LDS one kernel offset at a time (double buffered, one barrier per offset):
+// rows are gathered once, indices are read once, and every gathered 16-byte fragment feeds
+// NC/16 MFMAs.  The software pipeline per offset k: issue the gathers of k+1, the weight loads of
+// k+1 and the indices of k+2, then run the MFMAs of k out of registers/LDS that were filled one
+// iteration earlier.  The barrier only waits for LDS (lgkmcnt): global loads stay in flight
+// across it.
+constexpr int kStreamThreads = 256;
+
+__device__ __forceinline__ void lds_barrier() {
+  // workgroup barrier that only waits for this wave's LDS traffic: global loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int KD, int NC, bool OUT_BF16>
+__global__ void __launch_bounds__(kStreamThreads, 2)
+gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ wn,
+                          int kvol, const int32_t* __restrict__ table,
+                          const uint32_t* __restrict__ blockmask, int64_t n_out,
+                          const float* __restrict__ bias, void* __restrict__ out_) {
+  constexpr int RB = 4;
+  constexpr int KSTEPS = KD / 32;
+  constexpr int NB = NC / 16;
+  constexpr int GS = NB < 4 ? NB : 4;     // weight fragments fetched from LDS per group
+  constexpr int PPR = KD / 8;             // 16-byte pieces per weight row
+  constexpr int RPB = 256 / (KD * 2);     // weight rows per 256-byte LDS bank row
+  constexpr int PIECES = NC * PPR;        // per offset
+  constexpr int NWAVES = kStreamThreads / 64;
+  static_assert(KD % 32 == 0, "stream kernel wants whole k-steps");
+  // weights of one offset, row-major [NC][KD] in 16-byte pieces; piece j of row r sits in slot
+  // j ^ swz(r) of its row so that the 16 rows an MFMA operand read touches hit 16 different bank
+  // groups without padding
+  __shared__ __attribute__((aligned(16))) u32x4 wl[2][PIECES];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15;
+  const int kg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * (NWAVES * RB * 16) + wave * (RB * 16);
+  const int64_t n_blocks = (n_out + 15) >> 4;
+  const bool nomask = blockmask == nullptr;
+
+  uint32_t m[RB];
+  uint32_t wm = 0;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int64_t blk = (row0 >> 4) + rb;
+    uint32_t v = 0;
+    if (blk < n_blocks) v = nomask ? 0xffffffffu : blockmask[blk];
+    m[rb] = __builtin_amdgcn_readfirstlane(v);
+    wm |= m[rb];
+  }
+  const int64_t row_l = row0 + lane;
+  const bool row_ok = row_l < n_out;
+  const int64_t row_c = row_ok ? row_l : (n_out - 1);
+
+  f32x4 acc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto swz = [](int row) -> int { return (row / RPB) & (PPR - 1); };
+  // global -> registers -> LDS.  (global_load_lds would save the registers, but with an LDS-DMA load
+  // in flight the compiler turns every later vector-memory wait into vmcnt(0), which serialises
+  // the gathers behind the weight stage.)
+  constexpr int WPT = (PIECES + kStreamThreads - 1) / kStreamThreads;
+  u32x4 wreg[WPT];
+  auto load_w = [&](int k) {
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      int q = u * kStreamThreads + threadIdx.x;
+      if (PIECES % kStreamThreads != 0 && q >= PIECES) q -= PIECES;
+      const int row = q / PPR, slot = q % PPR;
+      wreg[u] = *(const u32x4*)(wn + (int64_t)k * NC * KD + (row * PPR + (slot ^ swz(row))) * 8);
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < WPT; ++u) {
+      int q = u * kStreamThreads + threadIdx.x;
+      if (PIECES % kStreamThreads != 0 && q >= PIECES) q -= PIECES;
+      wl[buf][q] = wreg[u];
+    }
+  };
+  // Unconditional: a block without a neighbour at this offset reads the zero row.  The extra loads
+  // are L1 hits; in exchange the number of loads in flight is a compile-time constant, so the
+  // waits before the MFMAs of offset k leave the gathers of k+1 in flight.
+  auto gather = [&](bf16x8 (&x)[RB][KSTEPS], int32_t idx) {
+    int32_t ibv[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) ibv[rb] = __shfl(idx, rb * 16 + lrow, 64);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const uint16_t* src = (ibv[rb] >= 0 ? feat + (int64_t)ibv[rb] * KD : g_zero_row) + kg * 8;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) x[rb][ks] = *(const bf16x8*)(src + ks * 32);
+    }
+  };
+  // indices of offset k for this wave's 64 rows (lane -> row); offsets past the end re-read the last
+  // one (the result is never used) so that the load count per iteration stays fixed
+  const int32_t* tcol = table + row_c;  // rows past the end copy the last row; never stored
+  auto load_idx = [&](int k) -> int32_t {
+    const int kk = k < kvol ? k : kvol - 1;
+    return tcol[(int64_t)kk * n_out];
+  };
+  // The MFMAs of an offset are gated per wave tile only (one scalar branch): gating each 16-row
+  // block separately costs ~100 scalar instructions per offset, more than the MFMAs it saves, while
+  // the matrix pipe is otherwise idle (blocks without a neighbour multiply the zero row).
+  auto mma = [&](const bf16x8 (&x)[RB][KSTEPS], int buf, int k) {
+    if (!(nomask || ((wm >> (k & 31)) & 1u))) return;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+      for (int h = 0; h < NB / GS; ++h) {
+        bf16x8 w[GS];
+#pragma unroll
+        for (int g = 0; g < GS; ++g) {
+          const int row = (h * GS + g) * 16 + lrow;
+          w[g] = __builtin_bit_cast(bf16x8, wl[buf][row * PPR + ((ks * 4 + kg) ^ swz(row))]);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+          for (int g = 0; g < GS; ++g)
+            acc[rb][h * GS + g] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g], x[rb][ks], acc[rb][h * GS + g], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  bf16x8 xa[RB][KSTEPS], xb[RB][KSTEPS];
+  // prologue: weights of offset 0 into buffer 0, rows of offset 0 into xa, indices of offset 1
+  int32_t i_nxt = load_idx(0);
+  const int32_t i_one = load_idx(1);
+  load_w(0);
+  gather(xa, i_nxt);
+  i_nxt = i_one;
+  store_w(0);
+  lds_barrier();
+
+  const int klast = kvol - 1;
+  for (int k = 0; k < kvol; k += 2) {
+    // ---- offset k: operands xa / buffer 0; prefetch k+1 into xb / buffer 1 ----
+    {
+      const int32_t i_nn = load_idx(k + 2);  // oldest of this iteration's loads: its consumer (the
+                                             // next gather) must not have to drain the gathers below
+      load_w(k + 1 < kvol ? k + 1 : klast);
+      gather(xb, i_nxt);
+      mma(xa, 0, k);
+      store_w(1);
+      lds_barrier();
+      i_nxt = i_nn;
+    }
+    if (k + 1 >= kvol) break;
+    // ---- offset k+1: operands xb / buffer 1; prefetch k+2 into xa / buffer 0 ----
+    {
+      const int32_t i_nn = load_idx(k + 3);
+      load_w(k + 2 < kvol ? k + 2 : klast);
+      gather(xa, i_nxt);
+      mma(xb, 1, k + 1);
+      store_w(0);
+      lds_barrier();
+      i_nxt = i_nn;
+    }
+  }
+
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int64_t r = row0 + rb * 16 + lrow;
+    if (r >= n_out) continue;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const int ch = cb * 16 + kg * 4;
+      f32x4 v = acc[rb][cb];
+      if (bias) {
+        const f32x4 b = *(const f32x4*)(bias + ch);
+        v += b;
+      }
+      if (OUT_BF16) {
+        u32x2 p;
+        p.x = (uint32_t)ococc_f32_to_bf16(v.x) | ((uint32_t)ococc_f32_to_bf16(v.y) << 16);
+        p.y = (uint32_t)ococc_f32_to_bf16(v.z) | ((uint32_t)ococc_f32_to_bf16(v.w) << 16);
+        *(u32x2*)((uint16_t*)out_ + r * NC + ch) = p;
+      } else {
+        *(f32x4*)((float*)out_ + r * NC + ch) = v;
+      }
+    }
+  }
+}
+
+template <int KD, int NC>
+int launch_gather_gemm_stream(const uint16_t* feat, const uint16_t* wn, int kvol, const int32_t* table,
+                              const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
+                              int out_dtype, hipStream_t stream) {
+  const dim3 grid((unsigned)ococc_cdiv(n_out, kStreamThreads / 64 * 64));
+  if (out_dtype == OCOCC_BF16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, true>), grid, dim3(kStreamThreads), 0,
+                       stream, feat, wn, kvol, table, blockmask, n_out, bias, out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, false>), grid, dim3(kStreamThreads), 0,
+                       stream, feat, wn, kvol, table, blockmask, n_out, bias, out);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+// Returns -1 when the shape has no full-width instantiation.
+template <int KD>
+int dispatch_stream(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
+                    const uint32_t* blockmask, int64_t n_out, const float* bias, void* out, int out_dtype,
+                    hipStream_t stream) {
+  if constexpr (KD % 32 != 0) {
+    return -1;
+  } else {
+    switch (ncols) {
+      case 32: return launch_gather_gemm_stream<KD, 32>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+      case 64: return launch_gather_gemm_stream<KD, 64>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+      case 128:
+        if constexpr (KD <= 64)
+          return launch_gather_gemm_stream<KD, 128>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+        else
+          return -1;
+      default: return -1;
+    }
+  }
+}
+
 template <int KD>
 int dispatch_cs(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                 const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
@@ -298,6 +531,10 @@ int dispatch_cs(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, c
       cs = cands[i];
       break;
     }
+  if (cs != 0 && ncols / cs > 1) {
+    const int rc = dispatch_stream<KD>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    if (rc >= 0) return rc;
+  }
   if (cs == 64)
     return launch_gather_gemm<KD, 64, (KD >= 128 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask,
                                                           n_out, bias, out, out_dtype, stream);
@@ -346,36 +583,59 @@ constexpr int kWgThreads = 256;
 constexpr int kWgSteps = 8;  // 32-pair MFMA k-steps per workgroup
 
 // Flattened (offset, part) work list: offset k owns ceil(ceil(num[k]/32) / kWgSteps) consecutive
-// items.  A one-wave kernel writes the exclusive prefix (kvol+1 ints) so that the thousands of
-// surplus workgroups of the worst-case grid leave after a single load.
-__global__ void wgrad_prefix_kernel(const int32_t* __restrict__ num, int kvol, int32_t* __restrict__ prefix) {
-  if (threadIdx.x == 0) {
-    int base = 0;
-    for (int k = 0; k < kvol; ++k) {
-      prefix[k] = base;
-      const int ksteps = (num[k] + 31) >> 5;
-      base += (ksteps + kWgSteps - 1) / kWgSteps;
+// items.  Every wave locates its item with one coalesced load of num[] and a wave scan, so the
+// thousands of surplus workgroups of the worst-case grid leave after ~30 instructions.
+__device__ __forceinline__ int wg_items(int32_t n) { return (((n + 31) >> 5) + kWgSteps - 1) / kWgSteps; }
+
+__device__ __forceinline__ bool wg_locate(const int32_t* __restrict__ num, int kvol, int g, int* k_out,
+                                          int* part_out, int* base_out) {
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  for (int k0 = 0; k0 < kvol; k0 += 64) {
+    const int k = k0 + lane;
+    const int cnt = k < kvol ? wg_items(num[k]) : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
     }
-    prefix[kvol] = base;
+    const int tot = __shfl(inc, 63, 64);
+    if (g < base + tot) {
+      const int excl = base + inc - cnt;
+      const unsigned long long hit = __ballot(cnt > 0 && g >= excl && g < excl + cnt);
+      const int src = __ffsll((long long)hit) - 1;
+      const int b = __shfl(excl, src, 64);
+      *k_out = k0 + src;
+      *base_out = b;
+      *part_out = g - b;
+      return true;
+    }
+    base += tot;
   }
+  return false;
 }
 
-__device__ __forceinline__ bool wg_locate(const int32_t* __restrict__ prefix, int kvol, int g, int* k_out,
-                                          int* part_out, int* base_out) {
-  if (g >= prefix[kvol]) return false;
-  int k = 0;
-  while (k + 1 < kvol && prefix[k + 1] <= g) ++k;
-  *k_out = k;
-  *part_out = g - prefix[k];
-  *base_out = prefix[k];
-  return true;
+// number of items before offset k, and of offset k itself
+__device__ __forceinline__ void wg_span(const int32_t* __restrict__ num, int k, int* base_out, int* count_out) {
+  const int lane = threadIdx.x & 63;
+  int s = 0;
+  for (int j0 = 0; j0 < k; j0 += 64) {
+    const int j = j0 + lane;
+    int c = j < k ? wg_items(num[j]) : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    s += c;
+  }
+  *base_out = s;
+  *count_out = wg_items(num[k]);
 }
 
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(kWgThreads)
 wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num,
-             const int32_t* __restrict__ prefix, int kvol, int64_t cap, float* __restrict__ slabs) {
+             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
+             int64_t cap, float* __restrict__ slabs) {
   constexpr int MB = CIN / 16, NB = COUT / 16;
   constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
   constexpr int WM = 4 / WN;            // waves along the cin blocks
@@ -386,7 +646,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
 
   int k, part, base;
-  if (!wg_locate(prefix, kvol, blockIdx.x, &k, &part, &base)) return;
+  if (!wg_locate(num, kvol, blockIdx.x, &k, &part, &base)) return;
   const int nk = num[k];
   const int ksteps = (nk + 31) >> 5;
   const int first = part * kWgSteps;
@@ -521,12 +781,12 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
 // block; lane p adds slabs p, p+16, ...; a fixed tree joins the 16 lanes.
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ prefix, int kvol,
+wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
                     int64_t elems, float* __restrict__ dw) {
   __shared__ float red[4][16];
   const int k = blockIdx.y;
-  const int base = prefix[k];
-  const int nslabs = prefix[k + 1] - base;
+  int base, nslabs;
+  wg_span(num, k, &base, &nslabs);
   const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
   float s = 0.f;
@@ -547,14 +807,13 @@ inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
 
 template <int CIN>
 int dispatch_wgrad_cout(const uint16_t* x, const uint16_t* dy, int cout, const int32_t* pairs,
-                        const int32_t* num, const int32_t* prefix, int kvol, int64_t cap, float* slabs,
-                        hipStream_t stream) {
+                        const int32_t* num, int kvol, int64_t cap, float* slabs, hipStream_t stream) {
   dim3 grid((unsigned)wgrad_max_groups(kvol, cap)), block(kWgThreads);
   switch (cout) {
-    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
-    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
-    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
-    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, prefix, kvol, cap, slabs); break;
+    case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 64: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 64>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
+    case 128: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 128>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cout must be 16/32/64/128");
   }
   OCOCC_CHECK_LAUNCH();
@@ -608,7 +867,7 @@ extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t
 extern "C" int64_t ococc_sparse_conv_wgrad_workspace_bytes(int32_t kvol, int64_t pair_capacity,
                                                            int32_t cin, int32_t cout) {
   if (kvol < 1 || cin < 1 || cout < 1 || pair_capacity < 0) return -1;
-  return 1024 + wgrad_max_groups(kvol, pair_capacity) * cin * cout * (int64_t)sizeof(float);
+  return wgrad_max_groups(kvol, pair_capacity) * cin * cout * (int64_t)sizeof(float);
 }
 
 extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin,
@@ -630,20 +889,17 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
   }
   OCOCC_REQUIRE(x && dy && indice_pairs && indice_num, "null pointer");
   int rc;
-  int32_t* prefix = (int32_t*)workspace;  // kvol + 1 ints, then the slabs (256-byte aligned)
-  float* slabs = (float*)((char*)workspace + 1024);
-  hipLaunchKernelGGL(wgrad_prefix_kernel, dim3(1), dim3(64), 0, stream, indice_num, (int)kvol, prefix);
-  OCOCC_CHECK_LAUNCH();
+  float* slabs = (float*)workspace;
   switch (cin) {
-    case 16: rc = dispatch_wgrad_cout<16>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
-    case 32: rc = dispatch_wgrad_cout<32>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
-    case 64: rc = dispatch_wgrad_cout<64>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
-    case 128: rc = dispatch_wgrad_cout<128>(x, dy, cout, indice_pairs, indice_num, prefix, kvol, pair_capacity, slabs, stream); break;
+    case 16: rc = dispatch_wgrad_cout<16>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 32: rc = dispatch_wgrad_cout<32>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 64: rc = dispatch_wgrad_cout<64>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
+    case 128: rc = dispatch_wgrad_cout<128>(x, dy, cout, indice_pairs, indice_num, kvol, pair_capacity, slabs, stream); break;
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cin must be 16/32/64/128");
   }
   if (rc != OCOCC_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ococc_cdiv(elems, 16), kvol), dim3(256), 0,
-                     stream, slabs, prefix, (int)kvol, elems, dw);
+                     stream, slabs, indice_num, (int)kvol, elems, dw);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -40,8 +40,8 @@ class _LayerNormAct(Function):
         n, c = x2.shape
         dy2 = dy.reshape(-1, c).to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
-        dgamma = torch.zeros((c,), dtype=torch.float32, device=x2.device)
-        dbeta = torch.zeros((c,), dtype=torch.float32, device=x2.device)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=x2.device)  # overwritten by the kernel
+        dbeta = torch.empty((c,), dtype=torch.float32, device=x2.device)
         nbytes = L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c)
         ws = L.workspace(nbytes, x2.device)
         L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(x2), L.ptr(dy2), n, c, L.ptr(w32), L.ptr(b32),

@@ -53,7 +53,7 @@ def grid_unique(coors, dims=None, static=False):
         out_coors = torch.empty((cap, ndim), dtype=torch.int32, device=c.device)
     inv = torch.empty((n,), dtype=torch.int32, device=c.device)
     counts = torch.empty((cap,), dtype=torch.int32, device=c.device)
-    meta = torch.zeros(2, dtype=torch.int32, device=c.device)  # [num_unique, status]
+    meta = torch.empty(2, dtype=torch.int32, device=c.device)  # [num_unique, status], zeroed by the C side
     L.check(L.lib.ococc_grid_unique_i32(L.ptr(c), n, ndim, L.i4(dims), L.ptr(out_coors), cap,
                                         L.ptr(inv), L.ptr(counts), meta.data_ptr(),
                                         meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()),

@@ -51,7 +51,7 @@ class _Voxelization(Function):
         """points [N, >=3] -> coors [N,3] (dynamic, max_points == -1 or max_voxels == -1) or
         (voxels [M,max_points,ndim], coors [M,3], num_points_per_voxel [M])."""
         if max_points == -1 or max_voxels == -1:
-            coors = points.new_zeros(size=(points.size(0), 3), dtype=torch.int)
+            coors = points.new_empty(size=(points.size(0), 3), dtype=torch.int)  # every row is written
             dynamic_voxelize(points, coors, voxel_size, coors_range, 3)
             return coors
         voxels = points.new_zeros(size=(max_voxels, max_points, points.size(1)))

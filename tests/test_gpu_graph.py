@@ -87,3 +87,23 @@ def test_graph_replay_matches_eager(dev):
     out_g = g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_g.features, want)
+
+
+def test_fused_adamw_matches_torch(dev):
+    """ococc_adamw_f32 against torch.optim.AdamW (same hyper-parameters, 5 steps, odd sizes)."""
+    from objectcentricocccompletion_amd.optim import AdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(27, 16, 32), (32,), (7,), (3, 3, 3, 64, 128), (1,), (1023,)]
+    pa = [torch.randn(*s, generator=g).to(dev).requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa = AdamW(pa, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ob = torch.optim.AdamW(pb, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    for it in range(5):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(dev)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+    assert float(oa.param_groups[0]['step_dev'].item()) == 5.0
