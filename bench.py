@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 GRIDS_PER_GPU = 64
 POINTS_PER_GRID = 2000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the dgrad of the 64->128 SubMConv3d,
+# gather_gemm_stream_kernel<128,64>: gathers dY rows (128 ch), writes dX rows (64 ch)
+PROBE_KD, PROBE_NC = 128, 64
+PMC_JSON = 'r01_pmc_gather_gemm_stream_128_64.json'
 
 
 def parse():
@@ -82,9 +86,9 @@ def cpu_baseline(sample_grids, points, model):
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_pmc_gather_gemm_64_128.json)."""
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_gather_gemm_64_128.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', PMC_JSON)) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except Exception:
         return None
@@ -223,7 +227,7 @@ def main():
     # nodes inside a captured graph are rejected by this ROCm (hipEventRecordExternal: invalid argument),
     # so in graph mode the events go around the same kernel in eager steps run right after the timed
     # replays (same process, same inputs); the rocprofv3 trace of the replays is the cross-check.
-    probe = sp_ops.KernelProbe(kd=64, ncols=128)
+    probe = sp_ops.KernelProbe(kd=PROBE_KD, ncols=PROBE_NC)
 
     graph_note = 'eager launches'
     if use_graph:
@@ -279,8 +283,9 @@ def main():
     if rank == 0:
         n_vox = int(n_act)
         kern_ms = probe.mean_ms()
-        # algorithmic (compulsory) bytes of one 64->128 forward launch, SURVEY.md 8d:
-        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
+        # algorithmic (compulsory) bytes of one launch on the 64<->128 layer, SURVEY.md 8d:
+        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16); the dgrad reads the 128-wide
+        # rows and writes the 64-wide ones, same total as the forward
         alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
         res = {
@@ -304,7 +309,7 @@ def main():
                 'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}', 'launch': graph_note,
             },
             'roofline': {
-                'kernel': 'gather_gemm_kernel<64,32,4,4,true> (SubMConv3d 64->128 forward)',
+                'kernel': 'gather_gemm_stream_kernel<128,64,true> (SubMConv3d 64->128 dgrad: gathers dY[.,128], writes dX[.,64])',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,

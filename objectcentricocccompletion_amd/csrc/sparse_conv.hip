@@ -287,64 +287,73 @@ int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int n
 
 // ---------------------------------------------------------------- full-width variant
 // When the kvol weight matrices of ALL output columns do not fit LDS the kernel above has to cut
-// the columns into slices and every slice re-reads the gather indices and re-gathers the input
-// rows: on the 64->128 layer that is 4x the vector-memory instructions, which is what bounds it
-// (each 64-lane 16-byte gather occupies the CU's address/data path for 16 cycles).
-// Here a workgroup of 4 waves owns 256 consecutive output rows at full width and the weights
-// stream through LDS one kernel offset at a time (double buffered, one barrier per offset):
-// rows are gathered once, indices are read once, and every gathered 16-byte fragment feeds
-// NC/16 MFMAs.  The software pipeline per offset k: issue the gathers of k+1, the weight loads of
-// k+1 and the indices of k+2, then run the MFMAs of k out of registers/LDS that were filled one
-// iteration earlier.  The barrier only waits for LDS (lgkmcnt): global loads stay in flight
-// across it.
+// the columns into slices, and every slice re-reads the gather indices and re-gathers the input
+// rows (4x on the 64->128 layer).  Here a workgroup of 4 waves owns 256 consecutive output rows at
+// full width and the weights stream through LDS one kernel offset at a time (double buffered,
+// global_load_lds so they never occupy registers, one barrier per offset): rows are gathered once,
+// indices are read once, and every gathered 16-byte fragment feeds NC/16 MFMAs.
+// Per offset k a wave issues the gathers of k+1, the weight DMA of k+1 and the index load of k+2,
+// then runs the MFMAs of k out of registers / LDS filled one iteration earlier.
+// Measured anatomy on the 64->128 layer (tools/prof_conv.py, 126 k rows, 27 offsets): ~20 us are
+// prologue + the 32 MB output store, the rest is the per-offset loop, which is bound by MFMA issue
+// and scalar bookkeeping and NOT by memory latency -- hence (i) the MFMAs of a 16-row block are
+// skipped with ONE scalar branch per 8 MFMAs when the block has no neighbour at the offset, and
+// (ii) gathers are unconditional buffer loads (out-of-range offset -> zeros, no memory access).
 constexpr int kStreamThreads = 256;
 
-__device__ __forceinline__ void lds_barrier() {
-  // workgroup barrier that only waits for this wave's LDS traffic: global loads stay in flight
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_barrier() {
+  // everything but the N youngest vector-memory operations has landed (global_load_lds writes
+  // included), this wave's LDS traffic is done, then the workgroup barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 template <int KD, int NC, bool OUT_BF16>
 __global__ void __launch_bounds__(kStreamThreads, 2)
-gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ wn,
-                          int kvol, const int32_t* __restrict__ table,
+gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes,
+                          const uint16_t* __restrict__ wn, int kvol, const int32_t* __restrict__ table,
                           const uint32_t* __restrict__ blockmask, int64_t n_out,
                           const float* __restrict__ bias, void* __restrict__ out_) {
   constexpr int RB = 4;
   constexpr int KSTEPS = KD / 32;
   constexpr int NB = NC / 16;
-  constexpr int GS = NB < 4 ? NB : 4;     // weight fragments fetched from LDS per group
   constexpr int PPR = KD / 8;             // 16-byte pieces per weight row
   constexpr int RPB = 256 / (KD * 2);     // weight rows per 256-byte LDS bank row
   constexpr int PIECES = NC * PPR;        // per offset
+  constexpr int CHUNKS = PIECES / 64;     // 1 KB chunks, one global_load_lds_dwordx4 each
   constexpr int NWAVES = kStreamThreads / 64;
-  static_assert(KD % 32 == 0, "stream kernel wants whole k-steps");
+  constexpr int CPW = (CHUNKS + NWAVES - 1) / NWAVES;
+  constexpr int NG = RB * KSTEPS;         // gathers per offset (the loads younger than the weight DMA)
+  static_assert(KD % 32 == 0 && PIECES % 64 == 0 && NB % 2 == 0, "stream kernel shape");
   // weights of one offset, row-major [NC][KD] in 16-byte pieces; piece j of row r sits in slot
   // j ^ swz(r) of its row so that the 16 rows an MFMA operand read touches hit 16 different bank
-  // groups without padding
+  // groups without padding (global_load_lds writes lane i at base + 16 i: no room for pad bytes)
   __shared__ __attribute__((aligned(16))) u32x4 wl[2][PIECES];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lrow = lane & 15;
   const int kg = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * (NWAVES * RB * 16) + wave * (RB * 16);
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give XCD x the x-th
+  // contiguous eighth of the rows: a voxel's neighbours are a few thousand rows away at most, so
+  // the rows one XCD gathers are (almost) the rows it owns and stay in its 4 MB L2.
+  // (gridDim.x is a multiple of 8, see the launcher.)
+  const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if ((int64_t)wg * (NWAVES * RB * 16) >= n_out) return;  // padding workgroup: leaves as a whole
+  const int64_t row0 = (int64_t)wg * (NWAVES * RB * 16) + wave * (RB * 16);
   const int64_t n_blocks = (n_out + 15) >> 4;
   const bool nomask = blockmask == nullptr;
 
   uint32_t m[RB];
-  uint32_t wm = 0;
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t blk = (row0 >> 4) + rb;
     uint32_t v = 0;
     if (blk < n_blocks) v = nomask ? 0xffffffffu : blockmask[blk];
     m[rb] = __builtin_amdgcn_readfirstlane(v);
-    wm |= m[rb];
   }
   const int64_t row_l = row0 + lane;
-  const bool row_ok = row_l < n_out;
-  const int64_t row_c = row_ok ? row_l : (n_out - 1);
+  const int64_t row_c = row_l < n_out ? row_l : (n_out - 1);
 
   f32x4 acc[RB][NB];
 #pragma unroll
@@ -353,40 +362,38 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, const uint16_t* __r
     for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto swz = [](int row) -> int { return (row / RPB) & (PPR - 1); };
-  // global -> registers -> LDS.  (global_load_lds would save the registers, but with an LDS-DMA load
-  // in flight the compiler turns every later vector-memory wait into vmcnt(0), which serialises
-  // the gathers behind the weight stage.)
-  constexpr int WPT = (PIECES + kStreamThreads - 1) / kStreamThreads;
-  u32x4 wreg[WPT];
-  auto load_w = [&](int k) {
+  // MFMA block cb, row i (= 4*kg' + r of the accumulator layout) carries output channel
+  // chan(cb, i): blocks 2p and 2p+1 interleave in groups of 4 so that a lane's two accumulators
+  // hold 8 CONSECUTIVE channels 32p + 8kg .. +7 and the epilogue stores 16 bytes per lane.
+  auto chan = [](int cb, int i) -> int { return (cb >> 1) * 32 + (i >> 2) * 8 + (cb & 1) * 4 + (i & 3); };
+  // global -> LDS without a register hop; CPW loads per wave (waves past CHUNKS re-load a chunk
+  // with identical data, to keep the per-wave load count fixed)
+  auto stage_w = [&](int k, int buf) {
 #pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-      int q = u * kStreamThreads + threadIdx.x;
-      if (PIECES % kStreamThreads != 0 && q >= PIECES) q -= PIECES;
+    for (int u = 0; u < CPW; ++u) {
+      int c = u * NWAVES + wave;
+      if (CHUNKS % NWAVES != 0 && c >= CHUNKS) c = c % CHUNKS;
+      const int q = c * 64 + lane;
       const int row = q / PPR, slot = q % PPR;
-      wreg[u] = *(const u32x4*)(wn + (int64_t)k * NC * KD + (row * PPR + (slot ^ swz(row))) * 8);
+      const uint16_t* src = wn + (int64_t)k * NC * KD + (row * PPR + (slot ^ swz(row))) * 8;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                       (void __attribute__((address_space(3)))*)(&wl[buf][c * 64]), 16, 0, 0);
     }
   };
-  auto store_w = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-      int q = u * kStreamThreads + threadIdx.x;
-      if (PIECES % kStreamThreads != 0 && q >= PIECES) q -= PIECES;
-      wl[buf][q] = wreg[u];
-    }
-  };
-  // Unconditional: a block without a neighbour at this offset reads the zero row.  The extra loads
-  // are L1 hits; in exchange the number of loads in flight is a compile-time constant, so the
-  // waits before the MFMAs of offset k leave the gathers of k+1 in flight.
+  // Unconditional buffer loads: a row without a neighbour at this offset gets an out-of-range
+  // offset, for which the buffer unit returns zeros WITHOUT touching memory.
+  const __amdgpu_buffer_rsrc_t frs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
   auto gather = [&](bf16x8 (&x)[RB][KSTEPS], int32_t idx) {
     int32_t ibv[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) ibv[rb] = __shfl(idx, rb * 16 + lrow, 64);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const uint16_t* src = (ibv[rb] >= 0 ? feat + (int64_t)ibv[rb] * KD : g_zero_row) + kg * 8;
+      const uint32_t off = ibv[rb] >= 0 ? (uint32_t)ibv[rb] * (KD * 2) + kg * 16 : 0xffffff00u;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) x[rb][ks] = *(const bf16x8*)(src + ks * 32);
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        x[rb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, off + ks * 64, 0, 0));
     }
   };
   // indices of offset k for this wave's 64 rows (lane -> row); offsets past the end re-read the last
@@ -396,27 +403,36 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, const uint16_t* __r
     const int kk = k < kvol ? k : kvol - 1;
     return tcol[(int64_t)kk * n_out];
   };
-  // The MFMAs of an offset are gated per wave tile only (one scalar branch): gating each 16-row
-  // block separately costs ~100 scalar instructions per offset, more than the MFMAs it saves, while
-  // the matrix pipe is otherwise idle (blocks without a neighbour multiply the zero row).
   auto mma = [&](const bf16x8 (&x)[RB][KSTEPS], int buf, int k) {
-    if (!(nomask || ((wm >> (k & 31)) & 1u))) return;
+    // 4-bit activity of the wave's 16-row blocks at this offset
+    uint32_t act = 0xfu;
+    if (!nomask) {
+      act = 0;
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+      for (int rb = 0; rb < RB; ++rb) act |= ((m[rb] >> (k & 31)) & 1u) << rb;
+    }
+    if (!act) return;
+    // weight fragments are fetched 8 at a time (FG k-steps x NB column blocks), then each active
+    // 16-row block runs its 8 MFMAs behind one scalar branch
+    constexpr int FG = (NB >= 8) ? 1 : ((8 / NB) < KSTEPS ? (8 / NB) : KSTEPS);
 #pragma unroll
-      for (int h = 0; h < NB / GS; ++h) {
-        bf16x8 w[GS];
+    for (int k0 = 0; k0 < KSTEPS; k0 += FG) {
+      bf16x8 w[FG][NB];
 #pragma unroll
-        for (int g = 0; g < GS; ++g) {
-          const int row = (h * GS + g) * 16 + lrow;
-          w[g] = __builtin_bit_cast(bf16x8, wl[buf][row * PPR + ((ks * 4 + kg) ^ swz(row))]);
+      for (int f = 0; f < FG; ++f)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          const int row = chan(cb, lrow);
+          w[f][cb] = __builtin_bit_cast(bf16x8, wl[buf][row * PPR + (((k0 + f) * 4 + kg) ^ swz(row))]);
         }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
+      for (int rb = 0; rb < RB; ++rb) {
+        if ((act >> rb) & 1u) {
 #pragma unroll
-          for (int g = 0; g < GS; ++g)
-            acc[rb][h * GS + g] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g], x[rb][ks], acc[rb][h * GS + g], 0, 0, 0);
+          for (int f = 0; f < FG; ++f)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][cb], x[rb][k0 + f], acc[rb][cb], 0, 0, 0);
         }
       }
     }
@@ -426,91 +442,93 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, const uint16_t* __r
   // prologue: weights of offset 0 into buffer 0, rows of offset 0 into xa, indices of offset 1
   int32_t i_nxt = load_idx(0);
   const int32_t i_one = load_idx(1);
-  load_w(0);
+  stage_w(0, 0);
   gather(xa, i_nxt);
   i_nxt = i_one;
-  store_w(0);
-  lds_barrier();
+  wait_vmcnt_barrier<NG>();
 
   const int klast = kvol - 1;
   for (int k = 0; k < kvol; k += 2) {
     // ---- offset k: operands xa / buffer 0; prefetch k+1 into xb / buffer 1 ----
     {
-      const int32_t i_nn = load_idx(k + 2);  // oldest of this iteration's loads: its consumer (the
-                                             // next gather) must not have to drain the gathers below
-      load_w(k + 1 < kvol ? k + 1 : klast);
+      const int32_t i_nn = load_idx(k + 2);
+      stage_w(k + 1 < kvol ? k + 1 : klast, 1);
       gather(xb, i_nxt);
       mma(xa, 0, k);
-      store_w(1);
-      lds_barrier();
+      wait_vmcnt_barrier<NG>();
       i_nxt = i_nn;
     }
     if (k + 1 >= kvol) break;
     // ---- offset k+1: operands xb / buffer 1; prefetch k+2 into xa / buffer 0 ----
     {
       const int32_t i_nn = load_idx(k + 3);
-      load_w(k + 2 < kvol ? k + 2 : klast);
+      stage_w(k + 2 < kvol ? k + 2 : klast, 0);
       gather(xa, i_nxt);
       mma(xb, 1, k + 1);
-      store_w(0);
-      lds_barrier();
+      wait_vmcnt_barrier<NG>();
       i_nxt = i_nn;
     }
   }
 
+  // ---- epilogue: lane holds channels 32p + 8kg .. +7 of voxel lrow in acc[rb][2p], acc[rb][2p+1] ----
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t r = row0 + rb * 16 + lrow;
     if (r >= n_out) continue;
 #pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int ch = cb * 16 + kg * 4;
-      f32x4 v = acc[rb][cb];
+    for (int p = 0; p < NB / 2; ++p) {
+      const int ch = p * 32 + kg * 8;
+      f32x4 v0 = acc[rb][2 * p], v1 = acc[rb][2 * p + 1];
       if (bias) {
-        const f32x4 b = *(const f32x4*)(bias + ch);
-        v += b;
+        v0 += *(const f32x4*)(bias + ch);
+        v1 += *(const f32x4*)(bias + ch + 4);
       }
       if (OUT_BF16) {
-        u32x2 p;
-        p.x = (uint32_t)ococc_f32_to_bf16(v.x) | ((uint32_t)ococc_f32_to_bf16(v.y) << 16);
-        p.y = (uint32_t)ococc_f32_to_bf16(v.z) | ((uint32_t)ococc_f32_to_bf16(v.w) << 16);
-        *(u32x2*)((uint16_t*)out_ + r * NC + ch) = p;
+        u32x4 q;
+        q.x = (uint32_t)ococc_f32_to_bf16(v0.x) | ((uint32_t)ococc_f32_to_bf16(v0.y) << 16);
+        q.y = (uint32_t)ococc_f32_to_bf16(v0.z) | ((uint32_t)ococc_f32_to_bf16(v0.w) << 16);
+        q.z = (uint32_t)ococc_f32_to_bf16(v1.x) | ((uint32_t)ococc_f32_to_bf16(v1.y) << 16);
+        q.w = (uint32_t)ococc_f32_to_bf16(v1.z) | ((uint32_t)ococc_f32_to_bf16(v1.w) << 16);
+        *(u32x4*)((uint16_t*)out_ + r * NC + ch) = q;
       } else {
-        *(f32x4*)((float*)out_ + r * NC + ch) = v;
+        *(f32x4*)((float*)out_ + r * NC + ch) = v0;
+        *(f32x4*)((float*)out_ + r * NC + ch + 4) = v1;
       }
     }
   }
 }
 
 template <int KD, int NC>
-int launch_gather_gemm_stream(const uint16_t* feat, const uint16_t* wn, int kvol, const int32_t* table,
+int launch_gather_gemm_stream(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, const int32_t* table,
                               const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
                               int out_dtype, hipStream_t stream) {
-  const dim3 grid((unsigned)ococc_cdiv(n_out, kStreamThreads / 64 * 64));
+  // (grid rounded up to a multiple of 8 so that the XCD permutation inside the kernel is a bijection)
+  const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, kStreamThreads / 64 * 64), 8));
   if (out_dtype == OCOCC_BF16)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, true>), grid, dim3(kStreamThreads), 0,
-                       stream, feat, wn, kvol, table, blockmask, n_out, bias, out);
+                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, false>), grid, dim3(kStreamThreads), 0,
-                       stream, feat, wn, kvol, table, blockmask, n_out, bias, out);
+                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
 
 // Returns -1 when the shape has no full-width instantiation.
 template <int KD>
-int dispatch_stream(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
+int dispatch_stream(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                     const uint32_t* blockmask, int64_t n_out, const float* bias, void* out, int out_dtype,
                     hipStream_t stream) {
   if constexpr (KD % 32 != 0) {
     return -1;
   } else {
+    if (n_in * KD * 2 >= 0xffffff00ll) return -1;  // the gathers address feat through a 32-bit buffer offset
     switch (ncols) {
-      case 32: return launch_gather_gemm_stream<KD, 32>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
-      case 64: return launch_gather_gemm_stream<KD, 64>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+      case 32: return launch_gather_gemm_stream<KD, 32>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+      case 64: return launch_gather_gemm_stream<KD, 64>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
       case 128:
         if constexpr (KD <= 64)
-          return launch_gather_gemm_stream<KD, 128>(feat, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+          return launch_gather_gemm_stream<KD, 128>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
         else
           return -1;
       default: return -1;
@@ -519,7 +537,7 @@ int dispatch_stream(const uint16_t* feat, const uint16_t* wn, int kvol, int ncol
 }
 
 template <int KD>
-int dispatch_cs(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
+int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                 const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
                 int out_dtype, hipStream_t stream) {
   // widest column slice whose kvol weight slices fit the LDS budget
@@ -532,7 +550,7 @@ int dispatch_cs(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols, c
       break;
     }
   if (cs != 0 && ncols / cs > 1) {
-    const int rc = dispatch_stream<KD>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    const int rc = dispatch_stream<KD>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
     if (rc >= 0) return rc;
   }
   if (cs == 64)
@@ -836,10 +854,10 @@ extern "C" int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t 
   OCOCC_REQUIRE(wn && table && out, "null pointer");
   OCOCC_REQUIRE(feat || n_in == 0, "null feat");
   switch (kd) {
-    case 16: return dispatch_cs<16>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
-    case 32: return dispatch_cs<32>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
-    case 64: return dispatch_cs<64>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
-    case 128: return dispatch_cs<128>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 16: return dispatch_cs<16>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 32: return dispatch_cs<32>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 64: return dispatch_cs<64>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    case 128: return dispatch_cs<128>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 16/32/64/128");
   }
 }

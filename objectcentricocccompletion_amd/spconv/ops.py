@@ -16,8 +16,9 @@ _KD_OK = (16, 32, 64, 128)
 
 class KernelProbe(object):
     """HIP-event timer for one gather-GEMM shape (bench.py's roofline line): events are
-    recorded on the stream the kernel is launched on, around every matching forward launch
-    inside the timed region, and read back after the final synchronize."""
+    recorded on the stream the kernel is launched on, around every matching launch (forward
+    with kd = Cin / ncols = Cout, or dgrad with kd = Cout / ncols = Cin), and read back after
+    the final synchronize."""
 
     def __init__(self, kd, ncols, max_events=4096, external=False):
         self.kd, self.ncols, self.max_events = kd, ncols, max_events
@@ -275,7 +276,10 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         mode = 1 if (rb.subm and subm) else 2
         wn = _prep_weights(filters, mode, kd_out, nc)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
-        gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype)
+        if _probe is not None:
+            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype))
+        else:
+            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()
     if need_filter_grad:
         x = _x_bf16 if _x_bf16 is not None else _to_bf16_padded(features, kd_in)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage: tools/pmc_hbm.sh <tag> <kernel-substring> [prof_conv args] -- HBM-side bytes of one conv kernel.
+# FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, PMC slots): separate bounded passes.
+tag=$1; kern=$2; shift 2
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out -o h$i -- python3 $GRAFT_REPO_ROOT/tools/prof_conv.py --iters 3 "$@" > /dev/null 2>$out/herr$i.txt || echo "pass $i failed/timeout"
+done
+python3 - <<PY
+import csv, glob, collections, json
+acc=collections.defaultdict(list)
+for f in sorted(glob.glob('$out/h*counter_collection.csv')):
+    for r in csv.DictReader(open(f)):
+        if '$kern' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+m={k: sum(v)/len(v) for k,v in acc.items()}
+print(m)
+if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+    res={'kernel': '$kern', 'FETCH_SIZE_KB_raw': m['FETCH_SIZE'], 'WRITE_SIZE_KB': m['WRITE_SIZE'],
+         'fetch_correction': 'x2: gfx950 FETCH_SIZE reports half of 16 B/lane reads (MI355X_MICROARCH.md, HBM section)',
+         'traffic_bytes_per_launch': int(m['FETCH_SIZE']*2*1024 + m['WRITE_SIZE']*1024),
+         'TCC_HIT_sum': m.get('TCC_HIT_sum'), 'TCC_MISS_sum': m.get('TCC_MISS_sum'),
+         'collected': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum, separate passes (tools/pmc_hbm.sh), tools/prof_conv.py 64 grids x 2000 voxels'}
+    json.dump(res, open('$out/hbm.json','w'), indent=1)
+    print(json.dumps(res))
+PY
