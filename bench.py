@@ -48,8 +48,8 @@ def parse():
     ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
     ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet'],
-                    help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]')
+    ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet', 'sst'],
+                    help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]; sst = configs[4] per-GPU share')
     ap.add_argument('--tracklets', type=int, default=4)
     ap.add_argument('--split-graph', action='store_true',
                     help='use the N>1 launch plan (fwd+bwd graph, eager all-reduce, optimizer graph) at N=1 too')
@@ -152,6 +152,107 @@ def bench_ococcnet(args, world, rank, dev):
             'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
+def bench_sst(args, world, rank, dev):
+    """configs[4], one GPU's share: 32 object grids of 80x80x64 cells at 0.1 m (the reference's window
+    partition asserts z < x, sst_ops.py:283, so the cube is cut to 6.4 m in z; ~8 000 active voxels each),
+    voxelise -> scatter-mean -> Linear(16->128) -> SSTInputLayerV2 (3-D windows 8x8x8, drop levels
+    30/60/100 tokens) -> 2 BasicShiftBlockV2 (d_model 128, 8 heads, ffn 256), bf16 attention core,
+    fwd + bwd + AdamW.  The roofline line is the window-attention forward kernel against the dense
+    bf16 MFMA peak (flops = 4 T^2 d per window and head over the padded T the kernel runs)."""
+    from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
+    from objectcentricocccompletion_amd.occ_encoder import synthetic_object_grids
+    from objectcentricocccompletion_amd.optim import AdamW
+    from objectcentricocccompletion_amd.sst import sst_modules as sm
+    from objectcentricocccompletion_amd.voxel import dynamic_scatter, voxelization
+    torch.manual_seed(0)
+    G, P = 32, 8200
+    shape = (64, 80, 80)   # (D, H, W) = (z, y, x) cells
+    rng = [-4, -4, -3.2, 4, 4, 3.2]
+    drop = {0: dict(max_tokens=30, drop_range=(0, 30)), 1: dict(max_tokens=60, drop_range=(30, 60)),
+            2: dict(max_tokens=100, drop_range=(60, 100000))}
+    inp = sm.SSTInputLayerV2(drop, (8, 8, 8), (80, 80, 64), shuffle_voxels=False, debug=False, mute=True).to(dev)
+    model = sm.SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, dropout=0.0,
+                     activation='gelu', num_attached_conv=0, to_bev=False, debug=False,
+                     layer_cfg=dict(compute_dtype=torch.bfloat16)).to(dev).train()
+    embed = torch.nn.Linear(16, 128).to(dev)  # voxel encoder stand-in: the input layer wants d_model channels
+    broadcast_parameters(model)
+    broadcast_parameters(embed)
+    params = list(model.parameters()) + list(embed.parameters())
+    opt = AdamW(params, lr=1e-4)
+    buckets = GradBuckets(params)
+    xyz, feats, bidx = synthetic_object_grids(G, P, seed=rank, device=dev)
+    xyz[:, 2] *= 0.8
+
+    class AttnProbe(object):
+        def __init__(self):
+            self.items = []
+
+        def wrap(self, nW, T, H, D, launch):
+            a, b = L_.Timer(), L_.Timer()
+            a.record()
+            launch()
+            b.record()
+            self.items.append((a, b, 4.0 * nW * H * T * T * D))
+
+    from objectcentricocccompletion_amd import _lib as L_
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        zyx = voxelization(xyz, [0.1, 0.1, 0.1], rng, -1, -1)
+        coors = torch.cat([bidx.view(-1, 1).to(torch.int32), zyx], 1)
+        vfeats, vcoors = dynamic_scatter(feats, coors, 'mean', grid_shape=[G] + list(shape))
+        info = inp(embed(vfeats), vcoors.long())
+        out = model(info)[0]['voxel_feats']
+        out.backward(d_out)
+        buckets.all_reduce()
+        opt.step()
+        return out
+
+    with torch.no_grad():
+        zyx = voxelization(xyz, [0.1, 0.1, 0.1], rng, -1, -1)
+        n_act = dynamic_scatter(feats, torch.cat([bidx.view(-1, 1).to(torch.int32), zyx], 1), 'mean',
+                                grid_shape=[G] + list(shape))[0].shape[0]
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+    d_out = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
+    for _ in range(args.warmup):
+        step()
+    probe = AttnProbe()
+    sm.set_attn_probe(probe)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    sm.set_attn_probe(None)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        ms = sum(a.elapsed_ms(b) for a, b, _ in probe.items)
+        fl = sum(f for _, _, f in probe.items)
+        tflops = fl / (ms * 1e-3) / 1e12 if ms else None
+        print(json.dumps({
+            'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * G * args.steps / dt, 1),
+            'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'configs[4] per-GPU share: {G} grids x 80x80x64 cells at 0.1 m, {P} random points each, '
+                                   'SST path (windows 8x8x8, drop levels 30/60/100, d_model 128, 8 heads, ffn 256, '
+                                   '2 BasicShiftBlockV2), fwd+bwd+AdamW', 'grids_per_gpu': G, 'active_voxels': int(n_act),
+                       'parallelism': f'dp{world}', 'launch': 'eager launches'},
+            'roofline': {'kernel': 'window_attn_fwd_kernel (all drop levels, both shifts)', 'bound': 'mfma',
+                         'achieved': round(tflops, 2) if tflops else None, 'peak': 2500.0, 'unit': 'TFLOP/s',
+                         'frac': round(tflops / 2500.0, 5) if tflops else None, 'traffic': None,
+                         'launches_timed': len(probe.items)},
+            'cpu_baseline': None}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -165,8 +266,8 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
 
-    if args.workload == 'ococcnet':
-        bench_ococcnet(args, world, rank, dev)
+    if args.workload in ('ococcnet', 'sst'):
+        (bench_ococcnet if args.workload == 'ococcnet' else bench_sst)(args, world, rank, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -127,6 +127,14 @@ class SSTInputLayerV2(nn.Module):
         return {k: v.logical_not().squeeze(2) for k, v in d.items()}
 
 
+_attn_probe = None  # measurement hook (bench.py --workload sst): .wrap(T, launch) times the forward kernel
+
+
+def set_attn_probe(probe):
+    global _attn_probe
+    _attn_probe = probe
+
+
 class _WindowAttnCore(torch.autograd.Function):
     """softmax(q k^T / sqrt(d) + mask) v on padded windows, bf16 MFMA kernel."""
 
@@ -138,9 +146,14 @@ class _WindowAttnCore(torch.autograd.Function):
         out = torch.empty_like(qb)
         lse = torch.empty((nW, num_heads, T), dtype=torch.float32, device=q.device)
         scale = float(D) ** -0.5
-        L.check(L.lib.ococc_window_attn_fwd_bf16(L.ptr(qb), L.ptr(kb), L.ptr(vb), C, C, C, L.ptr(key_len), nW, T,
-                                                 num_heads, D, scale, L.ptr(out), C, L.ptr(lse), L.stream()),
-                'window_attn_fwd')
+        def launch():
+            L.check(L.lib.ococc_window_attn_fwd_bf16(L.ptr(qb), L.ptr(kb), L.ptr(vb), C, C, C, L.ptr(key_len), nW, T,
+                                                     num_heads, D, scale, L.ptr(out), C, L.ptr(lse), L.stream()),
+                    'window_attn_fwd')
+        if _attn_probe is not None:
+            _attn_probe.wrap(nW, T, num_heads, D, launch)
+        else:
+            launch()
         ctx.save_for_backward(qb, kb, vb, out, lse, key_len)
         ctx.meta = (num_heads, D, scale, q.dtype)
         return out.to(q.dtype)
@@ -156,6 +169,116 @@ class _WindowAttnCore(torch.autograd.Function):
                                                  L.ptr(lse), L.ptr(key_len), nW, T, H, D, scale, L.ptr(dq), L.ptr(dk),
                                                  L.ptr(dv), C, C, C, L.stream()), 'window_attn_bwd')
         return dq.to(dt), dk.to(dt), dv.to(dt), None, None
+
+
+class _WindowAttnPacked(torch.autograd.Function):
+    """Same kernel on a packed bf16 [nW, T, 3E] tensor (q | k | v per token, row stride 3E): no
+    per-operand copies, and the backward writes dq | dk | dv into one packed tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_len, num_heads):
+        nW, T, C3 = qkv.shape
+        E = C3 // 3
+        D = E // num_heads
+        assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+        out = torch.empty((nW, T, E), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((nW, num_heads, T), dtype=torch.float32, device=qkv.device)
+        scale = float(D) ** -0.5
+        base = qkv.data_ptr()
+
+        def launch():
+            L.check(L.lib.ococc_window_attn_fwd_bf16(base, base + 2 * E, base + 4 * E, C3, C3, C3, L.ptr(key_len), nW,
+                                                     T, num_heads, D, scale, L.ptr(out), E, L.ptr(lse), L.stream()),
+                    'window_attn_fwd')
+        if _attn_probe is not None:
+            _attn_probe.wrap(nW, T, num_heads, D, launch)
+        else:
+            launch()
+        ctx.save_for_backward(qkv, out, lse, key_len)
+        ctx.meta = (num_heads, D, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, key_len = ctx.saved_tensors
+        H, D, scale = ctx.meta
+        nW, T, C3 = qkv.shape
+        E = C3 // 3
+        do = dout.to(torch.bfloat16).contiguous()
+        dqkv = torch.empty_like(qkv)
+        b, g = qkv.data_ptr(), dqkv.data_ptr()
+        L.check(L.lib.ococc_window_attn_bwd_bf16(b, b + 2 * E, b + 4 * E, C3, C3, C3, L.ptr(out), L.ptr(do), E,
+                                                 L.ptr(lse), L.ptr(key_len), nW, T, H, D, scale, g, g + 2 * E,
+                                                 g + 4 * E, C3, C3, C3, L.stream()), 'window_attn_bwd')
+        return dqkv, None, None
+
+
+class _TokenLinear(torch.autograd.Function):
+    """y = x W^T + b over ~1e5..1e6 token rows with a tiny [out, in] weight.  The weight gradient
+    dW = dY^T X contracts over the token dimension; the BLAS heuristics give that one output tile
+    per 64x128 of dW (a dozen workgroups on a 256-CU part, ~0.6 ms).  Here the token dimension is cut
+    into 64 slabs, a batched GEMM produces 64 partial dW (thousands of tiles), and the partials are
+    summed in f32."""
+    SLABS = 64
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        n, s = x.shape[0], _TokenLinear.SLABS
+        m = (n // s) * s
+        dw = None
+        if m:
+            part = torch.bmm(dy[:m].view(s, m // s, -1).transpose(1, 2), x[:m].view(s, m // s, -1))
+            dw = part.float().sum(0)
+        if m < n:
+            tail = (dy[m:].t() @ x[m:]).float()
+            dw = tail if dw is None else dw + tail
+        db = dy.float().sum(0).to(dy.dtype) if ctx.has_bias else None
+        return dx, dw.to(w.dtype), db
+
+
+class _ScatterRows(torch.autograd.Function):
+    """out[slot[i]] = feat[pos[i]] into a zero [rows, C] tensor; slot and pos are injective, so the
+    backward is the mirror gather (no sort-based index_put backward)."""
+
+    @staticmethod
+    def forward(ctx, feat, pos, slot, rows):
+        out = feat.new_zeros((rows, feat.shape[1]))
+        out.index_copy_(0, slot, feat.index_select(0, pos))
+        ctx.save_for_backward(pos, slot)
+        ctx.n = feat.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        pos, slot = ctx.saved_tensors
+        g = grad.new_zeros((ctx.n, grad.shape[1]))
+        g.index_copy_(0, pos, grad.index_select(0, slot))
+        return g, None, None, None
+
+
+def _window_maps(ind_dict, key_padding_dict):
+    """Per drop level (slot, pos, num_windows, max_tokens, key_len), cached on the index dict."""
+    maps = ind_dict.get('_ococc_maps')
+    if maps is None:
+        maps = {}
+        info = ind_dict['batching_info']
+        for dl in info:
+            if dl not in ind_dict:
+                continue
+            slot, flat_pos = ind_dict[dl]
+            mask = key_padding_dict[dl]
+            maps[dl] = (slot, flat_pos[0], mask.shape[0], mask.shape[1], (~mask).sum(1).to(torch.int32))
+        ind_dict['_ococc_maps'] = maps
+    return maps
 
 
 class WindowMultiheadAttention(nn.Module):
@@ -181,6 +304,25 @@ class WindowMultiheadAttention(nn.Module):
                                   key_len, self.num_heads)
         return self.out_proj(o.reshape(nW * T, E)).view(nW, T, E)
 
+    def forward_flat(self, x, pos_flat, maps, dtype):
+        """MI355X form of the same layer: the q/k/v and output projections are per-token, so they
+        run on the V real tokens (not on the ~3x larger padded windows) as bf16 GEMMs; one packed
+        [V, 3E] tensor is scattered into the padded window layout per drop level, the attention core
+        reads it in place, and its output is gathered straight back to token order."""
+        E, H = self.embed_dim, self.num_heads
+        w, b = self.in_proj_weight.to(dtype), self.in_proj_bias.to(dtype)
+        x16 = x.to(dtype)
+        qk = _TokenLinear.apply(x16 + pos_flat, w[:2 * E], b[:2 * E])
+        v = _TokenLinear.apply(x16, w[2 * E:], b[2 * E:])
+        qkv = torch.cat([qk, v], 1)
+        o_flat = None
+        for dl, (slot, pos, nW, T, key_len) in maps.items():
+            packed = _ScatterRows.apply(qkv, pos, slot, nW * T).view(nW, T, 3 * E)
+            o = _WindowAttnPacked.apply(packed, key_len, H).view(nW * T, E)
+            part = _ScatterRows.apply(o, slot, pos, x.shape[0])
+            o_flat = part if o_flat is None else o_flat + part
+        return _TokenLinear.apply(o_flat, self.out_proj.weight.to(dtype), self.out_proj.bias.to(dtype))
+
 
 class WindowAttention(nn.Module):
 
@@ -191,8 +333,16 @@ class WindowAttention(nn.Module):
         self.nhead = nhead
         self.self_attn = WindowMultiheadAttention(d_model, nhead, dropout=dropout)
         self.layer_id = layer_id
+        self.compute_dtype = layer_cfg.get('compute_dtype', None)  # torch.bfloat16 -> flat-token bf16 path
 
     def forward(self, feat_2d, pos_dict, ind_dict, key_padding_dict):
+        if self.compute_dtype is not None:
+            maps = _window_maps(ind_dict, key_padding_dict)
+            pos_flat = ind_dict.get('_ococc_pos_flat')
+            if pos_flat is None:
+                pos_flat = window2flat_v2(pos_dict, ind_dict).to(self.compute_dtype)
+                ind_dict['_ococc_pos_flat'] = pos_flat
+            return self.self_attn.forward_flat(feat_2d, pos_flat, maps, self.compute_dtype)
         feat_3d_dict = flat2window_v2(feat_2d, ind_dict)
         out = {}
         for name, feat_3d in feat_3d_dict.items():
@@ -220,12 +370,25 @@ class EncoderLayer(nn.Module):
         self.dropout1, self.dropout2 = nn.Dropout(mlp_dropout), nn.Dropout(mlp_dropout)
         self.activation = _activation(activation)
         self.post_norm = layer_cfg.get('post_norm', True)
+        self.compute_dtype = layer_cfg.get('compute_dtype', None)
 
     @staticmethod
     def _ln(norm, x):
         return layer_norm_act(x, norm.weight, norm.bias, norm.eps, 'none')
 
+    def _ffn(self, x):
+        if self.compute_dtype is None:
+            return self.linear2(self.dropout(self.activation(self.linear1(x))))
+        dt, lin = self.compute_dtype, _TokenLinear.apply
+        h = self.activation(lin(x.to(dt), self.linear1.weight.to(dt), self.linear1.bias.to(dt)))
+        return lin(self.dropout(h), self.linear2.weight.to(dt), self.linear2.bias.to(dt))
+
     def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
+        if self.compute_dtype is not None:
+            src = src.to(self.compute_dtype)  # bf16 residual stream; LN statistics and GEMM accumulation stay f32
+            assert self.post_norm
+            src = self._ln(self.norm1, src + self.dropout1(self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)))
+            return self._ln(self.norm2, src + self.dropout2(self._ffn(src)))
         if self.post_norm:
             src = self._ln(self.norm1, src + self.dropout1(self.win_attn(src, pos_dict, ind_dict, key_padding_mask_dict)))
             src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
