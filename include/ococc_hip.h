@@ -99,6 +99,11 @@ int ococc_hard_voxelize_f32(const float* points, int64_t num_points, int32_t num
  * written to out_coors/counts (use min(n, prod(dims))).
  * ------------------------------------------------------------------------ */
 int64_t ococc_grid_unique_workspace_bytes(int32_t ndim, const int32_t host_dims[4]);
+/* Byte offsets of the cell bitmap (1 bit per cell, row-major over dims) and of its exclusive popcount
+ * prefix (one u32 per 32 cells) inside the grid_unique workspace: after ococc_grid_unique_i32 they
+ * describe the sorted voxel set and can be handed to ococc_subm_rulebook_build_sorted. */
+int ococc_grid_unique_workspace_layout(int32_t ndim, const int32_t host_dims[4], int64_t* bitmap_offset,
+                                       int64_t* prefix_offset);
 int ococc_grid_unique_i32(const int32_t* coors, int64_t n, int32_t ndim, const int32_t host_dims[4],
                           int32_t* out_coors, int64_t out_capacity, int32_t* inv, int32_t* counts,
                           int32_t* num_unique, int32_t* status, void* workspace,
@@ -127,6 +132,17 @@ int ococc_segment_reduce_f32(const float* feats, const int32_t* inv, int64_t n, 
 int ococc_segment_reduce_bwd_f32(const float* grad_out, const int32_t* inv, int64_t n, int32_t c,
                                  int32_t reduce_type, const int32_t* counts, const int32_t* arg,
                                  float* grad_feats, int64_t num_segments, ococc_stream_t stream);
+
+/* Same rulebook when the rows of `indices` are exactly the occupied cells of a [batch, D, H, W] grid in
+ * ascending cell order and the caller still holds that grid's bitmap + popcount prefix (the state
+ * ococc_grid_unique_i32 leaves in its workspace, see ococc_grid_unique_workspace_layout): the
+ * marking, scanning and row-permutation passes are skipped.  Rows with negative coordinates
+ * (fixed-capacity padding) take part in no pair.  Workspace size as for ococc_subm_rulebook_build. */
+int ococc_subm_rulebook_build_sorted(const int32_t* indices, int64_t n, int32_t batch_size,
+                                     const int32_t host_shape[3], const int32_t host_ksize[3],
+                                     const uint32_t* grid_bitmap, const uint32_t* grid_prefix, int32_t* nbr_t,
+                                     uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num,
+                                     void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * B3  sub-manifold rulebook

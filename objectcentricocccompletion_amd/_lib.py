@@ -31,6 +31,7 @@ SIGNATURES = {
     'ococc_hard_voxelize_f32': (c_i32, [c_vp, c_i64, c_i32, _F3, _F6, c_i32, c_i32, c_vp, c_vp,
                                         c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_grid_unique_workspace_bytes': (c_i64, [c_i32, _I4]),
+    'ococc_grid_unique_workspace_layout': (c_i32, [c_i32, _I4, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     'ococc_grid_unique_i32': (c_i32, [c_vp, c_i64, c_i32, _I4, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),
     'ococc_segment_count_i32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
@@ -41,6 +42,8 @@ SIGNATURES = {
     'ococc_subm_rulebook_workspace_bytes': (c_i64, [c_i64, c_i32, _I3, _I3]),
     'ococc_subm_rulebook_build': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, _I3, c_vp, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_vp]),
+    'ococc_subm_rulebook_build_sorted': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_i64, c_vp]),
     'ococc_conv_rulebook_workspace_bytes': (c_i64, [c_i64, c_i32, _I3, _I3]),
     'ococc_conv_rulebook_build': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, _I3, _I3, _I3, c_i32, c_vp, c_i64, c_vp,
                                           c_vp, c_vp, c_vp, c_i64, c_vp]),

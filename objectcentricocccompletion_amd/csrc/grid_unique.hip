@@ -116,6 +116,16 @@ extern "C" int64_t ococc_grid_unique_workspace_bytes(int32_t ndim, const int32_t
   return L.total;
 }
 
+extern "C" int ococc_grid_unique_workspace_layout(int32_t ndim, const int32_t host_dims[4],
+                                                  int64_t* bitmap_offset, int64_t* prefix_offset) {
+  Layout L;
+  OCOCC_REQUIRE(host_dims && make_layout(ndim, host_dims, &L), "ndim must be 1..4 and prod(dims) < 2^31");
+  OCOCC_REQUIRE(bitmap_offset && prefix_offset, "null output");
+  *bitmap_offset = L.off_bitmap;
+  *prefix_offset = L.off_prefix;
+  return OCOCC_OK;
+}
+
 extern "C" int ococc_grid_unique_i32(const int32_t* coors, int64_t n, int32_t ndim,
                                      const int32_t host_dims[4], int32_t* out_coors,
                                      int64_t out_capacity, int32_t* inv, int32_t* counts,

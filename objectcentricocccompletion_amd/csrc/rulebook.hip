@@ -78,10 +78,13 @@ __global__ void __launch_bounds__(256)
 neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
                        const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
                        const int32_t* __restrict__ perm, int32_t* __restrict__ nbr_t,
-                       uint32_t* __restrict__ blockmask) {
+                       uint32_t* __restrict__ blockmask, uint32_t* __restrict__ blk_cnt) {
+  // perm == nullptr: rows are in ascending cell order (the output of ococc_grid_unique_i32), rank = row
+  // blk_cnt[k * gridDim.x + block]: valid entries of this 256-row block at offset k (for the compaction)
+  __shared__ uint32_t wcnt[4][64];
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int kd = KS ? KS : g.kd, kh = KS ? KS : g.kh, kw = KS ? KS : g.kw;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int32_t b = -1, z0 = 0, y0 = 0, x0 = 0;
   if (o < n) {
     b = indices[o * 4];
@@ -98,11 +101,15 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
         (unsigned)x < (unsigned)g.W) {
       const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
       const int32_t r = rank_of(bitmap, prefix, cell);
-      if (r >= 0) v = perm[r] - 1;  // perm holds row + 1 (0 = empty)
+      if (r >= 0) v = perm ? perm[r] - 1 : r;  // perm holds row + 1 (0 = empty)
     }
     if (o < n) nbr_t[(int64_t)k * n + o] = v;
     const unsigned long long m = __ballot(v >= 0);
     if (k < 32 && ((m >> (lane & 48)) & 0xffffull)) mask |= 1u << k;
+    if (blk_cnt && lane == 0) {
+      if (k < 64) wcnt[wave][k] = (uint32_t)__popcll(m);
+      else atomicAdd(blk_cnt + (int64_t)k * gridDim.x + blockIdx.x, (uint32_t)__popcll(m));  // kvol > 64: rare
+    }
   };
   if constexpr (KS != 0) {
 #pragma unroll
@@ -114,28 +121,66 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
         for (int kx = 0; kx < kw; ++kx, ++k) visit(kz, ky, kx, k);
   }
   if (blockmask && (lane & 15) == 0 && o < n) blockmask[o >> 4] = mask;
+  if (blk_cnt) {
+    __syncthreads();
+    const int kvol = kd * kh * kw;
+    if ((int)threadIdx.x < kvol && threadIdx.x < 64)
+      blk_cnt[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] =
+          wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+  }
+}
+
+// one workgroup per offset: exclusive scan of the per-block counts (in place) and the pair count of
+// the reference-format rulebook, indice_num[k] = total of offset kvol-1-k (geometry.h:247-297 order)
+__global__ void __launch_bounds__(256)
+block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t* __restrict__ indice_num) {
+  __shared__ uint32_t wsum[4];
+  const int k = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (int64_t b0 = 0; b0 < nblk; b0 += 256) {
+    const int64_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nblk ? blk[(int64_t)k * nblk + b] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) before += wsum[w];
+      total += wsum[w];
+    }
+    if (b < nblk) blk[(int64_t)k * nblk + b] = carry + before + inc - v;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && indice_num) indice_num[kvol - 1 - k] = (int32_t)carry;
 }
 
 // pairs[k][0][pos] = j, pairs[k][1][pos] = nbr_t[K-1-k][j]  for valid entries
 __global__ void __launch_bounds__(256)
-compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ pos,
+compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ blk_off,
                      int64_t n, int kvol, int32_t* __restrict__ pairs) {
+  // grid (row blocks of 256, kvol): same blocking as neighbour_table_kernel, order preserving
+  __shared__ uint32_t wsum[4];
   const int k = blockIdx.y;
   const int src = kvol - 1 - k;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n;
-       j += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t o = nbr_t[(int64_t)src * n + j];
-    if (o < 0) continue;
-    const int64_t p = pos[(int64_t)src * n + j];
-    pairs[((int64_t)k * 2 + 0) * n + p] = (int32_t)j;
-    pairs[((int64_t)k * 2 + 1) * n + p] = o;
-  }
-}
-
-__global__ void reverse_totals_kernel(const uint32_t* __restrict__ totals, int kvol,
-                                      int32_t* __restrict__ indice_num) {
-  const int k = threadIdx.x;
-  if (k < kvol) indice_num[k] = (int32_t)totals[kvol - 1 - k];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t o = j < n ? nbr_t[(int64_t)src * n + j] : -1;
+  const unsigned long long m = __ballot(o >= 0);
+  if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (o < 0) return;
+  uint32_t p = blk_off[(int64_t)src * gridDim.x + blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) p += wsum[w];
+  pairs[((int64_t)k * 2 + 0) * n + p] = (int32_t)j;
+  pairs[((int64_t)k * 2 + 1) * n + p] = o;
 }
 
 // generic rulebook -> gather table
@@ -306,10 +351,9 @@ inline bool make_layout(int64_t n, int32_t batch, const int32_t* shape, const in
   L->off_bitmap = off;  off += ococc_align_up(L->words * 4, 256);
   L->off_perm = off;    off += ococc_align_up(n * 4, 256);  // directly behind the bitmap: one zero fill
   L->off_prefix = off;  off += ococc_align_up(L->words * 4, 256);
-  L->off_pos = off;     off += ococc_align_up(kvol * n * 4, 256);
+  L->off_pos = off;     off += ococc_align_up(kvol * ococc_cdiv(n > 0 ? n : 1, 256) * 4, 256);  // per-(offset, block) counts
   int64_t sw = ococc_scan::scratch_words(L->words, 1);
-  int64_t sw2 = ococc_scan::scratch_words(n, (int)kvol);
-  L->off_scratch = off; off += ococc_align_up((sw > sw2 ? sw : sw2) * 4, 256);
+  L->off_scratch = off; off += ococc_align_up(sw * 4, 256);
   L->off_totals = off;  off += ococc_align_up((kvol + 1) * 4, 256);
   L->total = off;
   return true;
@@ -325,13 +369,13 @@ extern "C" int64_t ococc_subm_rulebook_workspace_bytes(int64_t n, int32_t batch_
   return L.total;
 }
 
-extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
-                                         const int32_t host_shape[3], const int32_t host_ksize[3],
-                                         const int32_t host_dilation[3], int32_t* nbr_t,
-                                         uint32_t* blockmask, int32_t* indice_pairs,
-                                         int32_t* indice_num, void* workspace,
-                                         int64_t workspace_bytes, ococc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+
+int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, const int32_t host_shape[3],
+                       const int32_t host_ksize[3], const int32_t host_dilation[3],
+                       const uint32_t* grid_bitmap, const uint32_t* grid_prefix, int32_t* nbr_t,
+                       uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
+                       int64_t workspace_bytes, hipStream_t stream) {
   Layout L;
   OCOCC_REQUIRE(n >= 0, "n < 0");
   OCOCC_REQUIRE(make_layout(n, batch_size, host_shape, host_ksize, &L),
@@ -350,45 +394,76 @@ extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int3
   OCOCC_REQUIRE(indices && nbr_t, "null indices/nbr_t");
   OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
   char* ws = (char*)workspace;
-  uint32_t* bitmap = (uint32_t*)(ws + L.off_bitmap);
-  uint32_t* prefix = (uint32_t*)(ws + L.off_prefix);
-  int32_t* perm = (int32_t*)(ws + L.off_perm);
-  uint32_t* pos = (uint32_t*)(ws + L.off_pos);
-  uint32_t* scratch = (uint32_t*)(ws + L.off_scratch);
-  uint32_t* totals = (uint32_t*)(ws + L.off_totals);
+  const uint32_t* bitmap = grid_bitmap;
+  const uint32_t* prefix = grid_prefix;
+  const int32_t* perm = nullptr;  // identity when the caller's rows are already in cell order
+  uint32_t* blk = (uint32_t*)(ws + L.off_pos);
   Geom g{batch_size, host_shape[0], host_shape[1], host_shape[2],
          host_ksize[0], host_ksize[1], host_ksize[2]};
+  const int64_t nblk = ococc_cdiv(n, 256);
 
-  // bitmap and perm (row + 1, 0 = empty) in one fill; blockmask and indice_num are fully written
-  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.off_prefix - L.off_bitmap, stream));
-  const int g1 = ococc_grid_1d(n, 256);
-  hipLaunchKernelGGL(mark_voxels_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
-                     (int32_t*)nullptr);
-  OCOCC_CHECK_LAUNCH();
-  OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bitmap, L.words, L.words, 1, prefix,
-                                                         L.words, scratch, nullptr, stream));
-  hipLaunchKernelGGL(fill_perm_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bitmap,
-                     prefix, perm);
-  OCOCC_CHECK_LAUNCH();
+  if (!grid_bitmap) {
+    uint32_t* bm = (uint32_t*)(ws + L.off_bitmap);
+    uint32_t* pf = (uint32_t*)(ws + L.off_prefix);
+    int32_t* pm = (int32_t*)(ws + L.off_perm);
+    uint32_t* scratch = (uint32_t*)(ws + L.off_scratch);
+    // bitmap and perm (row + 1, 0 = empty) in one fill; blockmask and indice_num are fully written
+    OCOCC_HIP(hipMemsetAsync(bm, 0, L.off_prefix - L.off_bitmap, stream));
+    const int g1 = ococc_grid_1d(n, 256);
+    hipLaunchKernelGGL(mark_voxels_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bm,
+                       (int32_t*)nullptr);
+    OCOCC_CHECK_LAUNCH();
+    OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bm, L.words, L.words, 1, pf, L.words, scratch,
+                                                           nullptr, stream));
+    hipLaunchKernelGGL(fill_perm_kernel, dim3(g1), dim3(256), 0, stream, indices, n, g, bm, pf, pm);
+    OCOCC_CHECK_LAUNCH();
+    bitmap = bm;
+    prefix = pf;
+    perm = pm;
+  }
+  uint32_t* cnt = indice_pairs ? blk : nullptr;
+  if (cnt && kvol > 64) OCOCC_HIP(hipMemsetAsync(blk, 0, (int64_t)kvol * nblk * 4, stream));
   if (g.kd == 3 && g.kh == 3 && g.kw == 3)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<3>), dim3((unsigned)ococc_cdiv(n, 256)), dim3(256), 0,
-                       stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<3>), dim3((unsigned)nblk), dim3(256), 0, stream,
+                       indices, n, g, bitmap, prefix, perm, nbr_t, blockmask, cnt);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<0>), dim3((unsigned)ococc_cdiv(n, 256)), dim3(256), 0,
-                       stream, indices, n, g, bitmap, prefix, perm, nbr_t, blockmask);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream,
+                       indices, n, g, bitmap, prefix, perm, nbr_t, blockmask, cnt);
   OCOCC_CHECK_LAUNCH();
   if (indice_pairs) {
     OCOCC_HIP(hipMemsetAsync(indice_pairs, 0xff, (int64_t)kvol * 2 * n * 4, stream));
-    OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::NONNEG>((const uint32_t*)nbr_t, n, n, kvol,
-                                                             pos, n, scratch, totals, stream));
-    hipLaunchKernelGGL(compact_pairs_kernel, dim3(ococc_grid_1d(n, 256, 1024), kvol), dim3(256), 0,
-                       stream, nbr_t, pos, n, kvol, indice_pairs);
+    hipLaunchKernelGGL(block_offsets_kernel, dim3(kvol), dim3(256), 0, stream, blk, nblk, kvol, indice_num);
     OCOCC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reverse_totals_kernel, dim3(1), dim3(256), 0, stream, totals, kvol,
-                       indice_num);
+    hipLaunchKernelGGL(compact_pairs_kernel, dim3((unsigned)nblk, kvol), dim3(256), 0, stream, nbr_t, blk, n,
+                       kvol, indice_pairs);
     OCOCC_CHECK_LAUNCH();
   }
   return OCOCC_OK;
+}
+
+}  // namespace
+
+extern "C" int ococc_subm_rulebook_build(const int32_t* indices, int64_t n, int32_t batch_size,
+                                         const int32_t host_shape[3], const int32_t host_ksize[3],
+                                         const int32_t host_dilation[3], int32_t* nbr_t,
+                                         uint32_t* blockmask, int32_t* indice_pairs,
+                                         int32_t* indice_num, void* workspace,
+                                         int64_t workspace_bytes, ococc_stream_t stream) {
+  return subm_rulebook_impl(indices, n, batch_size, host_shape, host_ksize, host_dilation, nullptr, nullptr,
+                            nbr_t, blockmask, indice_pairs, indice_num, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+extern "C" int ococc_subm_rulebook_build_sorted(const int32_t* indices, int64_t n, int32_t batch_size,
+                                                const int32_t host_shape[3], const int32_t host_ksize[3],
+                                                const uint32_t* grid_bitmap, const uint32_t* grid_prefix,
+                                                int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
+                                                int32_t* indice_num, void* workspace, int64_t workspace_bytes,
+                                                ococc_stream_t stream) {
+  OCOCC_REQUIRE(grid_bitmap && grid_prefix, "null grid bitmap / prefix");
+  return subm_rulebook_impl(indices, n, batch_size, host_shape, host_ksize, nullptr, grid_bitmap, grid_prefix,
+                            nbr_t, blockmask, indice_pairs, indice_num, workspace, workspace_bytes,
+                            (hipStream_t)stream);
 }
 
 extern "C" int ococc_rulebook_pairs_to_table(const int32_t* indice_pairs,

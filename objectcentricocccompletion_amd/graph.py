@@ -46,7 +46,8 @@ class GraphedStep(object):
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with (capture_ctx if capture_ctx is not None else contextlib.nullcontext()):
-            with torch.cuda.graph(self.graph, pool=pool, stream=self.stream):
+            # thread_local: other threads (RCCL watchdog, autograd workers) may keep calling the runtime
+            with torch.cuda.graph(self.graph, pool=pool, stream=self.stream, capture_error_mode='thread_local'):
                 self.out = fn()
         torch.cuda.synchronize()
 

@@ -138,11 +138,23 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     mask = torch.empty(((n + 15) // 16,), dtype=torch.int32, device=dev) if kvol <= 32 else None
     pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
     num = torch.empty((kvol,), dtype=torch.int32, device=dev)
-    L.check(L.lib.ococc_subm_rulebook_build(L.ptr(indices), n, int(batch_size),
-                                            L.i3(spatial_shape), L.i3(ksize), L.i3(dilation),
-                                            L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
-                                            L.ptr(ws), ws.numel(), L.stream()),
-            'subm_rulebook_build')
+    grid = getattr(indices, '_ococc_grid', None)
+    if (grid is not None and grid[3] == (int(batch_size),) + tuple(int(v) for v in spatial_shape)
+            and all(int(d) == 1 for d in dilation)):
+        # the rows come straight from grid_unique over this very grid: reuse its cell bitmap + prefix
+        gws, boff, poff, _ = grid
+        L.check(L.lib.ococc_subm_rulebook_build_sorted(L.ptr(indices), n, int(batch_size), L.i3(spatial_shape),
+                                                       L.i3(ksize), gws.data_ptr() + boff, gws.data_ptr() + poff,
+                                                       L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
+                                                       L.ptr(ws), ws.numel(), L.stream()),
+                'subm_rulebook_build_sorted')
+        pairs._ococc_keepalive = gws
+    else:
+        L.check(L.lib.ococc_subm_rulebook_build(L.ptr(indices), n, int(batch_size),
+                                                L.i3(spatial_shape), L.i3(ksize), L.i3(dilation),
+                                                L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
+                                                L.ptr(ws), ws.numel(), L.stream()),
+                'subm_rulebook_build')
     rb = RulebookTables(True, kvol)
     rb.tables[(False, 'fwd')] = (nbr_t, mask, n)
     rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights

@@ -58,15 +58,25 @@ def grid_unique(coors, dims=None, static=False):
                                         L.ptr(inv), L.ptr(counts), meta.data_ptr(),
                                         meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()),
             'grid_unique')
+    def tag(t):
+        # the workspace still holds the cell bitmap + prefix of exactly these rows: a sub-manifold
+        # rulebook over the same grid can reuse them (spconv.ops.get_indice_pairs)
+        if ndim == 4:
+            bo, po = L.c_i64(), L.c_i64()
+            L.check(L.lib.ococc_grid_unique_workspace_layout(ndim, L.i4(dims), bo, po), 'grid_unique_layout')
+            t._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims))
+        return t
     if static:
         inv._ococc_counts = counts
-        return (out_coors[:, 0] if squeeze else out_coors), inv, counts, meta
+        return (out_coors[:, 0] if squeeze else tag(out_coors)), inv, counts, meta
     num, status = meta.tolist()
     if status:
         raise L.OcoccError(f'grid_unique: a coordinate is outside the declared bounds {dims}')
     out_coors = out_coors[:num]
     if squeeze:
         out_coors = out_coors[:, 0]
+    else:
+        tag(out_coors)
     counts = counts[:num]
     inv._ococc_counts = counts  # rides along so later reductions skip the counting pass
     return out_coors, inv, counts

@@ -325,3 +325,30 @@ def test_sparse_conv3d_and_inverse_modules_vs_dense(dev):
 
 def rel_close(a, b, tol):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12)) < tol
+
+
+def test_subm_rulebook_sorted_grid_fast_path_matches_generic(dev):
+    """get_indice_pairs on coordinates that come straight from grid_unique reuses the unique's cell bitmap
+    (ococc_subm_rulebook_build_sorted); it must produce the same rulebook as the generic build, in both the
+    exactly-sized and the fixed-capacity (static, -1 padded) forms."""
+    from objectcentricocccompletion_amd.spconv import ops
+    from objectcentricocccompletion_amd.voxel.scatter_points import grid_unique
+    g = torch.Generator().manual_seed(11)
+    B, shape = 3, [12, 10, 14]
+    coors = torch.stack([torch.randint(0, B, (4000,), generator=g)] +
+                        [torch.randint(0, s, (4000,), generator=g) for s in shape], 1).int().to(dev)
+    uc, _, _ = grid_unique(coors, [B] + shape)
+    assert hasattr(uc, '_ococc_grid')
+    _, p_fast, n_fast = ops.get_indice_pairs(uc, B, shape, 3, subm=True)
+    _, p_ref, n_ref = ops.get_indice_pairs(uc.clone(), B, shape, 3, subm=True)   # clone: no tag -> generic path
+    assert torch.equal(n_fast, n_ref) and torch.equal(p_fast, p_ref)
+    assert torch.equal(p_fast._ococc.tables[(False, 'fwd')][0], p_ref._ococc.tables[(False, 'fwd')][0])
+    assert torch.equal(p_fast._ococc.tables[(False, 'fwd')][1], p_ref._ococc.tables[(False, 'fwd')][1])
+    us, _, _, meta = grid_unique(coors, [B] + shape, static=True)
+    m = int(meta[0])
+    _, p_s, n_s = ops.get_indice_pairs(us, B, shape, 3, subm=True)
+    assert torch.equal(n_s, n_ref)
+    for k in range(27):
+        c = int(n_ref[k])
+        assert torch.equal(p_s[k, :, :c], p_ref[k, :, :c]) and bool((p_s[k, :, c:] == -1).all())
+    assert bool((p_s._ococc.tables[(False, 'fwd')][0][:, m:] == -1).all())
