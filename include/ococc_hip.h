@@ -227,6 +227,17 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
  *   mode 1 (dgrad, sub-manifold): wn[k][cin][cout] = W[kvol-1-k][cin][cout]
  *   mode 2 (dgrad, generic table side 0): wn[k][cin][cout] = W[k][cin][cout]
  * always bf16 out. */
+/* Forward gather-GEMM with the norm/activation pair of make_sparse_convmodule
+ * (mmdet3d/ops/sparse_block.py:216-289: conv -> LayerNorm -> GELU) fused into the epilogue:
+ * conv_out [n_out, ncols] bf16 (kept for the backward), y = act(LN(conv_out)) bf16, mean_rstd [n_out,2]
+ * f32 as ococc_layernorm_act_fwd writes them.  gamma / beta [ncols] f32.  Returns OCOCC_EUNSUPPORTED
+ * when the shape has no fused kernel (then call the two separate entry points). */
+int ococc_sparse_conv_gather_gemm_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                          int32_t kvol, int32_t ncols, const int32_t* table,
+                                          const uint32_t* blockmask, int64_t n_out, const float* gamma,
+                                          const float* beta, float eps, int32_t act, uint16_t* conv_out,
+                                          uint16_t* y, float* mean_rstd, ococc_stream_t stream);
+
 int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t kvol, int32_t cin,
                               int32_t cout, int32_t mode, uint16_t* wn, ococc_stream_t stream);
 

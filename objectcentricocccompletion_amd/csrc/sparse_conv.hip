@@ -44,17 +44,38 @@ constexpr int kLdsBudget = 144 * 1024;
 // zero-select is needed after the loads (it stays L1 resident).
 __device__ __attribute__((aligned(256))) uint16_t g_zero_row[256];
 
+// Optional fused epilogue: LayerNorm (+ exact GELU) over the output row, the norm/act pair that
+// make_sparse_convmodule puts behind the convolution (ops/sparse_block.py:216-289).  The row statistics
+// are taken from the bf16-rounded conv output, exactly what the separate LN kernel would read.
+struct LnArgs {
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int act;             // 0 none, 1 GELU(erf)
+  uint16_t* y;         // [n_out, ncols] bf16
+  float* mean_rstd;    // [n_out, 2]
+};
+
+__device__ __forceinline__ float conv_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float round_bf16(float v) { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); }
+// sum over the 4 lanes (kg = 0..3) that share an output row
+__device__ __forceinline__ float row_sum4(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
   u32x4 z = {0u, 0u, 0u, 0u};
   return __builtin_bit_cast(bf16x8, z);
 }
 
-template <int KD, int CS, int RB, int G, bool OUT_BF16>
+template <int KD, int CS, int RB, int G, bool OUT_BF16, bool LN = false>
 __global__ void __launch_bounds__(kConvThreads)
 gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict__ wn, int kvol,
                    int ncols, const int32_t* __restrict__ table,
                    const uint32_t* __restrict__ blockmask, int64_t n_out,
-                   const float* __restrict__ bias, void* __restrict__ out_) {
+                   const float* __restrict__ bias, void* __restrict__ out_, LnArgs ln) {
   constexpr int KSTEPS = (KD + 31) / 32;
   constexpr int NB = CS / 16;
   constexpr int LDW = KD + 8;  // LDS row stride in elements (16 B pad)
@@ -233,6 +254,7 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
     for (int rb = 0; rb < RB; ++rb) {
       const int64_t r = (tile * RB + rb) * 16 + lrow;
       if (r >= n_out) continue;
+      float rs = 0.f;
 #pragma unroll
       for (int cb = 0; cb < NB; ++cb) {
         const int ch = cs0 + cb * 16 + kg * 4;
@@ -249,6 +271,45 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
         } else {
           *(f32x4*)((float*)out_ + r * ncols + ch) = v;
         }
+        if (LN) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = round_bf16(v[j]);
+            rs += v[j];
+          }
+          acc[rb][cb] = v;
+        }
+      }
+      if (LN) {  // single column slice (CS == ncols): the 4 kg lanes of a row hold all of it
+        const float mean = row_sum4(rs) * (1.f / CS);
+        float sq = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = acc[rb][cb][j] - mean;
+            sq += d * d;
+          }
+        const float rstd = rsqrtf(row_sum4(sq) * (1.f / CS) + ln.eps);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+          const int ch = cb * 16 + kg * 4;
+          const f32x4 gm = *(const f32x4*)(ln.gamma + ch), bt = *(const f32x4*)(ln.beta + ch);
+          f32x4 z;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = (acc[rb][cb][j] - mean) * rstd * gm[j] + bt[j];
+            z[j] = ln.act == 1 ? conv_gelu(t) : t;
+          }
+          u32x2 p;
+          p.x = (uint32_t)ococc_f32_to_bf16(z.x) | ((uint32_t)ococc_f32_to_bf16(z.y) << 16);
+          p.y = (uint32_t)ococc_f32_to_bf16(z.z) | ((uint32_t)ococc_f32_to_bf16(z.w) << 16);
+          *(u32x2*)(ln.y + r * ncols + ch) = p;
+        }
+        if (kg == 0) {
+          ln.mean_rstd[r * 2] = mean;
+          ln.mean_rstd[r * 2 + 1] = rstd;
+        }
       }
     }
   }
@@ -257,7 +318,8 @@ gather_gemm_kernel(const uint16_t* __restrict__ feat, const uint16_t* __restrict
 template <int KD, int CS, int RB>
 int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int ncols,
                        const int32_t* table, const uint32_t* blockmask, int64_t n_out,
-                       const float* bias, void* out, int out_dtype, hipStream_t stream) {
+                       const float* bias, void* out, int out_dtype, hipStream_t stream,
+                       const LnArgs* ln = nullptr) {
   const int lds = kvol * CS * (KD + 8) * 2;
   const int n_slices = ncols / CS;
   const int64_t n_tiles = ococc_cdiv(ococc_cdiv(n_out, 16), RB);
@@ -270,16 +332,25 @@ int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int n
   if (gx > need) gx = need;
   if (gx < 1) gx = 1;
   dim3 grid((unsigned)gx, (unsigned)n_slices);
+  if (ln) {
+    if (n_slices != 1 || out_dtype != OCOCC_BF16) return -1;  // no fused instantiation
+    auto kern = gather_gemm_kernel<KD, CS, RB, (KD >= 128 ? 2 : 4), true, true>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
+                       blockmask, n_out, bias, out, *ln);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   if (out_dtype == OCOCC_BF16) {
     auto kern = gather_gemm_kernel<KD, CS, RB, (KD >= 128 ? 2 : 4), true>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
-                       blockmask, n_out, bias, out);
+                       blockmask, n_out, bias, out, LnArgs{});
   } else {
     auto kern = gather_gemm_kernel<KD, CS, RB, (KD >= 128 ? 2 : 4), false>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, grid, dim3(kConvThreads), lds, stream, feat, wn, kvol, ncols, table,
-                       blockmask, n_out, bias, out);
+                       blockmask, n_out, bias, out, LnArgs{});
   }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
@@ -308,12 +379,12 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int KD, int NC, bool OUT_BF16>
+template <int KD, int NC, bool OUT_BF16, bool LN = false>
 __global__ void __launch_bounds__(kStreamThreads, 2)
 gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes,
                           const uint16_t* __restrict__ wn, int kvol, const int32_t* __restrict__ table,
                           const uint32_t* __restrict__ blockmask, int64_t n_out,
-                          const float* __restrict__ bias, void* __restrict__ out_) {
+                          const float* __restrict__ bias, void* __restrict__ out_, LnArgs ln) {
   constexpr int RB = 4;
   constexpr int KSTEPS = KD / 32;
   constexpr int NB = NC / 16;
@@ -475,6 +546,7 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   for (int rb = 0; rb < RB; ++rb) {
     const int64_t r = row0 + rb * 16 + lrow;
     if (r >= n_out) continue;
+    float rs = 0.f;
 #pragma unroll
     for (int p = 0; p < NB / 2; ++p) {
       const int ch = p * 32 + kg * 8;
@@ -494,6 +566,52 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
         *(f32x4*)((float*)out_ + r * NC + ch) = v0;
         *(f32x4*)((float*)out_ + r * NC + ch + 4) = v1;
       }
+      if (LN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v0[j] = round_bf16(v0[j]);
+          v1[j] = round_bf16(v1[j]);
+          rs += v0[j] + v1[j];
+        }
+        acc[rb][2 * p] = v0;
+        acc[rb][2 * p + 1] = v1;
+      }
+    }
+    if (LN) {
+      const float mean = row_sum4(rs) * (1.f / NC);
+      float sq = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = acc[rb][cb][j] - mean;
+          sq += d * d;
+        }
+      const float rstd = rsqrtf(row_sum4(sq) * (1.f / NC) + ln.eps);
+#pragma unroll
+      for (int p = 0; p < NB / 2; ++p) {
+        const int ch = p * 32 + kg * 8;
+        float z[8];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x4 gm = *(const f32x4*)(ln.gamma + ch + 4 * h2), bt = *(const f32x4*)(ln.beta + ch + 4 * h2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = (acc[rb][2 * p + h2][j] - mean) * rstd * gm[j] + bt[j];
+            z[4 * h2 + j] = ln.act == 1 ? conv_gelu(t) : t;
+          }
+        }
+        u32x4 q;
+        q.x = (uint32_t)ococc_f32_to_bf16(z[0]) | ((uint32_t)ococc_f32_to_bf16(z[1]) << 16);
+        q.y = (uint32_t)ococc_f32_to_bf16(z[2]) | ((uint32_t)ococc_f32_to_bf16(z[3]) << 16);
+        q.z = (uint32_t)ococc_f32_to_bf16(z[4]) | ((uint32_t)ococc_f32_to_bf16(z[5]) << 16);
+        q.w = (uint32_t)ococc_f32_to_bf16(z[6]) | ((uint32_t)ococc_f32_to_bf16(z[7]) << 16);
+        *(u32x4*)(ln.y + r * NC + ch) = q;
+      }
+      if (kg == 0) {
+        ln.mean_rstd[r * 2] = mean;
+        ln.mean_rstd[r * 2 + 1] = rstd;
+      }
     }
   }
 }
@@ -501,15 +619,19 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
 template <int KD, int NC>
 int launch_gather_gemm_stream(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, const int32_t* table,
                               const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
-                              int out_dtype, hipStream_t stream) {
+                              int out_dtype, hipStream_t stream, const LnArgs* ln = nullptr) {
   // (grid rounded up to a multiple of 8 so that the XCD permutation inside the kernel is a bijection)
   const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, kStreamThreads / 64 * 64), 8));
-  if (out_dtype == OCOCC_BF16)
+  if (ln) {
+    if (out_dtype != OCOCC_BF16) return -1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, true, true>), grid, dim3(kStreamThreads), 0,
+                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out, *ln);
+  } else if (out_dtype == OCOCC_BF16)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, true>), grid, dim3(kStreamThreads), 0,
-                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out);
+                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out, LnArgs{});
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, false>), grid, dim3(kStreamThreads), 0,
-                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out);
+                       stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table, blockmask, n_out, bias, out, LnArgs{});
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
@@ -518,17 +640,17 @@ int launch_gather_gemm_stream(const uint16_t* feat, int64_t n_in, const uint16_t
 template <int KD>
 int dispatch_stream(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                     const uint32_t* blockmask, int64_t n_out, const float* bias, void* out, int out_dtype,
-                    hipStream_t stream) {
+                    hipStream_t stream, const LnArgs* ln = nullptr) {
   if constexpr (KD % 32 != 0) {
     return -1;
   } else {
     if (n_in * KD * 2 >= 0xffffff00ll) return -1;  // the gathers address feat through a 32-bit buffer offset
     switch (ncols) {
-      case 32: return launch_gather_gemm_stream<KD, 32>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
-      case 64: return launch_gather_gemm_stream<KD, 64>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+      case 32: return launch_gather_gemm_stream<KD, 32>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
+      case 64: return launch_gather_gemm_stream<KD, 64>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
       case 128:
         if constexpr (KD <= 64)
-          return launch_gather_gemm_stream<KD, 128>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream);
+          return launch_gather_gemm_stream<KD, 128>(feat, n_in, wn, kvol, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
         else
           return -1;
       default: return -1;
@@ -539,7 +661,7 @@ int dispatch_stream(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int 
 template <int KD>
 int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                 const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
-                int out_dtype, hipStream_t stream) {
+                int out_dtype, hipStream_t stream, const LnArgs* ln = nullptr) {
   // widest column slice whose kvol weight slices fit the LDS budget
   const int per_col = kvol * (KD + 8) * 2;
   int cs = 0;
@@ -549,19 +671,22 @@ int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
       cs = cands[i];
       break;
     }
-  if (cs != 0 && ncols / cs > 1) {
-    const int rc = dispatch_stream<KD>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+  if (cs != 0 && (ncols / cs > 1 || (ln && cs != ncols))) {
+    const int rc = dispatch_stream<KD>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype,
+                                       stream, ln);
     if (rc >= 0) return rc;
   }
+  int rc = -1;
   if (cs == 64)
-    return launch_gather_gemm<KD, 64, (KD >= 128 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask,
-                                                          n_out, bias, out, out_dtype, stream);
-  if (cs == 32)
-    return launch_gather_gemm<KD, 32, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
-                                         out_dtype, stream);
-  if (cs == 16)
-    return launch_gather_gemm<KD, 16, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
-                                         out_dtype, stream);
+    rc = launch_gather_gemm<KD, 64, (KD >= 128 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
+                                                        out_dtype, stream, ln);
+  else if (cs == 32)
+    rc = launch_gather_gemm<KD, 32, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
+  else if (cs == 16)
+    rc = launch_gather_gemm<KD, 16, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
+  if (rc >= 0) return rc;
+  if (ln && cs != 0)
+    return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "no fused LayerNorm epilogue for this shape (use the separate calls)");
   return ococc_fail(OCOCC_EUNSUPPORTED, __func__,
                     "kernel volume x channels does not fit the LDS-resident weight plan");
 }
@@ -858,6 +983,30 @@ extern "C" int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t 
     case 32: return dispatch_cs<32>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
     case 64: return dispatch_cs<64>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
     case 128: return dispatch_cs<128>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream);
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 16/32/64/128");
+  }
+}
+
+extern "C" int ococc_sparse_conv_gather_gemm_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd,
+                                                     const uint16_t* wn, int32_t kvol, int32_t ncols,
+                                                     const int32_t* table, const uint32_t* blockmask,
+                                                     int64_t n_out, const float* gamma, const float* beta,
+                                                     float eps, int32_t act, uint16_t* conv_out, uint16_t* y,
+                                                     float* mean_rstd, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n_in >= 0 && n_out >= 0, "negative row count");
+  OCOCC_REQUIRE(kvol >= 1 && kvol <= 32, "kernel volume must be 1..32");
+  OCOCC_REQUIRE(ncols >= 16 && ncols % 16 == 0, "ncols must be a multiple of 16");
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  if (n_out == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(wn && table && conv_out && y && mean_rstd && gamma && beta, "null pointer");
+  OCOCC_REQUIRE(feat || n_in == 0, "null feat");
+  const LnArgs ln{gamma, beta, eps, (int)act, y, mean_rstd};
+  switch (kd) {
+    case 16: return dispatch_cs<16>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, nullptr, conv_out, OCOCC_BF16, stream, &ln);
+    case 32: return dispatch_cs<32>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, nullptr, conv_out, OCOCC_BF16, stream, &ln);
+    case 64: return dispatch_cs<64>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, nullptr, conv_out, OCOCC_BF16, stream, &ln);
+    case 128: return dispatch_cs<128>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, nullptr, conv_out, OCOCC_BF16, stream, &ln);
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 16/32/64/128");
   }
 }

@@ -72,7 +72,18 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, input):
+    def _ln_fusable(self, features):
+        import torch
+        from . import ops as _ops
+        from .ops import _KD_OK
+        return (_ops._probe is None and features.dtype == torch.bfloat16 and self.in_channels in _KD_OK and self.out_channels % 16 == 0
+                and self.out_channels in (16, 32, 64, 128) and int(np.prod(self.kernel_size)) <= 32
+                and features.shape[0] > 0)
+
+    def forward(self, input, _ln=None):
+        """``_ln``: the LayerNorm module that follows this conv in a make_sparse_convmodule block; when the
+        shape allows, it (and its fused GELU) run in the conv kernel's epilogue and the returned tensor is
+        marked ``_ln_applied`` so that the container skips the norm."""
         assert isinstance(input, SparseConvTensor)
         features = input.features
         indices = input.indices
@@ -120,6 +131,16 @@ class SparseConvolution(SparseModule):
                                                  indice_pair_num, outids.shape[0], self.inverse,
                                                  self.subm)
         else:
+            if _ln is not None and self.bias is None and self._ln_fusable(features):
+                # norm (+ GELU) of the enclosing make_sparse_convmodule, fused into the conv epilogue
+                out_features = Fsp.indice_conv_ln(features, self.weight, _ln.weight, _ln.bias, indice_pairs,
+                                                  indice_pair_num, outids.shape[0], _ln.eps,
+                                                  1 if _ln.fused_act == 'gelu' else 0, self.inverse, self.subm)
+                out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+                out_tensor.indice_dict = input.indice_dict
+                out_tensor.grid = input.grid
+                out_tensor._ln_applied = True
+                return out_tensor
             if self.subm:
                 out_features = Fsp.indice_subm_conv(features, self.weight, indice_pairs,
                                                     indice_pair_num, outids.shape[0])

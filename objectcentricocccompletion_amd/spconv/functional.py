@@ -64,6 +64,52 @@ class SubMConvFunction(_IndiceConvBase):
         return SubMConvFunction._bwd(ctx, grad_output)
 
 
+class _IndiceConvLN(Function):
+    """conv -> LayerNorm -> act with the norm in the conv kernel's epilogue (forward) and the existing LN
+    backward kernel in front of indice_conv_backward (backward).  mode: (inverse, subm)."""
+
+    @staticmethod
+    def forward(ctx, features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out, eps, act,
+                inverse, subm):
+        saved = {}
+        res = ops.indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indice_pair_num,
+                                 num_activate_out, inverse, subm, _saved=saved)
+        if res is None:
+            raise ops.L.OcoccError('no fused conv+LN kernel for this shape')
+        conv_out, y, stats = res
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters, saved['x_bf16'], conv_out, stats,
+                              saved['g32'], saved['b32'])
+        ctx.meta = (int(act), bool(inverse), bool(subm), gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch
+        L = ops.L
+        indice_pairs, indice_pair_num, features, filters, x_bf16, conv_out, stats, g32, b32 = ctx.saved_tensors
+        act, inverse, subm, wdtype = ctx.meta
+        n, c = conv_out.shape
+        dy2 = dy.to(torch.bfloat16).contiguous()
+        dconv = torch.empty_like(conv_out)
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dy.device)
+        ws = L.workspace(L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c), dy.device)
+        L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(conv_out), L.ptr(dy2), n, c, L.ptr(g32), L.ptr(b32), L.ptr(stats),
+                                              act, L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.BF16, L.ptr(ws),
+                                              ws.numel(), L.stream()), 'layernorm_act_bwd')
+        input_bp, filters_bp = ops.indice_conv_backward(
+            features, filters, dconv, indice_pairs, indice_pair_num, inverse, subm, _x_bf16=x_bf16,
+            need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1])
+        return (input_bp, filters_bp, dgamma.to(wdtype), dbeta.to(wdtype), None, None, None, None, None, None,
+                None)
+
+
+def indice_conv_ln(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out, eps, act,
+                   inverse=False, subm=False):
+    return _IndiceConvLN.apply(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out,
+                               eps, act, inverse, subm)
+
+
 indice_conv = SparseConvFunction.apply
 indice_inverse_conv = SparseInverseConvFunction.apply
 indice_subm_conv = SubMConvFunction.apply

@@ -16,6 +16,18 @@ def is_spconv_module(module):
     return isinstance(module, SparseModule)
 
 
+# Run the LayerNorm (+GELU) that follows a sparse conv inside the conv kernel's epilogue
+# (ococc_sparse_conv_gather_gemm_ln_bf16).  Off by default: measured on configs[1] the fused epilogue costs
+# what the separate LN kernel costs (the workgroups of the conv kernel reach their epilogue together, so the
+# extra erf / statistics work is not hidden behind anyone's MFMA phase) -- 560 vs 551 us of kernels per step.
+FUSE_CONV_LN = False
+
+
+def _is_fusable_norm(module):
+    from ..norm import LayerNorm
+    return FUSE_CONV_LN and isinstance(module, LayerNorm) and module.fused_act in ('none', 'gelu')
+
+
 class SparseSequential(SparseModule):
     """Sequential container: sparse modules receive the SparseConvTensor, dense ones
     (norm, activation) its feature matrix (modules.py:127-140)."""
@@ -56,11 +68,23 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.items())
+        skip = False
+        for i, (k, module) in enumerate(mods):
+            if skip:  # this norm already ran inside the preceding conv kernel
+                skip = False
+                continue
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
-                input = module(input)
+                nxt = mods[i + 1][1] if i + 1 < len(mods) else None
+                if _is_fusable_norm(nxt) and hasattr(module, '_ln_fusable'):
+                    input = module(input, _ln=nxt)
+                    if getattr(input, '_ln_applied', False):
+                        input._ln_applied = False
+                        skip = True
+                else:
+                    input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     input.features = module(input.features)

@@ -264,6 +264,36 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     return out if nc == cout else out[:, :cout].contiguous()
 
 
+def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indice_pair_num, num_activate_out,
+                   inverse=False, subm=False, _saved=None):
+    """indice_conv with the LayerNorm(+GELU) that follows it in make_sparse_convmodule fused into the
+    kernel epilogue.  Returns (conv_out, y, mean_rstd), or None when the shape has no fused kernel
+    (caller then runs the two ops separately).  bf16 features only."""
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    if features.dtype != torch.bfloat16 or cin not in _KD_OK or cout % 16 != 0 or _probe is not None:
+        return None
+    L.require_device(features, filters, indice_pairs)
+    rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd',
+                                          int(num_activate_out), subm)
+    x = _to_bf16_padded(features, cin)
+    wn = _prep_weights(filters, 0, cin, cout)
+    conv_out = torch.empty((rows, cout), dtype=torch.bfloat16, device=x.device)
+    y = torch.empty_like(conv_out)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+    kvol = wn.shape[0]
+    rc = L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
+                                                     L.ptr(mask), rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
+                                                     L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
+    if rc == -3:  # OCOCC_EUNSUPPORTED: no fused kernel for this shape
+        return None
+    L.check(rc, 'sparse_conv_gather_gemm_ln')
+    if _saved is not None:
+        _saved['x_bf16'] = x
+        _saved['g32'], _saved['b32'] = g32, b32
+    return conv_out, y, stats
+
+
 def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out,
                       inverse, subm):
     """ops.py:128-139: convolution with the bias folded into the output (here: added in the

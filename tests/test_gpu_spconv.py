@@ -352,3 +352,41 @@ def test_subm_rulebook_sorted_grid_fast_path_matches_generic(dev):
         c = int(n_ref[k])
         assert torch.equal(p_s[k, :, :c], p_ref[k, :, :c]) and bool((p_s[k, :, c:] == -1).all())
     assert bool((p_s._ococc.tables[(False, 'fwd')][0][:, m:] == -1).all())
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (64, 128), (64, 32)])
+def test_fused_conv_ln_gelu_matches_unfused(dev, cin, cout):
+    """make_sparse_convmodule(SubMConv3d -> LN -> GELU) with the norm in the conv epilogue
+    (ococc_sparse_conv_gather_gemm_ln_bf16) against the same block run op by op."""
+    from objectcentricocccompletion_amd.sparse_block import make_sparse_convmodule
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor
+    from objectcentricocccompletion_amd.spconv import modules as spm
+    g = torch.Generator().manual_seed(cin + cout)
+    B, shape, n = 2, [10, 12, 9], 900
+    cells = torch.stack([torch.randperm(10 * 12 * 9, generator=g)[:n].sort().values + b * 1080 for b in range(B)]).flatten()
+    idx = torch.stack([cells // 1080, (cells // 108) % 10, (cells // 9) % 12, cells % 9], 1).int().to(dev)
+    block = make_sparse_convmodule(cin, cout, 3, 'k', padding=1, conv_type='SubMConv3d', act_type='gelu',
+                                   norm_cfg=dict(type='LN', eps=1e-3)).to(dev)
+    with torch.no_grad():
+        block[1].weight.uniform_(0.5, 1.5, generator=None)
+        block[1].bias.uniform_(-0.5, 0.5)
+    feats = torch.randn(idx.shape[0], cin, generator=g).to(dev).bfloat16()
+    dout = torch.randn(idx.shape[0], cout, generator=g).to(dev).bfloat16()
+    res = []
+    for fused in (True, False):
+        orig = spm.FUSE_CONV_LN
+        spm.FUSE_CONV_LN = fused
+        try:
+            x = feats.clone().requires_grad_(True)
+            block.zero_grad(set_to_none=True)
+            y = block(SparseConvTensor(x, idx, shape, B)).features
+            y.backward(dout)
+            res.append((y.detach().float(), x.grad.float(), [p.grad.float().clone() for p in block.parameters()]))
+        finally:
+            spm.FUSE_CONV_LN = orig
+    (yf, gxf, gpf), (yu, gxu, gpu) = res
+    assert float((yf - yu).abs().max()) <= 2e-2 * float(yu.abs().max())      # bf16 outputs: <= 1-2 ulp apart
+    assert float((yf - yu).abs().mean()) <= 1e-3 * float(yu.abs().max())
+    assert float((gxf - gxu).abs().max()) <= 2e-2 * float(gxu.abs().max())
+    for a, b in zip(gpf, gpu):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
