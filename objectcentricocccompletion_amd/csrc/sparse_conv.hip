@@ -371,6 +371,7 @@ int launch_gather_gemm(const uint16_t* feat, const uint16_t* wn, int kvol, int n
 // skipped with ONE scalar branch per 8 MFMAs when the block has no neighbour at the offset, and
 // (ii) gathers are unconditional buffer loads (out-of-range offset -> zeros, no memory access).
 constexpr int kStreamThreads = 256;
+constexpr int kStreamRB = 4;  // 16-row blocks per wave (2 was measured slower: 55 vs 46 us)
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_barrier() {
@@ -385,7 +386,7 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
                           const uint16_t* __restrict__ wn, int kvol, const int32_t* __restrict__ table,
                           const uint32_t* __restrict__ blockmask, int64_t n_out,
                           const float* __restrict__ bias, void* __restrict__ out_, LnArgs ln) {
-  constexpr int RB = 4;
+  constexpr int RB = kStreamRB;
   constexpr int KSTEPS = KD / 32;
   constexpr int NB = NC / 16;
   constexpr int PPR = KD / 8;             // 16-byte pieces per weight row
@@ -621,7 +622,7 @@ int launch_gather_gemm_stream(const uint16_t* feat, int64_t n_in, const uint16_t
                               const uint32_t* blockmask, int64_t n_out, const float* bias, void* out,
                               int out_dtype, hipStream_t stream, const LnArgs* ln = nullptr) {
   // (grid rounded up to a multiple of 8 so that the XCD permutation inside the kernel is a bijection)
-  const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, kStreamThreads / 64 * 64), 8));
+  const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, kStreamThreads / 64 * kStreamRB * 16), 8));
   if (ln) {
     if (out_dtype != OCOCC_BF16) return -1;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_stream_kernel<KD, NC, true, true>), grid, dim3(kStreamThreads), 0,
