@@ -227,6 +227,12 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
  *   mode 1 (dgrad, sub-manifold): wn[k][cin][cout] = W[kvol-1-k][cin][cout]
  *   mode 2 (dgrad, generic table side 0): wn[k][cin][cout] = W[k][cin][cout]
  * always bf16 out. */
+/* Same conversion for up to 16 f32 weight tensors in ONE launch (host arrays of device pointers and
+ * sizes; argument meaning per entry as ococc_weight_prepare_bf16). */
+int ococc_weight_prepare_multi_bf16(int32_t count, const void* const* w, const int32_t* kvol, const int32_t* cin,
+                                    const int32_t* cout, const int32_t* mode, void* const* wn,
+                                    ococc_stream_t stream);
+
 /* Forward gather-GEMM with the norm/activation pair of make_sparse_convmodule
  * (mmdet3d/ops/sparse_block.py:216-289: conv -> LayerNorm -> GELU) fused into the epilogue:
  * conv_out [n_out, ncols] bf16 (kept for the backward), y = act(LN(conv_out)) bf16, mean_rstd [n_out,2]

@@ -53,6 +53,8 @@ SIGNATURES = {
                                                    c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     'ococc_sparse_conv_gather_gemm_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64,
                                                       c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_weight_prepare_multi_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                                ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_vp), c_vp]),
     'ococc_weight_prepare_bf16': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'ococc_sparse_conv_wgrad_workspace_bytes': (c_i64, [c_i32, c_i64, c_i32, c_i32]),
     'ococc_sparse_conv_wgrad_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp,

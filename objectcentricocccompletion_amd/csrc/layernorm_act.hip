@@ -28,9 +28,25 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
   return v;
 }
 
+// GELU derivative without libm's erff: Abramowitz & Stegun 7.1.26,
+//   erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2),  t = 1 / (1 + p x),  |error| <= 1.5e-7  (x >= 0),
+// whose exponential exp(-z^2/2) is the one the Gaussian density of the GELU derivative needs anyway.
+// Phi(z) = (1 + erf(z / sqrt 2)) / 2; e = exp(-z^2/2) is returned for the caller.
+__device__ __forceinline__ float norm_cdf(float z, float* e_out) {
+  const float x = fabsf(z) * kInvSqrt2;
+  const float e = __expf(-x * x);
+  const float t = __frcp_rn(1.f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float half_tail = 0.5f * poly * e;  // (1 - erf(x)) / 2
+  *e_out = e;
+  return z >= 0.f ? 1.f - half_tail : half_tail;
+}
+// forward: libm erff is cheaper here (post-LN |z| is mostly < 2, its no-exp polynomial branch)
 __device__ __forceinline__ float gelu(float z) { return 0.5f * z * (1.f + erff(z * kInvSqrt2)); }
 __device__ __forceinline__ float gelu_grad(float z) {
-  return 0.5f * (1.f + erff(z * kInvSqrt2)) + z * kInvSqrt2Pi * expf(-0.5f * z * z);
+  float e;
+  const float cdf = norm_cdf(z, &e);
+  return cdf + z * kInvSqrt2Pi * e;
 }
 
 // VPL = channels per lane held in registers (c <= VPL * lpr)

@@ -722,6 +722,39 @@ weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int 
   }
 }
 
+// several (weight, mode) pairs in one launch: one graph node instead of one per conv call
+constexpr int kMaxPrep = 16;
+struct PrepPack {
+  const float* w[kMaxPrep];
+  uint16_t* wn[kMaxPrep];
+  int32_t kvol[kMaxPrep], cin[kMaxPrep], cout[kMaxPrep], mode[kMaxPrep];
+  int32_t first_block[kMaxPrep + 1];
+  int32_t count;
+};
+
+__global__ void __launch_bounds__(256) weight_prepare_multi_kernel(PrepPack pk) {
+  int t = 0;
+  while (t + 1 < pk.count && (int)blockIdx.x >= pk.first_block[t + 1]) ++t;
+  const int cin = pk.cin[t], cout = pk.cout[t], kvol = pk.kvol[t], mode = pk.mode[t];
+  const int64_t total = (int64_t)kvol * cin * cout;
+  const int nblk = pk.first_block[t + 1] - pk.first_block[t];
+  for (int64_t i = (int64_t)(blockIdx.x - pk.first_block[t]) * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+    int64_t src;
+    if (mode == 0) {
+      const int ci = (int)(i % cin);
+      const int co = (int)((i / cin) % cout);
+      const int k = (int)(i / ((int64_t)cin * cout));
+      src = ((int64_t)k * cin + ci) * cout + co;
+    } else {
+      const int64_t rem = i % ((int64_t)cin * cout);
+      const int k = (int)(i / ((int64_t)cin * cout));
+      const int ks = mode == 1 ? kvol - 1 - k : k;
+      src = (int64_t)ks * cin * cout + rem;
+    }
+    pk.wn[t][i] = ococc_f32_to_bf16(pk.w[t][src]);
+  }
+}
+
 // ---------------------------------------------------------------- wgrad
 constexpr int kWgThreads = 256;
 constexpr int kWgSteps = 8;  // 32-pair MFMA k-steps per workgroup
@@ -1028,6 +1061,35 @@ extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(weight_prepare_kernel<uint16_t>), dim3(grid), dim3(256), 0,
                        stream, (const uint16_t*)w, (int)kvol, (int)cin, (int)cout, (int)mode, wn);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_weight_prepare_multi_bf16(int32_t count, const void* const* w, const int32_t* kvol,
+                                               const int32_t* cin, const int32_t* cout, const int32_t* mode,
+                                               void* const* wn, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(count >= 0 && count <= kMaxPrep, "at most 16 weight tensors per call");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(w && kvol && cin && cout && mode && wn, "null pointer table");
+  PrepPack pk;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    OCOCC_REQUIRE(w[i] && wn[i] && kvol[i] >= 1 && cin[i] >= 1 && cout[i] >= 1 && mode[i] >= 0 && mode[i] <= 2,
+                  "bad weight descriptor");
+    pk.w[i] = (const float*)w[i];
+    pk.wn[i] = (uint16_t*)wn[i];
+    pk.kvol[i] = kvol[i];
+    pk.cin[i] = cin[i];
+    pk.cout[i] = cout[i];
+    pk.mode[i] = mode[i];
+    pk.first_block[i] = blocks;
+    const int64_t total = (int64_t)kvol[i] * cin[i] * cout[i];
+    blocks += (int)(ococc_cdiv(total, 256) < 256 ? ococc_cdiv(total, 256) : 256);
+  }
+  pk.first_block[count] = blocks;
+  pk.count = count;
+  hipLaunchKernelGGL(weight_prepare_multi_kernel, dim3(blocks), dim3(256), 0, stream, pk);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -12,6 +12,7 @@ from torch import nn
 
 from .sparse_block import make_sparse_convmodule
 from .spconv import SparseConvTensor
+from .spconv import ops as sp_ops
 from .voxel import dynamic_scatter, voxelization
 
 
@@ -48,6 +49,12 @@ class SubMOccEncoder(nn.Module):
         voxel rows carry -1 coordinates, take part in no rulebook pair and must get a zero
         upstream gradient), so that the whole step has no device read-back and can be captured
         in a HIP graph (graph.GraphedStep)."""
+        # all conv weights to their bf16 kernel layouts in one launch (forward operands, and the dgrad
+        # operands of the layers whose input needs a gradient)
+        grad = torch.is_grad_enabled()
+        items = [(layer[0].weight, 0) for layer in self.conv_layers]
+        items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
+        sp_ops.prepare_weights(items)
         coors = self.voxelize(points, batch_idx, batch_size)
         vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
                                          grid_shape=[batch_size] + self.sparse_shape, static=static)

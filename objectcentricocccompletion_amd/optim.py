@@ -71,4 +71,6 @@ class AdamW(torch.optim.Optimizer):
                     (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']), float(b1),
                     float(b2), float(group['eps']), float(group['weight_decay']), step_ptr.data_ptr(),
                     group['ticket'].data_ptr(), L.stream()), 'adamw')
+            for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
+                torch.autograd.graph.increment_version(p)
         return loss

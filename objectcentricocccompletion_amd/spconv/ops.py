@@ -207,8 +207,44 @@ def _to_bf16_padded(t, cols):
     return out
 
 
+_weight_cache = None  # {(data_ptr, mode, kd, nc): wn} filled by prepare_weights() for ONE forward+backward
+
+
+def prepare_weights(items):
+    """Convert several conv weights in one launch.  items: [(filters, mode), ...] with mode 0 = forward
+    operand, 1 = sub-manifold dgrad operand, 2 = generic dgrad operand; channel counts must already be
+    kernel sizes (16/32/64/128, multiples of 16) and the tensors f32 -- other cases are left to the
+    per-call path.  The results serve the conv calls of the current step (forward and backward); the next
+    call replaces them, so call it once at the start of every forward."""
+    import ctypes
+    global _weight_cache
+    _weight_cache = {}
+    todo = []
+    for filters, mode in items:
+        cin, cout = filters.shape[-2], filters.shape[-1]
+        if filters.dtype != torch.float32 or not filters.is_contiguous() or cin not in _KD_OK or cout not in _KD_OK:
+            continue
+        kd, nc = (cin, cout) if mode == 0 else (cout, cin)
+        kvol = filters.numel() // (cin * cout)
+        wn = torch.empty((kvol, nc, kd), dtype=torch.bfloat16, device=filters.device)
+        todo.append((filters, mode, kvol, cin, cout, wn))
+        _weight_cache[(filters.data_ptr(), mode, kd, nc)] = (wn, filters._version)
+    for lo in range(0, len(todo), 16):
+        ch = todo[lo:lo + 16]
+        n = len(ch)
+        vp, i32 = ctypes.c_void_p * n, ctypes.c_int32 * n
+        L.check(L.lib.ococc_weight_prepare_multi_bf16(
+            n, vp(*[c[0].data_ptr() for c in ch]), i32(*[c[2] for c in ch]), i32(*[c[3] for c in ch]),
+            i32(*[c[4] for c in ch]), i32(*[c[1] for c in ch]), vp(*[c[5].data_ptr() for c in ch]), L.stream()),
+            'weight_prepare_multi')
+
+
 def _prep_weights(filters, mode, kd_pad, nc_pad):
     """filters [..., cin, cout] -> bf16 wn [kvol, ncols, kd] for the gather-GEMM kernel."""
+    if _weight_cache is not None:
+        hit = _weight_cache.get((filters.data_ptr(), mode, kd_pad, nc_pad))
+        if hit is not None and hit[1] == filters._version:  # the weights have not been updated since
+            return hit[0]
     cin, cout = filters.shape[-2], filters.shape[-1]
     w = filters.reshape(-1, cin, cout)
     kvol = w.size(0)
