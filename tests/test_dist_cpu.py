@@ -38,8 +38,9 @@ def _worker(rank, world, port, q):
     assert len(buckets.buckets) > 1
     buckets.all_reduce()
     avg = reduce_mean(torch.tensor([float(rank + 1)]))
-    q.put((rank, [p.grad.clone() for p in model.parameters()], [p.detach().clone() for p in model.parameters()],
-           float(avg), (lo, hi)))
+    # plain numpy payloads: torch tensors travel through shared-memory handles that die with the sender
+    q.put((rank, [p.grad.numpy().copy() for p in model.parameters()],
+           [p.detach().numpy().copy() for p in model.parameters()], float(avg), (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +57,7 @@ def test_world_size_2_bucketed_allreduce_matches_single_process():
         p.join(60)
         assert p.exitcode == 0
     (_, g0, w0, a0, s0), (_, g1, w1, a1, s1) = out
+    g0, w0, g1, w1 = ([torch.from_numpy(a) for a in t] for t in (g0, w0, g1, w1))
     assert s0 == (0, 4) and s1 == (4, 8) and a0 == a1 == 1.5
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)                 # broadcast made the replicas identical
