@@ -13,6 +13,7 @@
 
 namespace {
 
+constexpr int kBwdMaxBlocks = 512;  // one dgamma/dbeta slab per block; 8 blocks per CU keep the streams busy
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 
@@ -224,29 +225,47 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
     b[j] = beta[li * 8 + j];
     dg[j] = db[j] = 0.f;
   }
-  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
-    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
-    float xv[8], dv[8], dzg[8];
-    unpack8(*(const u32x4*)(x + r * C + li * 8), xv);
-    unpack8(*(const u32x4*)(dy + r * C + li * 8), dv);
-    float s1 = 0.f, s2 = 0.f;
+  // two rows per trip: both rows' loads are issued before either is consumed (the kernel is a stream of
+  // 16-byte loads at 8 waves per CU, so loads in flight per lane are what buys bandwidth)
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB + rloc; r0 < n; r0 += 2 * stride) {
+    const int64_t r1 = r0 + stride;
+    const bool two = r1 < n;
+    const int64_t rr[2] = {r0, two ? r1 : r0};
+    u32x4 xin[2], din[2];
+    float mean[2], rstd[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      xv[j] = (xv[j] - mean) * rstd;  // xhat
-      float dz = dv[j];
-      if (act == 1) dz *= gelu_grad(xv[j] * g[j] + b[j]);
-      dg[j] += dz * xv[j];
-      db[j] += dz;
-      dzg[j] = dz * g[j];
-      s1 += dzg[j];
-      s2 += dzg[j] * xv[j];
+    for (int u = 0; u < 2; ++u) {
+      xin[u] = *(const u32x4*)(x + rr[u] * C + li * 8);
+      din[u] = *(const u32x4*)(dy + rr[u] * C + li * 8);
+      mean[u] = mean_rstd[rr[u] * 2];
+      rstd[u] = mean_rstd[rr[u] * 2 + 1];
     }
-    s1 = group_sum(s1, LPR) * (1.f / C);
-    s2 = group_sum(s2, LPR) * (1.f / C);
-    float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[j] - s1 - xv[j] * s2);
-    *(u32x4*)(dx + r * C + li * 8) = pack8(o);
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      float xv[8], dv[8], dzg[8];
+      unpack8(xin[u], xv);
+      unpack8(din[u], dv);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[j] = (xv[j] - mean[u]) * rstd[u];  // xhat
+        float dz = dv[j];
+        if (act == 1) dz *= gelu_grad(xv[j] * g[j] + b[j]);
+        dg[j] += dz * xv[j];
+        db[j] += dz;
+        dzg[j] = dz * g[j];
+        s1 += dzg[j];
+        s2 += dzg[j] * xv[j];
+      }
+      s1 = group_sum(s1, LPR) * (1.f / C);
+      s2 = group_sum(s2, LPR) * (1.f / C);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (dzg[j] - s1 - xv[j] * s2);
+      *(u32x4*)(dx + rr[u] * C + li * 8) = pack8(o);
+    }
   }
   extern __shared__ __attribute__((aligned(16))) float red[];  // [RPB][2*C]
   float* mine = red + rloc * 2 * C;
@@ -292,7 +311,7 @@ inline int pick_lpr(int c) {
 }
 inline int bwd_blocks(int64_t n, int lpr) {
   int64_t b = ococc_cdiv(n, 256 / lpr);
-  if (b > 512) b = 512;
+  if (b > kBwdMaxBlocks) b = kBwdMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -358,7 +377,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
                const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
                hipStream_t stream) {
   if (sizeof(T) == 2 && vec_ok(c)) {
-    const int grid = vec_blocks(n, c, 512);
+    const int grid = vec_blocks(n, c, kBwdMaxBlocks);
 #define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
@@ -404,7 +423,7 @@ extern "C" int ococc_layernorm_act_fwd(const void* x, int64_t n, int32_t c, cons
 
 extern "C" int64_t ococc_layernorm_act_bwd_workspace_bytes(int64_t n, int32_t c) {
   if (n < 0 || c < 1) return -1;
-  return (int64_t)512 * 2 * c * (int64_t)sizeof(float);  // one slab per block, <= 512 blocks
+  return (int64_t)kBwdMaxBlocks * 2 * c * (int64_t)sizeof(float);  // one slab per block
 }
 
 extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
