@@ -28,8 +28,14 @@ adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float w
              float* __restrict__ step, uint32_t* __restrict__ ticket) {
   // every block reads the step count before the last block to finish bumps it
   const float t = *step + 1.f;
-  int ti = 0;
-  while (ti + 1 < pk.count && (int)blockIdx.x >= pk.first_block[ti + 1]) ++ti;
+  // binary search of this block's tensor (the table sits in kernel-argument memory: every probe is a
+  // dependent scalar load, so a linear walk over 48 entries costs microseconds per block)
+  int lo = 0, hi = pk.count - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= pk.first_block[mid]) lo = mid; else hi = mid - 1;
+  }
+  const int ti = lo;
   const int64_t base = (int64_t)(blockIdx.x - pk.first_block[ti]) * kElemsPerBlock + threadIdx.x * 4;
   const int64_t n = pk.n[ti];
   const float bc1 = 1.f - powf(beta1, t);

@@ -283,6 +283,111 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
   }
 }
 
+// Wide rows (C = 512 * VEC, e.g. the 1024-wide layers of the occupancy decoder): one wave per row, VEC
+// 16-byte pieces per lane interleaved by 64 pieces so that every load of a wave is one contiguous 1 KB.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+ln_act_fwd_wide_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, float eps, int act,
+                       uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
+  constexpr int C = 512 * VEC;
+  const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + rloc; r < n; r += (int64_t)gridDim.x * 4) {
+    float v[VEC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      unpack8(*(const u32x4*)(x + r * C + (u * 64 + li) * 8), v[u]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[u][j];
+    }
+    const float mean = group_sum(s, 64) * (1.f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[u][j] - mean; sq += d * d; }
+    const float rstd = rsqrtf(group_sum(sq, 64) * (1.f / C) + eps);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      const int ch = (u * 64 + li) * 8;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = (v[u][j] - mean) * rstd * gamma[ch + j] + beta[ch + j];
+        o[j] = act == 1 ? gelu(z) : z;
+      }
+      *(u32x4*)(y + r * C + ch) = pack8(o);
+    }
+    if (mean_rstd && li == 0) {
+      mean_rstd[r * 2] = mean;
+      mean_rstd[r * 2 + 1] = rstd;
+    }
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
+                       float* __restrict__ partials) {
+  constexpr int C = 512 * VEC;
+  const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
+  float dg[VEC][8], db[VEC][8];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dg[u][j] = db[u][j] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + rloc; r < n; r += (int64_t)gridDim.x * 4) {
+    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+    float xv[VEC][8], dzg[VEC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      const int ch = (u * 64 + li) * 8;
+      float dv[8];
+      unpack8(*(const u32x4*)(x + r * C + ch), xv[u]);
+      unpack8(*(const u32x4*)(dy + r * C + ch), dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[u][j] = (xv[u][j] - mean) * rstd;
+        const float gm = gamma[ch + j];
+        float dz = dv[j];
+        if (act == 1) dz *= gelu_grad(xv[u][j] * gm + beta[ch + j]);
+        dg[u][j] += dz * xv[u][j];
+        db[u][j] += dz;
+        dzg[u][j] = dz * gm;
+        s1 += dzg[u][j];
+        s2 += dzg[u][j] * xv[u][j];
+      }
+    }
+    s1 = group_sum(s1, 64) * (1.f / C);
+    s2 = group_sum(s2, 64) * (1.f / C);
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[u][j] - s1 - xv[u][j] * s2);
+      *(u32x4*)(dx + r * C + (u * 64 + li) * 8) = pack8(o);
+    }
+  }
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*C]
+  float* mine = red + rloc * 2 * C;
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    const int ch = (u * 64 + li) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mine[ch + j] = dg[u][j];
+      mine[C + ch + j] = db[u][j];
+    }
+  }
+  __syncthreads();
+  float* slab = partials + (int64_t)blockIdx.x * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) slab[i] = (red[i] + red[2 * C + i]) + (red[4 * C + i] + red[6 * C + i]);
+}
+
 // 8 outputs per block, 32 lanes each: lane l adds partials l, l+32, ... (fixed order),
 // then a fixed-shape butterfly combines the 32 lanes -> deterministic.
 __global__ void __launch_bounds__(256)
@@ -357,6 +462,14 @@ int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* be
     OCOCC_CHECK_LAUNCH();
     return OCOCC_OK;
   }
+  if (sizeof(T) == 2 && (c == 1024 || c == 1536 || c == 2048)) {
+    const int grid = (int)(ococc_cdiv(n, 4) < 8192 ? ococc_cdiv(n, 4) : 8192);
+#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_wide_kernel<V>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd)
+    if (c == 1024) CALLW(2); else if (c == 1536) CALLW(3); else CALLW(4);
+#undef CALLW
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = ococc_grid_1d(ococc_cdiv(n, 256 / lpr) * 256, 256);
@@ -384,6 +497,18 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
     OCOCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials,
                        grid, c, dgamma, dbeta);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
+  if (sizeof(T) == 2 && (c == 1024 || c == 1536 || c == 2048)) {
+    int64_t gb = ococc_cdiv(n, 4);
+    const int grid = (int)(gb > kBwdMaxBlocks ? kBwdMaxBlocks : (gb < 1 ? 1 : gb));
+#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_wide_kernel<V>), dim3(grid), dim3(256), 4 * 2 * c * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
+    if (c == 1024) CALLW(2); else if (c == 1536) CALLW(3); else CALLW(4);
+#undef CALLW
+    OCOCC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials, grid, c,
+                       dgamma, dbeta);
     OCOCC_CHECK_LAUNCH();
     return OCOCC_OK;
   }

@@ -114,7 +114,7 @@ def test_user_supplied_rulebook_without_cached_tables(dev):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('c', [16, 32, 128, 131, 1536])
+@pytest.mark.parametrize('c', [16, 32, 128, 131, 1024, 1536, 2048])
 @pytest.mark.parametrize('act', ['none', 'gelu'])
 def test_layernorm_act_vs_torch(dev, dtype, c, act):
     from objectcentricocccompletion_amd.norm import layer_norm_act
