@@ -355,13 +355,14 @@ int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc
  * configs/ococc/ococcnet.py:468-470).  params / grads / exp_avg / exp_avg_sq are HOST arrays of
  * num_tensors (<= 48) device pointers to contiguous f32 tensors of numel[i] elements.  `step` is a
  * DEVICE float holding the number of steps taken so far: the kernel uses step + 1 for the bias
- * corrections and stores it back, so the call can be replayed from a captured HIP graph.
- * `ticket` is a DEVICE uint32 scratch word, zero before the first call.
+ * corrections; with bump_step != 0 a one-thread kernel queued behind it stores step + 1 (pass 0 on all
+ * but the last call when one optimizer step needs several calls), so the sequence can be replayed from
+ * a captured HIP graph.
  * ------------------------------------------------------------------------------------------- */
 int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
                     void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float* step,
-                    uint32_t* ticket, ococc_stream_t stream);
+                    int32_t bump_step, ococc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stream timers (HIP events) for the measurement harness (bench.py roofline line).  No reference

@@ -25,8 +25,9 @@ struct AdamPack {
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float wd,
-             float* __restrict__ step, uint32_t* __restrict__ ticket) {
-  // every block reads the step count before the last block to finish bumps it
+             const float* __restrict__ step) {
+  // the step count is bumped by a one-thread kernel queued behind this one (a last-block-done ticket
+  // would serialise one same-address atomic per workgroup: ~0.5 ms for the 66 M parameters of OcOccNet)
   const float t = *step + 1.f;
   // binary search of this block's tensor (the table sits in kernel-argument memory: every probe is a
   // dependent scalar load, so a linear walk over 48 entries costs microseconds per block)
@@ -38,10 +39,15 @@ adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float w
   const int ti = lo;
   const int64_t base = (int64_t)(blockIdx.x - pk.first_block[ti]) * kElemsPerBlock + threadIdx.x * 4;
   const int64_t n = pk.n[ti];
-  const float bc1 = 1.f - powf(beta1, t);
-  const float bc2 = 1.f - powf(beta2, t);
-  const float step_size = lr / bc1;
-  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  // bias corrections once per workgroup (two powf per thread would cost more than the update itself)
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    bc[0] = lr / (1.f - powf(beta1, t));
+    bc[1] = 1.f / sqrtf(1.f - powf(beta2, t));
+  }
+  __syncthreads();
+  const float step_size = bc[0];
+  const float inv_sqrt_bc2 = bc[1];
   float* __restrict__ p = pk.p[ti];
   const float* __restrict__ g = pk.g[ti];
   float* __restrict__ m = pk.m[ti];
@@ -71,26 +77,19 @@ adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float w
       p[i] = pj; m[i] = mj; v[i] = vj;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const uint32_t done = atomicAdd(ticket, 1u);
-    if (done == gridDim.x - 1) {
-      *step = t;
-      *ticket = 0;
-    }
-  }
 }
+
+__global__ void adamw_bump_kernel(float* step) { *step += 1.f; }
 
 }  // namespace
 
 extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
                                void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
                                float lr, float beta1, float beta2, float eps, float weight_decay,
-                               float* step, uint32_t* ticket, ococc_stream_t stream_) {
+                               float* step, int32_t bump_step, ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE(num_tensors >= 0, "negative tensor count");
-  OCOCC_REQUIRE(step && ticket, "step / ticket must be device pointers");
+  OCOCC_REQUIRE(step, "step must be a device pointer");
   if (num_tensors == 0) return OCOCC_OK;
   OCOCC_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "null pointer table");
   OCOCC_REQUIRE(num_tensors <= kMaxTensors, "at most 48 tensors per call (split the parameter list)");
@@ -113,7 +112,11 @@ extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const v
   pk.first_block[cnt] = blocks;
   pk.count = cnt;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, pk, lr, beta1, beta2, eps,
-                     weight_decay, step, ticket);
+                     weight_decay, (const float*)step);
   OCOCC_CHECK_LAUNCH();
+  if (bump_step) {
+    hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step);
+    OCOCC_CHECK_LAUNCH();
+  }
   return OCOCC_OK;
 }

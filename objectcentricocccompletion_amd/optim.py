@@ -30,7 +30,6 @@ class AdamW(torch.optim.Optimizer):
         if 'step_dev' not in group:
             dev = group['params'][0].device
             group['step_dev'] = torch.zeros(1, dtype=torch.float32, device=dev)
-            group['ticket'] = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def init_state(self):
         """Allocate the moment buffers and the device step counter now (call before capturing
@@ -57,20 +56,19 @@ class AdamW(torch.optim.Optimizer):
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise L.OcoccError('AdamW kernel takes contiguous parameters and gradients')
             b1, b2 = group['betas']
-            # every launch of one step must see the same step count: only the last one stores it
+            # every launch of one step must see the same step count: only the last one bumps it
             for lo in range(0, len(ps), _MAX):
                 chunk = ps[lo:lo + _MAX]
                 n = len(chunk)
                 arr = ctypes.c_void_p * n
                 last = lo + _MAX >= len(ps)
-                step_ptr = group['step_dev'] if last else group['step_dev'].clone()
                 L.check(L.lib.ococc_adamw_f32(
                     n, arr(*[p.data_ptr() for p in chunk]), arr(*[p.grad.data_ptr() for p in chunk]),
                     arr(*[self.state[p]['exp_avg'].data_ptr() for p in chunk]),
                     arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
                     (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']), float(b1),
-                    float(b2), float(group['eps']), float(group['weight_decay']), step_ptr.data_ptr(),
-                    group['ticket'].data_ptr(), L.stream()), 'adamw')
+                    float(b2), float(group['eps']), float(group['weight_decay']), group['step_dev'].data_ptr(),
+                    int(last), L.stream()), 'adamw')
             for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
                 torch.autograd.graph.increment_version(p)
         return loss
