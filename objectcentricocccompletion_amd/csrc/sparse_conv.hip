@@ -33,6 +33,7 @@
 // over pairs.  Partial sums are written to per-workgroup slabs and added in a
 // fixed order (deterministic, no float atomics).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -672,6 +673,8 @@ int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
       cs = cands[i];
       break;
     }
+  // (the streamed-weights kernel was also tried on the small layers: 21.6 / 25.3 us against 21.1 / 21.2 us
+  // for the resident-weights kernel, so it is only used where slicing would be needed)
   if (cs != 0 && (ncols / cs > 1 || (ln && cs != ncols))) {
     const int rc = dispatch_stream<KD>(feat, n_in, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype,
                                        stream, ln);
