@@ -48,7 +48,7 @@ def parse():
     ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
     ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet', 'sst'],
+    ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet', 'sst', 'decode'],
                     help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]; sst = configs[4] per-GPU share')
     ap.add_argument('--tracklets', type=int, default=4)
     ap.add_argument('--f32-decoder', action='store_true',
@@ -262,6 +262,58 @@ def bench_sst(args, world, rank, dev):
             'cpu_baseline': None}), flush=True)
 
 
+def bench_decode(args, world, rank, dev):
+    """SURVEY 8(f) row 2, the step after the path: dense-grid decode of the occupancy of B x 32 RoIs
+    (OccDecoder.get_occ, ococcnet decoder 1536 -> 512 -> 1024 -> 1024 -> 1, 0.2 m cells over the box enlarged by
+    0.5 m: ~20 k cells per vehicle-sized RoI), inference only, bf16 decoder MLP.  Metric: object grids decoded/s."""
+    from objectcentricocccompletion_amd.occ.occ_base import OccDecoder
+    torch.manual_seed(0)
+    dec = OccDecoder(1536, [512, 1024, 1024], pos_encode_L=10, norm_cfg=dict(type='LN', eps=1e-3), act='gelu',
+                     occ_dropout=0.1, use_ln=True).to(dev).eval()
+    dec.compute_dtype = None if args.f32_decoder else torch.bfloat16
+    g = torch.Generator().manual_seed(7 + rank)
+    R = args.tracklets * 32
+    rois = torch.zeros(R, 8)
+    rois[:, 0] = torch.arange(R) // 32
+    rois[:, 1:4] = torch.randn(R, 3, generator=g) * torch.tensor([30., 30., 1.])
+    rois[:, 4:7] = torch.rand(R, 3, generator=g) * torch.tensor([0.4, 0.8, 0.4]) + torch.tensor([1.8, 4.2, 1.5])
+    rois[:, 7] = (torch.rand(R, generator=g) * 2 - 1) * 3.14
+    rois, feats = rois.to(dev), torch.randn(R, 1536, generator=g).to(dev)
+    run = lambda: dec.get_occ(feats, rois, 0.2, [1.0, 1.0, 1.0], [0.5, 0.5, 0.5], transform=True)
+    for _ in range(args.warmup):
+        occ = run()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        occ = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        from objectcentricocccompletion_amd.occ import occ_ops
+        cells = int(occ_ops.dense_voxel_centers_batched(rois[:, 4:7], 0.2, [1.0] * 3, [0.5] * 3)[2].sum())
+        flops = cells * 2.0 * (60 * 512 + 512 * 1024 + 1024 * 1024 + 1024) + R * 2.0 * 1536 * 512
+        print(json.dumps({
+            'metric': 'object-grids/sec (dense occupancy decode)', 'value': round(world * R * args.steps / dt, 1),
+            'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.f32_decoder else 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'dense-grid decode (occ_base.py:238-342) of {R} RoIs/GPU, {cells} cells of 0.2 m, '
+                                   'ococcnet decoder MLP, inference', 'grids_per_gpu': R, 'cells': cells,
+                       'occupied': int(sum(len(t) for s_ in occ for t in s_)), 'parallelism': f'dp{world}'},
+            'roofline': {'kernel': 'decoder MLP GEMMs (library)', 'bound': 'mfma',
+                         'achieved': round(flops * args.steps / dt / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                         'frac': round(flops * args.steps / dt / 1e12 / 2500.0, 4), 'traffic': None},
+            'cpu_baseline': None}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -275,8 +327,8 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
 
-    if args.workload in ('ococcnet', 'sst'):
-        (bench_ococcnet if args.workload == 'ococcnet' else bench_sst)(args, world, rank, dev)
+    if args.workload in ('ococcnet', 'sst', 'decode'):
+        {'ococcnet': bench_ococcnet, 'sst': bench_sst, 'decode': bench_decode}[args.workload](args, world, rank, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -152,6 +152,16 @@ class OccAutoEncoder(nn.Module, SparseHeadMixin):
     def decode(self, roi_feats, smp_pts_xyz_local, smp_pts_roi_inds):
         return self.occ_decoder(roi_feats, smp_pts_xyz_local, smp_pts_roi_inds)
 
+    def get_occ(self, local_roi_feats, rois, transform=True):
+        """occ_ae_head.py:421-438: explicit occupancy of every RoI (dense grid decode)."""
+        return self.occ_decoder.get_occ(local_roi_feats, rois, self.voxel_size, self.scale_wlh, self.offset_wlh,
+                                        transform=transform)
+
+    def get_roi_occ(self, local_roi_feats, rois, transform=True, return_score=False):
+        """occ_ae_head.py:440-449."""
+        return self.occ_decoder.get_roi_occ(local_roi_feats, rois, self.voxel_size, self.scale_wlh,
+                                            self.offset_wlh, transform, return_score)
+
 
 class _Sampling(object):
     """What get_targets reads from an mmdet SamplingResult (tracklet_roi_head_occ.py:880-991)."""
@@ -286,6 +296,15 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         return ret
 
     # ------------------------------------------------------------------ temporal transformer
+    def get_occ(self, local_roi_feats, rois, transform=True, ori_roi_feats=None):
+        """ococc_bbox_head.py:813-841: explicit occupancy of every RoI from the fused features (and, when
+        given, the union with the decode of the single-frame features)."""
+        occ_list = self.occ_ae_head.get_occ(local_roi_feats, rois, transform=transform)
+        if ori_roi_feats is None:
+            return occ_list
+        ori_list = self.occ_ae_head.get_occ(ori_roi_feats, rois, transform=transform)
+        return [[torch.cat([a, b], dim=0) for a, b in zip(occs, oris)] for occs, oris in zip(occ_list, ori_list)]
+
     def transformer_forward(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):
         if not self.training or self.train_cfg.get('fixed_length', True):
             return self.transformer_forward_fixed_length(rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc)

@@ -1,5 +1,5 @@
 """Implicit occupancy decoder -- host mirror of mmdet3d/models/occ/occ_base.py: PosEncode
-(:26-57), OccDecoder (:59-153).  Parameter names: ln.{weight,bias}, conv_occ.<i>.0.weight,
+(:26-57), OccDecoder (:59-153) and its dense-grid decode get_occ / get_roi_occ (:155-342).  Parameter names: ln.{weight,bias}, conv_occ.<i>.0.weight,
 conv_occ.<i>.1.{weight,bias}, conv_occ.<n>.{weight,bias}.
 
 MI355X formulation of the decoder's first layer.  The reference repeats each RoI feature K
@@ -16,6 +16,7 @@ from torch import nn
 
 from ..norm import layer_norm_act
 from ..sst.sst_ops import build_mlp
+from . import occ_ops
 
 
 class PosEncode(nn.Module):
@@ -107,6 +108,102 @@ class OccDecoder(nn.Module):
         point, any leading shape [..., D] / [..., 3]."""
         x = torch.cat([self._ln(roi_feats_per_points), self.pos_encode(smp_xyzs)], dim=-1)
         return self.conv_occ(x)
+
+    # ------------------------------------------------------------------ dense grid decode (occ_base.py:155-342)
+    def _dense_logits(self, roi_feats, sizes, voxel_size, scale_wlh, offset_wlh, chunk=1 << 20):
+        """Logits of every cell of every box's dense grid in ONE batched pass: the reference loops over boxes
+        and repeats the 1536-wide RoI feature K times per box (occ_base.py:190-194,300-308); here the cells of
+        all boxes are one flat list and the decoder's first layer is factorised per RoI (forward())."""
+        centers, box, k = occ_ops.dense_voxel_centers_batched(sizes, voxel_size, scale_wlh, offset_wlh)
+        out = []
+        with torch.no_grad():
+            for lo in range(0, centers.size(0), chunk):
+                out.append(self.forward(roi_feats, centers[lo:lo + chunk], box[lo:lo + chunk]))
+        logits = torch.cat(out, 0) if out else centers.new_zeros((0, self.cls_dim))
+        return centers, box, k, logits
+
+    def _occupied(self, logits):
+        if self.cls_dim == 1:
+            return logits.sigmoid().view(-1) > self.pos_thresh
+        return logits[..., 1] > logits[..., 0]
+
+    @staticmethod
+    def _to_lidar(pts, box, centers, sizes, yaw):
+        """Box frame (origin at the gravity centre) -> LiDAR frame: rotate by the box yaw about z, add the
+        bottom centre and half the height (occ_base.py:220-230,330-336; rotation_3d_in_axis axis=2)."""
+        # the reference multiplies by the transposed matrix (einsum 'aij,jka->aik'): a clockwise turn
+        c, s_ = torch.cos(yaw)[box], torch.sin(yaw)[box]
+        x = pts[:, 0] * c + pts[:, 1] * s_
+        y = -pts[:, 0] * s_ + pts[:, 1] * c
+        out = torch.stack([x, y, pts[:, 2]], 1) + centers[box]
+        out[:, 2] += sizes[box, 2] / 2
+        return out
+
+    def get_roi_occ(self, roi_feats, rois, voxel_size, scale_wlh, offset_wlh, transform=True, return_score=False,
+                    random_sample_size=2048, occ_only=False):
+        """occ_base.py:155-235.  occ_only: occupied cell centres of every RoI; otherwise (return_score) a
+        random subset of ``random_sample_size`` cells per RoI (all cells when <= 0) with their scores."""
+        if roi_feats.size(0) == 0:
+            return []
+        assert roi_feats.size(0) == rois.size(0), f'{roi_feats.size(0)}, {rois.size(0)}'
+        assert rois.size(1) in (8, 10)
+        centers, box, k, logits = self._dense_logits(roi_feats, rois[:, 4:7], voxel_size, scale_wlh, offset_wlh)
+        if occ_only:
+            sel = self._occupied(logits)
+        else:
+            assert return_score
+            if random_sample_size > 0:
+                # a random subset of <= random_sample_size cells per RoI (the reference draws torch.randperm(K)
+                # per box on the host RNG: the same distribution, not the same stream)
+                start = torch.cumsum(k, 0) - k
+                key = torch.rand(centers.size(0), device=centers.device) + box.to(torch.float)
+                order = torch.argsort(key)
+                rank = torch.empty_like(order)
+                rank[order] = torch.arange(order.numel(), device=order.device)
+                sel = (rank - start[box]) < random_sample_size
+            else:
+                sel = torch.ones_like(box, dtype=torch.bool)
+        pts, pbox = centers[sel], box[sel]
+        if transform:
+            pts = self._to_lidar(pts, pbox, rois[:, 1:4], rois[:, 4:7], rois[:, 7])
+        if return_score:
+            score = logits[sel].sigmoid().view(-1, 1) if self.cls_dim == 1 else logits[sel].softmax(-1)[..., 1].view(-1, 1)
+            return pts, pbox, score
+        return pts, pbox
+
+    def get_occ(self, roi_feats, rois, voxel_size, scale_wlh, offset_wlh, concat_batch=False, local_xyz=None,
+                local_pts_roi_inds=None, return_full=False, transform=True):
+        """occ_base.py:238-342: per batch sample a list with the occupied cell centres of each of its RoIs
+        (LiDAR frame when ``transform``); ``concat_batch`` joins them per sample; ``return_full`` returns every
+        cell; ``local_xyz`` substitutes given box-frame points for the prediction."""
+        if roi_feats.size(0) == 0:
+            return []
+        assert roi_feats.size(0) == rois.size(0), f'{roi_feats.size(0)}, {rois.size(0)}'
+        assert rois.size(1) in (8, 10)
+        roi_batch_idx = rois[:, 0]
+        batch_size = int(roi_batch_idx.max().item() + 1)
+        sizes, yaw, ctr = rois[:, 4:7], rois[:, 7], rois[:, 1:4]
+        if local_xyz is not None and not return_full:
+            assert len(local_xyz) == len(local_pts_roi_inds), f'{len(local_xyz)}, {len(local_pts_roi_inds)}'
+            order = torch.argsort(local_pts_roi_inds, stable=True)
+            pts, pbox = local_xyz[order], local_pts_roi_inds[order].long()
+        else:
+            if return_full:
+                pts, pbox, _ = occ_ops.dense_voxel_centers_batched(sizes, voxel_size, scale_wlh, offset_wlh)
+            else:
+                centers, box, _, logits = self._dense_logits(roi_feats, sizes, voxel_size, scale_wlh, offset_wlh)
+                sel = self._occupied(logits)
+                pts, pbox = centers[sel], box[sel]
+        if transform:
+            pts = self._to_lidar(pts, pbox, ctr, sizes, yaw)
+        counts = torch.bincount(pbox, minlength=rois.size(0)).tolist()
+        per_roi = list(torch.split(pts, counts))
+        res = []
+        for i in range(batch_size):
+            ids = torch.nonzero(roi_batch_idx == i).squeeze(1).tolist()
+            cur = [per_roi[j] for j in ids]
+            res.append(torch.cat(cur, 0) if concat_batch else cur)
+        return res
 
     def get_cls_from_pred(self, pred):
         if self.cls_dim == 1:

@@ -39,3 +39,25 @@ def quantize_points(points, rois, rois_points_idx, voxel_size, scale_wlh=[1.0, 1
 
 def jitter_voxel_center(voxel_size, voxel_centers):
     return voxel_centers + torch.rand_like(voxel_centers) * voxel_size - voxel_size / 2
+
+
+def dense_voxel_centers_batched(bbox_sizes, voxel_size, scale_wlh=[1.0, 1.0, 1.0], offset_wlh=[0.0, 0.0, 0.0]):
+    """All boxes of generate_dense_voxel_centers in one flat tensor: (centers [sum K, 3], box index [sum K],
+    K per box [R]).  Same cell order (x slowest, z fastest) and the same float expression per element, so
+    ``centers[box == j]`` equals ``generate_dense_voxel_centers(...)[j]`` bit for bit; one host read-back
+    (the total) instead of a Python loop over boxes."""
+    dev = bbox_sizes.device
+    if bbox_sizes.size(0) == 0:
+        z = torch.zeros((0,), dtype=torch.long, device=dev)
+        return bbox_sizes.new_zeros((0, 3)), z, z
+    size = bbox_sizes * bbox_sizes.new_tensor(scale_wlh) + bbox_sizes.new_tensor(offset_wlh)     # [R,3]
+    dims = torch.ceil(size / voxel_size).to(torch.long)                                             # [R,3]
+    k = dims[:, 0] * dims[:, 1] * dims[:, 2]
+    total = int(k.sum())
+    start = torch.cumsum(k, 0) - k
+    box = torch.repeat_interleave(torch.arange(size.size(0), device=dev), k, output_size=total)
+    local = torch.arange(total, device=dev) - start[box]
+    ys, zs = dims[box, 1], dims[box, 2]
+    coors = torch.stack([local // (ys * zs), (local // zs) % ys, local % zs], 1)
+    centers = coors.to(torch.float) * voxel_size + (-size / 2)[box] + voxel_size / 2
+    return centers, box, k

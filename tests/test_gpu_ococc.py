@@ -283,3 +283,57 @@ def test_occ_decoder_bf16_compute_matches_f32(dev):
     for a, b in zip(grads[0], grads[1]):
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.995, cos
+
+
+def test_dense_grid_decode_vs_reference_golden(dev, golden_dir):
+    """§8(f) row 2: OccDecoder.get_occ / get_roi_occ (dense 40^3-class grid decode) against the imported
+    reference (tests/golden/occ_decode.npz, oracle/gen_golden_decode.py).  Cell centres bit-exact; logits
+    within 2e-3; the occupied set identical except where the reference logit is within 1e-3 of the threshold."""
+    import os
+    from objectcentricocccompletion_amd.occ import occ_ops
+    from objectcentricocccompletion_amd.occ.occ_base import OccDecoder
+    gd = np.load(os.path.join(golden_dir, 'occ_decode.npz'))
+    dec = OccDecoder(256, [64, 128, 128], pos_encode_L=10, norm_cfg=dict(type='LN', eps=1e-3), act='gelu',
+                     occ_dropout=0.0, use_ln=True)
+    sd = dec.state_dict()
+    ref = dict(zip(gd['param_names'].tolist(), gd['param_shapes'].tolist()))
+    assert set(sd) == set(ref) and all(','.join(map(str, v.shape)) == ref[k] for k, v in sd.items())
+    dec.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=11))
+    dec = dec.to(dev).eval()
+    rois, feats = torch.from_numpy(gd['rois']).to(dev), torch.from_numpy(gd['feats']).to(dev)
+    V, S, O_ = 0.2, [1.0, 1.0, 1.0], [0.5, 0.5, 0.5]
+    centers, box, k = occ_ops.dense_voxel_centers_batched(rois[:, 4:7], V, S, O_)
+    assert np.array_equal(k.cpu().numpy(), gd['cells_per_roi'])
+    assert np.array_equal(centers.cpu().numpy(), gd['centers'])                       # bit-exact cell centres
+    one = occ_ops.generate_dense_voxel_centers(rois[:, 4:7], V, S, O_)
+    assert torch.equal(torch.cat(one), centers)
+    _, _, _, logits = dec._dense_logits(feats, rois[:, 4:7], V, S, O_, chunk=10000)  # several chunks
+    lg, lr = logits.view(-1).cpu().numpy(), gd['logits']
+    assert np.abs(lg - lr).max() <= 2e-3 * max(1.0, np.abs(lr).max())
+    sure = np.abs(lr) > 1e-3
+    assert np.array_equal((lg > 0)[sure], (lr > 0)[sure])
+    # list structure / transforms: compare on the reference's own occupied set when no logit is borderline
+    occ = dec.get_occ(feats, rois, V, S, O_, transform=True)
+    assert [len(s) for s in occ] == gd['samples'].tolist()
+    flat = [t for s in occ for t in s]
+    if bool(sure.all()) or np.array_equal(lg > 0, lr > 0):
+        assert [len(t) for t in flat] == gd['occ_counts'].tolist()
+        assert np.allclose(torch.cat(flat).cpu().numpy(), gd['occ_pts'], atol=2e-5)
+        loc = dec.get_occ(feats, rois, V, S, O_, transform=False)
+        assert np.array_equal(torch.cat([t for s in loc for t in s]).cpu().numpy(), gd['occ_local_pts'])
+        p, i = dec.get_roi_occ(feats, rois, V, S, O_, transform=True, occ_only=True)
+        assert np.array_equal(i.cpu().numpy(), gd['roi_occ_only_inds'])
+        assert np.allclose(p.cpu().numpy(), gd['roi_occ_only_pts'], atol=2e-5)
+    full = dec.get_occ(feats, rois, V, S, O_, return_full=True, transform=True, concat_batch=True)
+    assert [len(t) for t in full] == gd['full_counts'].tolist()
+    assert np.allclose(torch.cat(full).cpu().numpy(), gd['full_pts'], atol=2e-5)
+    p, i, sc = dec.get_roi_occ(feats, rois, V, S, O_, transform=True, return_score=True, random_sample_size=0)
+    assert np.array_equal(i.cpu().numpy(), gd['roi_occ_inds'])
+    assert np.allclose(p.cpu().numpy(), gd['roi_occ_pts'], atol=2e-5)
+    assert np.allclose(sc.view(-1).cpu().numpy(), gd['roi_occ_score'], atol=1e-3)
+    # random subset: at most n cells per RoI, all of them cells of that RoI
+    p, i, sc = dec.get_roi_occ(feats, rois, V, S, O_, transform=False, return_score=True, random_sample_size=100)
+    cnt = torch.bincount(i, minlength=rois.shape[0])
+    assert bool((cnt == 100).all()) and sc.shape == (700, 1)
+    # empty input
+    assert dec.get_occ(feats[:0], rois[:0], V, S, O_) == []
