@@ -124,6 +124,193 @@ class OccAutoEncoder(nn.Module, SparseHeadMixin):
         self.with_voxelize_centers = with_voxelize_centers
         self.compensate_encoder_coors = compensate_encoder_coors
         self.add_train_prob = add_train_prob
+        self.loss_need_squeeze = loss_occ_ae['type'] == 'CrossEntropyLoss' and loss_occ_ae['use_sigmoid']
+
+    # ------------------------------------------------------------------ observation rasterisation
+    def sample_observation(self, local_xyz, rois, pts_roi_inds, downsample_size=-1, balance_sample=False):
+        """occ_ae_head.py:65-201: rasterise the pooled points of every RoI into its dense 0.2 m grid (label 1 =
+        a point fell into the cell) and return (cell centres [S,3], labels [S], RoI index [S]), optionally
+        sub-sampled per RoI.
+
+        The reference builds one [X,Y,Z] label volume per RoI in a Python loop; here all grids are one flat
+        list of cells (occ_ops.dense_voxel_centers_batched) and the labels are ONE scatter of the points'
+        flat cell ids -- the "point-to-voxel scatter over per-object occupancy grids".  Without sub-sampling
+        the result is identical (same cells, same order); the sampled variants draw from the same
+        distributions with torch's device RNG instead of per-RoI torch.multinomial calls."""
+        assert rois.size(1) in (8, 10)
+        if not self.compensate_encoder_coors:
+            r = local_xyz.new_tensor((np.pi / 2,))
+            local_xyz = rotation_3d_in_axis(local_xyz[None, :, :], r, axis=2).squeeze(0)
+        R = rois.size(0)
+        dev = local_xyz.device
+        if R == 0:
+            return local_xyz.new_zeros((0, 3)), local_xyz.new_zeros((0,)), local_xyz.new_zeros((0,))
+        pts_roi_inds = pts_roi_inds.long()
+        coors = occ_ops.quantize_points(local_xyz, rois, pts_roi_inds, self.voxel_size, scale_wlh=self.scale_wlh,
+                                        offset_wlh=self.offset_wlh)                                  # [M,3] long
+        centers, box, k = occ_ops.dense_voxel_centers_batched(rois[:, 4:7], self.voxel_size, self.scale_wlh,
+                                                              self.offset_wlh)
+        size = rois[:, 4:7] * rois.new_tensor(self.scale_wlh) + rois.new_tensor(self.offset_wlh)
+        dims = torch.ceil(size / self.voxel_size).to(torch.long)
+        start = torch.cumsum(k, 0) - k
+        d = dims[pts_roi_inds]
+        valid = ((coors < d) & (coors >= 0)).all(dim=1)      # points exactly on the far boundary fall outside
+        flat = start[pts_roi_inds] + (coors[:, 0] * d[:, 1] + coors[:, 1]) * d[:, 2] + coors[:, 2]
+        labels = torch.zeros(centers.size(0), dtype=torch.long, device=dev)
+        labels[flat[valid]] = 1
+        keep = None
+        if balance_sample:
+            keep = self._balanced_subset(labels, box, k, start, downsample_size)
+        elif downsample_size > 0:
+            keep = self._weighted_subset(labels, box, k, start, downsample_size)
+        if keep is not None:
+            centers, labels, box = centers[keep], labels[keep], box[keep]
+        return centers, labels, box
+
+    @staticmethod
+    def _rank_in_roi(key, box, start):
+        """rank of every cell among the cells of its RoI when ordered by descending key"""
+        order = torch.argsort(box.to(torch.float64) * 4.0 - key.to(torch.float64).clamp(0, 1) , stable=True)
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=order.device)
+        return rank - start[box]
+
+    def _weighted_subset(self, labels, box, k, start, n):
+        """RoIs with more than n cells keep n of them, drawn without replacement with weight 100 for observed
+        cells and 1 for the rest (occ_ae_head.py:167-181; Efraimidis-Spirakis keys u^(1/w) give the
+        distribution of sequential weighted draws)."""
+        w = torch.where(labels == 1, 100.0, 1.0)
+        key = torch.rand(labels.numel(), device=labels.device, dtype=torch.float64).clamp_min(1e-300) ** (1.0 / w)
+        rank = self._rank_in_roi(key, box, start)
+        keep = (rank < n) | (k[box] <= n)
+        return torch.nonzero(keep).squeeze(1)
+
+    def _balanced_subset(self, labels, box, k, start, n):
+        """occ_ae_head.py:129-166: all observed cells of a RoI plus as many free cells (with replacement when
+        there are fewer free than observed cells); a RoI without observed cells contributes its first cell;
+        then at most n cells per RoI, uniformly."""
+        dev = labels.device
+        R = k.numel()
+        pos = labels == 1
+        npos = torch.zeros(R, dtype=torch.long, device=dev).index_add_(0, box, pos.long())
+        nneg = k - npos
+        u = torch.rand(labels.numel(), device=dev, dtype=torch.float64)
+        # free cells ranked by a random key inside their RoI (observed cells pushed to the end)
+        rank_neg = self._rank_in_roi(torch.where(pos, torch.zeros_like(u), 0.5 + 0.5 * u), box, start)
+        take_neg = (~pos) & (rank_neg < npos[box]) & (npos[box] <= nneg[box])
+        first_only = (npos[box] == 0) & (torch.arange(labels.numel(), device=dev) == start[box])
+        # (a RoI whose cells are ALL observed is skipped, as the reference's `continue` does)
+        keep = torch.nonzero((pos & (nneg[box] > 0)) | take_neg | first_only).squeeze(1)
+        # RoIs with fewer free than observed cells draw their free cells WITH replacement
+        short = torch.nonzero((npos > nneg) & (nneg > 0)).squeeze(1)
+        if short.numel() > 0:
+            neg_idx = torch.nonzero(~pos).squeeze(1)
+            neg_start = torch.cumsum(nneg, 0) - nneg
+            reps = npos[short]
+            rb = torch.repeat_interleave(short, reps)
+            pick = torch.minimum((torch.rand(rb.numel(), device=dev) * nneg[rb]).long(), nneg[rb] - 1)
+            keep = torch.cat([keep, neg_idx[neg_start[rb] + pick]])
+            keep = keep[torch.argsort(box[keep], stable=True)]
+        if n > 0:
+            kb = box[keep]
+            cnt = torch.zeros(R, dtype=torch.long, device=dev).index_add_(0, kb, torch.ones_like(kb))
+            st = torch.cumsum(cnt, 0) - cnt
+            r2 = self._rank_in_roi(torch.rand(keep.numel(), device=dev, dtype=torch.float64), kb, st)
+            keep = keep[(r2 < n) | (cnt[kb] <= n)]
+        return keep
+
+    # ------------------------------------------------------------------ auto-encoder stage (occ_ae_head.py:270-344)
+    def forward_train_ae(self, pts_xyz, pts_features, pts_info, roi_inds, rois, start_add_train=False):
+        local_roi_feats, nonempty_roi_mask, local_xyz = self.encode(pts_xyz, pts_features, pts_info, roi_inds, rois)
+        if start_add_train and torch.rand(1).item() < self.add_train_prob:
+            # merge every RoI with a random partner: max of the two features, union of the two point sets,
+            # the larger of the two boxes (occ_ae_head.py:277-318).  perm[i] = partner of RoI i; the points of
+            # RoI j are appended to RoI inv[j], no per-RoI loop
+            perm = torch.randperm(len(rois), device=rois.device)
+            local_roi_feats = torch.max(torch.stack([local_roi_feats, local_roi_feats[perm]], dim=0), dim=0)[0]
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(len(rois), device=rois.device)
+            new_xyz = torch.cat([local_xyz, local_xyz], dim=0)
+            new_inds = torch.cat([roi_inds.long(), inv[roi_inds.long()]], dim=0)
+            new_rois = rois.clone()
+            new_rois[:, 4:7] = torch.max(torch.stack([rois[:, 4:7], rois[perm][:, 4:7]], dim=0), dim=0)[0]
+            smp_xyz, labels, smp_inds = self._sample_obs(new_xyz, new_rois, new_inds)
+        else:
+            smp_xyz, labels, smp_inds = self._sample_obs(local_xyz, rois, roi_inds)
+        occ_preds = self.decode(local_roi_feats, smp_xyz, smp_inds)
+        return self.loss(occ_preds, local_roi_feats, smp_xyz, smp_inds, labels, nonempty_roi_mask)
+
+    def _sample_obs(self, local_xyz, rois, roi_inds):
+        return self.sample_observation(local_xyz, rois, roi_inds, downsample_size=self.online_sample_size,
+                                       balance_sample=self.balance_sample)
+
+    def loss(self, occ_preds, local_roi_feats, smp_pts_xyz_local, smp_pts_roi_inds, obs_occ_labels, nonempty_roi_mask):
+        """occ_ae_head.py:451-509."""
+        num_occupied = obs_occ_labels.sum().float()
+        num_free = obs_occ_labels.numel() - num_occupied
+        per_points_masks = nonempty_roi_mask[smp_pts_roi_inds]
+        num_valid_occupied = ((obs_occ_labels == 1) & (per_points_masks == 1)).sum().float()
+        num_valid_free = ((obs_occ_labels == 0) & (per_points_masks == 1)).sum().float()
+        occ_preds = occ_preds.view(-1) if self.loss_need_squeeze else occ_preds.view(-1, 1)
+        assert len(smp_pts_xyz_local) > 0
+        loss_ae = self.loss_occ_ae(occ_preds, obs_occ_labels.view(-1)).mean()
+        assert (smp_pts_roi_inds >= 0).all()
+        if self.loss_need_squeeze:
+            pred_cls = (occ_preds.sigmoid() > 0.5).long().view(-1)
+        else:
+            pred_cls = (occ_preds.sigmoid() < 0.5).long().view(-1)
+        num_pred_occupied = pred_cls.sum().float()
+        num_pred_free = pred_cls.numel() - num_pred_occupied
+        num_gt_occupied = obs_occ_labels.sum().float()
+        num_gt_free = obs_occ_labels.numel() - num_gt_occupied
+        num_correct_occupied = ((pred_cls == 1) & (obs_occ_labels == 1)).sum().float()
+        num_correct_free = ((pred_cls == 0) & (obs_occ_labels == 0)).sum().float()
+        return dict(recall_free=num_correct_free / (num_gt_free + 1e-6),
+                    recall_occupied=num_correct_occupied / (num_gt_occupied + 1e-6),
+                    precision_free=num_correct_free / (num_pred_free + 1e-6),
+                    precision_occupied=num_correct_occupied / (num_pred_occupied + 1e-6),
+                    loss_ae=loss_ae, num_occupied=num_occupied, num_free=num_free,
+                    num_valid_occupied=num_valid_occupied, num_valid_free=num_valid_free)
+
+    def online_tuning_forward(self, roi_features, pts_smp, pts_labels, pts_weights, pts_roi_inds, num_ttt_iter,
+                              apply_jitter=False):
+        """occ_ae_head.py:346-391: test-time tuning of the RoI embeddings -- num_ttt_iter Adam(lr 0.01) steps on
+        the observation loss with the decoder frozen."""
+        roi_embed = roi_features.clone().detach()
+        roi_embed.requires_grad = True
+        if pts_weights is None:
+            pts_weights = torch.ones_like(pts_labels, dtype=torch.float32)
+        train_state = self.training
+        with torch.enable_grad():
+            optimizer = torch.optim.Adam([roi_embed], lr=0.01)
+            scheduler = torch.optim.lr_scheduler.StepLR(optimizer, 1000, 0.1)
+            self.eval()
+            for param in self.parameters():
+                param.requires_grad = False
+            for _ in range(num_ttt_iter):
+                optimizer.zero_grad()
+                occ_preds = self.decode(roi_embed, pts_smp, pts_roi_inds)
+                occ_preds = occ_preds.view(-1) if self.loss_need_squeeze else occ_preds.view(-1, 1)
+                if len(occ_preds) > 0:
+                    loss_ae = self.loss_occ_ae(occ_preds, pts_labels.view(-1), pts_weights).mean()
+                    loss_ae.backward()
+                    optimizer.step()
+                    scheduler.step()
+        self.train(train_state)
+        for param in self.parameters():
+            param.requires_grad = train_state
+        return roi_embed
+
+    def forward_test_ae(self, pts_xyz, pts_features, pts_info, roi_inds, rois):
+        """occ_ae_head.py:393-419."""
+        local_roi_feats, _, local_xyz = self.encode(pts_xyz, pts_features, pts_info, roi_inds, rois)
+        if self.test_cfg and self.test_cfg.get('online_tuning', False):
+            smp_xyz, labels, smp_inds = self.sample_observation(
+                local_xyz, rois, roi_inds, downsample_size=self.test_cfg.get('downsample_size', -1),
+                balance_sample=self.test_cfg.get('balance_sample', False))
+            local_roi_feats = self.online_tuning_forward(local_roi_feats, smp_xyz, labels, None, smp_inds,
+                                                         self.test_cfg.get('num_iter', 10))
+        return self.get_occ(local_roi_feats, rois)
 
     def encode(self, pts_xyz, pts_features, pts_info, roi_inds, rois, point_encoder=None, cat_global_xyz=False):
         """occ_ae_head.py:203-264 -> (local_roi_feats [R,D], nonempty mask [R], rotated local xyz)."""
