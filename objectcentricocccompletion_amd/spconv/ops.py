@@ -207,6 +207,31 @@ def _to_bf16_padded(t, cols):
     return out
 
 
+class overlap_wgrad(object):
+    """Context manager around a backward pass: weight gradients of the sparse convolutions are computed on a
+    side stream, concurrently with the input-gradient chain; on exit the current stream waits for the side
+    stream, so everything enqueued afterwards (optimizer, all-reduce) sees finished gradients.  Inside a
+    HIP-graph capture this becomes a fork / join of graph branches."""
+    _streams = {}
+
+    def __enter__(self):
+        global _overlap
+        dev = torch.cuda.current_device()
+        if dev not in overlap_wgrad._streams:
+            overlap_wgrad._streams[dev] = torch.cuda.Stream()
+        self.side, self.used = overlap_wgrad._streams[dev], False
+        self._prev, _overlap = _overlap, self
+        return self
+
+    def __exit__(self, *exc):
+        global _overlap
+        _overlap = self._prev
+        if self.used:
+            torch.cuda.current_stream().wait_stream(self.side)
+        return False
+
+
+_overlap = None
 _weight_cache = None  # {(data_ptr, mode, kd, nc): wn} filled by prepare_weights() for ONE forward+backward
 
 
@@ -347,6 +372,37 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     kd_in, kd_out = _round_kd(cin), _round_kd(cout)
     dy = _to_bf16_padded(out_bp, kd_out)
     input_bp = filters_bp = None
+    # (weight gradient first: with overlap_wgrad() it forks onto the side stream before the long dgrad kernel)
+    if need_filter_grad:
+        x = _x_bf16 if _x_bf16 is not None else _to_bf16_padded(features, kd_in)
+        kvol = indice_pairs.size(0)
+        cap = indice_pairs.size(2)
+        pairs = indice_pairs
+        if inverse:  # wgrad pairs x rows with dy rows: swap the two pair rows
+            pairs = indice_pairs.flip(1).contiguous()
+
+        def run():
+            nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)
+            ws = L.workspace(nbytes, features.device)
+            dw = torch.empty((kvol, kd_in, kd_out), dtype=torch.float32, device=features.device)
+            L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
+                                                       L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
+                                                       L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
+                    'sparse_conv_wgrad')
+            return dw[:, :cin, :cout].reshape(filters.shape).to(filters.dtype)
+
+        if _overlap is not None:
+            # the weight gradient feeds nothing until the optimizer: run it on a side stream next to the
+            # LN-backward / dgrad chain of the earlier layers (both are latency bound at one wave of work)
+            side, cur = _overlap.side, torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                filters_bp = run()
+            for t in (x, dy, pairs, indice_pair_num):
+                t.record_stream(side)
+            _overlap.used = True
+        else:
+            filters_bp = run()
     if need_input_grad:
         rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'bwd', n_in,
                                               subm)
@@ -359,19 +415,4 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         else:
             gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()
-    if need_filter_grad:
-        x = _x_bf16 if _x_bf16 is not None else _to_bf16_padded(features, kd_in)
-        kvol = indice_pairs.size(0)
-        cap = indice_pairs.size(2)
-        pairs = indice_pairs
-        if inverse:  # wgrad pairs x rows with dy rows: swap the two pair rows
-            pairs = indice_pairs.flip(1).contiguous()
-        nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)
-        ws = L.workspace(nbytes, features.device)
-        dw = torch.empty((kvol, kd_in, kd_out), dtype=torch.float32, device=features.device)
-        L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
-                                                   L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
-                                                   L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
-                'sparse_conv_wgrad')
-        filters_bp = dw[:, :cin, :cout].reshape(filters.shape).to(filters.dtype)
     return input_bp, filters_bp
