@@ -322,10 +322,18 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # test hook: OCOCC_BENCH_BACKEND=gloo with OCOCC_BENCH_SHARE_GPU=1 runs several ranks on ONE GPU, to exercise
+    # the N>1 launch plan (two graphs + eager all-reduce) on a 1-GPU box; the driver's runs use RCCL, one GPU each
+    backend = os.environ.get('OCOCC_BENCH_BACKEND', 'nccl')
+    if os.environ.get('OCOCC_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload in ('ococcnet', 'sst', 'decode'):
         {'ococcnet': bench_ococcnet, 'sst': bench_sst, 'decode': bench_decode}[args.workload](args, world, rank, dev)
