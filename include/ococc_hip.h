@@ -345,6 +345,24 @@ int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint1
                                float scale, uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dq_stride,
                                int64_t dk_stride, int64_t dv_stride, ococc_stream_t stream);
 
+/* Flat-token forms of the two calls above: q/k/v/out (and dout, dq/dk/dv) are [num_tokens, .] tensors in
+ * the model's token order and token_index [num_windows * max_tokens] int32 names the row of every window
+ * slot (-1 = padding; valid slots are a prefix of each window, key_len of them).  The kernel gathers a
+ * window's tokens itself and writes every output row exactly once, so the padded [nW, T, C] copies that
+ * flat2window / window2flat build in the reference (sst_ops.py:66-148) never exist. lse stays [nW, H, T]. */
+int ococc_window_attn_fwd_gather_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride,
+                                      int64_t k_stride, int64_t v_stride, const int32_t* token_index,
+                                      const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                                      int32_t num_heads, int32_t head_dim, float scale, uint16_t* out,
+                                      int64_t out_stride, float* lse, ococc_stream_t stream);
+int ococc_window_attn_bwd_gather_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride,
+                                      int64_t k_stride, int64_t v_stride, const uint16_t* out, const uint16_t* dout,
+                                      int64_t o_stride, const float* lse, const int32_t* token_index,
+                                      const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                                      int32_t num_heads, int32_t head_dim, float scale, uint16_t* dq, uint16_t* dk,
+                                      uint16_t* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
+                                      ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

@@ -74,6 +74,11 @@ SIGNATURES = {
                                            c_f32, c_vp, c_i64, c_vp, c_vp]),
     'ococc_window_attn_bwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64,
                                            c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    'ococc_window_attn_fwd_gather_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32,
+                                                  c_i32, c_f32, c_vp, c_i64, c_vp, c_vp]),
+    'ococc_window_attn_bwd_gather_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                                  c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64,
+                                                  c_i64, c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_adamw_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),

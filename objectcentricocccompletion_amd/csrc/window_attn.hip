@@ -56,22 +56,27 @@ __global__ void __launch_bounds__(256)
 window_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                        const uint16_t* __restrict__ v, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                        const int32_t* __restrict__ key_len, int T, int H, int HG, float scale,
-                       uint16_t* __restrict__ out, int64_t out_stride, float* __restrict__ lse) {
+                       uint16_t* __restrict__ out, int64_t out_stride, float* __restrict__ lse,
+                       const int32_t* __restrict__ tok) {
+  // tok == nullptr: padded layout, token t of window w is row w*T + t of q/k/v/out.
+  // tok != nullptr: flat-token layout, row tok[w*T + t] (-1 = padding slot): the kernel gathers the
+  // window's tokens itself and writes each output row exactly once; no padded copy exists in HBM.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint16_t* rows = (uint16_t*)smem_raw;
   const int w = blockIdx.x, hg0 = blockIdx.y * HG;
+  auto rowof = [&](int t) -> int64_t { return tok ? (int64_t)tok[(int64_t)w * T + t] : (int64_t)w * T + t; };
   const int tiles = (T + 15) >> 4;
   const int TPE = ((tiles + 1) >> 1) * 32;  // PV consumes key tiles in pairs: rows up to TPE are zero filled
   const int LDR = 2 * HG * kD + 16;         // elements per LDS row (32 B pad)
   const int PP = 4 * HG;                    // 16-byte pieces per row (K then V)
   const int len = key_len[w];
-  const int64_t row0 = (int64_t)w * T;
   for (int i = threadIdx.x; i < TPE * PP; i += 256) {
     const int t = i / PP, pc = i % PP;
     u32x4 val = {0u, 0u, 0u, 0u};
-    if (t < T) {
-      const uint16_t* src = pc < 2 * HG ? k + (row0 + t) * k_stride + hg0 * kD + pc * 8
-                                        : v + (row0 + t) * v_stride + hg0 * kD + (pc - 2 * HG) * 8;
+    const int64_t r = t < T ? rowof(t) : -1;
+    if (r >= 0) {
+      const uint16_t* src = pc < 2 * HG ? k + r * k_stride + hg0 * kD + pc * 8
+                                        : v + r * v_stride + hg0 * kD + (pc - 2 * HG) * 8;
       val = *(const u32x4*)src;
     }
     *(u32x4*)(rows + t * LDR + pc * 8) = val;
@@ -86,8 +91,9 @@ window_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
     const uint16_t* vs = rows + (HG + hh) * kD;
     for (int qt = 0; qt < tiles; ++qt) {
       const int qi = qt * 16 + c;  // this lane's query
+      const int64_t qrow = qi < T ? rowof(qi) : -1;
       s16x4 bq = {0, 0, 0, 0};
-      if (qi < T) bq = ld4(q + (row0 + qi) * q_stride + h * kD + 4 * g);
+      if (qrow >= 0) bq = ld4(q + qrow * q_stride + h * kD + 4 * g);
       f32x4 s[MT + 1];  // one spare tile so that an odd MT pairs its last tile with zeros
       s[MT] = f32x4{0.f, 0.f, 0.f, 0.f};
       float m = -INFINITY;
@@ -134,7 +140,7 @@ window_attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
         }
       }
       if (qi < T) {
-        st4(out + (row0 + qi) * out_stride + h * kD + 4 * g, o);
+        if (qrow >= 0) st4(out + qrow * out_stride + h * kD + 4 * g, o);
         if (lse && g == 0) lse[((int64_t)w * H + h) * T + qi] = sum > 0.f ? m + __logf(sum) : 0.f;
       }
     }
@@ -155,9 +161,11 @@ window_attn_bwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
                        const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout, int64_t o_stride,
                        const float* __restrict__ lse, const int32_t* __restrict__ key_len, int T, int H, int HG,
                        float scale, uint16_t* __restrict__ dq, uint16_t* __restrict__ dk,
-                       uint16_t* __restrict__ dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride) {
+                       uint16_t* __restrict__ dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
+                       const int32_t* __restrict__ tok) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int w = blockIdx.x, hg0 = blockIdx.y * HG;
+  auto rowof = [&](int t) -> int64_t { return tok ? (int64_t)tok[(int64_t)w * T + t] : (int64_t)w * T + t; };
   const int tiles = (T + 15) >> 4;
   const int TPE = ((tiles + 1) >> 1) * 32;
   const int LDR = 4 * HG * kD + 16;  // Q | K | V | dO, 32 B pad
@@ -166,22 +174,22 @@ window_attn_bwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
   float* lse_s = (float*)(smem_raw + (size_t)TPE * LDR * 2);
   float* delta_s = lse_s + HG * TPE;
   const int len = key_len[w];
-  const int64_t row0 = (int64_t)w * T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < TPE * PP; i += 256) {  // TPE*PP is a multiple of 256: uniform trip count
     const int t = i / PP, pc = i % PP;
     const int sel = pc / (2 * HG), sub = pc % (2 * HG);  // matrix, piece inside it
     u32x4 val = {0u, 0u, 0u, 0u};
     float part = 0.f;
-    if (t < T) {
+    const int64_t r = t < T ? rowof(t) : -1;
+    if (r >= 0) {
       const int col = hg0 * kD + sub * 8;
-      const uint16_t* src = sel == 0 ? q + (row0 + t) * q_stride + col
-                          : sel == 1 ? k + (row0 + t) * k_stride + col
-                          : sel == 2 ? v + (row0 + t) * v_stride + col
-                                     : dout + (row0 + t) * o_stride + col;
+      const uint16_t* src = sel == 0 ? q + r * q_stride + col
+                          : sel == 1 ? k + r * k_stride + col
+                          : sel == 2 ? v + r * v_stride + col
+                                     : dout + r * o_stride + col;
       val = *(const u32x4*)src;
       if (sel == 3) {
-        const u32x4 ov = *(const u32x4*)(out + (row0 + t) * o_stride + col);
+        const u32x4 ov = *(const u32x4*)(out + r * o_stride + col);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           part += ococc_bf16_to_f32((uint16_t)(val[j] & 0xffffu)) * ococc_bf16_to_f32((uint16_t)(ov[j] & 0xffffu));
@@ -242,7 +250,8 @@ window_attn_bwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(a0, a0 + 16 * LDR), pb, acc, 0, 0, 0);
         }
       }
-      if (qi < T) st4(dq + (row0 + qi) * dq_stride + h * kD + 4 * g, acc);
+      const int64_t qrow = qi < T ? rowof(qi) : -1;
+      if (qrow >= 0) st4(dq + qrow * dq_stride + h * kD + 4 * g, acc);
     }
     // ---- pass 2: dK, dV of key tile kt (lane: key c) ----
     for (int kt = 0; kt < tiles; ++kt) {
@@ -286,9 +295,10 @@ window_attn_bwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restric
                                                          pack_tiles(pv[2 * u], pv[2 * u + 1]), accv, 0, 0, 0);
         }
       }
-      if (kj < T) {
-        st4(dk + (row0 + kj) * dk_stride + h * kD + 4 * g, acck);
-        st4(dv + (row0 + kj) * dv_stride + h * kD + 4 * g, accv);
+      const int64_t krow = kj < T ? rowof(kj) : -1;
+      if (krow >= 0) {
+        st4(dk + krow * dk_stride + h * kD + 4 * g, acck);
+        st4(dv + krow * dv_stride + h * kD + 4 * g, accv);
       }
     }
   }
@@ -311,11 +321,10 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-extern "C" int ococc_window_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
-                                          int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                          const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
-                                          int32_t num_heads, int32_t head_dim, float scale, uint16_t* out,
-                                          int64_t out_stride, float* lse, ococc_stream_t stream) {
+static int attn_fwd_impl(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                         int32_t num_heads, int32_t head_dim, float scale, uint16_t* out, int64_t out_stride,
+                         float* lse, const int32_t* tok, ococc_stream_t stream) {
   OCOCC_REQUIRE(head_dim == kD, "window attention is built for head_dim 16 (d_model 128, 8 heads)");
   OCOCC_REQUIRE(max_tokens >= 1 && max_tokens <= kMaxTiles * 16, "max_tokens must be 1..160");
   OCOCC_REQUIRE(num_windows >= 0 && num_heads >= 1, "bad sizes");
@@ -334,7 +343,7 @@ extern "C" int ococc_window_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(window_attn_fwd_kernel<MT>),                                          \
                        dim3((unsigned)num_windows, (unsigned)(num_heads / HG)), dim3(256), lds,              \
                        (hipStream_t)stream, q, k, v, q_stride, k_stride, v_stride, key_len, T,               \
-                       (int)num_heads, HG, scale, out, out_stride, lse);                                     \
+                       (int)num_heads, HG, scale, out, out_stride, lse, tok);                                \
   } while (0)
   if (tiles <= 2) OCOCC_ATTN_FWD(2);
   else if (tiles <= 4) OCOCC_ATTN_FWD(4);
@@ -345,13 +354,32 @@ extern "C" int ococc_window_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, 
   return OCOCC_OK;
 }
 
-extern "C" int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+extern "C" int ococc_window_attn_fwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
                                           int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                          const uint16_t* out, const uint16_t* dout, int64_t o_stride,
-                                          const float* lse, const int32_t* key_len, int64_t num_windows,
-                                          int32_t max_tokens, int32_t num_heads, int32_t head_dim, float scale,
-                                          uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dq_stride,
-                                          int64_t dk_stride, int64_t dv_stride, ococc_stream_t stream) {
+                                          const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                                          int32_t num_heads, int32_t head_dim, float scale, uint16_t* out,
+                                          int64_t out_stride, float* lse, ococc_stream_t stream) {
+  return attn_fwd_impl(q, k, v, q_stride, k_stride, v_stride, key_len, num_windows, max_tokens, num_heads, head_dim,
+                       scale, out, out_stride, lse, nullptr, stream);
+}
+
+extern "C" int ococc_window_attn_fwd_gather_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                                 int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                                 const int32_t* token_index, const int32_t* key_len,
+                                                 int64_t num_windows, int32_t max_tokens, int32_t num_heads,
+                                                 int32_t head_dim, float scale, uint16_t* out, int64_t out_stride,
+                                                 float* lse, ococc_stream_t stream) {
+  OCOCC_REQUIRE(token_index || num_windows == 0, "null token_index");
+  return attn_fwd_impl(q, k, v, q_stride, k_stride, v_stride, key_len, num_windows, max_tokens, num_heads, head_dim,
+                       scale, out, out_stride, lse, token_index, stream);
+}
+
+static int attn_bwd_impl(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, const uint16_t* out, const uint16_t* dout, int64_t o_stride,
+                         const float* lse, const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                         int32_t num_heads, int32_t head_dim, float scale, uint16_t* dq, uint16_t* dk, uint16_t* dv,
+                         int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, const int32_t* tok,
+                         ococc_stream_t stream) {
   OCOCC_REQUIRE(head_dim == kD, "window attention is built for head_dim 16");
   OCOCC_REQUIRE(max_tokens >= 1 && max_tokens <= kMaxTiles * 16, "max_tokens must be 1..160");
   if (num_windows == 0) return OCOCC_OK;
@@ -370,7 +398,8 @@ extern "C" int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(window_attn_bwd_kernel<MT>),                                          \
                        dim3((unsigned)num_windows, (unsigned)(num_heads / HG)), dim3(256), lds,              \
                        (hipStream_t)stream, q, k, v, q_stride, k_stride, v_stride, out, dout, o_stride, lse, \
-                       key_len, T, (int)num_heads, HG, scale, dq, dk, dv, dq_stride, dk_stride, dv_stride);  \
+                       key_len, T, (int)num_heads, HG, scale, dq, dk, dv, dq_stride, dk_stride, dv_stride,   \
+                       tok);                                                                                 \
   } while (0)
   if (tiles <= 2) OCOCC_ATTN_BWD(2);
   else if (tiles <= 4) OCOCC_ATTN_BWD(4);
@@ -379,4 +408,30 @@ extern "C" int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, 
 #undef OCOCC_ATTN_BWD
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
+}
+
+extern "C" int ococc_window_attn_bwd_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                          int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                          const uint16_t* out, const uint16_t* dout, int64_t o_stride,
+                                          const float* lse, const int32_t* key_len, int64_t num_windows,
+                                          int32_t max_tokens, int32_t num_heads, int32_t head_dim, float scale,
+                                          uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dq_stride,
+                                          int64_t dk_stride, int64_t dv_stride, ococc_stream_t stream) {
+  return attn_bwd_impl(q, k, v, q_stride, k_stride, v_stride, out, dout, o_stride, lse, key_len, num_windows,
+                       max_tokens, num_heads, head_dim, scale, dq, dk, dv, dq_stride, dk_stride, dv_stride, nullptr,
+                       stream);
+}
+
+extern "C" int ococc_window_attn_bwd_gather_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                                 int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                                 const uint16_t* out, const uint16_t* dout, int64_t o_stride,
+                                                 const float* lse, const int32_t* token_index,
+                                                 const int32_t* key_len, int64_t num_windows, int32_t max_tokens,
+                                                 int32_t num_heads, int32_t head_dim, float scale, uint16_t* dq,
+                                                 uint16_t* dk, uint16_t* dv, int64_t dq_stride, int64_t dk_stride,
+                                                 int64_t dv_stride, ococc_stream_t stream) {
+  OCOCC_REQUIRE(token_index || num_windows == 0, "null token_index");
+  return attn_bwd_impl(q, k, v, q_stride, k_stride, v_stride, out, dout, o_stride, lse, key_len, num_windows,
+                       max_tokens, num_heads, head_dim, scale, dq, dk, dv, dq_stride, dk_stride, dv_stride,
+                       token_index, stream);
 }

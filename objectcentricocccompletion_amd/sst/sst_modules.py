@@ -213,6 +213,59 @@ class _WindowAttnPacked(torch.autograd.Function):
         return dqkv, None, None
 
 
+class _WindowAttnFlat(torch.autograd.Function):
+    """Attention over all drop levels on the flat packed [V, 3E] token tensor: the kernels gather each
+    window's tokens through a slot -> row index (ococc_window_attn_*_gather_bf16), so no padded window copy is
+    built and the output / gradients are written straight in token order."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads, *level_args):
+        V, C3 = qkv.shape
+        E = C3 // 3
+        D = E // num_heads
+        assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+        levels = [level_args[i:i + 4] for i in range(0, len(level_args), 4)]   # (tok, key_len, nW, T)
+        out = torch.empty((V, E), dtype=torch.bfloat16, device=qkv.device)
+        scale = float(D) ** -0.5
+        b = qkv.data_ptr()
+        lses = []
+        for tok, key_len, nW, T in levels:
+            lse = torch.empty((nW, num_heads, T), dtype=torch.float32, device=qkv.device)
+
+            def launch():
+                L.check(L.lib.ococc_window_attn_fwd_gather_bf16(b, b + 2 * E, b + 4 * E, C3, C3, C3, L.ptr(tok),
+                                                                L.ptr(key_len), nW, T, num_heads, D, scale,
+                                                                L.ptr(out), E, L.ptr(lse), L.stream()),
+                        'window_attn_fwd_gather')
+            if _attn_probe is not None:
+                _attn_probe.wrap(nW, T, num_heads, D, launch)
+            else:
+                launch()
+            lses.append(lse)
+        ctx.save_for_backward(qkv, out, *lses, *[t for lv in levels for t in lv[:2]])
+        ctx.meta = (num_heads, D, scale, [(lv[2], lv[3]) for lv in levels])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        H, D, scale, shapes = ctx.meta
+        n = len(shapes)
+        saved = ctx.saved_tensors
+        qkv, out, lses, rest = saved[0], saved[1], saved[2:2 + n], saved[2 + n:]
+        V, C3 = qkv.shape
+        E = C3 // 3
+        do = dout.to(torch.bfloat16).contiguous()
+        dqkv = torch.empty_like(qkv)   # every token belongs to exactly one window of one level: fully written
+        b, g = qkv.data_ptr(), dqkv.data_ptr()
+        for i, (nW, T) in enumerate(shapes):
+            tok, key_len = rest[2 * i], rest[2 * i + 1]
+            L.check(L.lib.ococc_window_attn_bwd_gather_bf16(b, b + 2 * E, b + 4 * E, C3, C3, C3, L.ptr(out), L.ptr(do), E,
+                                                            L.ptr(lses[i]), L.ptr(tok), L.ptr(key_len), nW, T, H, D,
+                                                            scale, g, g + 2 * E, g + 4 * E, C3, C3, C3, L.stream()),
+                    'window_attn_bwd_gather')
+        return (dqkv, None) + (None,) * (4 * n)
+
+
 class _TokenLinear(torch.autograd.Function):
     """y = x W^T + b over ~1e5..1e6 token rows with a tiny [out, in] weight.  The weight gradient
     dW = dY^T X contracts over the token dimension; the BLAS heuristics give that one output tile
@@ -276,7 +329,10 @@ def _window_maps(ind_dict, key_padding_dict):
                 continue
             slot, flat_pos = ind_dict[dl]
             mask = key_padding_dict[dl]
-            maps[dl] = (slot, flat_pos[0], mask.shape[0], mask.shape[1], (~mask).sum(1).to(torch.int32))
+            nW, T = mask.shape
+            tok = torch.full((nW * T,), -1, dtype=torch.int32, device=slot.device)
+            tok[slot] = flat_pos[0].to(torch.int32)
+            maps[dl] = (slot, flat_pos[0], nW, T, (~mask).sum(1).to(torch.int32), tok)
         ind_dict['_ococc_maps'] = maps
     return maps
 
@@ -315,12 +371,19 @@ class WindowMultiheadAttention(nn.Module):
         qk = _TokenLinear.apply(x16 + pos_flat, w[:2 * E], b[:2 * E])
         v = _TokenLinear.apply(x16, w[2 * E:], b[2 * E:])
         qkv = torch.cat([qk, v], 1)
-        o_flat = None
-        for dl, (slot, pos, nW, T, key_len) in maps.items():
-            packed = _ScatterRows.apply(qkv, pos, slot, nW * T).view(nW, T, 3 * E)
-            o = _WindowAttnPacked.apply(packed, key_len, H).view(nW * T, E)
-            part = _ScatterRows.apply(o, slot, pos, x.shape[0])
-            o_flat = part if o_flat is None else o_flat + part
+        covered = sum(int(m[0].numel()) for m in maps.values())
+        if covered == x.shape[0]:   # every token sits in a window (always, after drop_voxel): gather kernels
+            args = []
+            for dl, (slot, pos, nW, T, key_len, tok) in maps.items():
+                args += [tok, key_len, nW, T]
+            o_flat = _WindowAttnFlat.apply(qkv, H, *args)
+        else:
+            o_flat = None
+            for dl, (slot, pos, nW, T, key_len, tok) in maps.items():
+                packed = _ScatterRows.apply(qkv, pos, slot, nW * T).view(nW, T, 3 * E)
+                o = _WindowAttnPacked.apply(packed, key_len, H).view(nW * T, E)
+                part = _ScatterRows.apply(o, slot, pos, x.shape[0])
+                o_flat = part if o_flat is None else o_flat + part
         return _TokenLinear.apply(o_flat, self.out_proj.weight.to(dtype), self.out_proj.bias.to(dtype))
 
 

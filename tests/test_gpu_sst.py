@@ -156,3 +156,32 @@ def test_sst_bf16_flat_path_vs_f32_path(dev, gold):
     for a, b in zip(grads[0], grads[1]):
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.99, cos
+
+
+def test_window_attention_gather_kernels_match_padded(dev):
+    """ococc_window_attn_{fwd,bwd}_gather_bf16 on flat tokens = the padded kernels on the scattered copy."""
+    from objectcentricocccompletion_amd.sst.sst_modules import _WindowAttnFlat, _WindowAttnPacked
+    g = torch.Generator().manual_seed(9)
+    nW, T, H, E = 53, 60, 8, 128
+    key_len = torch.randint(1, T + 1, (nW,), generator=g).int()
+    V = int(key_len.sum())
+    perm = torch.randperm(V, generator=g)
+    tok = torch.full((nW * T,), -1, dtype=torch.int32)
+    pos = 0
+    for w in range(nW):
+        n = int(key_len[w])
+        tok[w * T:w * T + n] = perm[pos:pos + n].int()
+        pos += n
+    qkv = torch.randn(V, 3 * E, generator=g).bfloat16().to(dev)
+    dout = torch.randn(V, E, generator=g).bfloat16().to(dev)
+    tok, key_len = tok.to(dev), key_len.to(dev)
+    a = qkv.clone().requires_grad_(True)
+    out_a = _WindowAttnFlat.apply(a, H, tok, key_len, nW, T)
+    out_a.backward(dout)
+    b = qkv.clone().requires_grad_(True)
+    slot = torch.nonzero(tok >= 0).squeeze(1)
+    packed = torch.zeros(nW * T, 3 * E, dtype=torch.bfloat16, device=dev).index_copy(0, slot, b[tok[slot].long()])
+    out_p = _WindowAttnPacked.apply(packed.view(nW, T, 3 * E), key_len, H).view(nW * T, E)
+    out_b = torch.zeros(V, E, dtype=torch.bfloat16, device=dev).index_copy(0, tok[slot].long(), out_p[slot])
+    out_b.backward(dout)
+    assert torch.equal(out_a, out_b) and torch.equal(a.grad, b.grad)
