@@ -294,7 +294,7 @@ class _TokenLinear(torch.autograd.Function):
         if m < n:
             tail = (dy[m:].t() @ x[m:]).float()
             dw = tail if dw is None else dw + tail
-        db = dy.float().sum(0).to(dy.dtype) if ctx.has_bias else None
+        db = dy.sum(0, dtype=torch.float32).to(dy.dtype) if ctx.has_bias else None  # f32 accumulation, no f32 copy
         return dx, dw.to(w.dtype), db
 
 
