@@ -341,7 +341,7 @@ class WindowMultiheadAttention(nn.Module):
     """Parameter layout of nn.MultiheadAttention (in_proj_weight [3E,E], in_proj_bias,
     out_proj.{weight,bias}); batch-first padded windows [nW, T, E]; attention core on the HIP kernel."""
 
-    def __init__(self, embed_dim, num_heads, dropout=0.0):
+    def __init__(self, embed_dim, num_heads, dropout=0.0, cosine=False, tau_min=0.01, non_shared_tau=False):
         super().__init__()
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
@@ -349,6 +349,23 @@ class WindowMultiheadAttention(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
+        # scaled cosine attention (CosineMultiheadAttention, cosine_msa.py:123-185,449-466): per-head unit
+        # vectors, logits = cos / clamp(tau, tau_min); tau shared ([1,1,1]) or one per head ([1,H,1,1])
+        self.tau_min = tau_min
+        self.tau = (nn.Parameter(torch.ones(1, num_heads, 1, 1) if non_shared_tau else torch.ones(1, 1, 1))
+                    if cosine else None)
+
+    def _cosine_q_k(self, q, k):
+        """q, k [..., E] -> unit vectors per head, q additionally divided by tau and multiplied by sqrt(d) so
+        that the kernel's fixed 1/sqrt(d) scale leaves cos / tau."""
+        H = self.num_heads
+        D = self.embed_dim // H
+        shp = q.shape
+        qh = torch.nn.functional.normalize(q.reshape(-1, H, D).float(), dim=-1)
+        kh = torch.nn.functional.normalize(k.reshape(-1, H, D).float(), dim=-1)
+        tau = self.tau.clamp(min=self.tau_min).reshape(1, -1, 1).float()   # [1,1,1] or [1,H,1]
+        qh = qh * (float(D) ** 0.5 / tau)
+        return qh.reshape(shp).to(q.dtype), kh.reshape(shp).to(k.dtype)
 
     def forward(self, qk_in, v_in, key_padding_mask):
         nW, T, E = qk_in.shape
@@ -356,7 +373,10 @@ class WindowMultiheadAttention(nn.Module):
         qk = torch.addmm(b[:2 * E], qk_in.reshape(nW * T, E), w[:2 * E].t())
         v = torch.addmm(b[2 * E:], v_in.reshape(nW * T, E), w[2 * E:].t())
         key_len = (~key_padding_mask).sum(1).to(torch.int32)  # valid tokens are a prefix of each window
-        o = _WindowAttnCore.apply(qk[:, :E].reshape(nW, T, E), qk[:, E:].reshape(nW, T, E), v.view(nW, T, E),
+        q_, k_ = qk[:, :E], qk[:, E:]
+        if self.tau is not None:
+            q_, k_ = self._cosine_q_k(q_, k_)
+        o = _WindowAttnCore.apply(q_.reshape(nW, T, E), k_.reshape(nW, T, E), v.view(nW, T, E),
                                   key_len, self.num_heads)
         return self.out_proj(o.reshape(nW * T, E)).view(nW, T, E)
 
@@ -370,7 +390,11 @@ class WindowMultiheadAttention(nn.Module):
         x16 = x.to(dtype)
         qk = _TokenLinear.apply(x16 + pos_flat, w[:2 * E], b[:2 * E])
         v = _TokenLinear.apply(x16, w[2 * E:], b[2 * E:])
-        qkv = torch.cat([qk, v], 1)
+        if self.tau is not None:
+            q_, k_ = self._cosine_q_k(qk[:, :E], qk[:, E:])
+            qkv = torch.cat([q_, k_, v], 1)
+        else:
+            qkv = torch.cat([qk, v], 1)
         covered = sum(int(m[0].numel()) for m in maps.values())
         if covered == x.shape[0]:   # every token sits in a window (always, after drop_voxel): gather kernels
             args = []
@@ -391,10 +415,11 @@ class WindowAttention(nn.Module):
 
     def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None, layer_cfg=dict()):
         super().__init__()
-        assert not layer_cfg.get('cosine', False) and not layer_cfg.get('linear', False), \
-            'cosine / linear attention variants are not built'
+        assert not layer_cfg.get('linear', False), 'the linear attention variant raises NotImplementedError upstream too'
         self.nhead = nhead
-        self.self_attn = WindowMultiheadAttention(d_model, nhead, dropout=dropout)
+        self.self_attn = WindowMultiheadAttention(d_model, nhead, dropout=dropout, cosine=layer_cfg.get('cosine', False),
+                                                  tau_min=layer_cfg.get('tau_min', 0.01),
+                                                  non_shared_tau=layer_cfg.get('non_shared_tau', False))
         self.layer_id = layer_id
         self.compute_dtype = layer_cfg.get('compute_dtype', None)  # torch.bfloat16 -> flat-token bf16 path
 

@@ -54,7 +54,19 @@ def main():
         out = model(info)[0]['voxel_feats']
         blk = model.block_list[0].encoder_list[0]
         one = blk(feats, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
+    # cosine attention variant of the same block (layer_cfg cosine / non_shared_tau, cosine_msa.py:123-185,449-466)
+    blkmod = sys.modules['mmdet3d.models.sst.sst_basic_block_v2']
+    cos = blkmod.EncoderLayer(128, 8, 256, 0.0, 'gelu', batch_first=False, layer_id=0,
+                              layer_cfg=dict(cosine=True, tau_min=0.01, non_shared_tau=True)).eval()
+    cshapes = {k: tuple(v.shape) for k, v in cos.state_dict().items()}
+    csd = synth.synth_state_dict(cshapes, seed=9)
+    csd['win_attn.self_attn.tau'] = torch.linspace(0.05, 0.4, 8).view(1, 8, 1, 1)
+    cos.load_state_dict(csd)
+    with torch.no_grad():
+        cos_out = cos(feats, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
     res = dict(coors=coors.numpy(), feats=feats.numpy(), out=out.numpy(), one_layer=one.numpy(),
+               cos_out=cos_out.numpy(), cos_param_names=np.array(list(cshapes)),
+               cos_param_shapes=np.array([','.join(map(str, s_)) for s_ in cshapes.values()]),
                param_names=np.array(list(shapes)), param_shapes=np.array([','.join(map(str, s)) for s in shapes.values()]))
     for i in range(2):
         res[f'batch_win_inds_shift{i}'] = info[f'batch_win_inds_shift{i}'].numpy()

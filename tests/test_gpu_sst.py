@@ -185,3 +185,31 @@ def test_window_attention_gather_kernels_match_padded(dev):
     out_b = torch.zeros(V, E, dtype=torch.bfloat16, device=dev).index_copy(0, tok[slot].long(), out_p[slot])
     out_b.backward(dout)
     assert torch.equal(out_a, out_b) and torch.equal(a.grad, b.grad)
+
+
+def test_cosine_window_attention_vs_reference_golden(dev, gold):
+    """layer_cfg cosine / non_shared_tau (CosineMultiheadAttention, cosine_msa.py) in an EncoderLayer against
+    the imported reference; both the reference-shaped f32 path and the flat bf16 path."""
+    from objectcentricocccompletion_amd.sst.sst_modules import EncoderLayer, SSTInputLayerV2
+    layer = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=False, mute=True).eval()
+    feats, coors = torch.from_numpy(gold['feats']).to(dev), torch.from_numpy(gold['coors']).to(dev)
+    info = layer(feats, coors)
+    ref_shapes = dict(zip(gold['cos_param_names'].tolist(), gold['cos_param_shapes'].tolist()))
+    for cfg, tol in ((dict(), 2e-2), (dict(compute_dtype=torch.bfloat16), 4e-2)):
+        enc = EncoderLayer(128, 8, 256, 0.0, 'gelu', layer_id=0,
+                           layer_cfg=dict(cosine=True, tau_min=0.01, non_shared_tau=True, **cfg))
+        sd = enc.state_dict()
+        assert set(sd) == set(ref_shapes) and all(','.join(map(str, v.shape)) == ref_shapes[k] for k, v in sd.items())
+        new = synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=9)
+        new['win_attn.self_attn.tau'] = torch.linspace(0.05, 0.4, 8).view(1, 8, 1, 1)
+        enc.load_state_dict(new)
+        enc = enc.to(dev).eval()
+        with torch.no_grad():
+            out = enc(feats, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
+        err = float(np.abs(out.float().cpu().numpy() - gold['cos_out']).max() / np.abs(gold['cos_out']).max())
+        assert err < tol, (cfg, err)
+    # tau receives a gradient
+    enc.train()
+    x = feats.clone().requires_grad_(True)
+    enc(x, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0']).float().pow(2).mean().backward()
+    assert enc.win_attn.self_attn.tau.grad is not None and bool(torch.isfinite(enc.win_attn.self_attn.tau.grad).all())
