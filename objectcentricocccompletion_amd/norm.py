@@ -72,3 +72,69 @@ class LayerNorm(nn.LayerNorm):
 
     def extra_repr(self):
         return super().extra_repr() + f', fused_act={self.fused_act}'
+
+
+class _AllGatherSum(Function):
+    """Sum of a small vector over ranks with a differentiable backward (all_gather forward, all_reduce backward,
+    mmdet3d/ops/norm.py:9-24) -- [2C] statistics, the only collective of the SST use_bn option."""
+
+    @staticmethod
+    def forward(ctx, input):
+        import torch.distributed as dist
+        parts = [torch.zeros_like(input) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, input, async_op=False)
+        return torch.stack(parts, dim=0).sum(dim=0)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        import torch.distributed as dist
+        grad_output = grad_output.contiguous()
+        dist.all_reduce(grad_output, async_op=False)
+        return grad_output
+
+
+class _NaiveSyncBNMixin(object):
+    """Batch statistics averaged over ranks as plain means of per-rank means (mmdet3d/ops/norm.py:28-163);
+    single process / eval: the stock BatchNorm."""
+
+    def _sync_forward(self, input, dims, shape):
+        import torch.distributed as dist
+        assert input.dtype == torch.float32, f'input should be in float32 type, got {input.dtype}'
+        assert input.shape[0] > 0, 'SyncBN does not support empty inputs'
+        C = input.shape[1]
+        mean = torch.mean(input, dim=dims)
+        meansqr = torch.mean(input * input, dim=dims)
+        vec = _AllGatherSum.apply(torch.cat([mean, meansqr], dim=0)) * (1.0 / dist.get_world_size())
+        mean, meansqr = torch.split(vec, C)
+        var = meansqr - mean * mean
+        self.running_mean += self.momentum * (mean.detach() - self.running_mean)
+        self.running_var += self.momentum * (var.detach() - self.running_var)
+        invstd = torch.rsqrt(var + self.eps)
+        scale = self.weight * invstd
+        bias = self.bias - mean * scale
+        return input * scale.reshape(shape) + bias.reshape(shape)
+
+    @staticmethod
+    def _synced():
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+@NORM_LAYERS.register_module('naiveSyncBN1d')
+class NaiveSyncBatchNorm1d(nn.BatchNorm1d, _NaiveSyncBNMixin):
+
+    def forward(self, input):
+        if not self._synced() or not self.training:
+            return super().forward(input)
+        if input.dim() == 2:
+            return self._sync_forward(input.unsqueeze(2), [0, 2], (1, -1, 1)).squeeze(2)
+        return self._sync_forward(input, [0, 2], (1, -1, 1))
+
+
+@NORM_LAYERS.register_module('naiveSyncBN2d')
+class NaiveSyncBatchNorm2d(nn.BatchNorm2d, _NaiveSyncBNMixin):
+
+    def forward(self, input):
+        if not self._synced() or not self.training:
+            return super().forward(input)
+        return self._sync_forward(input, [0, 2, 3], (1, -1, 1, 1))

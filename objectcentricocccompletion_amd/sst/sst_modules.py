@@ -453,8 +453,14 @@ class EncoderLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(mlp_dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
-        assert not layer_cfg.get('use_bn', False), 'use_bn (NaiveSyncBN) is not built; LayerNorm only'
-        self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.use_bn = layer_cfg.get('use_bn', False)
+        if self.use_bn:  # sst_basic_block_v2.py:90-93
+            from ..registry import build_norm_layer
+            mom = layer_cfg.get('mom', 0.1)
+            self.norm1 = build_norm_layer(dict(type='naiveSyncBN1d', momentum=mom), d_model)[1]
+            self.norm2 = build_norm_layer(dict(type='naiveSyncBN1d', momentum=mom), d_model)[1]
+        else:
+            self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.dropout1, self.dropout2 = nn.Dropout(mlp_dropout), nn.Dropout(mlp_dropout)
         self.activation = _activation(activation)
         self.post_norm = layer_cfg.get('post_norm', True)
@@ -462,6 +468,8 @@ class EncoderLayer(nn.Module):
 
     @staticmethod
     def _ln(norm, x):
+        if not isinstance(norm, nn.LayerNorm):  # use_bn: batch norm over the tokens
+            return norm(x.float()).to(x.dtype)
         return layer_norm_act(x, norm.weight, norm.bias, norm.eps, 'none')
 
     def _ffn(self, x):

@@ -213,3 +213,21 @@ def test_cosine_window_attention_vs_reference_golden(dev, gold):
     x = feats.clone().requires_grad_(True)
     enc(x, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0']).float().pow(2).mean().backward()
     assert enc.win_attn.self_attn.tau.grad is not None and bool(torch.isfinite(enc.win_attn.self_attn.tau.grad).all())
+
+
+def test_encoder_layer_use_bn_option(dev, gold):
+    """layer_cfg use_bn (sst_basic_block_v2.py:90-93): naiveSyncBN1d norms with the reference's parameter names;
+    single process = plain BatchNorm1d over the tokens."""
+    from objectcentricocccompletion_amd.norm import NaiveSyncBatchNorm1d
+    from objectcentricocccompletion_amd.sst.sst_modules import EncoderLayer, SSTInputLayerV2
+    enc = EncoderLayer(128, 8, 256, 0.0, 'gelu', layer_id=0, layer_cfg=dict(use_bn=True, mom=0.05)).to(dev).train()
+    assert isinstance(enc.norm1, NaiveSyncBatchNorm1d) and enc.norm1.momentum == 0.05
+    assert {'norm1.running_mean', 'norm2.running_var', 'norm1.weight'} <= set(enc.state_dict())
+    layer = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=False, mute=True).eval()
+    feats, coors = torch.from_numpy(gold['feats']).to(dev), torch.from_numpy(gold['coors']).to(dev)
+    info = layer(feats, coors)
+    x = feats.clone().requires_grad_(True)
+    y = enc(x, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
+    assert abs(float(y.mean())) < 1e-3 and abs(float(y.var(0).mean()) - 1.0) < 5e-2     # batch-normalised output
+    y.pow(2).mean().backward()
+    assert bool(torch.isfinite(x.grad).all()) and float(enc.norm1.running_mean.abs().sum()) > 0
