@@ -411,12 +411,23 @@ def main():
                     return g_all.replay()
             else:
                 # the gradient all-reduce stays an eager RCCL call between two graphs
-                g_fb = GraphedStep(fwd_bwd, warmup=3)
-                g_opt = GraphedStep(opt.step, warmup=0, pool=g_fb.pool())
+                # graph 1: forward + backward + gradients packed into the flat buckets; eager: the bucket
+                # all-reduce (the only RCCL call); graph 2: unpack (average, copy back) + AdamW
+                def fwd_bwd_pack():
+                    out = fwd_bwd()
+                    buckets.pack()
+                    return out
+
+                def unpack_step():
+                    buckets.unpack()
+                    opt.step()
+
+                g_fb = GraphedStep(fwd_bwd_pack, warmup=3)
+                g_opt = GraphedStep(unpack_step, warmup=0, pool=g_fb.pool())
 
                 def step():
                     out = g_fb.replay()
-                    buckets.all_reduce()
+                    buckets.reduce()
                     g_opt.replay()
                     return out
             graph_note = 'one hipGraphLaunch per step' if world == 1 and not args.split_graph else 'two HIP graphs + eager RCCL all-reduce'

@@ -64,26 +64,53 @@ class GradBuckets(object):
         dt = self.wire_dtype or p0.dtype
         self.buckets.append((torch.zeros(n, dtype=dt, device=p0.device), list(items)))
 
-    def all_reduce(self):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def pack(self):
+        """Gradients -> flat buckets (one fused copy per bucket).  Device work only: may be recorded at the end
+        of a forward+backward HIP graph."""
+        if not self._active():
             return
-        world = dist.get_world_size()
-        works = []
         for flat, items in self.buckets:
-            for p, off, n in items:
+            views = [flat[off:off + n].view_as(p) for p, off, n in items]
+            have = [(v, p.grad) for v, (p, _, _) in zip(views, items) if p.grad is not None]
+            for v, (p, _, _) in zip(views, items):
                 if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].copy_(p.grad.reshape(-1))
-            works.append(dist.all_reduce(flat, async_op=True))  # all buckets in flight together
-        for (flat, items), w in zip(self.buckets, works):
+                    v.zero_()
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+
+    def reduce(self):
+        """One collective per bucket, all in flight together; the only step that talks to RCCL."""
+        if not self._active():
+            return
+        works = [dist.all_reduce(flat, async_op=True) for flat, _ in self.buckets]
+        for w in works:
             w.wait()
-            flat.div_(world)
+
+    def unpack(self):
+        """Averaged buckets -> gradients (one fused scale + copy per bucket); may open the optimizer's graph."""
+        if not self._active():
+            return
+        inv = 1.0 / dist.get_world_size()
+        for flat, items in self.buckets:
+            flat.mul_(inv)
+            dst, src = [], []
             for p, off, n in items:
+                v = flat[off:off + n].view_as(p)
                 if p.grad is None:
-                    p.grad = flat[off:off + n].view_as(p).to(p.dtype).clone()
+                    p.grad = v.to(p.dtype).clone()
                 else:
-                    p.grad.copy_(flat[off:off + n].view_as(p))
+                    dst.append(p.grad)
+                    src.append(v)
+            if dst:
+                torch._foreach_copy_(dst, src)
+
+    def all_reduce(self):
+        self.pack()
+        self.reduce()
+        self.unpack()
 
 
 def broadcast_parameters(module, src=0):
