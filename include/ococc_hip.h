@@ -133,6 +133,37 @@ int ococc_segment_reduce_bwd_f32(const float* grad_out, const int32_t* inv, int6
                                  int32_t reduce_type, const int32_t* counts, const int32_t* arg,
                                  float* grad_feats, int64_t num_segments, ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * B1 + B2 fused: dynamic voxelisation followed by DynamicScatter(mean)
+ * replaces, for the per-object grid front end, the sequence
+ *   voxelization::dynamic_voxelize      (mmdet3d/ops/voxel/src/voxelization.h:77-88)
+ *   coors = cat(batch_idx, zyx)         (mmdet3d/models/detectors: every voxel pipeline)
+ *   DynamicScatter.forward_single(mean) (mmdet3d/ops/voxel/scatter_points.py:53-107,
+ *                                        scatter_points_cuda.cu:199-241)
+ * with the results of running ococc_dynamic_voxelize_f32 + ococc_grid_unique_i32 +
+ * ococc_segment_reduce_f32(MEAN) one after the other: voxel rows in ascending (b,z,y,x) order,
+ * inv[i] = row of point i (-1: batch_idx[i] < 0, dropped), counts, and the mean of the point
+ * features per voxel (sums of >= 3 points may differ in the last bit: float atomics, as there).
+ * points [n, num_point_features] f32 (x,y,z first), batch_idx [n] int32 in [0, batch_size)
+ * (>= batch_size sets *status = 1 and drops the point), feats [n, c] f32.
+ * host_grid_zyx must equal ceil((max - min) / voxel) per axis (checked).
+ * All out_capacity rows are written: rows past *num_voxels get -1 coordinates, count 0 and zero
+ * features (the fixed-capacity form HIP-graph capture needs; use out_capacity = min(n, cells)).
+ * voxel_feats [out_capacity, c] f32 is required (it is where the sums live); voxel_feats_bf16
+ * (optional) receives the same means rounded to bf16 for the convolutions.
+ * num_voxels / status: ONE device int32[2].  The workspace keeps the grid's cell bitmap and
+ * popcount prefix at the offsets ococc_grid_unique_workspace_layout reports for
+ * dims = {batch, D, H, W}, ready for ococc_subm_rulebook_build_sorted.
+ * ------------------------------------------------------------------------ */
+int64_t ococc_voxelize_scatter_workspace_bytes(int64_t n, int32_t batch_size, const int32_t host_grid_zyx[3]);
+int ococc_voxelize_scatter_mean_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
+                                    int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
+                                    const float host_coors_range[6], int32_t batch_size,
+                                    const int32_t host_grid_zyx[3], int32_t* voxel_coors, int64_t out_capacity,
+                                    int32_t* inv, int32_t* counts, float* voxel_feats, uint16_t* voxel_feats_bf16,
+                                    int32_t* num_voxels, int32_t* status, void* workspace, int64_t workspace_bytes,
+                                    ococc_stream_t stream);
+
 /* Same rulebook when the rows of `indices` are exactly the occupied cells of a [batch, D, H, W] grid in
  * ascending cell order and the caller still holds that grid's bitmap + popcount prefix (the state
  * ococc_grid_unique_i32 leaves in its workspace, see ococc_grid_unique_workspace_layout): the

@@ -34,6 +34,9 @@ SIGNATURES = {
     'ococc_grid_unique_workspace_layout': (c_i32, [c_i32, _I4, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     'ococc_grid_unique_i32': (c_i32, [c_vp, c_i64, c_i32, _I4, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),
+    'ococc_voxelize_scatter_workspace_bytes': (c_i64, [c_i64, c_i32, _I3]),
+    'ococc_voxelize_scatter_mean_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3,
+                                                c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_segment_count_i32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     'ococc_segment_reduce_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
                                          c_vp]),

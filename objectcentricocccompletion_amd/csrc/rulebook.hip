@@ -94,7 +94,7 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
   }
   const bool row_ok = (unsigned)b < (unsigned)g.batch;
   uint32_t mask = 0;
-  auto visit = [&](int kz, int ky, int kx, int k) {
+  auto lookup = [&](int kz, int ky, int kx) -> int32_t {
     const int32_t z = z0 + kz, y = y0 + ky, x = x0 + kx;
     int32_t v = -1;
     if (row_ok && (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H &&
@@ -103,6 +103,9 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
       const int32_t r = rank_of(bitmap, prefix, cell);
       if (r >= 0) v = perm ? perm[r] - 1 : r;  // perm holds row + 1 (0 = empty)
     }
+    return v;
+  };
+  auto emit = [&](int32_t v, int k) {
     if (o < n) nbr_t[(int64_t)k * n + o] = v;
     const unsigned long long m = __ballot(v >= 0);
     if (k < 32 && ((m >> (lane & 48)) & 0xffffull)) mask |= 1u << k;
@@ -112,13 +115,18 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
     }
   };
   if constexpr (KS != 0) {
+    // all lookups first (their loads are independent and overlap), then the ballots and stores: done
+    // one offset at a time the kernel is a chain of 27 dependent L2 round trips (17 us -> 6 us at 126 k rows)
+    int32_t v[KS * KS * KS];
 #pragma unroll
-    for (int k = 0; k < KS * KS * KS; ++k) visit(k / (KS * KS), (k / KS) % KS, k % KS, k);
+    for (int k = 0; k < KS * KS * KS; ++k) v[k] = lookup(k / (KS * KS), (k / KS) % KS, k % KS);
+#pragma unroll
+    for (int k = 0; k < KS * KS * KS; ++k) emit(v[k], k);
   } else {
     int k = 0;
     for (int kz = 0; kz < kd; ++kz)
       for (int ky = 0; ky < kh; ++ky)
-        for (int kx = 0; kx < kw; ++kx, ++k) visit(kz, ky, kx, k);
+        for (int kx = 0; kx < kw; ++kx, ++k) emit(lookup(kz, ky, kx), k);
   }
   if (blockmask && (lane & 15) == 0 && o < n) blockmask[o >> 4] = mask;
   if (blk_cnt) {
@@ -165,13 +173,19 @@ block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t
 // pairs[k][0][pos] = j, pairs[k][1][pos] = nbr_t[K-1-k][j]  for valid entries
 __global__ void __launch_bounds__(256)
 compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ blk_off,
-                     int64_t n, int kvol, int32_t* __restrict__ pairs) {
+                     int64_t n, int kvol, const int32_t* __restrict__ indice_num,
+                     int32_t* __restrict__ pairs) {
   // grid (row blocks of 256, kvol): same blocking as neighbour_table_kernel, order preserving
   __shared__ uint32_t wsum[4];
   const int k = blockIdx.y;
   const int src = kvol - 1 - k;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the unused tail of offset k reads -1 (ops.py:46-106 returns a -1 filled tensor); thread j owns slot j
+  if (j < n && j >= indice_num[k]) {
+    pairs[((int64_t)k * 2 + 0) * n + j] = -1;
+    pairs[((int64_t)k * 2 + 1) * n + j] = -1;
+  }
   const int32_t o = j < n ? nbr_t[(int64_t)src * n + j] : -1;
   const unsigned long long m = __ballot(o >= 0);
   if (lane == 0) wsum[wave] = (uint32_t)__popcll(m);
@@ -431,11 +445,10 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
                        indices, n, g, bitmap, prefix, perm, nbr_t, blockmask, cnt);
   OCOCC_CHECK_LAUNCH();
   if (indice_pairs) {
-    OCOCC_HIP(hipMemsetAsync(indice_pairs, 0xff, (int64_t)kvol * 2 * n * 4, stream));
     hipLaunchKernelGGL(block_offsets_kernel, dim3(kvol), dim3(256), 0, stream, blk, nblk, kvol, indice_num);
     OCOCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_pairs_kernel, dim3((unsigned)nblk, kvol), dim3(256), 0, stream, nbr_t, blk, n,
-                       kvol, indice_pairs);
+                       kvol, indice_num, indice_pairs);
     OCOCC_CHECK_LAUNCH();
   }
   return OCOCC_OK;

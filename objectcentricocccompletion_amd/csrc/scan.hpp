@@ -1,5 +1,5 @@
-// Device-wide exclusive prefix sums over uint32 (three launches, no atomics,
-// deterministic).  Used for (a) cell bitmaps -> voxel ranks (popcount scan) and
+// Device-wide exclusive prefix sums over uint32 (two launches -- three past 4096 blocks per row --
+// no atomics, deterministic).  Used for (a) cell bitmaps -> voxel ranks (popcount scan) and
 // (b) per-offset stream compaction of the rulebook.  Batched over `rows`
 // independent rows of equal length.  HBM-bound: reads the input twice and
 // writes it once.
@@ -81,11 +81,14 @@ scan_sums_kernel(uint32_t* __restrict__ block_sums, int blocks_per_row,
 
 // out[i] = exclusive prefix of xform(in) within the row.  Thread t owns kItems
 // CONSECUTIVE elements so the in-thread running sum is the prefix.
-template <int T>
+// SELF_BASE: block_sums holds the RAW block totals of reduce_kernel and every block adds up the ones
+// in front of it by itself (cheap while a row has few blocks; saves the scan_sums launch).  The row
+// total goes to totals[row] from the row's last block.
+template <int T, bool SELF_BASE>
 __global__ void __launch_bounds__(kThreads)
 apply_kernel(const uint32_t* __restrict__ in, int64_t n, int64_t row_stride,
              const uint32_t* __restrict__ block_sums, int blocks_per_row,
-             uint32_t* __restrict__ out, int64_t out_row_stride) {
+             uint32_t* __restrict__ out, int64_t out_row_stride, uint32_t* __restrict__ totals) {
   const int row = blockIdx.y;
   const uint32_t* src = in + (int64_t)row * row_stride;
   uint32_t* dst = out + (int64_t)row * out_row_stride;
@@ -98,9 +101,18 @@ apply_kernel(const uint32_t* __restrict__ in, int64_t n, int64_t row_stride,
     v[j] = i < n ? xform<T>(src[i]) : 0u;
     s += v[j];
   }
+  uint32_t before;
+  if (SELF_BASE) {
+    uint32_t part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kThreads) part += block_sums[(int64_t)row * blocks_per_row + j];
+    block_inclusive_scan(part, &before);
+  } else {
+    before = block_sums[(int64_t)row * blocks_per_row + blockIdx.x];
+  }
   uint32_t tot;
   uint32_t inc = block_inclusive_scan(s, &tot);
-  uint32_t run = block_sums[(int64_t)row * blocks_per_row + blockIdx.x] + inc - s;
+  if (SELF_BASE && totals && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) totals[row] = before + tot;
+  uint32_t run = before + inc - s;
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     int64_t i = base + j;
@@ -113,7 +125,7 @@ static inline int blocks_for(int64_t n) { return (int)((n + kTile - 1) / kTile);
 // scratch (uint32 count) needed for `rows` rows of length n
 static inline int64_t scratch_words(int64_t n, int rows) { return (int64_t)blocks_for(n) * rows; }
 
-// Queue the three launches.  totals may be NULL.  in/out may alias only if
+// Queue the launches.  totals may be NULL.  in/out may alias only if
 // row strides are equal (each element is read before it is written by the
 // same thread in apply_kernel, and reduce_kernel has finished by then).
 template <int T>
@@ -124,9 +136,14 @@ static inline hipError_t exclusive_scan(const uint32_t* in, int64_t n, int64_t r
   const int nb = blocks_for(n);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(reduce_kernel<T>), dim3(nb, rows), dim3(kThreads), 0, stream,
                      in, n, row_stride, scratch, nb);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(rows), dim3(kThreads), 0, stream, scratch, nb, totals);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(apply_kernel<T>), dim3(nb, rows), dim3(kThreads), 0, stream,
-                     in, n, row_stride, scratch, nb, out, out_row_stride);
+  if (nb <= 4096) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(apply_kernel<T, true>), dim3(nb, rows), dim3(kThreads), 0, stream,
+                       in, n, row_stride, scratch, nb, out, out_row_stride, totals);
+  } else {
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(rows), dim3(kThreads), 0, stream, scratch, nb, totals);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(apply_kernel<T, false>), dim3(nb, rows), dim3(kThreads), 0, stream,
+                       in, n, row_stride, scratch, nb, out, out_row_stride, (uint32_t*)nullptr);
+  }
   return hipGetLastError();
 }
 

@@ -13,15 +13,16 @@ from torch import nn
 from .sparse_block import make_sparse_convmodule
 from .spconv import SparseConvTensor
 from .spconv import ops as sp_ops
-from .voxel import dynamic_scatter, voxelization
+from .voxel import dynamic_scatter, voxelization, voxelize_scatter_mean
 
 
 class SubMOccEncoder(nn.Module):
 
     def __init__(self, in_channels=16, channels=(32, 64, 128), voxel_size=(0.2, 0.2, 0.2),
                  point_cloud_range=(-4, -4, -4, 4, 4, 4), norm_cfg=dict(type='LN', eps=1e-3),
-                 act_type='gelu', feature_dtype=torch.bfloat16):
+                 act_type='gelu', feature_dtype=torch.bfloat16, fused_front_end=True):
         super().__init__()
+        self.fused_front_end = bool(fused_front_end) and feature_dtype in (torch.bfloat16, torch.float32)
         self.voxel_size = list(voxel_size)
         self.point_cloud_range = list(point_cloud_range)
         self.grid = [int(round((point_cloud_range[3 + i] - point_cloud_range[i]) / voxel_size[i]))
@@ -55,10 +56,17 @@ class SubMOccEncoder(nn.Module):
         items = [(layer[0].weight, 0) for layer in self.conv_layers]
         items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
         sp_ops.prepare_weights(items)
-        coors = self.voxelize(points, batch_idx, batch_size)
-        vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
-                                         grid_shape=[batch_size] + self.sparse_shape, static=static)
-        x = SparseConvTensor(vfeats.to(self.feature_dtype), vcoors, self.sparse_shape, batch_size)
+        if self.fused_front_end:
+            # voxelize -> cat -> DynamicScatter(mean) -> cast in one C-ABI call (7 launches instead of 15)
+            vfeats, vcoors, _, _, _ = voxelize_scatter_mean(
+                points, batch_idx, feats, self.voxel_size, self.point_cloud_range, self.sparse_shape, batch_size,
+                static=static, out_dtype=self.feature_dtype)
+        else:
+            coors = self.voxelize(points, batch_idx, batch_size)
+            vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
+                                             grid_shape=[batch_size] + self.sparse_shape, static=static)
+            vfeats = vfeats.to(self.feature_dtype)
+        x = SparseConvTensor(vfeats, vcoors, self.sparse_shape, batch_size)
         for layer in self.conv_layers:
             x = layer(x)
         return x

@@ -6,6 +6,8 @@ ococc_weight_prepare_bf16, ococc_sparse_conv_gather_gemm_bf16 (forward and dgrad
 ococc_sparse_conv_wgrad_bf16.  The reference's per-offset gather/GEMM/scatter loop
 (include/spconv/spconv_ops.h:260-456) does not exist here.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -253,7 +255,7 @@ def prepare_weights(items):
         kvol = filters.numel() // (cin * cout)
         wn = torch.empty((kvol, nc, kd), dtype=torch.bfloat16, device=filters.device)
         todo.append((filters, mode, kvol, cin, cout, wn))
-        _weight_cache[(filters.data_ptr(), mode, kd, nc)] = (wn, filters._version)
+        _weight_cache[(filters.data_ptr(), mode, kd, nc)] = (wn, filters._version, weakref.ref(filters))
     for lo in range(0, len(todo), 16):
         ch = todo[lo:lo + 16]
         n = len(ch)
@@ -268,7 +270,8 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
     """filters [..., cin, cout] -> bf16 wn [kvol, ncols, kd] for the gather-GEMM kernel."""
     if _weight_cache is not None:
         hit = _weight_cache.get((filters.data_ptr(), mode, kd_pad, nc_pad))
-        if hit is not None and hit[1] == filters._version:  # the weights have not been updated since
+        # the very tensor object that was prepared (an address can be recycled by the allocator), not updated since
+        if hit is not None and hit[2]() is filters and hit[1] == filters._version:
             return hit[0]
     cin, cout = filters.shape[-2], filters.shape[-1]
     w = filters.reshape(-1, cin, cout)

@@ -170,6 +170,81 @@ def dynamic_scatter(feats, coors, reduce_type='max', grid_shape=None, static=Fal
     return voxel_feats, voxel_coors.to(coors.dtype)
 
 
+class _MeanOfPointsGrad(Function):
+    """Ties the voxel means computed by ococc_voxelize_scatter_mean_f32 to the point features they
+    came from: d feats[i] = d voxel[inv[i]] / counts[inv[i]] (the MEAN branch of _SegmentReduce)."""
+
+    @staticmethod
+    def forward(ctx, feats, vfeats, inv, counts):
+        ctx.save_for_backward(inv, counts)
+        ctx.shape = tuple(feats.shape)
+        return vfeats.view_as(vfeats)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inv, counts = ctx.saved_tensors
+        n, c = ctx.shape
+        grad_out = grad_out.contiguous().float()
+        grad = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+        L.check(L.lib.ococc_segment_reduce_bwd_f32(L.ptr(grad_out), L.ptr(inv), n, c, L.REDUCE['mean'],
+                                                   L.ptr(counts), None, L.ptr(grad), counts.size(0), L.stream()),
+                'voxelize_scatter_mean_bwd')
+        return grad, None, None, None
+
+
+def voxelize_scatter_mean(points, batch_idx, feats, voxel_size, coors_range, grid_zyx, batch_size,
+                          static=False, out_dtype=torch.float32):
+    """voxelization(points, voxel_size, coors_range, -1, -1) -> coors = cat(batch_idx, zyx) ->
+    dynamic_scatter(feats, coors, 'mean') in ONE C-ABI call (ococc_voxelize_scatter_mean_f32): same
+    results, same row order, no [N,3] / [N,4] coordinate tensors, no zero fills, float atomics only
+    for the points that share a cell with an earlier one.
+
+    Returns (voxel_feats [M,C] in out_dtype (float32 or bfloat16), voxel_coors [M,4] int32 (b,z,y,x),
+    inv [N] int32, counts [M] int32, meta int32[2] on the device = [num_voxels, status]).
+    ``static=True``: M is the fixed capacity min(N, cells) and nothing is read back (rows past
+    meta[0] have -1 coordinates, count 0, zero features); otherwise M = num_voxels (one sync).
+    The returned coordinates carry the grid bitmap tag spconv.ops.get_indice_pairs reuses."""
+    L.require_device(points, batch_idx, feats)
+    want16 = out_dtype == torch.bfloat16
+    assert want16 or out_dtype == torch.float32
+    assert points.dtype == torch.float32 and feats.dtype == torch.float32
+    pts, fts = points.detach().contiguous(), feats.detach().contiguous()
+    bidx = batch_idx if batch_idx.dtype == torch.int32 else batch_idx.to(torch.int32)
+    bidx = bidx.contiguous()
+    n, c = fts.shape
+    dev = fts.device
+    grid_zyx = [int(v) for v in grid_zyx]
+    dims = [int(batch_size)] + grid_zyx
+    cap = min(n, dims[0] * dims[1] * dims[2] * dims[3])
+    nbytes = L.lib.ococc_voxelize_scatter_workspace_bytes(n, int(batch_size), L.i3(grid_zyx))
+    if nbytes < 0:
+        raise L.OcoccError(f'voxelize_scatter_mean: grid {dims} too large for the bitmap plan')
+    ws = L.workspace(nbytes, dev)
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    inv = torch.empty((n,), dtype=torch.int32, device=dev)
+    counts = torch.empty((cap,), dtype=torch.int32, device=dev)
+    out = torch.empty((cap, c), dtype=torch.float32, device=dev)
+    out16 = torch.empty((cap, c), dtype=torch.bfloat16, device=dev) if want16 else None
+    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    L.check(L.lib.ococc_voxelize_scatter_mean_f32(
+        L.ptr(pts), pts.size(1), L.ptr(bidx), n, L.ptr(fts), c, L.f3(voxel_size), L.f6(coors_range),
+        int(batch_size), L.i3(grid_zyx), L.ptr(coors), cap, L.ptr(inv), L.ptr(counts), L.ptr(out), L.ptr(out16),
+        meta.data_ptr(), meta.data_ptr() + 4, L.ptr(ws), ws.numel(), L.stream()), 'voxelize_scatter_mean')
+    vfeats = out16 if want16 else out
+    if not static:
+        num, status = meta.tolist()
+        if status:
+            raise L.OcoccError(f'voxelize_scatter_mean: a batch index is outside [0, {batch_size})')
+        vfeats, coors, counts = vfeats[:num], coors[:num], counts[:num]
+    if feats.requires_grad and torch.is_grad_enabled():
+        vfeats = _MeanOfPointsGrad.apply(feats, vfeats, inv, counts)
+    bo, po = L.c_i64(), L.c_i64()
+    L.check(L.lib.ococc_grid_unique_workspace_layout(4, L.i4(dims), bo, po), 'grid_unique_layout')
+    coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims))
+    inv._ococc_counts = counts
+    return vfeats, coors, inv, counts, meta
+
+
 class DynamicScatter(nn.Module):
     """Same constructor / forward as mmdet3d/ops/voxel/scatter_points.py:53-107.  The
     reference loops over the batch in Python (:86-100); here the batch column is part of

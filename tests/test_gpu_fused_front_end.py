@@ -1,0 +1,121 @@
+"""ococc_voxelize_scatter_mean_f32 (voxelize -> cat -> DynamicScatter mean in one call) against the
+separate operators it replaces, which are themselves pinned to the oracle / golden vectors
+(test_gpu_voxel.py): mmdet3d/ops/voxel/voxelize.py:10-113, scatter_points.py:53-107."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _points(n, batch, c, seed, dev, extent=4.0, dup_frac=0.0):
+    g = torch.Generator().manual_seed(seed)
+    xyz = (torch.rand(n, 3, generator=g) * 2 - 1) * (extent * 1.05)  # a few land outside -> clamped
+    if dup_frac > 0:  # force shared cells: copy positions (with jitter inside the cell) of earlier points
+        k = int(n * dup_frac)
+        src = torch.randint(0, n - k, (k,), generator=g)
+        xyz[n - k:] = xyz[src] + (torch.rand(k, 3, generator=g) - 0.5) * 1e-3
+    bidx = torch.sort(torch.randint(0, batch, (n,), generator=g)).values.to(torch.int32)
+    if dup_frac > 0:
+        bidx[n - k:] = bidx[src]
+    feats = torch.randn(n, c, generator=g)
+    return xyz.to(dev), bidx.to(dev), feats.to(dev)
+
+
+def _reference(xyz, bidx, feats, voxel, rng, grid_zyx, batch, static):
+    from objectcentricocccompletion_amd.voxel import dynamic_scatter, voxelization
+    zyx = voxelization(xyz, voxel, rng, -1, -1)
+    coors = torch.cat([bidx.view(-1, 1), zyx], 1)
+    from objectcentricocccompletion_amd.voxel.scatter_points import grid_unique, segment_reduce
+    if static:
+        vc, inv, counts, meta = grid_unique(coors, [batch] + grid_zyx, static=True)
+    else:
+        vc, inv, counts = grid_unique(coors, [batch] + grid_zyx)
+        meta = None
+    vf = segment_reduce(feats, inv, vc.size(0), 'mean', counts)
+    return vf, vc, inv, counts, meta
+
+
+@pytest.mark.parametrize('n,batch,c,dup', [(5000, 3, 16, 0.0), (20000, 8, 16, 0.3), (777, 2, 7, 0.5),
+                                            (4096, 1, 3, 0.9), (128000, 64, 16, 0.0)])
+@pytest.mark.parametrize('static', [False, True])
+def test_fused_matches_separate_ops(dev, n, batch, c, dup, static):
+    from objectcentricocccompletion_amd.voxel import voxelize_scatter_mean
+    voxel, rng, grid_zyx = [0.2, 0.2, 0.2], [-4, -4, -4, 4, 4, 4], [40, 40, 40]
+    xyz, bidx, feats = _points(n, batch, c, 11 + n, dev, dup_frac=dup)
+    ef, ec, einv, ecnt, emeta = _reference(xyz, bidx, feats, voxel, rng, grid_zyx, batch, static)
+    for dt in (torch.float32, torch.bfloat16):
+        vf, vc, inv, cnt, meta = voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, grid_zyx, batch,
+                                                       static=static, out_dtype=dt)
+        assert vc.dtype == torch.int32 and torch.equal(vc, ec)        # rows, order, -1 padding: bit-exact
+        assert torch.equal(inv, einv) and torch.equal(cnt, ecnt)
+        num = int(meta[0])
+        assert int(meta[1]) == 0 and num == int((ecnt > 0).sum())
+        if static:
+            assert int(emeta[0]) == num
+            assert bool((vf[num:] == 0).all()) and bool((cnt[num:] == 0).all())
+        if dt == torch.float32:
+            # one point per voxel: a copy; two: a+b commutes; three and more: float atomics reorder the sum
+            single = ecnt <= 2
+            assert torch.equal(vf[single], ef[single])
+            assert torch.allclose(vf, ef, rtol=1e-6, atol=1e-6)
+        else:
+            assert vf.dtype == torch.bfloat16
+            assert torch.allclose(vf.float(), ef.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-6)
+            single = ecnt <= 2
+            assert torch.equal(vf[single], ef[single].to(torch.bfloat16))
+
+
+def test_fused_drops_negative_batch_and_flags_overflow(dev):
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.voxel import voxelize_scatter_mean
+    voxel, rng, grid_zyx = [0.2, 0.2, 0.2], [-4, -4, -4, 4, 4, 4], [40, 40, 40]
+    xyz, bidx, feats = _points(3000, 2, 8, 5, dev)
+    bidx = bidx.clone()
+    bidx[::7] = -1
+    ef, ec, einv, ecnt, _ = _reference(xyz, bidx, feats, voxel, rng, grid_zyx, 2, False)
+    vf, vc, inv, cnt, meta = voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, grid_zyx, 2)
+    assert torch.equal(vc, ec) and torch.equal(inv, einv) and torch.equal(cnt, ecnt)
+    assert bool((inv[::7] == -1).all()) and torch.allclose(vf, ef, rtol=1e-6, atol=1e-6)
+    bidx[5] = 2
+    with pytest.raises(L.OcoccError):
+        voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, grid_zyx, 2)
+    # static form reports through meta instead of raising
+    _, _, _, _, meta = voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, grid_zyx, 2, static=True)
+    assert int(meta[1]) == 1
+    with pytest.raises(L.OcoccError):  # grid that does not match range / voxel size
+        voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, [40, 40, 41], 2)
+
+
+def test_fused_backward_is_the_mean_adjoint(dev):
+    from objectcentricocccompletion_amd.voxel import voxelize_scatter_mean
+    voxel, rng, grid_zyx = [0.2, 0.2, 0.2], [-4, -4, -4, 4, 4, 4], [40, 40, 40]
+    xyz, bidx, feats = _points(6000, 3, 5, 9, dev, dup_frac=0.4)
+    feats.requires_grad_(True)
+    vf, vc, inv, cnt, _ = voxelize_scatter_mean(xyz, bidx, feats, voxel, rng, grid_zyx, 3)
+    go = torch.randn_like(vf)
+    vf.backward(go)
+    expect = go[inv.long()] / cnt[inv.long()].float().unsqueeze(1)
+    assert torch.allclose(feats.grad, expect, rtol=1e-6, atol=1e-7)
+
+
+def test_fused_front_end_feeds_the_sorted_rulebook(dev):
+    """The coordinates carry the bitmap tag: the encoder output is the same with and without fusion."""
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    torch.manual_seed(0)
+    enc = SubMOccEncoder().to(dev)
+    xyz, feats, bidx = synthetic_object_grids(4, 1500, seed=3, device=dev)
+    with torch.no_grad():
+        enc.fused_front_end = True
+        a = enc(xyz, feats, bidx, 4)
+        enc.fused_front_end = False
+        b = enc(xyz, feats, bidx, 4)
+    assert torch.equal(a.indices, b.indices)
+    assert torch.equal(a.features, b.features)
