@@ -94,12 +94,15 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
   }
   const bool row_ok = (unsigned)b < (unsigned)g.batch;
   uint32_t mask = 0;
+  // cell of the (0,0,0) corner of the window in 32-bit arithmetic (cells < 2^31, make_layout), then one
+  // add per offset; a negative corner coordinate makes base meaningless but those offsets are masked out
+  const int32_t base = row_ok ? ((b * g.D + z0) * g.H + y0) * g.W + x0 : 0;
   auto lookup = [&](int kz, int ky, int kx) -> int32_t {
     const int32_t z = z0 + kz, y = y0 + ky, x = x0 + kx;
     int32_t v = -1;
     if (row_ok && (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H &&
         (unsigned)x < (unsigned)g.W) {
-      const int64_t cell = (((int64_t)b * g.D + z) * g.H + y) * g.W + x;
+      const int32_t cell = base + (kz * g.H + ky) * g.W + kx;
       const int32_t r = rank_of(bitmap, prefix, cell);
       if (r >= 0) v = perm ? perm[r] - 1 : r;  // perm holds row + 1 (0 = empty)
     }

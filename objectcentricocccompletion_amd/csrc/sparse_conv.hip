@@ -381,8 +381,53 @@ __device__ __forceinline__ void wait_vmcnt_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// The loads of the per-offset loop are issued from inline asm.  The compiler's wait-count pass treats
+// an LDS-DMA in flight as a possible writer of every LDS address and put `s_waitcnt vmcnt(0)` in front
+// of the weight-fragment reads: the MFMAs of every second offset waited for the whole prefetch of the
+// next one, and no prefetch could run more than one offset ahead.  With asm loads the compiler knows
+// nothing about them, so EVERY consumer needs an explicit wait: stream_wait_vm<N>() followed by
+// stream_tie() on the registers about to be read pins the order.  Rules that keep this sound (checked on
+// the ISA by tools/check_stream_isa.py): destination registers stay integer vectors until they have
+// landed (a cast in flight is real instructions), the loop has ONE exit and no load is left in flight
+// into a register the compiler considers dead.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int OFF>
+__device__ __forceinline__ u32x4 stream_buffer_load(i32x4 rsrc, uint32_t voff) {
+  u32x4 r;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(r) : "v"(voff), "s"(rsrc), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ int32_t stream_load_i32(const int32_t* p) {
+  int32_t r;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p));
+  return r;
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// 64 lanes x 16 bytes, global -> LDS at lds_addr + 16 * lane (LDS base in M0), no register hop
+__device__ __forceinline__ void stream_dma_b128(const void* src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr)
+               : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N>
+__device__ __forceinline__ void stream_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+template <typename T>
+__device__ __forceinline__ void stream_tie(T& v) {
+  asm volatile("" : "+v"(v));
+}
+template <typename T>
+__device__ __forceinline__ void stream_keep(const T& v) {
+  asm volatile("" ::"v"(v));
+}
+
+// (the LayerNorm epilogue needs a few more registers; a spill inside the loop would put scratch traffic into
+// the hand-counted vmcnt queue, so that variant is built for one workgroup per CU and never spills)
 template <int KD, int NC, bool OUT_BF16, bool LN = false>
-__global__ void __launch_bounds__(kStreamThreads, 2)
+__global__ void __launch_bounds__(kStreamThreads, LN ? 1 : 2)
 gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes,
                           const uint16_t* __restrict__ wn, int kvol, const int32_t* __restrict__ table,
                           const uint32_t* __restrict__ blockmask, int64_t n_out,
@@ -449,34 +494,68 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       const int q = c * 64 + lane;
       const int row = q / PPR, slot = q % PPR;
       const uint16_t* src = wn + (int64_t)k * NC * KD + (row * PPR + (slot ^ swz(row))) * 8;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
-                                       (void __attribute__((address_space(3)))*)(&wl[buf][c * 64]), 16, 0, 0);
+      const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&wl[buf][c * 64]);
+      stream_dma_b128(src, __builtin_amdgcn_readfirstlane(dst));
     }
   };
   // Unconditional buffer loads: a row without a neighbour at this offset gets an out-of-range
   // offset, for which the buffer unit returns zeros WITHOUT touching memory.
-  const __amdgpu_buffer_rsrc_t frs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
-  auto gather = [&](bf16x8 (&x)[RB][KSTEPS], int32_t idx) {
+  i32x4 frs;  // raw buffer descriptor: base, stride 0, size in bytes, 32-bit data format
+  frs.x = (int)(uint32_t)(uintptr_t)feat;
+  frs.y = (int)(uint32_t)((uintptr_t)feat >> 32);
+  frs.z = (int)feat_bytes;
+  frs.w = 0x00020000;
+  static_assert(KSTEPS <= 4, "gather spells the k-steps out");
+  auto gather = [&](u32x4 (&x)[RB][KSTEPS], int32_t idx) {
     int32_t ibv[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) ibv[rb] = __shfl(idx, rb * 16 + lrow, 64);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const uint32_t off = ibv[rb] >= 0 ? (uint32_t)ibv[rb] * (KD * 2) + kg * 16 : 0xffffff00u;
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
-        x[rb][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, off + ks * 64, 0, 0));
+      x[rb][0] = stream_buffer_load<0>(frs, off);
+      if constexpr (KSTEPS > 1) x[rb][1] = stream_buffer_load<64>(frs, off);
+      if constexpr (KSTEPS > 2) x[rb][2] = stream_buffer_load<128>(frs, off);
+      if constexpr (KSTEPS > 3) x[rb][3] = stream_buffer_load<192>(frs, off);
     }
+  };
+  auto tie_rows = [&](u32x4 (&x)[RB][KSTEPS]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) stream_tie(x[rb][ks]);
+  };
+  auto keep_rows = [&](const u32x4 (&x)[RB][KSTEPS]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) stream_keep(x[rb][ks]);
   };
   // indices of offset k for this wave's 64 rows (lane -> row); offsets past the end re-read the last
   // one (the result is never used) so that the load count per iteration stays fixed
   const int32_t* tcol = table + row_c;  // rows past the end copy the last row; never stored
   auto load_idx = [&](int k) -> int32_t {
     const int kk = k < kvol ? k : kvol - 1;
-    return tcol[(int64_t)kk * n_out];
+    return stream_load_i32(tcol + (int64_t)kk * n_out);
   };
-  auto mma = [&](const bf16x8 (&x)[RB][KSTEPS], int buf, int k) {
+  // LDS byte offsets of this lane's weight fragments, split so that the k-step enters with one XOR:
+  // slot = (ks*4 + kg) ^ swz = ((ks*4) ^ (swz & ~3)) + (kg ^ (swz & 3)); swz has period 16 in the row
+  uint32_t wb[2], wh[2];
+#pragma unroll
+  for (int c1 = 0; c1 < 2; ++c1) {
+    const int row = chan(c1, lrow);
+    const int sw = swz(row);
+    wb[c1] = (uint32_t)(row * PPR + (kg ^ (sw & 3))) * 16u;
+    wh[c1] = (uint32_t)(sw & ~3) * 16u;
+  }
+  auto mma = [&](const u32x4 (&x)[RB][KSTEPS], int buf, int k) {
+    if (k >= kvol) return;  // the padding half-iteration of an odd kernel volume
+    // (opaque to the optimiser: otherwise all NB*KSTEPS fragment addresses are hoisted out of the loop,
+    // kept in registers and spilled)
+    stream_tie(wb[0]);
+    stream_tie(wb[1]);
+    stream_tie(wh[0]);
+    stream_tie(wh[1]);
     // 4-bit activity of the wave's 16-row blocks at this offset
     uint32_t act = 0xfu;
     if (!nomask) {
@@ -495,8 +574,8 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       for (int f = 0; f < FG; ++f)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-          const int row = chan(cb, lrow);
-          w[f][cb] = __builtin_bit_cast(bf16x8, wl[buf][row * PPR + (((k0 + f) * 4 + kg) ^ swz(row))]);
+          const uint32_t a = wb[cb & 1] + (uint32_t)((cb >> 1) * 32 * PPR * 16) + ((uint32_t)((k0 + f) * 64) ^ wh[cb & 1]);
+          w[f][cb] = __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)&wl[buf][0] + a));
         }
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
@@ -505,43 +584,61 @@ gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
           for (int f = 0; f < FG; ++f)
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb)
-              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][cb], x[rb][k0 + f], acc[rb][cb], 0, 0, 0);
+              acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][cb], __builtin_bit_cast(bf16x8, x[rb][k0 + f]),
+                                                                    acc[rb][cb], 0, 0, 0);
         }
       }
     }
   };
 
-  bf16x8 xa[RB][KSTEPS], xb[RB][KSTEPS];
-  // prologue: weights of offset 0 into buffer 0, rows of offset 0 into xa, indices of offset 1
+  u32x4 xa[RB][KSTEPS], xb[RB][KSTEPS];
+  constexpr int NI = 1 + CPW + NG;  // vector-memory operations one offset issues: index, weight DMA, gathers
+  // prologue: weights of offset 0 into buffer 0, rows of offset 0 into xa, indices of offset 1;
+  // everything has landed before the loop (no load in flight across the loop entry)
   int32_t i_nxt = load_idx(0);
-  const int32_t i_one = load_idx(1);
+  int32_t i_one = load_idx(1);
   stage_w(0, 0);
+  stream_wait_vm<CPW + 1>();
+  stream_tie(i_nxt);
   gather(xa, i_nxt);
+  wait_vmcnt_barrier<0>();
+  stream_tie(i_one);
+  tie_rows(xa);
   i_nxt = i_one;
-  wait_vmcnt_barrier<NG>();
 
   const int klast = kvol - 1;
+  // kvol rounded up to even: ONE loop exit; the padding half-iteration still issues its (clamped) loads
   for (int k = 0; k < kvol; k += 2) {
     // ---- offset k: operands xa / buffer 0; prefetch k+1 into xb / buffer 1 ----
     {
-      const int32_t i_nn = load_idx(k + 2);
+      int32_t i_nn = load_idx(k + 2);
       stage_w(k + 1 < kvol ? k + 1 : klast, 1);
       gather(xb, i_nxt);
+      stream_wait_vm<NI>();  // everything older than this offset's own loads: the rows of offset k
+      tie_rows(xa);
       mma(xa, 0, k);
-      wait_vmcnt_barrier<NG>();
+      wait_vmcnt_barrier<NG>();  // index of k+2 and weights of k+1 landed, buffer 0 is free again
+      stream_tie(i_nn);
       i_nxt = i_nn;
     }
-    if (k + 1 >= kvol) break;
     // ---- offset k+1: operands xb / buffer 1; prefetch k+2 into xa / buffer 0 ----
     {
-      const int32_t i_nn = load_idx(k + 3);
+      int32_t i_nn = load_idx(k + 3);
       stage_w(k + 2 < kvol ? k + 2 : klast, 0);
       gather(xa, i_nxt);
+      stream_wait_vm<NI>();
+      tie_rows(xb);
       mma(xb, 1, k + 1);
       wait_vmcnt_barrier<NG>();
+      stream_tie(i_nn);
       i_nxt = i_nn;
     }
   }
+  // the surplus prefetch of the last half-iteration: its destination registers stay allocated until it is in
+  stream_wait_vm<0>();
+  keep_rows(xa);
+  keep_rows(xb);
+  stream_keep(i_nxt);
 
   // ---- epilogue: lane holds channels 32p + 8kg .. +7 of voxel lrow in acc[rb][2p], acc[rb][2p+1] ----
 #pragma unroll
