@@ -1,0 +1,20 @@
+"""The streamed-weights sparse-conv kernel issues its loads from inline asm with hand-counted
+s_waitcnt values (csrc/sparse_conv.hip).  That is only sound while the compiler keeps its hands off
+registers with a load in flight; tools/check_stream_isa.py verifies it on the generated gfx950 code.
+Needs hipcc only (no GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='hipcc not on PATH')
+def test_stream_kernel_isa_keeps_in_flight_registers_untouched():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_stream_isa.py')],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert 'touches of in-flight registers:   0' in r.stdout
