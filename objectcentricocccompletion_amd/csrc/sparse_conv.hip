@@ -857,6 +857,7 @@ __global__ void __launch_bounds__(256) weight_prepare_multi_kernel(PrepPack pk) 
 
 // ---------------------------------------------------------------- wgrad
 constexpr int kWgThreads = 256;
+constexpr int kWgGrid = 2048;    // workgroups of the weight-gradient launch (8 per CU); items beyond that are looped over
 constexpr int kWgSteps = 8;  // 32-pair MFMA k-steps per workgroup
 
 // Flattened (offset, part) work list: offset k owns ceil(ceil(num[k]/32) / kWgSteps) consecutive
@@ -922,8 +923,13 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   constexpr int PT = (PX + PY + kWgThreads - 1) / kWgThreads;
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
 
+  // Work items (slabs) are dealt round-robin to a grid that no longer has to cover the worst case
+  // kvol * cap / 256 of them: on sparse grids most of those workgroups only found out that there was
+  // nothing for them (13.5 k launches for 0.9 k items, ~10 us per call).
+  for (int item = blockIdx.x;; item += gridDim.x) {
   int k, part, base;
-  if (!wg_locate(num, kvol, blockIdx.x, &k, &part, &base)) return;
+  if (!wg_locate(num, kvol, item, &k, &part, &base)) return;
+  if (item != (int)blockIdx.x) __syncthreads();  // the step buffers of the previous item are free
   const int nk = num[k];
   const int ksteps = (nk + 31) >> 5;
   const int first = part * kWgSteps;
@@ -1039,7 +1045,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   }
 
   // D[m = cin][n = cout]: lane holds rows 4*grp + {0..3}, column li of each 16x16 tile
-  float* slab = slabs + (int64_t)blockIdx.x * CIN * COUT;
+  float* slab = slabs + (int64_t)item * CIN * COUT;
 #pragma unroll
   for (int i = 0; i < MBW; ++i) {
     const int mb = wm + i * WM;
@@ -1053,10 +1059,11 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
         slab[(int64_t)(mb * 16 + grp * 4 + r) * COUT + nb * 16 + li] = acc[i][j][r];
     }
   }
+  }  // next item
 }
 
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
-// block; lane p adds slabs p, p+16, ...; a fixed tree joins the 16 lanes.
+// block; lane p adds slabs p, p+16, ... into eight interleaved sums; fixed trees join the sums and the lanes.
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
                     int64_t elems, float* __restrict__ dw) {
@@ -1066,9 +1073,23 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__
   wg_span(num, k, &base, &nslabs);
   const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int64_t i = (int64_t)blockIdx.x * 16 + e;
-  float s = 0.f;
-  if (i < elems)
-    for (int j = part; j < nslabs; j += 16) s += slabs[(int64_t)(base + j) * elems + i];
+  // eight running sums per lane: the centre offset has hundreds of slabs, and one sum per lane made its
+  // blocks a chain of dependent L2 round trips (11-16 us whatever the layer size)
+  float a[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  if (i < elems) {
+    const float* src = slabs + (int64_t)base * elems + i;
+    int j = part;
+    for (; j + 16 * 7 < nslabs; j += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(int64_t)(j + 16 * u) * elems];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j + 16 * u < nslabs) a[u] += src[(int64_t)(j + 16 * u) * elems];
+  }
+  float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
   if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][e] = s;
@@ -1085,7 +1106,8 @@ inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
 template <int CIN>
 int dispatch_wgrad_cout(const uint16_t* x, const uint16_t* dy, int cout, const int32_t* pairs,
                         const int32_t* num, int kvol, int64_t cap, float* slabs, hipStream_t stream) {
-  dim3 grid((unsigned)wgrad_max_groups(kvol, cap)), block(kWgThreads);
+  const int64_t maxg = wgrad_max_groups(kvol, cap);
+  dim3 grid((unsigned)(maxg < kWgGrid ? maxg : kWgGrid)), block(kWgThreads);
   switch (cout) {
     case 16: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 16>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
     case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<CIN, 32>), grid, block, 0, stream, x, dy, pairs, num, kvol, cap, slabs); break;
