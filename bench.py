@@ -34,10 +34,11 @@ sys.path.insert(0, ROOT)
 GRIDS_PER_GPU = 64
 POINTS_PER_GRID = 2000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the dgrad of the 64->128 SubMConv3d,
-# gather_gemm_stream_kernel<128,64>: gathers dY rows (128 ch), writes dX rows (64 ch)
+# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the dgrad of the 64->128 SubMConv3d, which
+# gathers dY rows (128 ch) and writes dX rows (64 ch): subm_tile_conv_kernel<128,64,512> on sparse grids
+# (the density hint below), gather_gemm_stream_kernel<128,64> otherwise
 PROBE_KD, PROBE_NC = 128, 64
-PMC_JSON = 'r01_pmc_gather_gemm_stream_128_64.json'
+PMC_JSON = {True: 'r01_pmc_subm_tile_conv_128_64.json', False: 'r01_pmc_gather_gemm_stream_128_64.json'}
 
 
 def parse():
@@ -86,11 +87,11 @@ def cpu_baseline(sample_grids, points, model):
                       f'{reps} repetitions, oracle/encoder_ref.py'}
 
 
-def pmc_traffic():
+def pmc_traffic(tile):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', PMC_JSON)) as f:
+        with open(os.path.join(ROOT, 'profiles', PMC_JSON[bool(tile)])) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except Exception:
         return None
@@ -366,6 +367,9 @@ def main():
         n_act = ref_out.features.shape[0]
         n_pairs = int(ref_out.indice_dict['subm1'][3].sum().item())
         del ref_out
+    # measured once on the host: lets the sub-manifold convolutions pick their kernel for this density
+    # (compact-then-multiply below ~6 rulebook pairs per row) without any device read-back inside the step
+    sp_ops.DEFAULT_PAIRS_PER_ROW = n_pairs / max(n_act, 1)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     d_act = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
 
@@ -470,6 +474,10 @@ def main():
         # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16); the dgrad reads the 128-wide
         # rows and writes the 64-wide ones, same total as the forward
         alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
+        tile_used = sp_ops._use_tile_kernel(sp_ops.RulebookTables(True, 27), PROBE_KD, PROBE_NC) if \
+            sp_ops.DEFAULT_PAIRS_PER_ROW is None else (
+                sp_ops.SPARSE_TILE_CONV if sp_ops.SPARSE_TILE_CONV is not None else
+                sp_ops.DEFAULT_PAIRS_PER_ROW <= sp_ops.SPARSE_TILE_MAX_PAIRS_PER_ROW)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
         res = {
             'metric': 'object-grids/sec (fwd+bwd)',
@@ -492,13 +500,14 @@ def main():
                 'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}', 'launch': graph_note,
             },
             'roofline': {
-                'kernel': 'gather_gemm_stream_kernel<128,64,true> (SubMConv3d 64->128 dgrad: gathers dY[.,128], writes dX[.,64])',
+                'kernel': ('subm_tile_conv_kernel<128,64,512,true>' if tile_used else 'gather_gemm_stream_kernel<128,64,true>')
+                          + ' (SubMConv3d 64->128 dgrad: gathers dY[.,128], writes dX[.,64])',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': pmc_traffic(),
+                'traffic': pmc_traffic(tile_used),
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),

@@ -1,0 +1,300 @@
+// B4  sub-manifold convolution for SPARSE active sets: compact-then-multiply.
+// Same contract as ococc_sparse_conv_gather_gemm_bf16 (out[o] = sum_k feat[table[k][o]] @ W[k],
+// replaces indiceConv / indiceConvBackward, spconv_ops.h:260-456) for sub-manifold tables.
+//
+// Why a second kernel.  The output-stationary kernels in sparse_conv.hip give every wave 64 output
+// rows and walk the kernel offsets; at offset k a 16-row MFMA block is issued if ANY of its rows has
+// a neighbour.  On the benchmark's grids (2000 random points in 40^3 cells) a voxel has 0.75
+// neighbours besides itself: a 16-row block has a neighbour at a given offset 37 % of the time and
+// then carries 1.3 useful rows, i.e. 8 % of the MFMA work and of the weight traffic behind it is
+// useful, and every wave re-reads every 16 KB weight slice from LDS for it.
+//
+// Here a workgroup (8 waves, one per CU) owns a tile of T output rows (512, or 256 for 128 output
+// columns) with the f32 accumulators in LDS.  The centre offset (every row is its own neighbour) is a
+// dense pass split over the waves.  Every other offset is taken by ONE wave: it reads the offset's
+// table column for the whole tile, ranks the rows that have a neighbour with wave ballots (typically
+// 15 of 512), gathers only those rows, multiplies them as full 16-row MFMA blocks by weight fragments
+// it loaded straight from L2 into registers (each weight slice is read once per tile, by the one wave
+// that needs it: no LDS staging, no per-offset barrier on the weights), and adds the products into
+// the tile.  A wave carries four offsets at a time (table columns, first blocks' rows and the next
+// offset's weights are all loaded ahead), eight waves work on eight offsets per round; their
+// additions into the shared tile are taken in wave order with a barrier in between, so the sum order
+// per output element is fixed (centre, then ascending offsets) and the result is deterministic, like
+// the other kernels.
+//
+// Any table is handled correctly; on DENSE neighbourhoods the blocks past an offset's first and
+// their ordered additions serialise and the output-stationary kernels are the better choice.
+// Measured on configs[1] (126 k rows, 1.76 pairs per row): 128 -> 64 channels 43.9 us against 50.1 us
+// for the streamed-weights kernel; 32 <-> 64 channels 25 us against 21 us for the resident-weights
+// kernel; 64 -> 128 (256-row tiles, two rounds of workgroups) 65 us against 40 us.  With one
+// workgroup per CU every phase exposes its load latency; the host therefore selects it only for the
+// shape it wins (spconv/ops.py), or when told to.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTileThreads = 512;
+constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
+
+template <int KD, int NC, int T, bool OUT_BF16>
+__global__ void __launch_bounds__(kTileThreads, 1)
+subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn,
+                      int kvol, int dense_k, const int32_t* __restrict__ table, int64_t n_out,
+                      const float* __restrict__ bias, void* __restrict__ out_) {
+  constexpr int KSTEPS = KD / 32, NB = NC / 16, LDT = NC + 4, U = T / 64;
+  constexpr int NW = kTileWaves, MAXO = kTileOffsetsPerWave, DB = T / 16 / NW;  // DB: dense blocks per wave
+  static_assert(KD % 32 == 0 && NC % 16 == 0 && T % (16 * NW) == 0, "tile kernel shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;  // [T][LDT] f32 accumulators
+  // the 16 (input row, tile row) pairs of the MFMA block a wave is about to multiply, per offset slot
+  __shared__ int32_t sl_in[NW][MAXO][16];
+  __shared__ uint16_t sl_row[NW][MAXO][16];
+  __shared__ int s_cnt[NW];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lrow = lane & 15, kg = lane >> 4;
+  // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; give each a contiguous eighth of the tiles
+  const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t row0 = (int64_t)wg * T;
+  if (row0 >= n_out) return;
+
+  for (int i = threadIdx.x; i < T * (NC / 4); i += kTileThreads) {
+    const int r = i / (NC / 4), c4 = i % (NC / 4);
+    *(f32x4*)(tile + r * LDT + c4 * 4) = bias ? *(const f32x4*)(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+  // fragment (cb, ks): lane (lrow, kg) holds W[k][channel 16 cb + lrow][32 ks + 8 kg .. +7], straight from L2
+  auto load_w = [&](bf16x8 (&w)[NB][KSTEPS], int k) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        w[cb][ks] = *(const bf16x8*)(wn + ((int64_t)k * NC + cb * 16 + lrow) * KD + ks * 32 + kg * 8);
+  };
+  // the rows of one 16-row block: lane (lrow, kg) names the input row of slot lrow; a negative row gives an
+  // out-of-range offset, for which the buffer unit returns zeros without touching memory
+  auto gather = [&](bf16x8 (&x)[KSTEPS], int32_t in) {
+    const uint32_t off = in >= 0 ? (uint32_t)in * (KD * 2) + kg * 16 : 0xffffff00u;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      x[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, off + ks * 64, 0, 0));
+  };
+  auto mma = [&](f32x4 (&acc)[NB], const bf16x8 (&w)[NB][KSTEPS], const bf16x8 (&x)[KSTEPS]) {
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][ks], x[ks], acc[cb], 0, 0, 0);
+    }
+  };
+  // accumulator layout: lane (lrow, kg) holds channels 16 cb + 4 kg .. +3 of the row in slot lrow
+  auto add_block = [&](const f32x4 (&acc)[NB], int row_local) {
+    float* dst = tile + row_local * LDT + 4 * kg;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      f32x4 v = *(f32x4*)(dst + cb * 16);
+      v += acc[cb];
+      *(f32x4*)(dst + cb * 16) = v;
+    }
+  };
+  auto table_col = [&](int32_t (&e)[U], int k) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + u * 64 + lane;
+      e[u] = (k >= 0 && row < n_out) ? table[(int64_t)k * n_out + row] : -1;
+    }
+  };
+  // ranks of the rows that have a neighbour (ballot prefix, row order); those ranked first .. first+15 leave
+  // (input row, tile row) in slot j's list.  Returns how many rows have a neighbour.
+  auto compact16 = [&](const int32_t (&e)[U], int j, int first) -> int {
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long m = __ballot(e[u] >= 0);
+      if (e[u] >= 0) {
+        const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) - first;
+        if ((unsigned)p < 16u) {
+          sl_in[wave][j][p] = e[u];
+          sl_row[wave][j][p] = (uint16_t)(u * 64 + lane);
+        }
+      }
+      cnt += (int)__popcll(m);
+    }
+    return cnt;
+  };
+  __syncthreads();
+
+  bf16x8 w[2][NB][KSTEPS];
+  // ---- the dense offset: row r of the tile is slot r; waves own disjoint 16-row blocks, loads batched ----
+  if (dense_k >= 0) {
+    load_w(w[0], dense_k);
+    int32_t in[DB];
+    bf16x8 x[DB][KSTEPS];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const int64_t row = row0 + 16 * (wave + NW * d) + lrow;
+      in[d] = row < n_out ? table[(int64_t)dense_k * n_out + row] : -1;
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) gather(x[d], in[d]);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      f32x4 acc[NB];
+      mma(acc, w[0], x[d]);
+      if (in[d] >= 0) add_block(acc, 16 * (wave + NW * d) + lrow);
+    }
+  }
+  __syncthreads();
+
+  // ---- the other offsets: in pass p, round j, wave v takes the (p*MAXO + j)*NW + v -th of them ----
+  const int nk = kvol - (dense_k >= 0 ? 1 : 0);
+  for (int pass = 0; pass * MAXO * NW < nk; ++pass) {
+    int kk[MAXO], cnt[MAXO], rowl[MAXO];
+    int32_t in[MAXO];
+    {
+      int32_t e[MAXO][U];
+#pragma unroll
+      for (int j = 0; j < MAXO; ++j) {
+        const int idx = (pass * MAXO + j) * NW + wave;
+        kk[j] = idx < nk ? ((dense_k >= 0 && idx >= dense_k) ? idx + 1 : idx) : -1;
+        table_col(e[j], kk[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < MAXO; ++j) cnt[j] = compact16(e[j], j, 0);
+    }
+    // (the lists are written and read by the same wave: LDS keeps a wave's operations in order)
+    bf16x8 x[MAXO][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      const bool ok = lrow < cnt[j];
+      in[j] = ok ? sl_in[wave][j][lrow] : -1;
+      rowl[j] = ok ? (int)sl_row[wave][j][lrow] : 0;
+      gather(x[j], in[j]);
+    }
+    if (cnt[0] > 0) load_w(w[0], kk[0]);
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) {
+      if (j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0) load_w(w[(j + 1) & 1], kk[(j + 1) % MAXO]);
+      f32x4 acc[NB];
+      if (cnt[j] > 0) mma(acc, w[j & 1], x[j]);
+      if (lane == 0) s_cnt[wave] = cnt[j];
+      __syncthreads();
+      int most = s_cnt[0];
+#pragma unroll
+      for (int t = 1; t < NW; ++t) most = s_cnt[t] > most ? s_cnt[t] : most;
+      // additions into the shared tile in wave order (offsets ascend with the wave index inside a round)
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
+        if (wave == t && in[j] >= 0) add_block(acc, rowl[j]);
+        __syncthreads();
+      }
+      // offsets with more than 16 rows (dense neighbourhoods): the remaining blocks one by one
+      for (int b = 1; b * 16 < most; ++b) {
+        const bool have = b * 16 < cnt[j];
+        int32_t in2 = -1;
+        int rowl2 = 0;
+        if (have) {
+          int32_t e2[U];
+          table_col(e2, kk[j]);
+          compact16(e2, j, b * 16);
+          const bool ok = b * 16 + lrow < cnt[j];
+          in2 = ok ? sl_in[wave][j][lrow] : -1;
+          rowl2 = ok ? (int)sl_row[wave][j][lrow] : 0;
+          bf16x8 x2[KSTEPS];
+          gather(x2, in2);
+          mma(acc, w[j & 1], x2);
+        }
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+          if (wave == t && in2 >= 0) add_block(acc, rowl2);
+          __syncthreads();
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: tile -> global, 8 channels (16 bytes of bf16) per thread ----
+  for (int i = threadIdx.x; i < T * (NC / 8); i += kTileThreads) {
+    const int r = i / (NC / 8), c8 = i % (NC / 8);
+    const int64_t row = row0 + r;
+    if (row >= n_out) continue;
+    const f32x4 v0 = *(const f32x4*)(tile + r * LDT + c8 * 8), v1 = *(const f32x4*)(tile + r * LDT + c8 * 8 + 4);
+    if (OUT_BF16) {
+      u32x4 q;
+      q.x = (uint32_t)ococc_f32_to_bf16(v0.x) | ((uint32_t)ococc_f32_to_bf16(v0.y) << 16);
+      q.y = (uint32_t)ococc_f32_to_bf16(v0.z) | ((uint32_t)ococc_f32_to_bf16(v0.w) << 16);
+      q.z = (uint32_t)ococc_f32_to_bf16(v1.x) | ((uint32_t)ococc_f32_to_bf16(v1.y) << 16);
+      q.w = (uint32_t)ococc_f32_to_bf16(v1.z) | ((uint32_t)ococc_f32_to_bf16(v1.w) << 16);
+      *(u32x4*)((uint16_t*)out_ + row * NC + c8 * 8) = q;
+    } else {
+      *(f32x4*)((float*)out_ + row * NC + c8 * 8) = v0;
+      *(f32x4*)((float*)out_ + row * NC + c8 * 8 + 4) = v1;
+    }
+  }
+}
+
+template <int KD, int NC>
+int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
+                int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
+  constexpr int T = NC >= 128 ? 256 : 512;
+  constexpr size_t lds = (size_t)T * (NC + 4) * 4;
+  const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, T), 8));
+  if (out_dtype == OCOCC_BF16) {
+    auto fn = subm_tile_conv_kernel<KD, NC, T, true>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
+                       table, n_out, bias, out);
+  } else {
+    auto fn = subm_tile_conv_kernel<KD, NC, T, false>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
+                       table, n_out, bias, out);
+  }
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+template <int KD>
+int dispatch_tile_nc(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, int dense_k,
+                     const int32_t* table, int64_t n_out, const float* bias, void* out, int out_dtype,
+                     hipStream_t stream) {
+  switch (ncols) {
+    case 32: return launch_tile<KD, 32>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 64: return launch_tile<KD, 64>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 128:
+      // (128 x 128: two sets of weight fragments alone are 256 registers)
+      if constexpr (KD <= 64)
+        return launch_tile<KD, 128>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+      else
+        return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "128 x 128 channels: use ococc_sparse_conv_gather_gemm_bf16");
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "ncols must be 32/64/128");
+  }
+}
+
+}  // namespace
+
+extern "C" int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                           int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
+                                           int64_t n_out, const float* bias, void* out, int32_t out_dtype,
+                                           ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n_in >= 0 && n_out >= 0, "negative row count");
+  OCOCC_REQUIRE(kvol >= 1, "kernel volume must be >= 1");
+  OCOCC_REQUIRE(dense_k >= -1 && dense_k < kvol, "dense_k must be -1 or an offset index");
+  OCOCC_REQUIRE(out_dtype == OCOCC_BF16 || out_dtype == OCOCC_F32, "out_dtype must be f32/bf16");
+  if (n_out == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(wn && table && out, "null pointer");
+  OCOCC_REQUIRE(feat || n_in == 0, "null feat");
+  OCOCC_REQUIRE(n_in * kd * 2 < 0xffffff00ll, "feat too large for the 32-bit buffer offsets of the gathers");
+  switch (kd) {
+    case 32: return dispatch_tile_nc<32>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 64: return dispatch_tile_nc<64>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 128: return dispatch_tile_nc<128>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
+    default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 32/64/128");
+  }
+}

@@ -158,6 +158,8 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
                                                 L.ptr(ws), ws.numel(), L.stream()),
                 'subm_rulebook_build')
     rb = RulebookTables(True, kvol)
+    if DEFAULT_PAIRS_PER_ROW is not None:
+        rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
     rb.tables[(False, 'fwd')] = (nbr_t, mask, n)
     rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights
     pairs._ococc = rb
@@ -290,9 +292,48 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
     return wn
 
 
-def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype):
+# Sub-manifold convolutions over SPARSE active sets (a voxel has only a few neighbours, e.g. random-point
+# object grids: 0.75 besides itself) run through the compact-then-multiply kernel
+# (ococc_sparse_conv_tile_bf16); dense neighbourhoods (surfaces, ~10 neighbours) stay on the
+# output-stationary kernels.  Both are correct for any input; this only picks the faster one.
+# None = decide per rulebook from ``RulebookTables.pairs_per_row`` when the caller provided it
+# (set_rulebook_density / DEFAULT_PAIRS_PER_ROW) and only for the shape it was measured faster on,
+# True / False = force.
+SPARSE_TILE_CONV = None
+SPARSE_TILE_MAX_PAIRS_PER_ROW = 6.0
+# density assumed for rulebooks built from now on (None: unknown); a training loop sets it once from a
+# measured step, e.g. bench.py before it captures the HIP graph
+DEFAULT_PAIRS_PER_ROW = None
+
+
+def set_rulebook_density(indice_pairs, pairs_per_row):
+    """Tell the convolutions how many rulebook pairs an output row has on average (a host number the caller
+    knows or measured once, e.g. before capturing a HIP graph: nothing is read back from the device here)."""
+    rb = getattr(indice_pairs, '_ococc', None)
+    if rb is not None:
+        rb.pairs_per_row = float(pairs_per_row)
+
+
+def _use_tile_kernel(rb, kd, ncols):
+    if (rb is None or not rb.subm or rb.kvol % 2 == 0 or kd not in (32, 64, 128) or ncols not in (32, 64, 128)
+            or kd * ncols >= 128 * 128):
+        return False
+    if SPARSE_TILE_CONV is not None:
+        return bool(SPARSE_TILE_CONV)
+    ppr = getattr(rb, 'pairs_per_row', None)
+    # measured (csrc/sparse_conv_tile.hip): ahead only with 128 contraction channels and 64 columns
+    return ppr is not None and ppr <= SPARSE_TILE_MAX_PAIRS_PER_ROW and (kd, ncols) == (128, 64)
+
+
+def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
     kvol, ncols, kd = wn.shape
     out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
+    if _use_tile_kernel(rb, kd, ncols):
+        L.check(L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
+                                                  L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
+                                                  L.dtype_code(out_dtype), L.stream()),
+                'sparse_conv_tile')
+        return out
     L.check(L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn),
                                                      kvol, ncols, L.ptr(table), L.ptr(mask), rows,
                                                      L.ptr(bias), L.ptr(out),
@@ -320,9 +361,9 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
         b[:cout] = bias.float()
     out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
     if _probe is not None:
-        out = _probe.wrap(kd, nc, lambda: _gather_gemm(x, wn, table, mask, rows, b, out_dtype))
+        out = _probe.wrap(kd, nc, lambda: _gather_gemm(x, wn, table, mask, rows, b, out_dtype, rb if subm else None))
     else:
-        out = _gather_gemm(x, wn, table, mask, rows, b, out_dtype)
+        out = _gather_gemm(x, wn, table, mask, rows, b, out_dtype, rb if subm else None)
     if _saved is not None:
         _saved['x_bf16'] = x
     return out if nc == cout else out[:, :cout].contiguous()
@@ -414,8 +455,8 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         wn = _prep_weights(filters, mode, kd_out, nc)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
         if _probe is not None:
-            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype))
+            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode == 1 else None))
         else:
-            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype)
+            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode == 1 else None)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()
     return input_bp, filters_bp

@@ -12,8 +12,11 @@ ap.add_argument('--grids', type=int, default=64)
 ap.add_argument('--vox', type=int, default=2000)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwd', 'both'])
+ap.add_argument('--tile', action='store_true', help='force the compact-then-multiply kernel (ococc_sparse_conv_tile_bf16)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
+if a.tile:
+    ops.SPARSE_TILE_CONV = True
 g = torch.Generator().manual_seed(3)
 B = a.grids
 cells = torch.stack([torch.randperm(64000, generator=g)[:a.vox].sort().values + b * 64000 for b in range(B)]).flatten()
