@@ -793,6 +793,17 @@ int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
 }
 
 // ---------------------------------------------------------------- weights
+// Destination index of element (k, r, c) of the prepared matrix wn[k][ncols][kd].  Bit 2 of the mode
+// (value 4) asks for the MFMA-FRAGMENT-major order of ococc_sparse_conv_tile_bf16, whose waves load
+// their weight fragments straight from global memory: fragment (column block r/16, k-step c/32) is 64
+// lanes x 16 bytes, lane = 16 * ((c % 32) / 8) + r % 16, so that one load instruction reads 1 KB of
+// consecutive bytes instead of 64 pieces of 16 bytes from 16 rows.
+__device__ __forceinline__ int64_t prep_dest(int mode, int64_t i, int k, int r, int c, int ncols, int kd) {
+  if (!(mode & 4)) return i;
+  const int nb = ncols / 16, ksteps = kd / 32;
+  const int lane = 16 * ((c % 32) / 8) + (r % 16);
+  return ((((int64_t)k * nb + r / 16) * ksteps + c / 32) * 64 + lane) * 8 + (c % 8);
+}
 template <typename T>
 __global__ void __launch_bounds__(256)
 weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int mode,
@@ -801,24 +812,27 @@ weight_prepare_kernel(const T* __restrict__ w, int kvol, int cin, int cout, int 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     // i indexes the destination
-    int64_t src;
-    if (mode == 0) {  // wn[k][co][ci] = W[k][ci][co]
+    int64_t src, dst;
+    const int base = mode & 3;
+    if (base == 0) {  // wn[k][co][ci] = W[k][ci][co]
       const int ci = (int)(i % cin);
       const int co = (int)((i / cin) % cout);
       const int k = (int)(i / ((int64_t)cin * cout));
       src = ((int64_t)k * cin + ci) * cout + co;
+      dst = prep_dest(mode, i, k, co, ci, cout, cin);
     } else {  // wn[k][ci][co] = W[k' ][ci][co]
       const int64_t rem = i % ((int64_t)cin * cout);
       const int k = (int)(i / ((int64_t)cin * cout));
-      const int ks = mode == 1 ? kvol - 1 - k : k;
+      const int ks = base == 1 ? kvol - 1 - k : k;
       src = (int64_t)ks * cin * cout + rem;
+      dst = prep_dest(mode, i, k, (int)(rem / cout), (int)(rem % cout), cin, cout);
     }
     float v;
     if (sizeof(T) == 4)
       v = ((const float*)w)[src];
     else
       v = ococc_bf16_to_f32(((const uint16_t*)w)[src]);
-    wn[i] = ococc_f32_to_bf16(v);
+    wn[dst] = ococc_f32_to_bf16(v);
   }
 }
 
@@ -839,19 +853,22 @@ __global__ void __launch_bounds__(256) weight_prepare_multi_kernel(PrepPack pk) 
   const int64_t total = (int64_t)kvol * cin * cout;
   const int nblk = pk.first_block[t + 1] - pk.first_block[t];
   for (int64_t i = (int64_t)(blockIdx.x - pk.first_block[t]) * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
-    int64_t src;
-    if (mode == 0) {
+    int64_t src, dst;
+    const int base = mode & 3;
+    if (base == 0) {
       const int ci = (int)(i % cin);
       const int co = (int)((i / cin) % cout);
       const int k = (int)(i / ((int64_t)cin * cout));
       src = ((int64_t)k * cin + ci) * cout + co;
+      dst = prep_dest(mode, i, k, co, ci, cout, cin);
     } else {
       const int64_t rem = i % ((int64_t)cin * cout);
       const int k = (int)(i / ((int64_t)cin * cout));
-      const int ks = mode == 1 ? kvol - 1 - k : k;
+      const int ks = base == 1 ? kvol - 1 - k : k;
       src = (int64_t)ks * cin * cout + rem;
+      dst = prep_dest(mode, i, k, (int)(rem / cout), (int)(rem % cout), cin, cout);
     }
-    pk.wn[t][i] = ococc_f32_to_bf16(pk.w[t][src]);
+    pk.wn[t][dst] = ococc_f32_to_bf16(pk.w[t][src]);
   }
 }
 
@@ -1172,7 +1189,8 @@ extern "C" int ococc_weight_prepare_bf16(const void* w, int32_t w_dtype, int32_t
                                          ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1, "bad sizes");
-  OCOCC_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0/1/2");
+  OCOCC_REQUIRE(mode >= 0 && mode < 8 && (mode & 3) <= 2, "mode must be 0/1/2, +4 for the fragment-major order");
+  OCOCC_REQUIRE(!(mode & 4) || (cin % 32 == 0 && cout % 32 == 0), "fragment-major order needs channels in multiples of 32");
   OCOCC_REQUIRE(w_dtype == OCOCC_F32 || w_dtype == OCOCC_BF16, "w_dtype must be f32/bf16");
   OCOCC_REQUIRE(w && wn, "null pointer");
   const int64_t total = (int64_t)kvol * cin * cout;
@@ -1197,7 +1215,8 @@ extern "C" int ococc_weight_prepare_multi_bf16(int32_t count, const void* const*
   PrepPack pk;
   int blocks = 0;
   for (int i = 0; i < count; ++i) {
-    OCOCC_REQUIRE(w[i] && wn[i] && kvol[i] >= 1 && cin[i] >= 1 && cout[i] >= 1 && mode[i] >= 0 && mode[i] <= 2,
+    OCOCC_REQUIRE(w[i] && wn[i] && kvol[i] >= 1 && cin[i] >= 1 && cout[i] >= 1 && mode[i] >= 0 && (mode[i] & 3) <= 2 && mode[i] < 8 &&
+                      (!(mode[i] & 4) || (cin[i] % 32 == 0 && cout[i] % 32 == 0)),
                   "bad weight descriptor");
     pk.w[i] = (const float*)w[i];
     pk.wn[i] = (uint16_t*)wn[i];

@@ -66,13 +66,16 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   }
 
   const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
-  // fragment (cb, ks): lane (lrow, kg) holds W[k][channel 16 cb + lrow][32 ks + 8 kg .. +7], straight from L2
+  // fragment (cb, ks): lane (lrow, kg) holds W[k][channel 16 cb + lrow][32 ks + 8 kg .. +7], straight from L2.
+  // wn is in FRAGMENT-major order (ococc_weight_prepare_bf16 mode + 4): [k][cb][ks][lane][8], so one load
+  // instruction reads 1 KB of consecutive bytes (row-major rows made it 64 pieces of 16 bytes from 16 rows:
+  // the sparse pass then took 31 of the kernel's 45 us)
   auto load_w = [&](bf16x8 (&w)[NB][KSTEPS], int k) {
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
-        w[cb][ks] = *(const bf16x8*)(wn + ((int64_t)k * NC + cb * 16 + lrow) * KD + ks * 32 + kg * 8);
+        w[cb][ks] = *(const bf16x8*)(wn + ((((int64_t)k * NB + cb) * KSTEPS + ks) * 64 + lane) * 8);
   };
   // the rows of one 16-row block: lane (lrow, kg) names the input row of slot lrow; a negative row gives an
   // out-of-range offset, for which the buffer unit returns zeros without touching memory

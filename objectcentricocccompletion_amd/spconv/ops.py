@@ -6,6 +6,7 @@ ococc_weight_prepare_bf16, ococc_sparse_conv_gather_gemm_bf16 (forward and dgrad
 ococc_sparse_conv_wgrad_bf16.  The reference's per-offset gather/GEMM/scatter loop
 (include/spconv/spconv_ops.h:260-456) does not exist here.
 """
+import os
 import weakref
 
 import numpy as np
@@ -254,6 +255,13 @@ def prepare_weights(items):
         if filters.dtype != torch.float32 or not filters.is_contiguous() or cin not in _KD_OK or cout not in _KD_OK:
             continue
         kd, nc = (cin, cout) if mode == 0 else (cout, cin)
+        if mode in (0, 1) and DEFAULT_PAIRS_PER_ROW is not None:
+            # the layer will go through the tile kernel (same test as in indice_conv / indice_conv_backward for a
+            # rulebook built under the current default density): fragment-major order
+            probe_rb = RulebookTables(True, filters.numel() // (cin * cout))
+            probe_rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+            if _use_tile_kernel(probe_rb, kd, nc):
+                mode += 4
         kvol = filters.numel() // (cin * cout)
         wn = torch.empty((kvol, nc, kd), dtype=torch.bfloat16, device=filters.device)
         todo.append((filters, mode, kvol, cin, cout, wn))
@@ -278,7 +286,7 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
     cin, cout = filters.shape[-2], filters.shape[-1]
     w = filters.reshape(-1, cin, cout)
     kvol = w.size(0)
-    cin_p, cout_p = (kd_pad, nc_pad) if mode == 0 else (nc_pad, kd_pad)
+    cin_p, cout_p = (kd_pad, nc_pad) if (mode & 3) == 0 else (nc_pad, kd_pad)
     if (cin_p, cout_p) != (cin, cout):
         wp = torch.zeros((kvol, cin_p, cout_p), dtype=w.dtype, device=w.device)
         wp[:, :cin, :cout] = w
@@ -299,7 +307,7 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
 # None = decide per rulebook from ``RulebookTables.pairs_per_row`` when the caller provided it
 # (set_rulebook_density / DEFAULT_PAIRS_PER_ROW) and only for the shape it was measured faster on,
 # True / False = force.
-SPARSE_TILE_CONV = None
+SPARSE_TILE_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_SPARSE_TILE_CONV'))  # env: force on / off
 SPARSE_TILE_MAX_PAIRS_PER_ROW = 6.0
 # density assumed for rulebooks built from now on (None: unknown); a training loop sets it once from a
 # measured step, e.g. bench.py before it captures the HIP graph
@@ -328,7 +336,7 @@ def _use_tile_kernel(rb, kd, ncols):
 def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
     kvol, ncols, kd = wn.shape
     out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
-    if _use_tile_kernel(rb, kd, ncols):
+    if _use_tile_kernel(rb, kd, ncols):  # (the caller prepared wn in fragment-major order under the same test)
         L.check(L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
                                                   L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
                                                   L.dtype_code(out_dtype), L.stream()),
@@ -354,7 +362,8 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     kd = _round_kd(cin)
     nc = (cout + 15) // 16 * 16
     x = _to_bf16_padded(features, kd)
-    wn = _prep_weights(filters, 0, kd, nc)
+    tile = _use_tile_kernel(rb if subm else None, kd, nc)
+    wn = _prep_weights(filters, 4 if tile else 0, kd, nc)  # +4: fragment-major order for the tile kernel
     b = None
     if bias is not None:
         b = torch.zeros((nc,), dtype=torch.float32, device=features.device)
@@ -452,11 +461,13 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
                                               subm)
         nc = (cin + 15) // 16 * 16
         mode = 1 if (rb.subm and subm) else 2
+        if mode == 1 and _use_tile_kernel(rb, kd_out, nc):
+            mode = 5  # fragment-major order for the tile kernel
         wn = _prep_weights(filters, mode, kd_out, nc)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
         if _probe is not None:
-            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode == 1 else None))
+            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None))
         else:
-            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode == 1 else None)
+            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()
     return input_bp, filters_bp
