@@ -34,11 +34,11 @@ sys.path.insert(0, ROOT)
 GRIDS_PER_GPU = 64
 POINTS_PER_GRID = 2000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the dgrad of the 64->128 SubMConv3d, which
-# gathers dY rows (128 ch) and writes dX rows (64 ch): subm_tile_conv_kernel<128,64,512> on sparse grids
-# (the density hint below), gather_gemm_stream_kernel<128,64> otherwise
-PROBE_KD, PROBE_NC = 128, 64
-PMC_JSON = {True: 'r01_pmc_subm_tile_conv_128_64.json', False: 'r01_pmc_gather_gemm_stream_128_64.json'}
+# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the forward of the 64->128 SubMConv3d,
+# gather_gemm_stream_kernel<64,128>: gathers X rows (64 ch), writes Y rows (128 ch).  (Its dgrad, which
+# gathers dY[.,128] and writes dX[.,64], was the dominant one until it moved to subm_tile_conv_kernel.)
+PROBE_KD, PROBE_NC = 64, 128
+PMC_JSON = 'r01_pmc_gather_gemm_stream_64_128.json'
 
 
 def parse():
@@ -87,11 +87,11 @@ def cpu_baseline(sample_grids, points, model):
                       f'{reps} repetitions, oracle/encoder_ref.py'}
 
 
-def pmc_traffic(tile):
+def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', PMC_JSON[bool(tile)])) as f:
+        with open(os.path.join(ROOT, 'profiles', PMC_JSON)) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except Exception:
         return None
@@ -471,13 +471,8 @@ def main():
         n_vox = int(n_act)
         kern_ms = probe.mean_ms()
         # algorithmic (compulsory) bytes of one launch on the 64<->128 layer, SURVEY.md 8d:
-        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16); the dgrad reads the 128-wide
-        # rows and writes the 64-wide ones, same total as the forward
+        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
         alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
-        tile_used = sp_ops._use_tile_kernel(sp_ops.RulebookTables(True, 27), PROBE_KD, PROBE_NC) if \
-            sp_ops.DEFAULT_PAIRS_PER_ROW is None else (
-                sp_ops.SPARSE_TILE_CONV if sp_ops.SPARSE_TILE_CONV is not None else
-                sp_ops.DEFAULT_PAIRS_PER_ROW <= sp_ops.SPARSE_TILE_MAX_PAIRS_PER_ROW)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
         res = {
             'metric': 'object-grids/sec (fwd+bwd)',
@@ -500,14 +495,13 @@ def main():
                 'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}', 'launch': graph_note,
             },
             'roofline': {
-                'kernel': ('subm_tile_conv_kernel<128,64,512,true>' if tile_used else 'gather_gemm_stream_kernel<128,64,true>')
-                          + ' (SubMConv3d 64->128 dgrad: gathers dY[.,128], writes dX[.,64])',
+                'kernel': 'gather_gemm_stream_kernel<64,128,true> (SubMConv3d 64->128 forward: gathers X[.,64], writes Y[.,128])',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': pmc_traffic(tile_used),
+                'traffic': pmc_traffic(),
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
