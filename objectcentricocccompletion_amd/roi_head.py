@@ -10,7 +10,7 @@ from torch import nn
 
 from .bbox import rotation_3d_in_axis
 from .registry import BBOX_ASSIGNERS, DETECTORS, HEADS, ROI_EXTRACTORS
-from .tracklet import SamplingResult
+from .tracklet import SamplingResult, Tracklet
 
 
 def bbox3d2roi(bbox_list):
@@ -154,6 +154,23 @@ class TrackletRoIHeadOCC(nn.Module):
                 out.update(self.test_occ(rois, gt_rois, res['fused_roi_feats'], [occs[0]]))
         return [out]
 
+    @staticmethod
+    def inverse_aug(trk, boxes, meta):
+        """Undo the test-time augmentation recorded in the sample's meta on the refined boxes [L,7] and on the
+        tracklet they refine (tracklet_roi_head_occ.py:746-757): flips first, then the rotation."""
+        holder = Tracklet(boxes, list(range(boxes.size(0))))
+        if meta.get('pcd_horizontal_flip', False):
+            holder.flip('horizontal')
+            trk.flip('horizontal')
+        if meta.get('pcd_vertical_flip', False):
+            holder.flip('vertical')
+            trk.flip('vertical')
+        if 'pcd_rot_angle' in meta:
+            assert getattr(trk, 'rot_angle', meta['pcd_rot_angle']) == meta['pcd_rot_angle']
+            holder.rotate(-meta['pcd_rot_angle'])
+            trk.rotate(-meta['pcd_rot_angle'])
+        return holder.boxes
+
     @torch.no_grad()
     def test_occ(self, occ_rois, gt_rois, fused_roi_feats, gt_occ_list):
         """Chunked decoding of all GT voxels in every matched RoI frame; integer inter / union per
@@ -222,6 +239,27 @@ class TrackletDetectorOCC(nn.Module):
         xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
         return self.roi_head.simple_test(xyz, feats, batch, frames, img_metas, tracklet, gt_tracklet_candidates,
                                          gt_occs, gt_occ_scores)
+
+    def aug_test(self, points, img_metas, pts_frame_inds, tracklet, rescale=False):
+        """Test-time augmentation (tracklet_detector_occ.py:200-221): points / metas / frame indices / tracklets
+        are lists over the augmentations, each a batch of ONE sample; every augmentation is refined on its own,
+        its boxes are mapped back through the augmentation (TrackletRoIHeadOCC.inverse_aug) and the per-frame
+        boxes are merged with Tracklet.merge_augs under test_cfg['tta'].  Returns one merged Tracklet per sample."""
+        assert len(points) == len(img_metas) == len(pts_frame_inds) == len(tracklet)
+        tta = self.roi_head.test_cfg['tta']
+        per_aug = []
+        for p, meta, inds, trks in zip(points, img_metas, pts_frame_inds, tracklet):
+            res = self.simple_test(p, inds, meta, trks)
+            outs = []
+            for i, trk in enumerate(trks):
+                t = trk.clone()
+                boxes = self.roi_head.inverse_aug(t, res[i]['boxes_3d'][:, :7].clone(), meta[i])
+                t.boxes, t.scores = boxes, res[i]['scores_3d'].clone()
+                outs.append(t)
+            per_aug.append(outs)
+        bsz = len(points[0])
+        return [Tracklet.merge_augs([per_aug[k][i] for k in range(len(points))], tta, points[0][0].device)
+                for i in range(bsz)]
 
     def forward(self, return_loss=True, **kwargs):
         return self.forward_train(**kwargs) if return_loss else self.simple_test(**kwargs)

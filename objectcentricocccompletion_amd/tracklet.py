@@ -1,7 +1,10 @@
 """Tracklet container and assignment -- the parts of LiDARTracklet
-(mmdet3d/core/bbox/structures/lidar_tracklet.py:278-339) and TrackletAssigner
-(mmdet3d/core/bbox/assigners/tracklet_assigner.py:14-57) the RoI head touches, on plain
-tensors: boxes [L,7] (x,y,z_bottom,w,l,h,yaw), timestamps, per-box scores, a class id."""
+(mmdet3d/core/bbox/structures/lidar_tracklet.py:253-339, 552-607) and TrackletAssigner
+(mmdet3d/core/bbox/assigners/tracklet_assigner.py:14-57) the RoI head and the test-time
+augmentation touch, on plain tensors: boxes [L,7] (x,y,z_bottom,w,l,h,yaw), timestamps,
+per-box scores, a class id."""
+import math
+
 import torch
 
 from . import _lib as L
@@ -17,6 +20,14 @@ def aligned_iou_3d(boxes1, boxes2):
     L.check(L.lib.ococc_aligned_iou3d_f32(L.ptr(b1), L.ptr(b2), b1.size(0), L.ptr(out), L.stream()),
             'aligned_iou3d')
     return out
+
+
+def _median_lower_upper_mean(x):
+    """numpy.median along dim 0 (for an even count: the mean of the two middle values; torch.median
+    would return the lower one)."""
+    v = torch.sort(x, 0).values
+    n = v.size(0)
+    return v[n // 2] if n % 2 == 1 else 0.5 * (v[n // 2 - 1] + v[n // 2])
 
 
 class Tracklet(object):
@@ -76,6 +87,76 @@ class Tracklet(object):
         idx = torch.tensor([self.ts2index[t] for t in inter], device=self.device, dtype=torch.long)
         out[idx] = self.intersection_ious(trk)
         return out
+
+    # ---- in-place geometric transforms: LiDARTracklet.flip / translate / scale / rotate
+    # (lidar_tracklet.py:253-276) applying LiDARInstance3DBoxes.flip / rotate (lidar_box3d.py:143-216)
+    # and BaseInstance3DBoxes.translate / scale (base_box3d.py:156-231) to every box ----
+    def flip(self, direction):
+        assert direction in ('horizontal', 'vertical')
+        if direction == 'horizontal':  # y -> -y, yaw -> pi - yaw
+            self.boxes[:, 1] = -self.boxes[:, 1]
+            self.boxes[:, 6] = -self.boxes[:, 6] + math.pi
+        else:                          # x -> -x, yaw -> -yaw
+            self.boxes[:, 0] = -self.boxes[:, 0]
+            self.boxes[:, 6] = -self.boxes[:, 6]
+
+    def translate(self, trans):
+        self.boxes[:, :3] += torch.as_tensor(trans, dtype=self.boxes.dtype, device=self.device).view(-1)[:3]
+
+    def scale(self, scale):
+        self.boxes[:, :6] *= scale
+
+    def rotate(self, angle):
+        a = torch.as_tensor(angle, dtype=self.boxes.dtype, device=self.device)
+        s, c = torch.sin(a), torch.cos(a)
+        rot_t = self.boxes.new_tensor([[c, -s, 0.], [s, c, 0.], [0., 0., 1.]])
+        self.boxes[:, :3] = self.boxes[:, :3] @ rot_t
+        self.boxes[:, 6] += a
+
+    def clone(self):
+        t = Tracklet(self.boxes.clone(), list(self.ts_list), self.scores.clone(), self.type, self.segment_name, self.id)
+        for k in ('rot_angle',):
+            if hasattr(self, k):
+                setattr(t, k, getattr(self, k))
+        return t
+
+    @classmethod
+    def merge_augs(cls, result_list, cfg, device=None):
+        """Merge the refined tracklets of the test-time augmentations of ONE tracklet
+        (LiDARTracklet.merge_augs, lidar_tracklet.py:552-607).  All have the same frames.
+        cfg['merge']: 'max' (box of the best-scoring augmentation per frame), 'weighted'
+        (score-weighted centre/size, median yaw, mean score) or 'iou_clamped_weighted' (weights of
+        augmentations whose box overlaps the first one's by <= cfg['iou_merge_thresh'] are zeroed;
+        aligned IoU on the device).  Returns the first tracklet, updated in place."""
+        base = result_list[0]
+        all_boxes = torch.stack([r.boxes[:, :7] for r in result_list], 0)      # [A, L, 7]
+        all_scores = torch.stack([r.scores for r in result_list], 0).clone()   # [A, L]
+        num_augs, len_trk = all_scores.shape
+        mode = cfg['merge']
+        if mode == 'max':
+            arg = all_scores.argmax(0)
+            cols = torch.arange(len_trk, device=arg.device)
+            merged_scores = all_scores[arg, cols]
+            merged_boxes = all_boxes[arg, cols]
+        elif mode in ('weighted', 'iou_clamped_weighted'):
+            if mode == 'iou_clamped_weighted':
+                flat = all_boxes.reshape(num_augs * len_trk, 7)
+                rep = all_boxes[0].repeat(num_augs, 1)
+                if device is not None:
+                    flat, rep = flat.to(device), rep.to(device)
+                ious = aligned_iou_3d(rep, flat).reshape(num_augs, len_trk).to(all_scores.device)
+                ious[0, :] = 1
+                all_scores = all_scores * (ious > cfg['iou_merge_thresh']).to(all_scores.dtype)
+            w = all_scores[..., None]
+            box6 = (all_boxes[..., :6] * w).sum(0) / all_scores.sum(0)[:, None]
+            yaw = _median_lower_upper_mean(all_boxes[..., 6])                    # np.median: mean of the middle two
+            merged_boxes = torch.cat([box6, yaw[:, None]], 1)
+            merged_scores = all_scores.mean(0)
+        else:
+            raise KeyError(f'unknown TTA merge mode {mode!r}')
+        base.boxes = merged_boxes.to(base.boxes.dtype)
+        base.scores = merged_scores.to(base.scores.dtype)
+        return base
 
     def concated_boxes_from_ts(self, ts_list):
         """Boxes at the given timestamps (zeros + False where this tracklet has none) (:318-339)."""

@@ -399,3 +399,53 @@ def test_auto_encoder_stage_vs_reference_golden(dev, head, gold, golden_dir):
     pos_in = torch.searchsorted(full_codes, code(x3, i3))
     assert bool((full_codes[pos_in.clamp_max(len(full_codes) - 1)] == code(x3, i3)).all())
     assert torch.equal(alll[order][pos_in], l3)
+
+
+def test_tta_iou_clamped_merge_and_aug_test(dev):
+    """LiDARTracklet.merge_augs 'iou_clamped_weighted' (lidar_tracklet.py:584-600; its aligned
+    IoU is the HIP kernel, checked against the oracle's IoU -- the TorchEx kernel itself is unpinned) and
+    TrackletDetectorOCC.aug_test (tracklet_detector_occ.py:200-221)."""
+    from objectcentricocccompletion_amd import heads, point_pool, roi_head  # noqa: F401 (register)
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    from objectcentricocccompletion_amd.tracklet import Tracklet
+    rng = np.random.default_rng(4)
+    L, A = 12, 3
+    base = np.concatenate([rng.uniform(-20, 20, (L, 3)), rng.uniform(1.5, 5, (L, 3)), rng.uniform(-3, 3, (L, 1))], 1)
+    augs = np.stack([base + rng.normal(0, 0.05, base.shape) for _ in range(A)], 0).astype(np.float32)
+    augs[2, ::3, :2] += 40.0                                    # every third box of the last aug is far away
+    scores = rng.uniform(0.1, 1.0, (A, L)).astype(np.float32)
+    res = [Tracklet(torch.from_numpy(augs[a]).to(dev), list(range(L)), torch.from_numpy(scores[a]).to(dev)) for a in range(A)]
+    m = Tracklet.merge_augs(res, dict(merge='iou_clamped_weighted', iou_merge_thresh=0.3), dev)
+    ious = O.aligned_iou3d(np.tile(augs[0], (A, 1)), augs.reshape(A * L, 7)).reshape(A, L)
+    ious[0] = 1
+    w = scores * (ious > 0.3)
+    assert (w[2, ::3] == 0).all() and (w[1] > 0).all()
+    exp6 = (augs[..., :6] * w[..., None]).sum(0) / w.sum(0)[:, None]
+    assert np.allclose(m.boxes[:, :6].cpu().numpy(), exp6, rtol=1e-5, atol=1e-5)
+    assert np.allclose(m.boxes[:, 6].cpu().numpy(), np.median(augs[..., 6], 0), atol=1e-6)
+    assert np.allclose(m.scores.cpu().numpy(), w.mean(0), rtol=1e-5)
+
+    torch.manual_seed(0)
+    cfg = ococcnet_model_cfg()
+    cfg['test_cfg']['tta'] = dict(merge='max')
+    model = DETECTORS.build(cfg).to(dev).eval()
+    points, frames, trks, _, _, _ = _synthetic_batch(dev, B=1, L=8)
+    p_flip = points[0].clone()
+    p_flip[:, 1] = -p_flip[:, 1]
+    t_flip = trks[0].clone()
+    t_flip.flip('horizontal')
+    with torch.no_grad():
+        single = model.simple_test([points[0]], [frames[0]], [dict()], [trks[0]])[0]
+        flipped = model.simple_test([p_flip], [frames[0]], [dict(pcd_horizontal_flip=True)], [t_flip])[0]
+        merged = model.aug_test([[points[0]], [p_flip]], [[dict()], [dict(pcd_horizontal_flip=True)]],
+                                [[frames[0]], [frames[0]]], [[trks[0]], [t_flip]])
+    assert len(merged) == 1 and merged[0].boxes.shape == (8, 7)
+    back = Tracklet(flipped['boxes_3d'][:, :7].clone(), list(range(8)))
+    back.flip('horizontal')
+    s0, s1 = single['scores_3d'], flipped['scores_3d']
+    pick = (s1 > s0)[:, None]                                   # 'max': per frame the better-scoring augmentation
+    exp = torch.where(pick, back.boxes, single['boxes_3d'][:, :7])
+    assert torch.allclose(merged[0].boxes, exp, atol=1e-5)
+    assert torch.allclose(merged[0].scores, torch.maximum(s0, s1))
+    assert torch.equal(trks[0].boxes, _synthetic_batch(dev, B=1, L=8)[2][0].boxes)   # inputs untouched
