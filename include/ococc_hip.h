@@ -164,6 +164,27 @@ int ococc_voxelize_scatter_mean_f32(const float* points, int32_t num_point_featu
                                     int32_t* num_voxels, int32_t* status, void* workspace, int64_t workspace_bytes,
                                     ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------ *
+ * visibility ray test of the GT-occupancy annotation
+ * replaces point_cloud_to_range_image_idx (tools/occ/occ_annotate.py:141-207) and the gather /
+ * compare / max-over-frames-and-sensors around it in OccAnnotator.annotate_trk (:488-556).
+ * centers [n,3] f64: unoccupied cell centres in the object frame.  Frame f, sensor c (index
+ * sf = c * frames + f):  p_ego = to_ego[f] (p),  p_sensor = to_sensor[sf] (p_ego)  with affines
+ * stored as 12 doubles (row-major 3x3 rotation, then the translation; to_sensor = inverse of the
+ * LiDAR extrinsic), az_corr[sf] = atan2(extrinsic[1][0], extrinsic[0][0]), inclinations
+ * [sensors*frames, height] f64 in the order the range-image rows use (the reference flips the beam
+ * table first), range_images[sf] -> device [height, width] f32 (range_dtype 0) or f64 (2).
+ * visibility [n] int32 (optional): 2 where some sensor in some frame measured a range >= the
+ * centre's range in the centre's pixel (the ray crossed the cell: empty), else 0.
+ * dbg_indices [sensors*frames, n, 2] int32 (row, col) / dbg_range [sensors*frames, n] f64 (optional,
+ * together): the outputs of point_cloud_to_range_image_idx, for parity tests.
+ * ------------------------------------------------------------------------ */
+int ococc_occ_visibility_f64(const double* centers, int64_t n, const double* to_ego, int32_t frames,
+                             const double* to_sensor, const double* az_corr, const double* inclinations,
+                             int32_t sensors, int32_t height, int32_t width, const void* const* range_images,
+                             int32_t range_dtype, int32_t* visibility, int32_t* dbg_indices, double* dbg_range,
+                             ococc_stream_t stream);
+
 /* Same rulebook when the rows of `indices` are exactly the occupied cells of a [batch, D, H, W] grid in
  * ascending cell order and the caller still holds that grid's bitmap + popcount prefix (the state
  * ococc_grid_unique_i32 leaves in its workspace, see ococc_grid_unique_workspace_layout): the

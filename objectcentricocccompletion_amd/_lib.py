@@ -37,6 +37,8 @@ SIGNATURES = {
     'ococc_voxelize_scatter_workspace_bytes': (c_i64, [c_i64, c_i32, _I3]),
     'ococc_voxelize_scatter_mean_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3,
                                                 c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_occ_visibility_f64': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
+                                         c_vp, c_vp, c_vp, c_vp]),
     'ococc_segment_count_i32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     'ococc_segment_reduce_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
                                          c_vp]),
