@@ -24,11 +24,13 @@
 //
 // Any table is handled correctly; on DENSE neighbourhoods the blocks past an offset's first and
 // their ordered additions serialise and the output-stationary kernels are the better choice.
-// Measured on configs[1] (126 k rows, 1.76 pairs per row): 128 -> 64 channels 43.9 us against 50.1 us
-// for the streamed-weights kernel; 32 <-> 64 channels 25 us against 21 us for the resident-weights
-// kernel; 64 -> 128 (256-row tiles, two rounds of workgroups) 65 us against 40 us.  With one
-// workgroup per CU every phase exposes its load latency; the host therefore selects it only for the
-// shape it wins (spconv/ops.py), or when told to.
+// Measured on configs[1] (126 k rows, 1.76 pairs per row; mean 15 rows per offset and tile, so the rows of
+// the first TWO blocks of every offset are gathered ahead -- with one, a third of the offsets fell to the
+// block-by-block path and stalled their round): 128 -> 64 channels 29.7 us against 50.1 us for the
+// streamed-weights kernel; 64 -> 32 19.7 us and 32 -> 64 21.1 us against 21.3 / 21.2 us for the
+// resident-weights kernel; 64 -> 128 (256-row tiles, two rounds of workgroups, spills) 65 us against 40 us.
+// With one workgroup per CU every phase exposes its load latency; the host selects the kernel per shape
+// (spconv/ops.py), or when told to.
 #include "common.hpp"
 
 namespace {
@@ -48,8 +50,10 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;  // [T][LDT] f32 accumulators
   // the 16 (input row, tile row) pairs of the MFMA block a wave is about to multiply, per offset slot
-  __shared__ int32_t sl_in[NW][MAXO][16];
-  __shared__ uint16_t sl_row[NW][MAXO][16];
+  constexpr int FB = 2;   // blocks per offset whose rows are gathered ahead (mean 15 rows per offset and tile: a second
+                          // block for a third of the offsets; past FB blocks an offset goes block by block)
+  __shared__ int32_t sl_in[NW][MAXO][16 * FB];
+  __shared__ uint16_t sl_row[NW][MAXO][16 * FB];
   __shared__ int s_cnt[NW];
 
   const int lane = threadIdx.x & 63;
@@ -111,16 +115,16 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       e[u] = (k >= 0 && row < n_out) ? table[(int64_t)k * n_out + row] : -1;
     }
   };
-  // ranks of the rows that have a neighbour (ballot prefix, row order); those ranked first .. first+15 leave
+  // ranks of the rows that have a neighbour (ballot prefix, row order); those ranked first .. first+span-1 leave
   // (input row, tile row) in slot j's list.  Returns how many rows have a neighbour.
-  auto compact16 = [&](const int32_t (&e)[U], int j, int first) -> int {
+  auto compact16 = [&](const int32_t (&e)[U], int j, int first, int span) -> int {
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned long long m = __ballot(e[u] >= 0);
       if (e[u] >= 0) {
         const int p = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) - first;
-        if ((unsigned)p < 16u) {
+        if ((unsigned)p < (unsigned)span) {
           sl_in[wave][j][p] = e[u];
           sl_row[wave][j][p] = (uint16_t)(u * 64 + lane);
         }
@@ -156,8 +160,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   // ---- the other offsets: in pass p, round j, wave v takes the (p*MAXO + j)*NW + v -th of them ----
   const int nk = kvol - (dense_k >= 0 ? 1 : 0);
   for (int pass = 0; pass * MAXO * NW < nk; ++pass) {
-    int kk[MAXO], cnt[MAXO], rowl[MAXO];
-    int32_t in[MAXO];
+    int kk[MAXO], cnt[MAXO];
     {
       int32_t e[MAXO][U];
 #pragma unroll
@@ -167,23 +170,33 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
         table_col(e[j], kk[j]);
       }
 #pragma unroll
-      for (int j = 0; j < MAXO; ++j) cnt[j] = compact16(e[j], j, 0);
+      for (int j = 0; j < MAXO; ++j) cnt[j] = compact16(e[j], j, 0, 16 * FB);
     }
     // (the lists are written and read by the same wave: LDS keeps a wave's operations in order)
-    bf16x8 x[MAXO][KSTEPS];
+    bf16x8 x[MAXO][FB][KSTEPS];
+    int32_t in[MAXO][FB];
+    int rowl[MAXO][FB];
 #pragma unroll
-    for (int j = 0; j < MAXO; ++j) {
-      const bool ok = lrow < cnt[j];
-      in[j] = ok ? sl_in[wave][j][lrow] : -1;
-      rowl[j] = ok ? (int)sl_row[wave][j][lrow] : 0;
-      gather(x[j], in[j]);
-    }
+    for (int j = 0; j < MAXO; ++j)
+#pragma unroll
+      for (int f = 0; f < FB; ++f) {
+        const bool ok = 16 * f + lrow < cnt[j];
+        in[j][f] = ok ? sl_in[wave][j][16 * f + lrow] : -1;
+        rowl[j][f] = ok ? (int)sl_row[wave][j][16 * f + lrow] : 0;
+        gather(x[j][f], in[j][f]);  // (no rows: every lane out of range, no memory access)
+      }
+    // weight fragments: two sets (the next offset's arrive during this one's work) where the registers allow,
+    // else one set, re-requested right behind the MFMAs that read it
+    constexpr int WB = (NB * KSTEPS * 4 * 2 + MAXO * FB * KSTEPS * 4 <= 200) ? 2 : 1;
     if (cnt[0] > 0) load_w(w[0], kk[0]);
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
-      if (j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0) load_w(w[(j + 1) & 1], kk[(j + 1) % MAXO]);
-      f32x4 acc[NB];
-      if (cnt[j] > 0) mma(acc, w[j & 1], x[j]);
+      if (WB == 2 && j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0) load_w(w[(j + 1) & 1], kk[(j + 1) % MAXO]);
+      f32x4 acc[FB][NB];
+#pragma unroll
+      for (int f = 0; f < FB; ++f)
+        if (16 * f < cnt[j]) mma(acc[f], w[WB == 2 ? (j & 1) : 0], x[j][f]);
+      if (WB == 1 && j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0 && cnt[j] <= 16 * FB) load_w(w[0], kk[(j + 1) % MAXO]);
       if (lane == 0) s_cnt[wave] = cnt[j];
       __syncthreads();
       int most = s_cnt[0];
@@ -192,31 +205,37 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       // additions into the shared tile in wave order (offsets ascend with the wave index inside a round)
 #pragma unroll
       for (int t = 0; t < NW; ++t) {
-        if (wave == t && in[j] >= 0) add_block(acc, rowl[j]);
+        if (wave == t) {
+#pragma unroll
+          for (int f = 0; f < FB; ++f)
+            if (in[j][f] >= 0) add_block(acc[f], rowl[j][f]);
+        }
         __syncthreads();
       }
-      // offsets with more than 16 rows (dense neighbourhoods): the remaining blocks one by one
-      for (int b = 1; b * 16 < most; ++b) {
+      // offsets with more than 16 FB rows (dense neighbourhoods): the remaining blocks one by one
+      for (int b = FB; b * 16 < most; ++b) {
         const bool have = b * 16 < cnt[j];
         int32_t in2 = -1;
         int rowl2 = 0;
         if (have) {
           int32_t e2[U];
           table_col(e2, kk[j]);
-          compact16(e2, j, b * 16);
+          compact16(e2, j, b * 16, 16);
           const bool ok = b * 16 + lrow < cnt[j];
           in2 = ok ? sl_in[wave][j][lrow] : -1;
           rowl2 = ok ? (int)sl_row[wave][j][lrow] : 0;
           bf16x8 x2[KSTEPS];
           gather(x2, in2);
-          mma(acc, w[j & 1], x2);
+          mma(acc[0], w[WB == 2 ? (j & 1) : 0], x2);
         }
 #pragma unroll
         for (int t = 0; t < NW; ++t) {
-          if (wave == t && in2 >= 0) add_block(acc, rowl2);
+          if (wave == t && in2 >= 0) add_block(acc[0], rowl2);
           __syncthreads();
         }
       }
+      // (one fragment set and a long offset: its fragments were still needed above)
+      if (WB == 1 && j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0 && cnt[j] > 16 * FB) load_w(w[0], kk[(j + 1) % MAXO]);
     }
     __syncthreads();
   }

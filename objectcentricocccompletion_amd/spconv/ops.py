@@ -312,6 +312,7 @@ SPARSE_TILE_MAX_PAIRS_PER_ROW = 6.0
 # density assumed for rulebooks built from now on (None: unknown); a training loop sets it once from a
 # measured step, e.g. bench.py before it captures the HIP graph
 DEFAULT_PAIRS_PER_ROW = None
+_TILE_SHAPES = {(128, 64), (64, 32), (32, 64)}
 
 
 def set_rulebook_density(indice_pairs, pairs_per_row):
@@ -329,8 +330,8 @@ def _use_tile_kernel(rb, kd, ncols):
     if SPARSE_TILE_CONV is not None:
         return bool(SPARSE_TILE_CONV)
     ppr = getattr(rb, 'pairs_per_row', None)
-    # measured (csrc/sparse_conv_tile.hip): ahead only with 128 contraction channels and 64 columns
-    return ppr is not None and ppr <= SPARSE_TILE_MAX_PAIRS_PER_ROW and (kd, ncols) == (128, 64)
+    # measured (csrc/sparse_conv_tile.hip): ahead on these shapes, behind with 128 columns (256-row tiles)
+    return ppr is not None and ppr <= SPARSE_TILE_MAX_PAIRS_PER_ROW and (kd, ncols) in _TILE_SHAPES
 
 
 def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
