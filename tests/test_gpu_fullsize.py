@@ -138,3 +138,54 @@ def test_graph_replay_matches_eager_full_size(dev, scene):
     for a, p in zip(grads_g, model.parameters()):
         assert torch.equal(a, p.grad)
     assert bool((out_e.indices[n:] == -1).all()) and bool(torch.isfinite(out_e.features.float()).all())
+
+
+def test_fused_front_end_properties_full_size(dev, scene):
+    """ococc_voxelize_scatter_mean_f32 at the benchmark size: sorted unique rows, an inverse map that reproduces the
+    cells, counts that sum to the points, conservation of the feature sums, padding rows inert."""
+    from objectcentricocccompletion_amd.voxel import voxelize_scatter_mean
+    xyz, feats, bidx, coors = scene
+    vf, vc, inv, cnt, meta = voxelize_scatter_mean(xyz, bidx, feats, [0.2, 0.2, 0.2], [-4, -4, -4, 4, 4, 4], SHAPE, B,
+                                                   static=True)
+    num = int(meta[0])
+    assert int(meta[1]) == 0 and vc.shape[0] == B * P and 0 < num <= B * P
+    key = ((vc[:num, 0].long() * 40 + vc[:num, 1]) * 40 + vc[:num, 2]) * 40 + vc[:num, 3]
+    assert bool((key[1:] > key[:-1]).all())
+    assert torch.equal(vc[inv.long()], coors)
+    assert int(cnt.sum()) == coors.shape[0] and int(cnt[:num].min()) >= 1
+    assert bool((vc[num:] == -1).all()) and bool((cnt[num:] == 0).all()) and bool((vf[num:] == 0).all())
+    torch.testing.assert_close((vf.double() * cnt[:, None]).sum(0), feats.double().sum(0), rtol=1e-5, atol=1e-3)
+    vf2, vc2, _, cnt2, meta2 = voxelize_scatter_mean(xyz, bidx, feats, [0.2, 0.2, 0.2], [-4, -4, -4, 4, 4, 4], SHAPE, B)
+    assert vc2.shape[0] == num and torch.equal(vc2, vc[:num]) and torch.equal(cnt2, cnt[:num])
+    assert torch.equal(vf2[cnt2 <= 2], vf[:num][cnt2 <= 2])          # deterministic up to the order of >= 3 atomics
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 32), (128, 64)])
+def test_tile_conv_adjoint_identities_full_size(dev, scene, cin, cout):
+    """The compact-then-multiply kernel at the benchmark size: <conv(x), dy> = <x, dgrad(dy)> (both through the
+    tile kernel: forward cin -> cout and its dgrad cout -> cin), and agreement with the output-stationary kernels."""
+    from objectcentricocccompletion_amd.spconv import ops
+    from objectcentricocccompletion_amd.voxel.scatter_points import grid_unique
+    _, _, _, coors = scene
+    uc, _, _ = grid_unique(coors, [B] + SHAPE)
+    n = uc.shape[0]
+    _, pairs, num = ops.get_indice_pairs(uc, B, SHAPE, 3, subm=True)
+    g = torch.Generator().manual_seed(cin + 1)
+    bf = lambda t: t.to(dev).bfloat16()
+    x, dy = bf(torch.randn(n, cin, generator=g)), bf(torch.randn(n, cout, generator=g))
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.05).to(dev).bfloat16().float()
+    res = {}
+    for tile in (False, True):
+        ops.SPARSE_TILE_CONV = tile
+        try:
+            y = ops.indice_conv(x, w, pairs, num, n, False, True).float()
+            dx, _ = ops.indice_conv_backward(x, w, dy, pairs, num, False, True)
+        finally:
+            ops.SPARSE_TILE_CONV = None
+        res[tile] = (y, dx.float())
+    for a, b in zip(res[False], res[True]):
+        assert float((a - b).abs().max()) <= 2e-2 * float(a.abs().max())
+    y, dx = res[True]
+    lhs = float((y.double() * dy.double()).sum())
+    rhs = float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0) + 1e-2 * float(y.abs().max()) * n ** 0.5
