@@ -278,8 +278,8 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
  * every other offset's rows are compacted to the ones that do have a neighbour before they are
  * gathered and multiplied, with f32 accumulators of a 512-row tile in LDS.  Same operands and the
  * same result (f32 accumulation, centre first, then ascending offsets: deterministic) as
- * ococc_sparse_conv_gather_gemm_bf16; faster below ~6 rulebook pairs per output row, slower on
- * dense neighbourhoods.  kd in {32, 64, 128}, ncols in {32, 64, 128}; no block masks needed. */
+ * ococc_sparse_conv_gather_gemm_bf16; faster below ~2-3 rulebook pairs per output row
+ * (tools/density_sweep.py), slower on dense neighbourhoods.  kd in {32, 64, 128}, ncols in {32, 64, 128}; no block masks needed. */
 int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                 int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
                                 const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);

@@ -305,14 +305,16 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
 # (ococc_sparse_conv_tile_bf16); dense neighbourhoods (surfaces, ~10 neighbours) stay on the
 # output-stationary kernels.  Both are correct for any input; this only picks the faster one.
 # None = decide per rulebook from ``RulebookTables.pairs_per_row`` when the caller provided it
-# (set_rulebook_density / DEFAULT_PAIRS_PER_ROW) and only for the shape it was measured faster on,
+# (set_rulebook_density / DEFAULT_PAIRS_PER_ROW) against the per-shape thresholds of _TILE_SHAPES,
 # True / False = force.
 SPARSE_TILE_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_SPARSE_TILE_CONV'))  # env: force on / off
-SPARSE_TILE_MAX_PAIRS_PER_ROW = 6.0
 # density assumed for rulebooks built from now on (None: unknown); a training loop sets it once from a
 # measured step, e.g. bench.py before it captures the HIP graph
 DEFAULT_PAIRS_PER_ROW = None
-_TILE_SHAPES = {(128, 64), (64, 32), (32, 64)}
+# (contraction channels, columns) -> rulebook pairs per output row up to which the tile kernel measured faster
+# (tools/density_sweep.py: random cells per 40^3 grid, 64 grids; 128 -> 64: 85 vs 109 us at 2.5 pairs / row, 249 vs
+# 224 us at 4.1; 32 <-> 64: 31 vs 32 us at 1.8, 58 vs 48 us at 2.5)
+_TILE_SHAPES = {(128, 64): 3.0, (64, 32): 2.0, (32, 64): 2.0}
 
 
 def set_rulebook_density(indice_pairs, pairs_per_row):
@@ -331,7 +333,7 @@ def _use_tile_kernel(rb, kd, ncols):
         return bool(SPARSE_TILE_CONV)
     ppr = getattr(rb, 'pairs_per_row', None)
     # measured (csrc/sparse_conv_tile.hip): ahead on these shapes, behind with 128 columns (256-row tiles)
-    return ppr is not None and ppr <= SPARSE_TILE_MAX_PAIRS_PER_ROW and (kd, ncols) in _TILE_SHAPES
+    return ppr is not None and ppr <= _TILE_SHAPES.get((kd, ncols), -1.0)
 
 
 def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):

@@ -88,5 +88,7 @@ def test_density_hint_selects_the_kernel(dev):
     assert not ops._use_tile_kernel(rb, 128, 64)                # no hint: the general kernels
     ops.set_rulebook_density(pairs, 1.8)
     assert ops._use_tile_kernel(rb, 128, 64) and not ops._use_tile_kernel(rb, 16, 32)
+    ops.set_rulebook_density(pairs, 2.5)
+    assert ops._use_tile_kernel(rb, 128, 64) and not ops._use_tile_kernel(rb, 64, 32)
     ops.set_rulebook_density(pairs, 11.0)
     assert not ops._use_tile_kernel(rb, 128, 64)
