@@ -1,0 +1,319 @@
+"""Tracklet training / test pipeline transforms (the in-memory part): the steps of
+configs/ococc/ococcnet.py's train_pipeline that act on points + tracklets, with the reference's names,
+constructor arguments, result-dict keys and random-number call order
+(mmdet3d/datasets/pipelines/tracklet_pipelines.py:175-225 TrackletRegularization, :306-465
+TrackletGlobalRotScaleTrans, :467-553 TrackletRandomFlip, :555-623 PointDecoration, :626-651 FrameDropout,
+:654-678 TrackletNoise; LiDARTracklet.add_*_noise lidar_tracklet.py:500-551).
+
+Containers: results['points'] is a list of per-frame [n_i, C] tensors (or, after a concatenating step, one
+[N, C] tensor), results['pts_frame_inds'] the matching frame-index tensors, results['tracklet'] a
+tracklet.Tracklet (boxes [L,7] tensor), results['gt_tracklet_candidates'] a list of them.  File loading
+(LoadTrackletPoints, LoadTrackletAnnotations, LoadAnnotationsOcc), the pose transform and the dataset class are
+not part of this module (they are bound to the Waymo tracklet file formats)."""
+import math
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .registry import PIPELINES
+
+
+def _points_list(results):
+    p = results['points']
+    return p if isinstance(p, (list, tuple)) else [p]
+
+
+def _apply_points(results, fn):
+    p = results['points']
+    if isinstance(p, (list, tuple)):
+        for t in p:
+            fn(t)
+    else:
+        fn(p)
+
+
+def _candidates(results):
+    return results.get('gt_tracklet_candidates', [])
+
+
+@PIPELINES.register_module()
+class TrackletRegularization(object):
+    """Pad (repeat the last frame) or cut (random head / tail) the tracklet to reg_len frames."""
+
+    def __init__(self, reg_len=150):
+        self.reg_len = reg_len
+
+    def __call__(self, results):
+        trk = results['tracklet']
+        if len(trk) == self.reg_len:
+            return results
+        points, frames = list(results['points']), list(results['pts_frame_inds'])
+        if len(trk) < self.reg_len:
+            warnings.warn(f'tracklet length {len(trk)} < {self.reg_len}')
+            pad = self.reg_len - len(trk)
+            trk.boxes = torch.cat([trk.boxes, trk.boxes[-1:].expand(pad, -1)], 0)
+            trk.scores = torch.cat([trk.scores, trk.scores[-1:].expand(pad)], 0)
+            trk.ts_list = trk.ts_list + [trk.ts_list[-1]] * pad
+            points = points + [points[-1]] * pad
+            frames = frames + [frames[-1]] * pad
+        else:
+            cut = len(trk) - self.reg_len
+            head = np.random.randint(0, cut)
+            tail = cut - head
+            points = points[head:-tail]
+            frames = [torch.ones(len(p), dtype=torch.int) * i for i, p in enumerate(points)]
+            keep = slice(head, len(trk) - tail)
+            trk.boxes, trk.scores, trk.ts_list = trk.boxes[keep], trk.scores[keep], trk.ts_list[keep]
+        trk.ts2index = {ts: i for i, ts in enumerate(trk.ts_list)}
+        results['points'], results['pts_frame_inds'] = points, frames
+        assert len(points) == len(trk)
+        return results
+
+
+@PIPELINES.register_module()
+class FrameDropout(object):
+    def __init__(self, drop_ratio=0.1):
+        self.drop_ratio = drop_ratio
+
+    def __call__(self, results):
+        trk = results['tracklet']
+        n = len(trk)
+        # LiDARTracklet.random_frame_drop (lidar_tracklet.py:120-128): np.random.choice WITH replacement over the
+        # timestamps, so up to drop_num distinct frames go
+        num_drop = int(n * self.drop_ratio)
+        if n - num_drop <= 0:
+            keep = list(range(n))
+        else:
+            drop = set(np.random.choice(trk.ts_list, num_drop).tolist())
+            keep = [i for i, ts in enumerate(trk.ts_list) if ts not in drop]
+        idx = torch.as_tensor(keep, dtype=torch.long, device=trk.device)
+        trk.boxes, trk.scores = trk.boxes[idx], trk.scores[idx]
+        trk.ts_list = [trk.ts_list[i] for i in keep]
+        trk.ts2index = {ts: i for i, ts in enumerate(trk.ts_list)}
+        results['points'] = [results['points'][i] for i in keep]
+        results['pts_frame_inds'] = [results['pts_frame_inds'][i] for i in keep]
+        return results
+
+
+@PIPELINES.register_module()
+class TrackletNoise(object):
+    """Uniform noise on centres (additive), sizes (multiplicative, 1 +- max) and yaw, per frame or one draw for
+    the whole tracklet ('consistent'); torch.rand draws in the reference's order and shapes."""
+
+    def __init__(self, center_noise_cfg=None, size_noise_cfg=None, yaw_noise_cfg=None):
+        self.c_cfg, self.s_cfg, self.y_cfg = center_noise_cfg, size_noise_cfg, yaw_noise_cfg
+
+    @staticmethod
+    def _rand(shape, like):
+        return torch.rand(shape, dtype=like.dtype, device=like.device)
+
+    def __call__(self, results):
+        trk = results['tracklet']
+        b = trk.boxes
+        if len(trk) == 0:
+            return results
+        if self.c_cfg is not None:
+            mx = b.new_tensor(self.c_cfg['max_noise'])
+            assert mx.numel() == 3
+            noise = (self._rand(3, b) - 0.5) * 2 * mx if self.c_cfg['consistent'] else \
+                (self._rand((len(trk), 3), b) - 0.5) * 2 * mx[None, :]
+            b[:, :3] += noise
+        if self.s_cfg is not None:
+            mx = b.new_tensor(self.s_cfg['max_noise'])
+            assert mx.numel() == 3 and bool((mx < 0.5).all())
+            noise = 1 + (self._rand(3, b) - 0.5) * 2 * mx if self.s_cfg['consistent'] else \
+                1 + (self._rand((len(trk), 3), b) - 0.5) * 2 * mx[None, :]
+            b[:, 3:6] *= noise
+        if self.y_cfg is not None:
+            mx = self.y_cfg['max_noise']
+            noise = (self._rand(1, b) - 0.5) * 2 * mx if self.y_cfg['consistent'] else \
+                (self._rand(len(trk), b) - 0.5) * 2 * mx
+            b[:, 6] += noise
+        return results
+
+
+@PIPELINES.register_module()
+class PointDecoration(object):
+    """Append per-frame box attributes to every point of the frame: yaw / 3.1415, size / 10, score,
+    (xyz - box centre) / 5, tracklet length / 100 -- the 'pts_feats' columns the RoI head reads."""
+
+    def __init__(self, properties, concat=True):
+        self.properties, self.concat = properties, concat
+
+    def __call__(self, results):
+        trk = results['tracklet']
+        points = list(results['points'])
+        assert len(points) == len(trk), f'{len(points)}, {len(trk)}'
+        for pro in self.properties:
+            points = getattr(self, pro)(points, trk)
+        if self.concat:
+            results['points'] = torch.cat(points, 0)
+            results['pts_frame_inds'] = torch.cat(list(results['pts_frame_inds']))
+        else:
+            results['points'] = points
+        return results
+
+    @staticmethod
+    def yaw(points, trk):
+        return [F.pad(p, (0, 1), 'constant', float(trk.boxes[i, 6]) / 3.1415) for i, p in enumerate(points)]
+
+    @staticmethod
+    def size(points, trk):
+        return [torch.cat([p, (trk.boxes[i:i + 1, 3:6] / 10).to(p).expand(len(p), -1)], 1) for i, p in enumerate(points)]
+
+    @staticmethod
+    def score(points, trk):
+        return [F.pad(p, (0, 1), 'constant', float(trk.scores[i])) for i, p in enumerate(points)]
+
+    @staticmethod
+    def center_offset(points, trk):
+        return [torch.cat([p, (p[:, :3] - trk.boxes[i:i + 1, :3].to(p)) / 5], 1) for i, p in enumerate(points)]
+
+    @staticmethod
+    def length(points, trk):
+        return [F.pad(p, (0, 1), 'constant', len(trk) / 100) for p in points]
+
+
+@PIPELINES.register_module()
+class TrackletRandomFlip(object):
+    """Flip points, the tracklet and the GT candidates along the BEV axes; records pcd_horizontal_flip /
+    pcd_vertical_flip (what TrackletRoIHeadOCC.inverse_aug reads at test time)."""
+
+    def __init__(self, flip_ratio_bev_horizontal=0.0, flip_ratio_bev_vertical=0.0, **kwargs):
+        for r in (flip_ratio_bev_horizontal, flip_ratio_bev_vertical):
+            assert r is None or (isinstance(r, (int, float)) and 0 <= r <= 1)
+        self.flip_ratio_bev_horizontal, self.flip_ratio_bev_vertical = flip_ratio_bev_horizontal, flip_ratio_bev_vertical
+
+    @staticmethod
+    def _flip(results, direction):
+        col = 1 if direction == 'horizontal' else 0
+
+        def f(p):
+            p[:, col] = -p[:, col]
+        _apply_points(results, f)
+        results['tracklet'].flip(direction)
+        for t in _candidates(results):
+            t.flip(direction)
+
+    def __call__(self, results):
+        if 'pcd_horizontal_flip' not in results:
+            results['pcd_horizontal_flip'] = bool(np.random.rand() < self.flip_ratio_bev_horizontal)
+        if 'pcd_vertical_flip' not in results:
+            results['pcd_vertical_flip'] = bool(np.random.rand() < self.flip_ratio_bev_vertical)
+        if results['pcd_horizontal_flip']:
+            self._flip(results, 'horizontal')
+        if results['pcd_vertical_flip']:
+            self._flip(results, 'vertical')
+        return results
+
+
+@PIPELINES.register_module()
+class TrackletGlobalRotScaleTrans(object):
+    """Random rotation about z, isotropic scaling and Gaussian translation of points, tracklet and GT candidates;
+    records pcd_rot_angle / pcd_scale_factor / pcd_trans (and tracklet.rot_angle)."""
+
+    def __init__(self, rot_range=(-0.78539816, 0.78539816), scale_ratio_range=(0.95, 1.05),
+                 translation_std=(0, 0, 0), shift_height=False):
+        if isinstance(rot_range, (int, float)):
+            rot_range = [-rot_range, rot_range]
+        self.rot_range = rot_range
+        assert isinstance(scale_ratio_range, (list, tuple))
+        self.scale_ratio_range = scale_ratio_range
+        if not isinstance(translation_std, (list, tuple, np.ndarray)):
+            translation_std = [translation_std] * 3
+        assert all(s >= 0 for s in translation_std)
+        self.translation_std = translation_std
+        self.shift_height = shift_height
+
+    def __call__(self, results):
+        trk, cands = results['tracklet'], _candidates(results)
+        if 'pcd_rot_angle' not in results:
+            results['pcd_rot_angle'] = np.random.uniform(self.rot_range[0], self.rot_range[1])
+        angle = results['pcd_rot_angle']
+        trk.rotate(angle)
+        trk.rot_angle = angle
+        for t in cands:
+            t.rotate(angle)
+
+        def rot(p):  # BasePoints.rotate(-angle): xyz @ [[c,-s,0],[s,c,0],[0,0,1]]^T with c, s of -angle
+            a = p.new_tensor(-angle)
+            s, c = torch.sin(a), torch.cos(a)
+            m = p.new_tensor([[c, -s, 0.], [s, c, 0.], [0., 0., 1.]]).T
+            p[:, :3] = p[:, :3] @ m
+        _apply_points(results, rot)
+
+        if 'pcd_scale_factor' not in results:
+            results['pcd_scale_factor'] = np.random.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1])
+        scale = results['pcd_scale_factor']
+
+        def sc(p):
+            p[:, :3] *= scale
+        _apply_points(results, sc)
+        trk.scale(scale)
+        for t in cands:
+            t.scale(scale)
+
+        trans = np.random.normal(scale=np.array(self.translation_std, dtype=np.float32), size=3).T
+        results['pcd_trans'] = trans
+
+        def tr(p):
+            p[:, :3] += p.new_tensor(trans)
+        _apply_points(results, tr)
+        trk.translate(trans)
+        for t in cands:
+            t.translate(trans)
+        return results
+
+
+@PIPELINES.register_module()
+class PointsRangeFilter(object):
+    """Keep the points inside point_cloud_range (strict inequalities, as BasePoints.in_range_3d)."""
+
+    def __init__(self, point_cloud_range):
+        self.pcd_range = np.array(point_cloud_range, dtype=np.float32)
+
+    def __call__(self, results):
+        r = self.pcd_range
+
+        def mask(p):
+            return ((p[:, 0] > r[0]) & (p[:, 1] > r[1]) & (p[:, 2] > r[2]) &
+                    (p[:, 0] < r[3]) & (p[:, 1] < r[4]) & (p[:, 2] < r[5]))
+        p = results['points']
+        if isinstance(p, (list, tuple)):
+            ms = [mask(t) for t in p]
+            results['points'] = [t[m] for t, m in zip(p, ms)]
+            results['pts_frame_inds'] = [f[m] for f, m in zip(results['pts_frame_inds'], ms)]
+        else:
+            m = mask(p)
+            results['points'] = p[m]
+            if 'pts_frame_inds' in results:
+                results['pts_frame_inds'] = results['pts_frame_inds'][m]
+        return results
+
+
+@PIPELINES.register_module()
+class PointShuffle(object):
+    def __call__(self, results):
+        p = results['points']
+        assert not isinstance(p, (list, tuple)), 'shuffle after the concatenating step'
+        idx = torch.randperm(p.shape[0], device=p.device)
+        results['points'] = p[idx]
+        if 'pts_frame_inds' in results:
+            results['pts_frame_inds'] = results['pts_frame_inds'][idx]
+        return results
+
+
+class Compose(object):
+    """mmdet Compose: a list of transform configs (dicts with 'type') or callables."""
+
+    def __init__(self, transforms):
+        self.transforms = [PIPELINES.build(t) if isinstance(t, dict) else t for t in transforms]
+
+    def __call__(self, results):
+        for t in self.transforms:
+            results = t(results)
+            if results is None:
+                return None
+        return results

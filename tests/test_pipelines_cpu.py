@@ -1,0 +1,95 @@
+"""SURVEY 8(f) row 1, in-memory part: the tracklet pipeline transforms against vectors produced by the imported
+reference under the same RNG seeds (oracle/gen_golden_pipelines.py -> tests/golden/pipelines.npz;
+mmdet3d/datasets/pipelines/tracklet_pipelines.py:175-225, 306-465, 467-553, 555-678)."""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from objectcentricocccompletion_amd import pipelines as P
+from objectcentricocccompletion_amd.tracklet import Tracklet
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'pipelines.npz'))
+L = G['boxes'].shape[0]
+
+
+def fresh(concat=False):
+    boxes = torch.from_numpy(G['boxes']).clone()
+    trk = Tracklet(boxes, list(range(100, 100 + L)), torch.from_numpy(G['scores']).clone())
+    pts = list(torch.split(torch.from_numpy(G['points']).clone(), [int(n) for n in G['npts']]))
+    frames = [torch.ones(len(p), dtype=torch.int) * i for i, p in enumerate(pts)]
+    d = dict(tracklet=trk, points=pts, pts_frame_inds=frames)
+    if concat:
+        d['points'], d['pts_frame_inds'] = torch.cat(pts, 0), torch.cat(frames)
+    return d
+
+
+def test_tracklet_noise_same_draws():
+    for consistent in (False, True):
+        d = fresh()
+        torch.manual_seed(7)
+        P.TrackletNoise(center_noise_cfg=dict(max_noise=[0.2, 0.2, 0.1], consistent=consistent),
+                        size_noise_cfg=dict(max_noise=[0.2, 0.2, 0.1], consistent=consistent),
+                        yaw_noise_cfg=dict(max_noise=0.2, consistent=False))(d)
+        assert np.allclose(d['tracklet'].boxes.numpy(), G[f'noise_{int(consistent)}'], rtol=1e-6, atol=1e-6)
+
+
+def test_point_decoration_columns():
+    d = fresh()
+    P.PIPELINES.build(dict(type='PointDecoration', properties=['yaw', 'size', 'score', 'center_offset', 'length'],
+                           concat=False))(d)
+    assert np.allclose(torch.cat(d['points'], 0).numpy(), G['decorated'], rtol=1e-6, atol=1e-6)
+    d = fresh()
+    P.PointDecoration(properties=['yaw', 'size', 'score'], concat=True)(d)      # the ococcnet.py setting: 5 + 5 columns
+    assert d['points'].shape == (int(G['npts'].sum()), 10) and d['pts_frame_inds'].shape == (int(G['npts'].sum()),)
+
+
+def test_flip_and_global_rot_scale_trans_same_draws():
+    d = fresh(concat=True)
+    cand = Tracklet(torch.from_numpy(G['boxes']).clone() + 0.1, list(range(100, 100 + L)))
+    d['gt_tracklet_candidates'] = [cand]
+    np.random.seed(11)
+    P.TrackletRandomFlip(flip_ratio_bev_horizontal=0.5, flip_ratio_bev_vertical=0.5)(d)
+    P.TrackletGlobalRotScaleTrans(rot_range=[-0.78539816, 0.78539816], scale_ratio_range=[0.95, 1.05],
+                                  translation_std=[0, 0, 0.2])(d)
+    meta = np.array([float(d['pcd_horizontal_flip']), float(d['pcd_vertical_flip']), d['pcd_rot_angle'],
+                     d['pcd_scale_factor'], *np.asarray(d['pcd_trans'], dtype=np.float64)])
+    assert np.allclose(meta, G['aug_meta'])
+    assert np.allclose(d['points'].numpy(), G['aug_points'], rtol=1e-5, atol=1e-5)
+    assert np.allclose(d['tracklet'].boxes.numpy(), G['aug_boxes'], rtol=1e-5, atol=1e-5)
+    assert np.allclose(cand.boxes.numpy(), G['aug_cand'], rtol=1e-5, atol=1e-5)
+    assert d['tracklet'].rot_angle == d['pcd_rot_angle']
+
+
+def test_regularization_cut_pad_and_frame_dropout():
+    d = fresh()
+    np.random.seed(3)
+    P.TrackletRegularization(reg_len=4)(d)
+    assert np.allclose(d['tracklet'].boxes.numpy(), G['reg_cut_boxes']) and d['tracklet'].ts_list == G['reg_cut_ts'].tolist()
+    assert [len(p) for p in d['points']] == G['reg_cut_npts'].tolist()
+    assert all(int(f[0]) == i for i, f in enumerate(d['pts_frame_inds']))      # frame indices renumbered from 0
+    d = fresh()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        P.TrackletRegularization(reg_len=10)(d)
+    assert np.allclose(d['tracklet'].boxes.numpy(), G['reg_pad_boxes']) and len(d['tracklet'].scores) == 10
+    assert [len(p) for p in d['points']] == G['reg_pad_npts'].tolist()
+    d = fresh()
+    np.random.seed(5)
+    P.FrameDropout(drop_ratio=0.45)(d)
+    assert d['tracklet'].ts_list == G['drop_ts'].tolist() and [len(p) for p in d['points']] == G['drop_npts'].tolist()
+
+
+def test_range_filter_shuffle_and_compose():
+    np.random.seed(1)
+    torch.manual_seed(1)
+    pipe = P.Compose([dict(type='PointDecoration', properties=['yaw', 'size', 'score'], concat=True),
+                      dict(type='TrackletRandomFlip', flip_ratio_bev_horizontal=0.5, flip_ratio_bev_vertical=0.5),
+                      dict(type='PointsRangeFilter', point_cloud_range=[-204.7, -204.7, -3.99, 204.7, 204.7, 7.99]),
+                      dict(type='PointShuffle')])
+    d = pipe(fresh())
+    n = d['points'].shape[0]
+    assert d['points'].shape[1] == 10 and d['pts_frame_inds'].shape == (n,) and n <= int(G['npts'].sum())
+    # every point still carries the score of its frame (decoration survived the shuffle together with the frame index)
+    assert torch.allclose(d['points'][:, 9], torch.from_numpy(G['scores'])[d['pts_frame_inds'].long()])
