@@ -317,3 +317,137 @@ class Compose(object):
             if results is None:
                 return None
         return results
+
+
+# ---- occupancy-label transforms (mmdet3d/datasets/pipelines/occ_pinelines.py) ----
+def _grid_coors(shape):
+    xs, ys, zs = shape
+    gx, gy, gz = torch.meshgrid(torch.arange(xs, dtype=torch.long), torch.arange(ys, dtype=torch.long),
+                                torch.arange(zs, dtype=torch.long), indexing='ij')
+    return gx, gy, gz
+
+
+def _mirror_fill(occ_grid):
+    """Unknown cells (0) take the label of the cell mirrored along x (occ_pinelines.py:96-121 / 209-224)."""
+    xs = occ_grid.shape[0]
+    flat = occ_grid.clone().view(-1)
+    unknown = flat == 0
+    gx, gy, gz = _grid_coors(occ_grid.shape)
+    mid = xs // 2
+    mx = ((gx + 0.5 - mid) * -1.0 + mid).long()
+    mc = torch.stack([mx, gy, gz], -1).view(-1, 3)[unknown]
+    flat[unknown] = occ_grid[mc[:, 0], mc[:, 1], mc[:, 2]]
+    return flat.view(occ_grid.shape)
+
+
+@PIPELINES.register_module()
+class MirrorOccLabel(object):
+    """occ_pinelines.py:83-127."""
+
+    def __call__(self, results):
+        if 'occ_label_list' in results:
+            results['occ_label_list'] = [_mirror_fill(g) for g in results['occ_label_list']]
+        return results
+
+
+@PIPELINES.register_module()
+class RandomSampleOccPoints(object):
+    """Sample the K occupancy query points of every annotated object grid (occ_pinelines.py:130-359): labels
+    {0 unknown, 1 occupied, 2 free} on an X x Y x Z grid -> sample_occs [N,K], sample_occ_centers [N,K,3]
+    (cell centres in the box frame, origin at the grid's centre), occ_sizes [N,3].  Same branches and the same
+    torch.multinomial / topk call order as the reference, so the same seed gives the same samples."""
+
+    def __init__(self, num_sample_points=1024, pos_sample_weight=0.5, voxel_size=0.2, use_unknown=False,
+                 use_potential=False, mirror_x=False, balance_sample=False, weighted_sample=True):
+        self.num_sample_points, self.pos_sample_weight, self.voxel_size = num_sample_points, pos_sample_weight, voxel_size
+        self.use_unknown, self.use_potential = use_unknown, use_potential
+        if use_potential:
+            self.potential = {}
+        self.mirror_x, self.balance_sample, self.weighted_sample = mirror_x, balance_sample, weighted_sample
+
+    def __call__(self, results):
+        if 'occ_label_list' not in results:
+            return results
+        infos, grids, scores = results['occ_infos'], results['occ_label_list'], results['occ_scores']
+        k_fixed = 0 if self.num_sample_points == -1 else self.num_sample_points
+        if len(grids) == 0:
+            results['sample_occs'] = torch.zeros((0, k_fixed))
+            results['sample_occ_centers'] = torch.zeros((0, k_fixed, 3))
+            results['occ_sizes'] = torch.zeros((0, 3))
+            return results
+        out_occ, out_ctr, out_size = [], [], []
+        K = self.num_sample_points
+        for i, (grid, score, info) in enumerate(zip(grids, scores, infos)):
+            if not bool((grid > 0).any()):  # nothing annotated: an empty sample of the right shape
+                assert score == 0, 'occ_score should be 0 if no occ grid is annotated'
+                ctr, occ = torch.zeros(k_fixed, 3), torch.zeros(k_fixed)
+                w = l = h = 0.0
+            else:
+                xs, ys, zs = grid.shape
+                flat = grid.view(-1)
+                gx, gy, gz = _grid_coors(grid.shape)
+                if self.mirror_x:
+                    filled = _mirror_fill(grid).view(-1)
+                    flat[flat == 0] = filled[flat == 0]     # (the reference writes through the view into the grid)
+                coors = torch.stack([gx, gy, gz], -1).view(-1, 3)
+                if not self.use_unknown:
+                    valid_coors, valid = coors[flat > 0], flat[flat > 0]
+                else:
+                    valid_coors, valid = coors, flat.clone()
+                w, l, h = float(xs) * self.voxel_size, float(ys) * self.voxel_size, float(zs) * self.voxel_size
+                min_bound = torch.tensor([-w / 2, -l / 2, -h / 2], dtype=torch.float32)
+                centers = valid_coors.to(torch.float) * self.voxel_size + min_bound + self.voxel_size / 2
+                if K == -1:
+                    idx = torch.arange(len(centers))
+                elif self.balance_sample:
+                    num_pos = int(K * self.pos_sample_weight)
+                    num_neg = K - num_pos
+                    ids = torch.arange(len(valid))
+                    pos, neg = ids[valid == 1], ids[valid != 1]
+                    if len(pos) == 0 or len(neg) == 0:
+                        idx = torch.multinomial(torch.ones_like(valid, dtype=torch.float), K, replacement=len(valid) < K)
+                        scores[i] = 0.0  # do not use this sample
+                    else:
+                        pc = torch.multinomial(torch.ones_like(pos, dtype=torch.float), num_pos, replacement=len(pos) < num_pos)
+                        nc = torch.multinomial(torch.ones_like(neg, dtype=torch.float), num_neg, replacement=len(neg) < num_neg)
+                        idx = torch.cat([pos[pc], neg[nc]], 0)
+                elif self.use_potential:
+                    pot = self.potential.get(info['occ_label_name'], torch.ones_like(valid, dtype=torch.float))
+                    if len(valid) < K:
+                        idx = torch.multinomial(1 / pot, K, replacement=True)
+                    else:
+                        _, idx = torch.topk(pot, K, dim=0, largest=False)
+                    pot[idx] += 1
+                    self.potential[info['occ_label_name']] = pot
+                elif self.weighted_sample:
+                    wts = torch.ones_like(valid, dtype=torch.float) * (1 - self.pos_sample_weight)
+                    wts[valid == 1] = self.pos_sample_weight
+                    if float(wts.sum()) <= 0:  # (the reference lands here through an exception)
+                        wts = torch.ones_like(valid, dtype=torch.float)
+                    idx = torch.multinomial(wts, K, replacement=len(valid) < K)
+                else:
+                    idx = torch.multinomial(torch.ones_like(valid, dtype=torch.float), K, replacement=len(valid) < K)
+                ctr, occ = centers[idx], valid[idx]
+            out_occ.append(occ)
+            out_ctr.append(ctr)
+            out_size.append(torch.tensor([w, l, h], dtype=torch.float32))
+        if K != -1:
+            results['sample_occs'] = torch.stack(out_occ, 0)
+            results['sample_occ_centers'] = torch.stack(out_ctr, 0)
+        else:
+            results['sample_occs'], results['sample_occ_centers'] = out_occ, out_ctr
+        results['occ_sizes'] = torch.stack(out_size, 0)
+        return results
+
+
+@PIPELINES.register_module()
+class JitterOccCenter(object):
+    """Move every sampled centre uniformly inside its cell (occ_pinelines.py:362-377)."""
+
+    def __init__(self, voxel_size=0.2):
+        self.voxel_size = voxel_size
+
+    def __call__(self, results):
+        c = results['sample_occ_centers']
+        results['sample_occ_centers'] = c + (torch.rand_like(c) * self.voxel_size - self.voxel_size / 2)
+        return results

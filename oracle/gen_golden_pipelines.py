@@ -121,6 +121,56 @@ def main():
     tp.FrameDropout(drop_ratio=0.45)(d)
     out['drop_ts'] = np.array(d['tracklet'].ts_list)
     out['drop_npts'] = np.array([len(p) for p in d['points']])
+    # ---- occupancy-label transforms (occ_pinelines.py): the module imports dataset base classes at the top
+    for name, attrs in (('mmdet3d.datasets.pipelines', ('LoadPointsFromFile',)),
+                        ('mmdet3d.datasets.pipelines.formating', ('DefaultFormatBundle3D',)),
+                        ('mmdet3d.datasets.pipelines.transforms_3d', ('ObjectNameFilter', 'ObjectRangeFilter', 'RandomFlip3D'))):
+        m = sys.modules.get(name)
+        if m is None:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+        for a in attrs:
+            setattr(m, a, object)
+    op = R.load('mmdet3d.datasets.pipelines.occ_pinelines')
+    gg = torch.Generator().manual_seed(99)
+    grids = [torch.randint(0, 3, (12, 9, 7), generator=gg), torch.randint(0, 3, (24, 10, 9), generator=gg),
+             torch.zeros(5, 5, 5, dtype=torch.long), (torch.rand(6, 4, 3, generator=gg) < 0.3).long() * 2]
+    for i, gr in enumerate(grids):
+        out[f'occ_grid_{i}'] = gr.numpy()
+    infos = [dict(occ_label_name=f'obj{i}') for i in range(len(grids))]
+
+    def occ_results():
+        return dict(occ_infos=infos, occ_label_list=[gr.clone() for gr in grids], occ_scores=torch.tensor([1.0, 0.7, 0.0, 0.5]))
+    cfgs = dict(balance=dict(num_sample_points=64, pos_sample_weight=0.5, balance_sample=True, weighted_sample=True),
+                weighted=dict(num_sample_points=64, pos_sample_weight=0.7, balance_sample=False, weighted_sample=True),
+                plain=dict(num_sample_points=600, balance_sample=False, weighted_sample=False),
+                unknown=dict(num_sample_points=64, use_unknown=True, balance_sample=False, weighted_sample=True),
+                mirror=dict(num_sample_points=64, mirror_x=True, balance_sample=True),
+                potential=dict(num_sample_points=64, use_potential=True, balance_sample=False, weighted_sample=False))
+    for name, cfg in cfgs.items():
+        d = occ_results()
+        torch.manual_seed(13)
+        t = op.RandomSampleOccPoints(voxel_size=0.2, **cfg)
+        t(d)
+        if name == 'potential':
+            t(d)   # second call: the potentials of the first call steer the choice
+        out[f'occ_{name}_labels'] = d['sample_occs'].numpy()
+        out[f'occ_{name}_centers'] = d['sample_occ_centers'].numpy()
+        out[f'occ_{name}_sizes'] = d['occ_sizes'].numpy()
+        out[f'occ_{name}_scores'] = d['occ_scores'].numpy()
+    d = occ_results()
+    op.RandomSampleOccPoints(voxel_size=0.2, num_sample_points=-1)(d)
+    for i in range(len(grids)):
+        out[f'occ_all_labels_{i}'] = d['sample_occs'][i].numpy()
+        out[f'occ_all_centers_{i}'] = d['sample_occ_centers'][i].numpy()
+    d = occ_results()
+    op.MirrorOccLabel()(d)
+    for i in range(len(grids)):
+        out[f'occ_mirrored_{i}'] = d['occ_label_list'][i].numpy()
+    torch.manual_seed(2)
+    dj = dict(sample_occ_centers=torch.from_numpy(out['occ_balance_centers']).clone())
+    op.JitterOccCenter(voxel_size=0.2)(dj)
+    out['occ_jittered'] = dj['sample_occ_centers'].numpy()
     path = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'pipelines.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, {k: v.shape for k, v in out.items()})

@@ -93,3 +93,47 @@ def test_range_filter_shuffle_and_compose():
     assert d['points'].shape[1] == 10 and d['pts_frame_inds'].shape == (n,) and n <= int(G['npts'].sum())
     # every point still carries the score of its frame (decoration survived the shuffle together with the frame index)
     assert torch.allclose(d['points'][:, 9], torch.from_numpy(G['scores'])[d['pts_frame_inds'].long()])
+
+
+def _occ_results():
+    grids = [torch.from_numpy(G[f'occ_grid_{i}']).clone() for i in range(4)]
+    infos = [dict(occ_label_name=f'obj{i}') for i in range(4)]
+    return dict(occ_infos=infos, occ_label_list=grids, occ_scores=torch.tensor([1.0, 0.7, 0.0, 0.5]))
+
+
+def test_random_sample_occ_points_all_branches_same_draws():
+    cfgs = dict(balance=dict(num_sample_points=64, pos_sample_weight=0.5, balance_sample=True, weighted_sample=True),
+                weighted=dict(num_sample_points=64, pos_sample_weight=0.7, balance_sample=False, weighted_sample=True),
+                plain=dict(num_sample_points=600, balance_sample=False, weighted_sample=False),
+                unknown=dict(num_sample_points=64, use_unknown=True, balance_sample=False, weighted_sample=True),
+                mirror=dict(num_sample_points=64, mirror_x=True, balance_sample=True),
+                potential=dict(num_sample_points=64, use_potential=True, balance_sample=False, weighted_sample=False))
+    for name, cfg in cfgs.items():
+        d = _occ_results()
+        torch.manual_seed(13)
+        t = P.RandomSampleOccPoints(voxel_size=0.2, **cfg)
+        t(d)
+        if name == 'potential':
+            t(d)
+        assert np.array_equal(d['sample_occs'].numpy(), G[f'occ_{name}_labels']), name
+        assert np.allclose(d['sample_occ_centers'].numpy(), G[f'occ_{name}_centers'], atol=1e-6), name
+        assert np.allclose(d['occ_sizes'].numpy(), G[f'occ_{name}_sizes']) and np.allclose(d['occ_scores'].numpy(), G[f'occ_{name}_scores'])
+    d = _occ_results()
+    P.RandomSampleOccPoints(voxel_size=0.2, num_sample_points=-1)(d)
+    for i in range(4):
+        assert np.array_equal(d['sample_occs'][i].numpy(), G[f'occ_all_labels_{i}'])
+        assert np.allclose(d['sample_occ_centers'][i].numpy(), G[f'occ_all_centers_{i}'], atol=1e-6)
+    e = dict(occ_infos=[], occ_label_list=[], occ_scores=torch.zeros(0))
+    P.RandomSampleOccPoints(num_sample_points=512)(e)
+    assert e['sample_occs'].shape == (0, 512) and e['sample_occ_centers'].shape == (0, 512, 3)
+
+
+def test_mirror_occ_label_and_jitter():
+    d = _occ_results()
+    P.MirrorOccLabel()(d)
+    for i in range(4):
+        assert np.array_equal(d['occ_label_list'][i].numpy(), G[f'occ_mirrored_{i}'])
+    torch.manual_seed(2)
+    dj = dict(sample_occ_centers=torch.from_numpy(G['occ_balance_centers']).clone())
+    P.JitterOccCenter(voxel_size=0.2)(dj)
+    assert np.allclose(dj['sample_occ_centers'].numpy(), G['occ_jittered'], atol=1e-7)
