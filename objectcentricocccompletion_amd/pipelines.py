@@ -210,6 +210,50 @@ class TrackletRandomFlip(object):
 
 
 @PIPELINES.register_module()
+class TrackletPoseTransform(object):
+    """Bring every frame's points and boxes from that frame's ego pose into the ego frame of the tracklet's middle
+    frame (tracklet_pipelines.py:228-303).  tracklet.pose_list holds the per-frame ego -> world 4x4 poses."""
+
+    def __init__(self, concat=True, centering=False):
+        self.concat, self.centering = concat, centering
+
+    @staticmethod
+    def points_frame_transform(src_points, src_pose, tgt_pose, tgt_pose_inv=None):
+        h = F.pad(src_points, (0, 1), 'constant', 1)
+        world2tgt = torch.inverse(tgt_pose) if tgt_pose_inv is None else tgt_pose_inv
+        mm = world2tgt @ src_pose
+        return (h @ mm.T.to(h.dtype))[:, :3]
+
+    def __call__(self, results):
+        points, trk = list(results['points']), results['tracklet']
+        poses = trk.pose_list
+        assert getattr(trk, 'shared_pose', None) is None
+        assert len(points) == len(trk) == len(poses)
+        center_pose = poses[len(poses) // 2]
+        trk.frame_transform(center_pose)
+        for t in _candidates(results):
+            t.frame_transform(center_pose)
+        inv = torch.linalg.inv(center_pose)
+        points = [torch.cat([self.points_frame_transform(p[:, :3], pose, None, inv), p[:, 3:]], 1)
+                  for pose, p in zip(poses, points)]
+        if self.centering:  # translation only: the middle frame's box centre becomes the origin
+            translation = -1 * trk.boxes[len(trk) // 2:len(trk) // 2 + 1, :3].clone()
+            for p in points:
+                p[:, :3] += translation.to(p)
+            trk.translate(translation)
+            for t in _candidates(results):
+                t.translate(translation)
+            trk.translation_factor = translation.cpu().numpy()
+        results['shared_pose'] = center_pose
+        if self.concat:
+            results['points'] = torch.cat(points, 0)
+            results['pts_frame_inds'] = torch.cat(list(results['pts_frame_inds']))
+        else:
+            results['points'] = points
+        return results
+
+
+@PIPELINES.register_module()
 class TrackletGlobalRotScaleTrans(object):
     """Random rotation about z, isotropic scaling and Gaussian translation of points, tracklet and GT candidates;
     records pcd_rot_angle / pcd_scale_factor / pcd_trans (and tracklet.rot_angle)."""

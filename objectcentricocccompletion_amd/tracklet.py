@@ -113,9 +113,29 @@ class Tracklet(object):
         self.boxes[:, :3] = self.boxes[:, :3] @ rot_t
         self.boxes[:, 6] += a
 
+    def frame_transform(self, pose):
+        """Every frame's box from that frame's ego pose (self.pose_list[i], ego -> world 4x4) into the frame of
+        ``pose`` (LiDARTracklet.frame_transform, lidar_tracklet.py:348-387): centres through
+        inv(pose) @ pose_i, the yaw from the transformed heading vector (sin, cos, 0)."""
+        assert getattr(self, 'shared_pose', None) is None and len(self.pose_list) == len(self)
+        world2tgt = torch.linalg.inv(pose)
+        out = self.boxes.clone()
+        for i in range(len(self)):
+            mm = (world2tgt @ self.pose_list[i]).to(self.boxes.dtype)
+            c = torch.cat([self.boxes[i, :3], self.boxes.new_ones(1)])
+            out[i, :3] = (mm @ c)[:3]
+            yaw = self.boxes[i, 6]
+            hv = torch.stack([torch.sin(yaw), torch.cos(yaw), yaw.new_zeros(()), yaw.new_ones(())])
+            mm = mm.clone()
+            mm[:3, 3] = 0
+            t = mm @ hv
+            out[i, 6] = torch.atan2(t[0], t[1])
+        self.boxes = out
+        self.shared_pose = pose
+
     def clone(self):
         t = Tracklet(self.boxes.clone(), list(self.ts_list), self.scores.clone(), self.type, self.segment_name, self.id)
-        for k in ('rot_angle',):
+        for k in ('rot_angle', 'pose_list', 'shared_pose'):
             if hasattr(self, k):
                 setattr(t, k, getattr(self, k))
         return t

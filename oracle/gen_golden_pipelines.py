@@ -121,6 +121,27 @@ def main():
     tp.FrameDropout(drop_ratio=0.45)(d)
     out['drop_ts'] = np.array(d['tracklet'].ts_list)
     out['drop_npts'] = np.array([len(p) for p in d['points']])
+    # TrackletPoseTransform: per-frame ego poses (a drive along a curve), GT candidate with its own poses
+    def pose(i):
+        a = 0.05 * i
+        m = torch.eye(4, dtype=torch.float64)
+        m[:3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        m[:3, 3] = torch.tensor([2.0 * i, 0.3 * i * i, 0.01 * i])
+        return m.float()
+    for centering in (False, True):
+        d = fresh()
+        d['tracklet'].pose_list = [pose(i) for i in range(L)]
+        d['tracklet'].shared_pose = None
+        cand = Trk('seg', 'gt', 1, False, box_list=[Boxes(boxes[i:i + 1].clone() + 0.1) for i in range(L)],
+                   ts_list=list(range(100, 100 + L)), score_list=[1.0] * L)
+        cand.pose_list = [pose(i) for i in range(L)]
+        cand.freeze()
+        d['gt_tracklet_candidates'] = [cand]
+        tp.TrackletPoseTransform(concat=False, centering=centering)(d)
+        out[f'pose_{int(centering)}_points'] = torch.cat(d['points'], 0).numpy()
+        out[f'pose_{int(centering)}_boxes'] = cat_boxes(d['tracklet'])
+        out[f'pose_{int(centering)}_cand'] = cat_boxes(cand)
+    out['poses'] = torch.stack([pose(i) for i in range(L)], 0).numpy()
     # ---- occupancy-label transforms (occ_pinelines.py): the module imports dataset base classes at the top
     for name, attrs in (('mmdet3d.datasets.pipelines', ('LoadPointsFromFile',)),
                         ('mmdet3d.datasets.pipelines.formating', ('DefaultFormatBundle3D',)),

@@ -137,3 +137,19 @@ def test_mirror_occ_label_and_jitter():
     dj = dict(sample_occ_centers=torch.from_numpy(G['occ_balance_centers']).clone())
     P.JitterOccCenter(voxel_size=0.2)(dj)
     assert np.allclose(dj['sample_occ_centers'].numpy(), G['occ_jittered'], atol=1e-7)
+
+
+def test_tracklet_pose_transform():
+    poses = [torch.from_numpy(p) for p in G['poses']]
+    for centering in (False, True):
+        d = fresh()
+        d['tracklet'].pose_list = list(poses)
+        cand = Tracklet(torch.from_numpy(G['boxes']).clone() + 0.1, list(range(100, 100 + L)))
+        cand.pose_list = list(poses)
+        d['gt_tracklet_candidates'] = [cand]
+        P.TrackletPoseTransform(concat=False, centering=centering)(d)
+        k = int(centering)
+        assert np.allclose(torch.cat(d['points'], 0).numpy(), G[f'pose_{k}_points'], rtol=1e-5, atol=2e-4)
+        assert np.allclose(d['tracklet'].boxes.numpy(), G[f'pose_{k}_boxes'], rtol=1e-5, atol=2e-4)
+        assert np.allclose(cand.boxes.numpy(), G[f'pose_{k}_cand'], rtol=1e-5, atol=2e-4)
+        assert torch.equal(d['shared_pose'], poses[L // 2]) and d['tracklet'].shared_pose is d['shared_pose']
