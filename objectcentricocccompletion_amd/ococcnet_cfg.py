@@ -50,3 +50,28 @@ def ococcnet_model_cfg(num_blocks=6, d_model=1536, class_names=('Car',)):
         test_cfg=dict(batch_inference=True, test_occ_iou=True, iou_chunk_size=10, ignore_outside_occ=True,
                       test_baseline=False))
     return rebuild(model)
+
+
+def ococcnet_train_pipeline(reg_len=32, occ_voxel_size=0.2, class_names=('Car',)):
+    """train_pipeline of configs/ococc/ococcnet.py:183-262 (built by pipelines.Compose / dataset.py)."""
+    return [
+        dict(type='LoadTrackletPoints', load_dim=6, use_dim=5, max_points=1024, debug=False),
+        dict(type='LoadTrackletAnnotations'),
+        dict(type='LoadAnnotationsOcc', compute_score=False),
+        dict(type='RandomSampleOccPoints', num_sample_points=512, pos_sample_weight=0.5, voxel_size=occ_voxel_size,
+             use_unknown=False, use_potential=False, balance_sample=True, weighted_sample=True),
+        dict(type='TrackletRegularization', reg_len=reg_len),
+        dict(type='TrackletPoseTransform', concat=False),
+        dict(type='TrackletNoise', center_noise_cfg=dict(max_noise=[0.2, 0.2, 0.1], consistent=False),
+             size_noise_cfg=dict(max_noise=[0.2, 0.2, 0.1], consistent=False),
+             yaw_noise_cfg=dict(max_noise=0.2, consistent=False)),
+        dict(type='PointDecoration', properties=['yaw', 'size', 'score'], concat=True),
+        dict(type='TrackletRandomFlip', flip_ratio_bev_horizontal=0.5, flip_ratio_bev_vertical=0.5),
+        dict(type='TrackletGlobalRotScaleTrans', rot_range=[-0.78539816, 0.78539816], scale_ratio_range=[0.95, 1.05],
+             translation_std=[0, 0, 0.2]),
+        dict(type='PointsRangeFilter', point_cloud_range=[-204.7, -204.7, -3.99, 204.7, 204.7, 7.99]),
+        dict(type='PointShuffle'),
+        dict(type='TrackletOccFormatBundle', class_names=list(class_names)),
+        dict(type='Collect3D', keys=['points', 'pts_frame_inds', 'tracklet', 'gt_tracklet_candidates', 'occ_labels',
+                                     'occ_labels_scores']),
+    ]

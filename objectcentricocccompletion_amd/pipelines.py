@@ -39,6 +39,92 @@ def _candidates(results):
 
 
 @PIPELINES.register_module()
+class LoadTrackletPoints(object):
+    """The points of one tracklet: a .npy holding an object array of per-frame [n_i, load_dim] float32 arrays
+    (tracklet_pipelines.py:26-91); keeps the first use_dim columns, caps every frame at max_points (random subset)."""
+
+    def __init__(self, load_dim=5, use_dim=5, coord_type='LIDAR', max_points=-1, debug=False):
+        self.load_dim, self.use_dim, self.coord_type, self.max_points, self.debug = load_dim, use_dim, coord_type, max_points, debug
+
+    def __call__(self, results):
+        trk = results['tracklet']
+        if self.debug:
+            pts = [np.random.rand(100, 6).astype(np.float32) * 2 for _ in range(len(trk))]
+            for i, p in enumerate(pts):
+                p[:, :3] += trk.boxes[i:i + 1, :3].float().cpu().numpy()
+        else:
+            pts = np.load(results['pts_filename'], allow_pickle=True)
+        if results.get('point_cloud_interval', None) is not None:
+            beg, end = results['point_cloud_interval']
+            pts = pts[beg:end]
+        assert len(pts) == len(trk)
+        assert self.load_dim == pts[0].shape[1]
+        pts = [torch.from_numpy(np.ascontiguousarray(p[:, :self.use_dim])) for p in pts]
+        frames = [torch.ones(len(p), dtype=torch.int) * i for i, p in enumerate(pts)]
+        if self.max_points > 0:
+            pts, frames = self.points_downsample(pts, frames)
+        results['points'], results['pts_frame_inds'] = pts, frames
+        return results
+
+    def points_downsample(self, pts, frames):
+        out_p, out_f = [], []
+        for p, f in zip(pts, frames):
+            if len(p) > self.max_points:
+                idx = torch.randperm(len(p))[:self.max_points]
+                p, f = p[idx], f[idx]
+            out_p.append(p)
+            out_f.append(f)
+        return out_p, out_f
+
+
+@PIPELINES.register_module()
+class LoadTrackletAnnotations(object):
+    """tracklet_pipelines.py:94-101."""
+
+    def __call__(self, results):
+        results['gt_tracklet_candidates'] = results['ann_info']
+        return results
+
+
+@PIPELINES.register_module()
+class LoadAnnotationsOcc(object):
+    """The occupancy label grid of every GT candidate: <occ_anno_root>/<segment>/<track id>.npz, key 'occ', an
+    X x Y x Z integer grid in {0 unknown, 1 occupied, 2 free} (occ_pinelines.py:33-80); a missing file or name gives
+    a 1x1x1 unknown grid with score 0."""
+
+    def __init__(self, compute_score=False):
+        self.compute_score = compute_score
+
+    def __call__(self, results):
+        grids, scores, lengths = [], [], []
+        for info in results['occ_infos']:
+            score, length = info['label_iou'], info['label_trk_length']
+            if info['occ_label_name'] is None:
+                grids.append(torch.zeros(1, 1, 1, dtype=torch.int))
+                score = 0.0
+            else:
+                try:
+                    occ = torch.from_numpy(np.load(info['occ_label_name'])['occ'])
+                    grids.append(occ)
+                    if self.compute_score:
+                        score = (occ.numel() - int((occ == 0).sum())) / occ.numel()
+                except FileNotFoundError:
+                    grids.append(torch.zeros(1, 1, 1, dtype=torch.int))
+                    score = 0.0
+            scores.append(score)
+            lengths.append(length)
+        if 'gt_bboxes_3d' in results and len(results['gt_bboxes_3d']) > len(grids):
+            for _ in range(len(results['gt_bboxes_3d']) - len(grids)):
+                grids.append(torch.zeros(1, 1, 1, dtype=torch.int))
+                scores.append(0.0)
+                lengths.append(0)
+        results['occ_label_list'] = grids
+        results['occ_scores'] = torch.tensor(scores)
+        results['occ_lengths'] = torch.tensor(lengths, dtype=torch.int)
+        return results
+
+
+@PIPELINES.register_module()
 class TrackletRegularization(object):
     """Pad (repeat the last frame) or cut (random head / tail) the tracklet to reg_len frames."""
 
@@ -56,6 +142,8 @@ class TrackletRegularization(object):
             trk.boxes = torch.cat([trk.boxes, trk.boxes[-1:].expand(pad, -1)], 0)
             trk.scores = torch.cat([trk.scores, trk.scores[-1:].expand(pad)], 0)
             trk.ts_list = trk.ts_list + [trk.ts_list[-1]] * pad
+            if getattr(trk, 'pose_list', None) is not None:
+                trk.pose_list = list(trk.pose_list) + [trk.pose_list[-1]] * pad
             points = points + [points[-1]] * pad
             frames = frames + [frames[-1]] * pad
         else:
@@ -64,8 +152,7 @@ class TrackletRegularization(object):
             tail = cut - head
             points = points[head:-tail]
             frames = [torch.ones(len(p), dtype=torch.int) * i for i, p in enumerate(points)]
-            keep = slice(head, len(trk) - tail)
-            trk.boxes, trk.scores, trk.ts_list = trk.boxes[keep], trk.scores[keep], trk.ts_list[keep]
+            trk.select(range(head, len(trk) - tail))
         trk.ts2index = {ts: i for i, ts in enumerate(trk.ts_list)}
         results['points'], results['pts_frame_inds'] = points, frames
         assert len(points) == len(trk)
@@ -88,10 +175,7 @@ class FrameDropout(object):
         else:
             drop = set(np.random.choice(trk.ts_list, num_drop).tolist())
             keep = [i for i, ts in enumerate(trk.ts_list) if ts not in drop]
-        idx = torch.as_tensor(keep, dtype=torch.long, device=trk.device)
-        trk.boxes, trk.scores = trk.boxes[idx], trk.scores[idx]
-        trk.ts_list = [trk.ts_list[i] for i in keep]
-        trk.ts2index = {ts: i for i, ts in enumerate(trk.ts_list)}
+        trk.select(keep)
         results['points'] = [results['points'][i] for i in keep]
         results['pts_frame_inds'] = [results['pts_frame_inds'][i] for i in keep]
         return results
@@ -495,3 +579,54 @@ class JitterOccCenter(object):
         c = results['sample_occ_centers']
         results['sample_occ_centers'] = c + (torch.rand_like(c) * self.voxel_size - self.voxel_size / 2)
         return results
+
+
+@PIPELINES.register_module()
+class TrackletOccFormatBundle(object):
+    """occ_labels [N,K,4] = sampled centres + label, occ_labels_scores (formating.py:337-355; the DataContainer
+    wrappers of mmcv are not needed without its collate)."""
+
+    def __init__(self, class_names=None, **kwargs):
+        self.class_names = class_names
+
+    def __call__(self, results):
+        if 'sample_occ_centers' in results and 'sample_occs' in results:
+            c, o = results['sample_occ_centers'], results['sample_occs']
+            if isinstance(c, list):
+                results['occ_labels'] = [torch.cat([ci, oi.unsqueeze(-1).to(ci)], -1) for ci, oi in zip(c, o)]
+            else:
+                results['occ_labels'] = torch.cat([c, o.unsqueeze(-1).to(c)], -1)
+        if 'occ_scores' in results:
+            results['occ_labels_scores'] = results['occ_scores']
+        return results
+
+
+@PIPELINES.register_module()
+class Collect3D(object):
+    def __init__(self, keys, meta_keys=('pcd_horizontal_flip', 'pcd_vertical_flip', 'pcd_rot_angle', 'pcd_scale_factor',
+                                         'pcd_trans', 'sample_idx', 'pts_filename')):
+        self.keys, self.meta_keys = keys, meta_keys
+
+    def __call__(self, results):
+        out = {k: results[k] for k in self.keys}
+        out['img_metas'] = {k: results[k] for k in self.meta_keys if k in results}
+        return out
+
+
+def collate_tracklets(samples, device):
+    """A batch of pipeline outputs -> the keyword arguments of TrackletDetectorOCC.forward (what mmcv's collate +
+    scatter hand the reference model, tracklet_detector_occ.py:96-150): per-sample lists, tensors on ``device``."""
+    def trk_to(t):
+        t = t.clone()
+        t.boxes, t.scores = t.boxes.to(device), t.scores.to(device)
+        return t
+    batch = dict(points=[s['points'].to(device) for s in samples],
+                 pts_frame_inds=[s['pts_frame_inds'].to(device).long() for s in samples],
+                 img_metas=[s.get('img_metas', {}) for s in samples],
+                 tracklet=[trk_to(s['tracklet']) for s in samples])
+    if 'gt_tracklet_candidates' in samples[0]:
+        batch['gt_tracklet_candidates'] = [[trk_to(c) for c in s['gt_tracklet_candidates']] for s in samples]
+    if 'occ_labels' in samples[0]:
+        batch['gt_occs'] = [[o.to(device).float() for o in s['occ_labels']] for s in samples]
+        batch['gt_occ_scores'] = [[sc.reshape(1).to(device).float() for sc in s['occ_labels_scores']] for s in samples]
+    return batch

@@ -59,6 +59,7 @@ MODELS = VOXEL_ENCODERS
 LOSSES = Registry('loss')
 BBOX_ASSIGNERS = Registry('bbox assigner')
 BBOX_CODERS = Registry('bbox coder')
+DATASETS = Registry('dataset')    # mmdet.datasets.DATASETS (waymo_tracklet_dataset.py:30)
 PIPELINES = Registry('pipeline')  # mmdet.datasets.builder.PIPELINES (tracklet_pipelines.py:24)
 
 CONV_LAYERS.register_module('Conv1d', module=nn.Conv1d)

@@ -113,6 +113,37 @@ class Tracklet(object):
         self.boxes[:, :3] = self.boxes[:, :3] @ rot_t
         self.boxes[:, 6] += a
 
+    # ---- on-disk form (LiDARTracklet.to_dump_format / from_dump_format, lidar_tracklet.py:130-161): the tuple
+    # (segment_name, id, type, in_world, [box [1,7] ndarray per frame], ts_list, score_list, num_pts_in_boxes)
+    # that the *_training.pkl proposal files and *_gt_candidates.pkl annotation files hold ----
+    type_mapping = {1: 'Car', 2: 'Pedestrian', 4: 'Cyclist'}  # Waymo label ids
+
+    @classmethod
+    def from_dump_format(cls, item, device='cpu'):
+        seg, id_, type_, in_world, boxes, ts_list, scores, num_pts = item
+        import numpy as np
+        b = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(1, -1) for x in boxes], 0)) \
+            if len(boxes) else torch.zeros((0, 7))
+        assert list(ts_list) == sorted(ts_list) and len(set(ts_list)) == len(ts_list)
+        t = cls(b.to(device), list(ts_list), torch.as_tensor(list(scores), dtype=torch.float32, device=device), type_, seg, id_)
+        t.in_world, t.num_pts_in_boxes, t.type_format = in_world, num_pts, 'waymo'
+        return t
+
+    def to_dump_format(self):
+        b = self.boxes.detach().cpu().numpy()
+        return (self.segment_name, self.id, self.type, getattr(self, 'in_world', False), [b[i:i + 1] for i in range(len(b))],
+                list(self.ts_list), [float(s) for s in self.scores], getattr(self, 'num_pts_in_boxes', None))
+
+    def set_poses(self, ts2poses):
+        self.pose_list = [ts2poses[ts] for ts in self.ts_list]
+
+    def set_type_name(self):
+        assert getattr(self, 'type_format', 'waymo') == 'waymo'
+        self.type_name = self.type_mapping[self.type]
+
+    def set_type(self, type, format):
+        self.type, self.type_format = type, format
+
     def frame_transform(self, pose):
         """Every frame's box from that frame's ego pose (self.pose_list[i], ego -> world 4x4) into the frame of
         ``pose`` (LiDARTracklet.frame_transform, lidar_tracklet.py:348-387): centres through
@@ -133,9 +164,19 @@ class Tracklet(object):
         self.boxes = out
         self.shared_pose = pose
 
+    def select(self, keep):
+        """Keep the frames with the given positions (LiDARTracklet.remove over its list fields, lidar_tracklet.py:106-118)."""
+        keep = list(keep)
+        idx = torch.as_tensor(keep, dtype=torch.long, device=self.device)
+        self.boxes, self.scores = self.boxes[idx], self.scores[idx]
+        self.ts_list = [self.ts_list[i] for i in keep]
+        if getattr(self, 'pose_list', None) is not None:
+            self.pose_list = [self.pose_list[i] for i in keep]
+        self.ts2index = {ts: i for i, ts in enumerate(self.ts_list)}
+
     def clone(self):
         t = Tracklet(self.boxes.clone(), list(self.ts_list), self.scores.clone(), self.type, self.segment_name, self.id)
-        for k in ('rot_angle', 'pose_list', 'shared_pose'):
+        for k in ('rot_angle', 'pose_list', 'shared_pose', 'in_world', 'num_pts_in_boxes', 'type_format', 'type_name'):
             if hasattr(self, k):
                 setattr(t, k, getattr(self, k))
         return t

@@ -5,8 +5,10 @@
 One process per GPU (torchrun-style env), RCCL gradient all-reduce, AdamW + cosine schedule of
 configs/_base_/schedules/cosine_2x.py, checkpoints with the reference's parameter names.
 
-The tracklet dataset + pipelines are not built yet: --synthetic (the
-default) trains on Waymo-shaped synthetic tracklets so the whole step runs end to end."""
+Data: by default Waymo-shaped synthetic tracklets generated in memory; with --data-root DIR the tracklet dataset
+and the ococcnet.py train pipeline (objectcentricocccompletion_amd/dataset.py, pipelines.py) read files in the
+reference's on-disk formats (tools/make_synthetic_dataset.py writes a small set of them; a real
+data/waymo tree prepared by the reference's converters has the same layout), sharded over the ranks."""
 import argparse
 import os
 import sys
@@ -30,6 +32,10 @@ def parse_args():
     ap.add_argument('--local_rank', type=int, default=0)
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--synthetic', action='store_true', default=True)
+    ap.add_argument('--data-root', default=None, help='tree with tracklet_data/*.pkl, poses.pkl, occ_gt/ (see the docstring)')
+    ap.add_argument('--proposals', default='tracklet_data/synth_training.pkl')
+    ap.add_argument('--candidates', default='tracklet_data/synth_training_gt_candidates.pkl')
+    ap.add_argument('--occ-root', default='occ_gt')
     return ap.parse_args()
 
 
@@ -67,9 +73,29 @@ def main():
     clip = (cfg.get('optimizer_config') or {}).get('grad_clip', dict(max_norm=10, norm_type=2))
     buckets = GradBuckets(model.parameters())
     samples = cfg.get('data', {}).get('samples_per_gpu', 4)
+    ds = None
+    if args.data_root:
+        import numpy as np
+        from objectcentricocccompletion_amd import dataset  # noqa: F401 (registers)
+        from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_train_pipeline
+        from objectcentricocccompletion_amd.pipelines import collate_tracklets
+        from objectcentricocccompletion_amd.registry import DATASETS
+        j = lambda p: os.path.join(args.data_root, p)
+        ds = DATASETS.build(dict(type='WaymoTrackletDatasetWithOcc', data_root=args.data_root, ann_file=j(args.candidates),
+                                 tracklet_proposals_file=j(args.proposals), occ_anno_root=j(args.occ_root),
+                                 pose_file=j('poses.pkl'), pipeline=ococcnet_train_pipeline(), classes=['Car'],
+                                 min_tracklet_points=100, min_tracklet_length=32))
+        np.random.seed(args.seed + rank)
+        order = np.random.permutation(len(ds))
+        if rank == 0:
+            print(f'{len(ds)} tracklets under {args.data_root}', flush=True)
     model.train()
     for it in range(start, start + args.iters):
-        batch = synthetic_training_batch(samples, 32, seed=args.seed + it * world + rank, device=dev)
+        if ds is not None:  # tracklets sharded over the ranks: rank r takes every world-th sample
+            idx = [int(order[((it * world + rank) * samples + b) % len(ds)]) for b in range(samples)]
+            batch = collate_tracklets([ds[i] for i in idx], dev)
+        else:
+            batch = synthetic_training_batch(samples, 32, seed=args.seed + it * world + rank, device=dev)
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         losses = model(return_loss=True, **batch)
