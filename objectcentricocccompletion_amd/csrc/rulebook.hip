@@ -117,9 +117,51 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
       else atomicAdd(blk_cnt + (int64_t)k * gridDim.x + blockIdx.x, (uint32_t)__popcll(m));  // kvol > 64: rare
     }
   };
-  if constexpr (KS != 0) {
-    // all lookups first (their loads are independent and overlap), then the ballots and stores: done
-    // one offset at a time the kernel is a chain of 27 dependent L2 round trips (17 us -> 6 us at 126 k rows)
+  if constexpr (KS == 3) {
+    // All lookups first (their loads are independent and overlap), then the ballots and stores.  The three
+    // x-neighbours of one (kz, ky) are consecutive cells: ONE bitmap word (two when they straddle a word
+    // boundary) and ONE prefix word serve all three -- rank(cell) = prefix[word] + popcount of the bits below
+    // it, taken over the 64-bit pair -- 9 + 9 loads per voxel instead of 27 + 27.
+    int32_t v[27];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int32_t z = z0 + kz, y = y0 + ky;
+        const bool zy_ok = row_ok && (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H;
+        const int32_t c0 = base + (kz * g.H + ky) * g.W;  // cell of kx = 0; -1 only for x0 = -1 at the grid's first cell
+        const int32_t cs = c0 < 0 ? 0 : c0;
+        const int sh = (cs & 31) - (c0 < 0 ? 1 : 0);      // bit position of the kx = 0 cell in the pair below
+        uint32_t w_lo = 0, w_hi = 0;
+        if (zy_ok) {
+          w_lo = bitmap[cs >> 5];
+          // (2 of 32 positions; behind the grid's last word this reads the start of the prefix array, which
+          // shares the workspace -- those bits belong to x >= W and are masked by the bound check below)
+          if ((cs & 31) > 29) w_hi = bitmap[(cs >> 5) + 1];
+        }
+        const unsigned long long both = ((unsigned long long)w_hi << 32) | w_lo;
+        uint32_t bits3 = 0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int pos = sh + kx;
+          if (zy_ok && (unsigned)(x0 + kx) < (unsigned)g.W && pos >= 0 && ((both >> pos) & 1ull)) bits3 |= 1u << kx;
+        }
+        uint32_t pre = 0;
+        if (bits3) pre = prefix[cs >> 5];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          int32_t val = -1;
+          if ((bits3 >> kx) & 1u) {
+            const int pos = sh + kx;
+            const int32_t r = (int32_t)(pre + (uint32_t)__popcll(both & ((1ull << pos) - 1ull)));
+            val = perm ? perm[r] - 1 : r;  // perm holds row + 1 (0 = empty)
+          }
+          v[(kz * 3 + ky) * 3 + kx] = val;
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) emit(v[k], k);
+  } else if constexpr (KS != 0) {
     int32_t v[KS * KS * KS];
 #pragma unroll
     for (int k = 0; k < KS * KS * KS; ++k) v[k] = lookup(k / (KS * KS), (k / KS) % KS, k % KS);
