@@ -189,12 +189,15 @@ int ococc_occ_visibility_f64(const double* centers, int64_t n, const double* to_
  * ascending cell order and the caller still holds that grid's bitmap + popcount prefix (the state
  * ococc_grid_unique_i32 leaves in its workspace, see ococc_grid_unique_workspace_layout): the
  * marking, scanning and row-permutation passes are skipped.  Rows with negative coordinates
- * (fixed-capacity padding) take part in no pair.  Workspace size as for ococc_subm_rulebook_build. */
+ * (fixed-capacity padding) take part in no pair.  fill_pair_tails = 0 leaves indice_pairs[k][.][indice_num[k]..]
+ * unwritten (the reference format fills them with -1: 27 MB of stores per call that a fixed-capacity training
+ * step never reads).  Workspace size as for ococc_subm_rulebook_build. */
 int ococc_subm_rulebook_build_sorted(const int32_t* indices, int64_t n, int32_t batch_size,
                                      const int32_t host_shape[3], const int32_t host_ksize[3],
                                      const uint32_t* grid_bitmap, const uint32_t* grid_prefix, int32_t* nbr_t,
                                      uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num,
-                                     void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+                                     int32_t fill_pair_tails, void* workspace, int64_t workspace_bytes,
+                                     ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * B3  sub-manifold rulebook

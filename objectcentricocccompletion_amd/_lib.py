@@ -48,7 +48,7 @@ SIGNATURES = {
     'ococc_subm_rulebook_build': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, _I3, c_vp, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_vp]),
     'ococc_subm_rulebook_build_sorted': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                                 c_vp, c_i64, c_vp]),
+                                                 c_i32, c_vp, c_i64, c_vp]),
     'ococc_conv_rulebook_workspace_bytes': (c_i64, [c_i64, c_i32, _I3, _I3]),
     'ococc_conv_rulebook_build': (c_i32, [c_vp, c_i64, c_i32, _I3, _I3, _I3, _I3, _I3, c_i32, c_vp, c_i64, c_vp,
                                           c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -219,7 +219,7 @@ block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t
 __global__ void __launch_bounds__(256)
 compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ blk_off,
                      int64_t n, int kvol, const int32_t* __restrict__ indice_num,
-                     int32_t* __restrict__ pairs) {
+                     int32_t* __restrict__ pairs, int fill_tails) {
   // grid (row blocks of 256, kvol): same blocking as neighbour_table_kernel, order preserving
   __shared__ uint32_t wsum[4];
   const int k = blockIdx.y;
@@ -227,7 +227,7 @@ compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   // the unused tail of offset k reads -1 (ops.py:46-106 returns a -1 filled tensor); thread j owns slot j
-  if (j < n && j >= indice_num[k]) {
+  if (fill_tails && j < n && j >= indice_num[k]) {
     pairs[((int64_t)k * 2 + 0) * n + j] = -1;
     pairs[((int64_t)k * 2 + 1) * n + j] = -1;
   }
@@ -434,7 +434,7 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
                        const int32_t host_ksize[3], const int32_t host_dilation[3],
                        const uint32_t* grid_bitmap, const uint32_t* grid_prefix, int32_t* nbr_t,
                        uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
-                       int64_t workspace_bytes, hipStream_t stream) {
+                       int64_t workspace_bytes, hipStream_t stream, int fill_tails = 1) {
   Layout L;
   OCOCC_REQUIRE(n >= 0, "n < 0");
   OCOCC_REQUIRE(make_layout(n, batch_size, host_shape, host_ksize, &L),
@@ -493,7 +493,7 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
     hipLaunchKernelGGL(block_offsets_kernel, dim3(kvol), dim3(256), 0, stream, blk, nblk, kvol, indice_num);
     OCOCC_CHECK_LAUNCH();
     hipLaunchKernelGGL(compact_pairs_kernel, dim3((unsigned)nblk, kvol), dim3(256), 0, stream, nbr_t, blk, n,
-                       kvol, indice_num, indice_pairs);
+                       kvol, indice_num, indice_pairs, fill_tails);
     OCOCC_CHECK_LAUNCH();
   }
   return OCOCC_OK;
@@ -516,12 +516,12 @@ extern "C" int ococc_subm_rulebook_build_sorted(const int32_t* indices, int64_t 
                                                 const int32_t host_shape[3], const int32_t host_ksize[3],
                                                 const uint32_t* grid_bitmap, const uint32_t* grid_prefix,
                                                 int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
-                                                int32_t* indice_num, void* workspace, int64_t workspace_bytes,
-                                                ococc_stream_t stream) {
+                                                int32_t* indice_num, int32_t fill_pair_tails, void* workspace,
+                                                int64_t workspace_bytes, ococc_stream_t stream) {
   OCOCC_REQUIRE(grid_bitmap && grid_prefix, "null grid bitmap / prefix");
   return subm_rulebook_impl(indices, n, batch_size, host_shape, host_ksize, nullptr, grid_bitmap, grid_prefix,
                             nbr_t, blockmask, indice_pairs, indice_num, workspace, workspace_bytes,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, fill_pair_tails ? 1 : 0);
 }
 
 extern "C" int ococc_rulebook_pairs_to_table(const int32_t* indice_pairs,

@@ -100,7 +100,9 @@ def _ilist(v, ndim):
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1,
                      out_padding=0, subm=False, transpose=False, grid=None):
-    """ops.py:46-106 -> (outids, indice_pairs [K,2,N] int32, indice_pair_num [K] int32)."""
+    """ops.py:46-106 -> (outids, indice_pairs [K,2,N] int32, indice_pair_num [K] int32).  indice_pairs[k] is -1 past
+    indice_pair_num[k] as in the reference, except for fixed-capacity coordinates (``static=True`` upstream), where
+    those 27 MB of stores are skipped and the tails are unspecified."""
     L.require_device(indices)
     ndim = indices.shape[1] - 1
     ksize, stride, padding = _ilist(ksize, ndim), _ilist(stride, ndim), _ilist(padding, ndim)
@@ -145,10 +147,12 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     if (grid is not None and grid[3] == (int(batch_size),) + tuple(int(v) for v in spatial_shape)
             and all(int(d) == 1 for d in dilation)):
         # the rows come straight from grid_unique over this very grid: reuse its cell bitmap + prefix
-        gws, boff, poff, _ = grid
+        gws, boff, poff = grid[:3]
+        # fixed-capacity coordinates (static=True upstream): nobody reads the -1 tails of the pair lists
+        fill_tails = 0 if (len(grid) > 4 and grid[4]) else 1
         L.check(L.lib.ococc_subm_rulebook_build_sorted(L.ptr(indices), n, int(batch_size), L.i3(spatial_shape),
                                                        L.i3(ksize), gws.data_ptr() + boff, gws.data_ptr() + poff,
-                                                       L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
+                                                       L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num), fill_tails,
                                                        L.ptr(ws), ws.numel(), L.stream()),
                 'subm_rulebook_build_sorted')
         pairs._ococc_keepalive = gws

@@ -64,7 +64,7 @@ def grid_unique(coors, dims=None, static=False):
         if ndim == 4:
             bo, po = L.c_i64(), L.c_i64()
             L.check(L.lib.ococc_grid_unique_workspace_layout(ndim, L.i4(dims), bo, po), 'grid_unique_layout')
-            t._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims))
+            t._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), bool(static))
         return t
     if static:
         inv._ococc_counts = counts
@@ -240,7 +240,7 @@ def voxelize_scatter_mean(points, batch_idx, feats, voxel_size, coors_range, gri
         vfeats = _MeanOfPointsGrad.apply(feats, vfeats, inv, counts)
     bo, po = L.c_i64(), L.c_i64()
     L.check(L.lib.ococc_grid_unique_workspace_layout(4, L.i4(dims), bo, po), 'grid_unique_layout')
-    coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims))
+    coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), bool(static))
     inv._ococc_counts = counts
     return vfeats, coors, inv, counts, meta
 
