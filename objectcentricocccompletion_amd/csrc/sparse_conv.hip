@@ -850,23 +850,24 @@ __global__ void __launch_bounds__(256) weight_prepare_multi_kernel(PrepPack pk) 
   int t = 0;
   while (t + 1 < pk.count && (int)blockIdx.x >= pk.first_block[t + 1]) ++t;
   const int cin = pk.cin[t], cout = pk.cout[t], kvol = pk.kvol[t], mode = pk.mode[t];
-  const int64_t total = (int64_t)kvol * cin * cout;
-  const int nblk = pk.first_block[t + 1] - pk.first_block[t];
-  for (int64_t i = (int64_t)(blockIdx.x - pk.first_block[t]) * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
-    int64_t src, dst;
-    const int base = mode & 3;
+  // 32-bit index arithmetic (a weight tensor has far fewer than 2^31 elements; the launcher checks): the 64-bit
+  // divisions of the general kernel were most of this launch
+  const uint32_t total = (uint32_t)kvol * cin * cout, kc = (uint32_t)cin * cout;
+  const uint32_t nblk = pk.first_block[t + 1] - pk.first_block[t];
+  const int base = mode & 3;
+  for (uint32_t i = (blockIdx.x - pk.first_block[t]) * 256u + threadIdx.x; i < total; i += nblk * 256u) {
+    const uint32_t k = i / kc, rem = i - k * kc;
+    uint32_t src;
+    int64_t dst;
     if (base == 0) {
-      const int ci = (int)(i % cin);
-      const int co = (int)((i / cin) % cout);
-      const int k = (int)(i / ((int64_t)cin * cout));
-      src = ((int64_t)k * cin + ci) * cout + co;
-      dst = prep_dest(mode, i, k, co, ci, cout, cin);
+      const uint32_t co = rem / cin, ci = rem - co * cin;
+      src = (k * cin + ci) * cout + co;
+      dst = prep_dest(mode, i, (int)k, (int)co, (int)ci, cout, cin);
     } else {
-      const int64_t rem = i % ((int64_t)cin * cout);
-      const int k = (int)(i / ((int64_t)cin * cout));
-      const int ks = base == 1 ? kvol - 1 - k : k;
-      src = (int64_t)ks * cin * cout + rem;
-      dst = prep_dest(mode, i, k, (int)(rem / cout), (int)(rem % cout), cin, cout);
+      const uint32_t ks = base == 1 ? kvol - 1 - k : k;
+      src = ks * kc + rem;
+      const uint32_t r = rem / cout;
+      dst = prep_dest(mode, i, (int)k, (int)r, (int)(rem - r * cout), cin, cout);
     }
     pk.wn[t][dst] = ococc_f32_to_bf16(pk.w[t][src]);
   }
@@ -1226,6 +1227,7 @@ extern "C" int ococc_weight_prepare_multi_bf16(int32_t count, const void* const*
     pk.mode[i] = mode[i];
     pk.first_block[i] = blocks;
     const int64_t total = (int64_t)kvol[i] * cin[i] * cout[i];
+    OCOCC_REQUIRE(total < 0x7fffffffLL, "weight tensor too large");
     blocks += (int)(ococc_cdiv(total, 256) < 256 ? ococc_cdiv(total, 256) : 256);
   }
   pk.first_block[count] = blocks;
