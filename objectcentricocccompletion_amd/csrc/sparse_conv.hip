@@ -876,7 +876,8 @@ __global__ void __launch_bounds__(256) weight_prepare_multi_kernel(PrepPack pk) 
 // ---------------------------------------------------------------- wgrad
 constexpr int kWgThreads = 256;
 constexpr int kWgGrid = 2048;    // workgroups of the weight-gradient launch (8 per CU); items beyond that are looped over
-constexpr int kWgSteps = 8;  // 32-pair MFMA k-steps per workgroup
+constexpr int kWgSteps = 16;  // 32-pair MFMA k-steps per work item (one slab per item)
+constexpr int kWgDepth = 4;   // steps whose rows are in flight (registers) ahead of the one being multiplied
 
 // Flattened (offset, part) work list: offset k owns ceil(ceil(num[k]/32) / kWgSteps) consecutive
 // items.  Every wave locates its item with one coalesced load of num[] and a wave scan, so the
@@ -940,6 +941,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   constexpr int PX = 32 * CIN / 8, PY = 32 * COUT / 8;  // 16-byte pieces per step
   constexpr int PT = (PX + PY + kWgThreads - 1) / kWgThreads;
   __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
+  __shared__ int32_t sidx[2][kWgSteps * 32];  // the item's pair list: input rows, output rows
 
   // Work items (slabs) are dealt round-robin to a grid that no longer has to cover the worst case
   // kvol * cap / 256 of them: on sparse grids most of those workgroups only found out that there was
@@ -965,63 +967,61 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
 #pragma unroll
     for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 stage[PT];
-  int32_t ridx[PT];  // row index of each piece, fetched one step ahead of the rows
-  auto load_idx = [&](int step) {
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      const int pc = threadIdx.x + t * kWgThreads;
-      int32_t v = -1;
-      if (pc < PX) {
-        const int p = step * 32 + pc / (CIN / 8);
-        if (p < nk) v = pin[p];
-      } else if (pc < PX + PY) {
-        const int p = step * 32 + (pc - PX) / (COUT / 8);
-        if (p < nk) v = pout[p];
-      }
-      ridx[t] = v;
-    }
-  };
-  auto load_step = [&]() {
+  // The item's pair indices go to LDS in one coalesced pass; the rows of kWgDepth steps are then in flight
+  // in registers ahead of the step being multiplied (with one step ahead every step cost a full global-load
+  // latency, which is why items had to stay short and the slab count high).
+  for (int p = threadIdx.x; p < (last - first) * 32; p += kWgThreads) {
+    const int gp = first * 32 + p;
+    sidx[0][p] = gp < nk ? pin[gp] : -1;
+    sidx[1][p] = gp < nk ? pout[gp] : -1;
+  }
+  __syncthreads();
+  u32x4 stage[kWgDepth][PT];
+  auto load_step = [&](u32x4 (&st)[PT], int step) {  // rows of `step` (item-relative) -> registers
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int pc = threadIdx.x + t * kWgThreads;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (ridx[t] >= 0) {
-        if (pc < PX)
-          v = *(const u32x4*)(x + (int64_t)ridx[t] * CIN + (pc % (CIN / 8)) * 8);
-        else
-          v = *(const u32x4*)(dy + (int64_t)ridx[t] * COUT + ((pc - PX) % (COUT / 8)) * 8);
+      if (step < last - first) {
+        if (pc < PX) {
+          const int32_t r = sidx[0][step * 32 + pc / (CIN / 8)];
+          if (r >= 0) v = *(const u32x4*)(x + (int64_t)r * CIN + (pc % (CIN / 8)) * 8);
+        } else if (pc < PX + PY) {
+          const int32_t r = sidx[1][step * 32 + (pc - PX) / (COUT / 8)];
+          if (r >= 0) v = *(const u32x4*)(dy + (int64_t)r * COUT + ((pc - PX) % (COUT / 8)) * 8);
+        }
       }
-      stage[t] = v;
+      st[t] = v;
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, const u32x4 (&st)[PT]) {
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int pc = threadIdx.x + t * kWgThreads;
       if (pc < PX) {
         const int row = pc / (CIN / 8), piece = pc % (CIN / 8);
-        *(u32x4*)(&lds[buf][row * LDX + piece * 8]) = stage[t];
+        *(u32x4*)(&lds[buf][row * LDX + piece * 8]) = st[t];
       } else if (pc < PX + PY) {
         const int pc2 = pc - PX;
         const int row = pc2 / (COUT / 8), piece = pc2 % (COUT / 8);
-        *(u32x4*)(&lds[buf][32 * LDX + row * LDY + piece * 8]) = stage[t];
+        *(u32x4*)(&lds[buf][32 * LDX + row * LDY + piece * 8]) = st[t];
       }
     }
   };
 
-  load_idx(first);
-  load_step();
-  if (first + 1 < last) load_idx(first + 1);
-  int buf = 0;
-  for (int step = first; step < last; ++step) {
-    store_step(buf);
+#pragma unroll
+  for (int d = 0; d < kWgDepth; ++d) load_step(stage[d], d);
+  const int nsteps = last - first;
+  // groups of kWgDepth steps so that the register ring has compile-time positions
+  for (int s0 = 0; s0 < nsteps; s0 += kWgDepth) {
+#pragma unroll
+  for (int d = 0; d < kWgDepth; ++d) {
+    const int step = s0 + d;
+    if (step >= nsteps) break;
+    const int buf = d & 1;  // (kWgDepth is even: consecutive steps alternate buffers across groups too)
+    store_step(buf, stage[d]);
     __syncthreads();
-    if (step + 1 < last) {
-      load_step();  // rows of step+1 (their indices arrived during the previous step)
-      if (step + 2 < last) load_idx(step + 2);
-    }
+    load_step(stage[d], step + kWgDepth);  // its registers are free again: the rows kWgDepth steps ahead
     // transposing reads: lane (grp, li) with q_=li>>2, p_=li&3 addresses row 8*grp+4h+q_,
     // columns 16*blk+4p_ .. +3 and receives column li of rows 8*grp+4h .. +3.
     const int q_ = li >> 2, p_ = li & 3;
@@ -1059,7 +1059,7 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
         }
       }
     }
-    buf ^= 1;
+  }
   }
 
   // D[m = cin][n = cout]: lane holds rows 4*grp + {0..3}, column li of each 16x16 tile
