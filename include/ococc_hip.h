@@ -324,6 +324,12 @@ int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, c
                                  const int32_t* indice_num, int32_t kvol, int64_t pair_capacity,
                                  float* dw, void* workspace, int64_t workspace_bytes,
                                  ococc_stream_t stream);
+/* dw == NULL above stops after the per-work-item slabs (left in `workspace`); this call finishes up to 8 such
+ * weight gradients in one launch: dw[i][k][e] = sum of the slabs of offset k, fixed order (deterministic).
+ * elems[i] = cin * cout of layer i.  Used to move the reductions of a backward pass behind its last kernel. */
+int ococc_sparse_conv_wgrad_reduce_multi(int32_t count, const void* const* workspaces,
+                                         const int32_t* const* indice_nums, const int32_t* kvols,
+                                         const int64_t* elems, float* const* dws, ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * B5  fused LayerNorm + GELU(erf) over feature rows (the norm/act pair that

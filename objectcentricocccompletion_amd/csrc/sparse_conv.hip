@@ -1082,15 +1082,13 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
 
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
 // block; lane p adds slabs p, p+16, ... into eight interleaved sums; fixed trees join the sums and the lanes.
-__global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
-                    int64_t elems, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slabs, const int32_t* __restrict__ num,
+                                                   int k, int chunk, int64_t elems, float* __restrict__ dw) {
   __shared__ float red[4][16];
-  const int k = blockIdx.y;
   int base, nslabs;
   wg_span(num, k, &base, &nslabs);
   const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int64_t i = (int64_t)blockIdx.x * 16 + e;
+  const int64_t i = (int64_t)chunk * 16 + e;
   // eight running sums per lane: the centre offset has hundreds of slabs, and one sum per lane made its
   // blocks a chain of dependent L2 round trips (11-16 us whatever the layer size)
   float a[8];
@@ -1114,6 +1112,90 @@ wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__
   __syncthreads();
   if (threadIdx.x < 16 && i < elems)
     dw[(int64_t)k * elems + i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ num, int kvol,
+                    int64_t elems, float* __restrict__ dw) {
+  wgrad_reduce_block(slabs, num, blockIdx.y, blockIdx.x, elems, dw);
+}
+
+// the slab reductions of several layers in one launch (the reductions of a backward pass feed nothing before
+// the optimizer: spconv/ops.py queues them to the end of the pass)
+constexpr int kMaxReduce = 8;
+struct ReducePack {
+  const float* slabs[kMaxReduce];
+  const int32_t* num[kMaxReduce];
+  float* dw[kMaxReduce];
+  int64_t elems[kMaxReduce];
+  int32_t kvol[kMaxReduce], first_block[kMaxReduce + 1], count;
+};
+// Persistent: a fixed grid walks the work units of every layer.  An offset with MANY slabs (the centre: hundreds) is
+// cut into units of 16 elements x 16 slab lanes (wgrad_reduce_block); an offset with at most 16 slabs (every other
+// offset of a sparse grid) into units of 256 elements, one thread each -- 27 x fewer, fatter units than one block per
+// 16 elements of every offset (18 k blocks of which 26/27 summed 8 values: 23 us for three layers).
+constexpr int kReduceGrid = 1024;
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReducePack pk) {
+  const int lane = threadIdx.x & 63;
+  for (int t = 0; t < pk.count; ++t) {
+    const int kvol = pk.kvol[t];
+    const int64_t elems = pk.elems[t];
+    const int deep_units = (int)((elems + 15) / 16), wide_units = (int)((elems + 255) / 256);
+    // units per offset (kvol <= 64 here: one lane per offset; larger kernels fall back to deep units for all)
+    for (int unit = blockIdx.x;; unit += gridDim.x) {
+      int k = -1, local = 0, nsl = 0, sbase = 0;
+      if (kvol <= 64) {
+        // lane = offset: its slab count and (exclusive scan) the index of its first slab
+        const int my_slabs = lane < kvol ? wg_items(pk.num[t][lane]) : 0;
+        int sinc = my_slabs;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(sinc, d, 64);
+          if (lane >= d) sinc += v;
+        }
+        const int my_base = sinc - my_slabs;
+        const int cnt = lane < kvol ? (my_slabs > 16 ? deep_units : wide_units) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int v = __shfl_up(inc, d, 64);
+          if (lane >= d) inc += v;
+        }
+        const int total = __shfl(inc, 63, 64);
+        if (unit >= total) break;
+        const unsigned long long hit = __ballot(cnt > 0 && unit >= inc - cnt && unit < inc);
+        const int src = __ffsll((long long)hit) - 1;
+        k = src;
+        local = unit - (__shfl(inc, src, 64) - __shfl(cnt, src, 64));
+        nsl = __shfl(my_slabs, src, 64);
+        sbase = __shfl(my_base, src, 64);
+      } else {
+        if (unit >= deep_units * kvol) break;
+        k = unit / deep_units;
+        local = unit % deep_units;
+        wg_span(pk.num[t], k, &sbase, &nsl);
+        nsl = 17;  // force the deep path
+      }
+      if (kvol <= 64 && nsl <= 16) {
+        const int64_t i = (int64_t)local * 256 + threadIdx.x;
+        if (i < elems) {
+          const float* src = pk.slabs[t] + (int64_t)sbase * elems + i;
+          float a[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) a[u] = 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (u < nsl) a[u] = src[(int64_t)u * elems];
+            if (u + 8 < nsl) a[u] += src[(int64_t)(u + 8) * elems];
+          }
+          pk.dw[t][(int64_t)k * elems + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+      } else {
+        __syncthreads();  // red[] of a previous deep unit
+        wgrad_reduce_block(pk.slabs[t], pk.num[t], k, local, elems, pk.dw[t]);
+      }
+    }
+  }
 }
 
 inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
@@ -1252,11 +1334,11 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE(n_in >= 0 && n_out >= 0 && pair_capacity >= 0, "negative size");
   OCOCC_REQUIRE(kvol >= 1, "kvol < 1");
-  OCOCC_REQUIRE(dw, "null dw");
   const int64_t need = ococc_sparse_conv_wgrad_workspace_bytes(kvol, pair_capacity, cin, cout);
   OCOCC_REQUIRE(workspace && workspace_bytes >= need, "workspace too small");
   const int64_t elems = (int64_t)cin * cout;
   if (pair_capacity == 0 || n_in == 0 || n_out == 0) {
+    OCOCC_REQUIRE(dw, "an empty problem has no slabs to reduce later: dw required");
     OCOCC_HIP(hipMemsetAsync(dw, 0, (int64_t)kvol * elems * sizeof(float), stream));
     return OCOCC_OK;
   }
@@ -1271,8 +1353,35 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "cin must be 16/32/64/128");
   }
   if (rc != OCOCC_OK) return rc;
+  if (!dw) return OCOCC_OK;  // slabs only: the caller reduces later (ococc_sparse_conv_wgrad_reduce_multi)
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ococc_cdiv(elems, 16), kvol), dim3(256), 0,
                      stream, slabs, indice_num, (int)kvol, elems, dw);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_sparse_conv_wgrad_reduce_multi(int32_t count, const void* const* workspaces,
+                                                    const int32_t* const* indice_nums, const int32_t* kvols,
+                                                    const int64_t* elems, float* const* dws, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(count >= 0 && count <= kMaxReduce, "at most 8 reductions per call");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(workspaces && indice_nums && kvols && elems && dws, "null pointer table");
+  ReducePack pk;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    OCOCC_REQUIRE(workspaces[i] && indice_nums[i] && dws[i] && kvols[i] >= 1 && elems[i] >= 1, "bad reduction descriptor");
+    pk.slabs[i] = (const float*)workspaces[i];
+    pk.num[i] = indice_nums[i];
+    pk.dw[i] = dws[i];
+    pk.elems[i] = elems[i];
+    pk.kvol[i] = kvols[i];
+    pk.first_block[i] = blocks;
+    blocks += (int)ococc_cdiv(elems[i], 16) * kvols[i];
+  }
+  pk.first_block[count] = blocks;
+  pk.count = count;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks < kReduceGrid ? blocks : kReduceGrid), dim3(256), 0, stream, pk);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -216,6 +216,39 @@ def _to_bf16_padded(t, cols):
     return out
 
 
+_pending_reduce = []
+
+
+def _flush_wgrad_reduce():
+    """Finish the weight gradients whose slabs are waiting (one launch per 8 layers)."""
+    import ctypes
+    global _pending_reduce
+    todo, _pending_reduce = _pending_reduce, []
+    for lo in range(0, len(todo), 8):
+        ch = todo[lo:lo + 8]
+        n = len(ch)
+        vp, i32, i64 = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
+        L.check(L.lib.ococc_sparse_conv_wgrad_reduce_multi(
+            n, vp(*[c[0].data_ptr() for c in ch]), vp(*[c[1].data_ptr() for c in ch]), i32(*[c[2] for c in ch]),
+            i64(*[c[3] for c in ch]), vp(*[c[4].data_ptr() for c in ch]), L.stream()), 'wgrad_reduce_multi')
+
+
+def _queue_wgrad_reduce(ws, indice_pair_num, kvol, elems, dw):
+    """True when the reduction could be queued to the end of the running autograd backward pass (the engine's
+    final callback: every .backward() / autograd.grad() returns with the gradients complete, and inside a HIP-graph
+    capture the launch simply lands behind the pass's last kernel); False outside a backward pass."""
+    first = not _pending_reduce
+    _pending_reduce.append((ws, indice_pair_num, int(kvol), int(elems), dw))
+    if not first:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reduce)
+        return True
+    except RuntimeError:  # "Final callbacks can only be installed during backward pass"
+        _pending_reduce.pop()
+        return False
+
+
 class overlap_wgrad(object):
     """Context manager around a backward pass: weight gradients of the sparse convolutions are computed on a
     side stream, concurrently with the input-gradient chain; on exit the current stream waits for the side
@@ -445,9 +478,13 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)
             ws = L.workspace(nbytes, features.device)
             dw = torch.empty((kvol, kd_in, kd_out), dtype=torch.float32, device=features.device)
+            # Inside an autograd backward pass only the slabs are computed now; the slab reductions of all layers
+            # go into ONE launch queued to the end of the pass (_queue_wgrad_reduce): dW feeds nothing before that.
+            defer = _overlap is None and cap > 0 and n_in > 0 and n_out > 0 and _queue_wgrad_reduce(
+                ws, indice_pair_num, kvol, kd_in * kd_out, dw)
             L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
                                                        L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
-                                                       L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
+                                                       None if defer else L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
                     'sparse_conv_wgrad')
             return dw[:, :cin, :cout].reshape(filters.shape).to(filters.dtype)
 
