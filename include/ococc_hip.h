@@ -349,6 +349,16 @@ int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
                             const float* gamma, const float* beta, const float* mean_rstd,
                             int32_t act, void* dx, float* dgamma, float* dbeta, int32_t dtype,
                             void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+/* dgamma == dbeta == NULL in ococc_layernorm_act_bwd: dx and the per-block partial sums only (the workspace
+ * then holds ococc_layernorm_act_bwd_partial_rows(n, c, dtype) rows of [2c] f32 and must stay alive).
+ * ococc_layernorm_param_reduce_multi finishes up to 16 such layers in ONE launch -- the host mirror queues it
+ * to the end of the autograd backward pass (torch's LayerNorm backward, which the reference's
+ * build_norm_layer(dict(type='LN')) layers use, returns the parameter gradients per layer:
+ * mmdet3d/ops/sparse_block.py:216-289). */
+int32_t ococc_layernorm_act_bwd_partial_rows(int64_t n, int32_t c, int32_t dtype);
+int ococc_layernorm_param_reduce_multi(int32_t count, const void* const* partials, const int32_t* rows,
+                                       const int32_t* c, void* const* dgamma, void* const* dbeta,
+                                       ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * A3  points-in-rotated-box pooling

@@ -72,6 +72,8 @@ SIGNATURES = {
     'ococc_layernorm_act_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'ococc_layernorm_act_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'ococc_layernorm_act_bwd_partial_rows': (c_i32, [c_i64, c_i32, c_i32]),
+    'ococc_layernorm_param_reduce_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_point_pool_workspace_bytes': (c_i64, [c_i64, c_i64]),
     'ococc_dynamic_point_pool_mixed': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, _F3, c_i32, c_i64, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

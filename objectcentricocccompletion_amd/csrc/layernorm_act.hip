@@ -390,10 +390,10 @@ ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restric
 
 // 8 outputs per block, 32 lanes each: lane l adds partials l, l+32, ... (fixed order),
 // then a fixed-shape butterfly combines the 32 lanes -> deterministic.
-__global__ void __launch_bounds__(256)
-ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
-                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+__device__ __forceinline__ void ln_param_reduce_block(const float* __restrict__ partials, int nblocks, int c,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int block) {
+  const int i = block * 8 + (threadIdx.x >> 5);
   const int l = threadIdx.x & 31;
   // eight running sums per lane (fixed combination order): one sum made the 16 strided loads of a lane a
   // chain of dependent L2 round trips (6.8 us per call whatever the width)
@@ -421,6 +421,28 @@ ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
       if (dbeta) dbeta[i - c] = s;
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  ln_param_reduce_block(partials, nblocks, c, dgamma, dbeta, blockIdx.x);
+}
+
+// The reductions of several layers in one launch: layer j owns blocks [first[j], first[j+1]).
+constexpr int kLnMultiMax = 16;
+struct LnReducePack {
+  const float* partials[kLnMultiMax];
+  float* dgamma[kLnMultiMax];
+  float* dbeta[kLnMultiMax];
+  int rows[kLnMultiMax];
+  int c[kLnMultiMax];
+  int first[kLnMultiMax + 1];
+};
+__global__ void __launch_bounds__(256) ln_param_reduce_multi_kernel(LnReducePack p, int count) {
+  int j = 0;
+  while (j + 1 < count && (int)blockIdx.x >= p.first[j + 1]) ++j;
+  ln_param_reduce_block(p.partials[j], p.rows[j], p.c[j], p.dgamma[j], p.dbeta[j], (int)blockIdx.x - p.first[j]);
 }
 
 inline int pick_lpr(int c) {
@@ -499,28 +521,39 @@ int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* be
   return OCOCC_OK;
 }
 
+// rows of the partials slab = blocks of the backward kernel (same choice as launch_bwd below)
+inline int bwd_partial_rows(int64_t n, int c, bool two_byte) {
+  if (two_byte && vec_ok(c)) return vec_blocks(n, c, kBwdMaxBlocks);
+  if (two_byte && (c == 1024 || c == 1536 || c == 2048)) {
+    int64_t gb = ococc_cdiv(n, 4);
+    return (int)(gb > kBwdMaxBlocks ? kBwdMaxBlocks : (gb < 1 ? 1 : gb));
+  }
+  return bwd_blocks(n, pick_lpr(c));
+}
+
 template <typename T>
 int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, const float* beta,
                const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
                hipStream_t stream) {
   if (sizeof(T) == 2 && vec_ok(c)) {
-    const int grid = vec_blocks(n, c, kBwdMaxBlocks);
+    const int grid = bwd_partial_rows(n, c, true);
 #define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
+    if (!dgamma && !dbeta) return OCOCC_OK;  // partials only: ococc_layernorm_param_reduce_multi finishes them
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials,
                        grid, c, dgamma, dbeta);
     OCOCC_CHECK_LAUNCH();
     return OCOCC_OK;
   }
   if (sizeof(T) == 2 && (c == 1024 || c == 1536 || c == 2048)) {
-    int64_t gb = ococc_cdiv(n, 4);
-    const int grid = (int)(gb > kBwdMaxBlocks ? kBwdMaxBlocks : (gb < 1 ? 1 : gb));
+    const int grid = bwd_partial_rows(n, c, true);
 #define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_wide_kernel<V>), dim3(grid), dim3(256), 4 * 2 * c * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
     if (c == 1024) CALLW(2); else if (c == 1536) CALLW(3); else CALLW(4);
 #undef CALLW
     OCOCC_CHECK_LAUNCH();
+    if (!dgamma && !dbeta) return OCOCC_OK;
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials, grid, c,
                        dgamma, dbeta);
     OCOCC_CHECK_LAUNCH();
@@ -538,6 +571,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
   else
     return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "c must be <= 2048");
   OCOCC_CHECK_LAUNCH();
+  if (!dgamma && !dbeta) return OCOCC_OK;
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0,
                      stream, partials, grid, c, dgamma, dbeta);
   OCOCC_CHECK_LAUNCH();
@@ -587,6 +621,35 @@ extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n,
                              (float*)dx, dgamma, dbeta, (float*)workspace, stream);
   return launch_bwd<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, n, c, gamma, beta, mean_rstd,
                               act, (uint16_t*)dx, dgamma, dbeta, (float*)workspace, stream);
+}
+
+extern "C" int32_t ococc_layernorm_act_bwd_partial_rows(int64_t n, int32_t c, int32_t dtype) {
+  if (n < 1 || c < 1 || (dtype != OCOCC_F32 && dtype != OCOCC_BF16)) return 0;
+  return bwd_partial_rows(n, c, dtype == OCOCC_BF16);
+}
+
+extern "C" int ococc_layernorm_param_reduce_multi(int32_t count, const void* const* partials,
+                                                  const int32_t* rows, const int32_t* c, void* const* dgamma,
+                                                  void* const* dbeta, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(count >= 0 && count <= kLnMultiMax, "count must be in [0, 16]");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(partials && rows && c && dgamma && dbeta, "null pointer");
+  LnReducePack p;
+  int blocks = 0;
+  for (int j = 0; j < count; ++j) {
+    OCOCC_REQUIRE(partials[j] && rows[j] >= 1 && c[j] >= 1, "bad layer");
+    p.partials[j] = (const float*)partials[j];
+    p.dgamma[j] = (float*)dgamma[j];
+    p.dbeta[j] = (float*)dbeta[j];
+    p.rows[j] = rows[j];
+    p.c[j] = c[j];
+    p.first[j] = blocks;
+    blocks += (2 * c[j] + 7) / 8;
+  }
+  p.first[count] = blocks;
+  hipLaunchKernelGGL(ln_param_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, p, count);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
 }
 
 extern "C" int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count,

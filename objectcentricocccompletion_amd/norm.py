@@ -10,6 +10,7 @@ import torch
 from torch import nn
 from torch.autograd import Function
 
+from . import _deferred
 from . import _lib as L
 from .registry import NORM_LAYERS
 
@@ -30,25 +31,55 @@ class _LayerNormAct(Function):
         L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(x2), n, c, L.ptr(w32), L.ptr(b32), float(eps),
                                               int(act), L.ptr(y), L.ptr(stats), dt, L.stream()),
                 'layernorm_act_fwd')
-        ctx.save_for_backward(x2, w32, b32, stats)
+        ctx.save_for_backward(x2, w32, b32, stats, weight, bias)
         ctx.act, ctx.shape, ctx.wdtype = int(act), shape, weight.dtype
         return y.reshape(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w32, b32, stats = ctx.saved_tensors
+        x2, w32, b32, stats, weight, bias = ctx.saved_tensors
         n, c = x2.shape
         dy2 = dy.reshape(-1, c).to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
-        dgamma = torch.empty((c,), dtype=torch.float32, device=x2.device)  # overwritten by the kernel
-        dbeta = torch.empty((c,), dtype=torch.float32, device=x2.device)
-        nbytes = L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c)
-        ws = L.workspace(nbytes, x2.device)
-        L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(x2), L.ptr(dy2), n, c, L.ptr(w32), L.ptr(b32),
-                                              L.ptr(stats), ctx.act, L.ptr(dx), L.ptr(dgamma),
-                                              L.ptr(dbeta), L.dtype_code(x2.dtype), L.ptr(ws),
-                                              ws.numel(), L.stream()), 'layernorm_act_bwd')
+        dgamma, dbeta = layernorm_act_backward(x2, dy2, w32, b32, stats, ctx.act, dx, weight, bias)
         return dx.reshape(ctx.shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+
+
+def _flush_param_reduce(todo):
+    """dgamma/dbeta of the queued layers in one launch per 16; jobs = (partials, rows, c, dgb [2, c])."""
+    import ctypes
+    for lo in range(0, len(todo), 16):
+        ch = todo[lo:lo + 16]
+        k = len(ch)
+        vp, i32 = ctypes.c_void_p * k, ctypes.c_int32 * k
+        L.check(L.lib.ococc_layernorm_param_reduce_multi(
+            k, vp(*[j[0].data_ptr() for j in ch]), i32(*[j[1] for j in ch]), i32(*[j[2] for j in ch]),
+            vp(*[j[3][0].data_ptr() for j in ch]), vp(*[j[3][1].data_ptr() for j in ch]), L.stream()),
+            'layernorm_param_reduce_multi')
+
+
+_deferred.register('ln', _flush_param_reduce)
+
+
+def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=None):
+    """dx into `dx`; -> (dgamma, dbeta) f32 [c].  With the parameters given and an autograd backward pass running,
+    only the per-block partial sums are computed now and the two sums join the pass's end-of-backward launch
+    (_deferred); otherwise they are reduced right behind the kernel."""
+    n, c = x2.shape
+    dgb = torch.empty((2, c), dtype=torch.float32, device=x2.device)  # overwritten by the kernel
+    dgamma, dbeta = dgb[0], dgb[1]  # views: what autograd is handed is never the queue's own reference
+    dt = L.dtype_code(x2.dtype)
+    ws = L.workspace(L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c), x2.device)
+    defer = False
+    if n > 0 and weight is not None and bias is not None and weight is not bias \
+            and _deferred.deferrable(weight, bias):
+        rows = L.lib.ococc_layernorm_act_bwd_partial_rows(n, c, dt)
+        defer = rows > 0 and _deferred.defer('ln', (ws, rows, c, dgb), [(weight, dgamma), (bias, dbeta)])
+    L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(x2), L.ptr(dy2), n, c, L.ptr(w32), L.ptr(b32), L.ptr(stats),
+                                          int(act), L.ptr(dx), None if defer else L.ptr(dgamma),
+                                          None if defer else L.ptr(dbeta), dt, L.ptr(ws), ws.numel(), L.stream()),
+            'layernorm_act_bwd')
+    return dgamma, dbeta
 
 
 def layer_norm_act(x, weight, bias, eps=1e-5, act='none'):

@@ -78,7 +78,7 @@ class _IndiceConvLN(Function):
             raise ops.L.OcoccError('no fused conv+LN kernel for this shape')
         conv_out, y, stats = res
         ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters, saved['x_bf16'], conv_out, stats,
-                              saved['g32'], saved['b32'])
+                              saved['g32'], saved['b32'], gamma, beta)
         ctx.meta = (int(act), bool(inverse), bool(subm), gamma.dtype)
         return y
 
@@ -86,17 +86,14 @@ class _IndiceConvLN(Function):
     def backward(ctx, dy):
         import torch
         L = ops.L
-        indice_pairs, indice_pair_num, features, filters, x_bf16, conv_out, stats, g32, b32 = ctx.saved_tensors
+        indice_pairs, indice_pair_num, features, filters, x_bf16, conv_out, stats, g32, b32, gamma, beta = \
+            ctx.saved_tensors
         act, inverse, subm, wdtype = ctx.meta
         n, c = conv_out.shape
         dy2 = dy.to(torch.bfloat16).contiguous()
         dconv = torch.empty_like(conv_out)
-        dgamma = torch.empty((c,), dtype=torch.float32, device=dy.device)
-        dbeta = torch.empty((c,), dtype=torch.float32, device=dy.device)
-        ws = L.workspace(L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c), dy.device)
-        L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(conv_out), L.ptr(dy2), n, c, L.ptr(g32), L.ptr(b32), L.ptr(stats),
-                                              act, L.ptr(dconv), L.ptr(dgamma), L.ptr(dbeta), L.BF16, L.ptr(ws),
-                                              ws.numel(), L.stream()), 'layernorm_act_bwd')
+        from ..norm import layernorm_act_backward
+        dgamma, dbeta = layernorm_act_backward(conv_out, dy2, g32, b32, stats, act, dconv, gamma, beta)
         input_bp, filters_bp = ops.indice_conv_backward(
             features, filters, dconv, indice_pairs, indice_pair_num, inverse, subm, _x_bf16=x_bf16,
             need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1])

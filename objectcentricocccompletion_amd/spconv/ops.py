@@ -12,6 +12,7 @@ import weakref
 import numpy as np
 import torch
 
+from .. import _deferred
 from .. import _lib as L
 
 _KD_OK = (16, 32, 64, 128)
@@ -216,14 +217,10 @@ def _to_bf16_padded(t, cols):
     return out
 
 
-_pending_reduce = []
-
-
-def _flush_wgrad_reduce():
-    """Finish the weight gradients whose slabs are waiting (one launch per 8 layers)."""
+def _flush_wgrad_reduce(todo):
+    """Finish the weight gradients whose slabs are waiting (one launch per 8 layers); jobs =
+    (workspace, indice_pair_num, kvol, kd_in * kd_out, dw)."""
     import ctypes
-    global _pending_reduce
-    todo, _pending_reduce = _pending_reduce, []
     for lo in range(0, len(todo), 8):
         ch = todo[lo:lo + 8]
         n = len(ch)
@@ -233,20 +230,7 @@ def _flush_wgrad_reduce():
             i64(*[c[3] for c in ch]), vp(*[c[4].data_ptr() for c in ch]), L.stream()), 'wgrad_reduce_multi')
 
 
-def _queue_wgrad_reduce(ws, indice_pair_num, kvol, elems, dw):
-    """True when the reduction could be queued to the end of the running autograd backward pass (the engine's
-    final callback: every .backward() / autograd.grad() returns with the gradients complete, and inside a HIP-graph
-    capture the launch simply lands behind the pass's last kernel); False outside a backward pass."""
-    first = not _pending_reduce
-    _pending_reduce.append((ws, indice_pair_num, int(kvol), int(elems), dw))
-    if not first:
-        return True
-    try:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_reduce)
-        return True
-    except RuntimeError:  # "Final callbacks can only be installed during backward pass"
-        _pending_reduce.pop()
-        return False
+_deferred.register('wgrad', _flush_wgrad_reduce)
 
 
 class overlap_wgrad(object):
@@ -478,15 +462,18 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)
             ws = L.workspace(nbytes, features.device)
             dw = torch.empty((kvol, kd_in, kd_out), dtype=torch.float32, device=features.device)
+            out = dw[:, :cin, :cout].reshape(filters.shape)  # a view: splitting kvol never copies
             # Inside an autograd backward pass only the slabs are computed now; the slab reductions of all layers
-            # go into ONE launch queued to the end of the pass (_queue_wgrad_reduce): dW feeds nothing before that.
-            defer = _overlap is None and cap > 0 and n_in > 0 and n_out > 0 and _queue_wgrad_reduce(
-                ws, indice_pair_num, kvol, kd_in * kd_out, dw)
+            # go into ONE launch queued to the end of the pass (_deferred): dW feeds nothing before that.
+            defer = (_overlap is None and cap > 0 and n_in > 0 and n_out > 0 and cin == kd_in and cout == kd_out
+                     and _deferred.deferrable(filters)
+                     and _deferred.defer('wgrad', (ws, indice_pair_num, int(kvol), kd_in * kd_out, dw),
+                                         [(filters, out)]))
             L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
                                                        L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
                                                        None if defer else L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
                     'sparse_conv_wgrad')
-            return dw[:, :cin, :cout].reshape(filters.shape).to(filters.dtype)
+            return out.to(filters.dtype)
 
         if _overlap is not None:
             # the weight gradient feeds nothing until the optimizer: run it on a side stream next to the

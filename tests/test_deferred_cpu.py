@@ -1,0 +1,113 @@
+"""Host logic of the end-of-backward reduction queue (objectcentricocccompletion_amd/_deferred.py) with a CPU
+stand-in for the reduce kernel: the gradient a parameter ends up with must equal the immediate one in every
+autograd usage (fresh .grad, accumulation, shared parameter, autograd.grad, hooks)."""
+import torch
+
+from objectcentricocccompletion_amd import _deferred as D
+
+_LOG = []
+
+
+def _flush(jobs):
+    _LOG.append(len(jobs))
+    for buf, val in jobs:
+        buf.copy_(val)
+
+
+D.register('cpu_test', _flush)
+
+
+class _Mul(torch.autograd.Function):
+    """y = x * w; dw = sum_rows(g * x) -- finished late when the queue admits it."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        val = (g * x).sum(0)
+        buf = torch.full((2, w.numel()), float('nan'))
+        out = buf[0]
+        if not (D.deferrable(w) and D.defer('cpu_test', (out.detach(), val), [(w, out)])):
+            out.copy_(val)
+        return g * w, out
+
+
+def _setup():
+    torch.manual_seed(0)
+    del _LOG[:]
+    return torch.nn.Parameter(torch.randn(4)), torch.randn(3, 4, requires_grad=True)
+
+
+def test_fresh_grad_is_handed_out_buffer_and_one_flush_per_pass():
+    w, x = _setup()
+    w2 = torch.nn.Parameter(torch.randn(4))
+    (_Mul.apply(_Mul.apply(x, w), w2)).sum().backward()
+    assert _LOG == [2] and D.pending() == 0
+    assert torch.equal(w.grad, (w2 * x).sum(0).detach())
+    assert torch.equal(w2.grad, (x * w).sum(0).detach())
+
+
+def test_accumulation_takes_the_immediate_path():
+    w, x = _setup()
+    _Mul.apply(x, w).sum().backward()
+    _Mul.apply(x, w).sum().backward()  # .grad exists: in-place add would read an unwritten buffer
+    assert _LOG == [1]
+    assert torch.allclose(w.grad, 2 * x.sum(0).detach())
+
+
+def test_shared_parameter_in_one_pass():
+    w, x = _setup()
+    _Mul.apply(_Mul.apply(x, w), w).sum().backward()  # d/dw sum(x w^2) = 2 w sum(x)
+    assert torch.allclose(w.grad, (2 * w * x.sum(0)).detach())
+    assert not torch.isnan(w.grad).any()
+
+
+def test_autograd_grad_returns_finished_values():
+    w, x = _setup()
+    gw, = torch.autograd.grad(_Mul.apply(x, w).sum(), [w])
+    assert torch.equal(gw, x.sum(0).detach()) and w.grad is None
+
+
+def test_hooks_and_create_graph_take_the_immediate_path():
+    w, x = _setup()
+    seen = []
+    w.register_hook(lambda g: seen.append(g.clone()))
+    _Mul.apply(x, w).sum().backward()
+    assert _LOG == [] and torch.equal(seen[0], x.sum(0).detach())
+    w2, x2 = _setup()
+    _Mul.apply(x2, w2).sum().backward(create_graph=True)
+    assert _LOG == [] and torch.allclose(w2.grad, x2.sum(0))
+
+
+def test_cloned_gradient_is_repaired():
+    """A second owner of the returned tensor makes AccumulateGrad clone it (stale copy): the flush overwrites it."""
+    w, x = _setup()
+    keep = []
+
+    class _Keep(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            out = torch.full((w.numel(),), float('nan'))
+            keep.append(out)
+            assert D.deferrable(w) and D.defer('cpu_test', (out, (g * x).sum(0)), [(w, out)])
+            return g * w, out
+
+    _Keep.apply(x, w).sum().backward()
+    assert w.grad.data_ptr() != keep[0].data_ptr()
+    assert torch.equal(w.grad, x.sum(0).detach())
+
+
+def test_outside_backward_nothing_is_queued():
+    w, _ = _setup()
+    assert D.defer('cpu_test', (torch.zeros(4), torch.zeros(4)), [(w, torch.zeros(4))]) is False
+    assert D.pending() == 0
