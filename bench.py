@@ -403,7 +403,9 @@ def main():
     # nodes inside a captured graph are rejected by this ROCm (hipEventRecordExternal: invalid argument),
     # so in graph mode the events go around the same kernel in eager steps run right after the timed
     # replays (same process, same inputs); the rocprofv3 trace of the replays is the cross-check.
-    probe = sp_ops.KernelProbe(kd=PROBE_KD, ncols=PROBE_NC)
+    # Graph mode: each event pair brackets 8 back-to-back launches of the kernel (it only writes its output), so the
+    # event-record overhead (~10 us around one 40 us launch) does not end up in the average.
+    probe = sp_ops.KernelProbe(kd=PROBE_KD, ncols=PROBE_NC, repeat=8 if use_graph else 1)
 
     graph_note = 'eager launches'
     if use_graph:
@@ -438,6 +440,7 @@ def main():
         except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, never to another device
             print(f'[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             use_graph = False
+            probe.repeat = 1
     if not use_graph:
         step = eager_step
 
@@ -505,7 +508,8 @@ def main():
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
-                'timed_in': 'timed region' if not use_graph else 'eager steps after the timed graph replays',
+                'timed_in': 'timed region' if not use_graph else
+                            'eager steps after the timed graph replays, 8 back-to-back launches per event pair',
             },
         }
         if not args.no_cpu_baseline:

@@ -22,10 +22,11 @@ class KernelProbe(object):
     """HIP-event timer for one gather-GEMM shape (bench.py's roofline line): events are
     recorded on the stream the kernel is launched on, around every matching launch (forward
     with kd = Cin / ncols = Cout, or dgrad with kd = Cout / ncols = Cin), and read back after
-    the final synchronize."""
+    the final synchronize.  repeat > 1 puts that many back-to-back launches of the (idempotent) kernel between
+    one event pair and divides: the ~10 us an event pair adds around a single launch then weighs 1/repeat."""
 
-    def __init__(self, kd, ncols, max_events=4096, external=False):
-        self.kd, self.ncols, self.max_events = kd, ncols, max_events
+    def __init__(self, kd, ncols, max_events=4096, external=False, repeat=1):
+        self.kd, self.ncols, self.max_events, self.repeat = kd, ncols, max_events, int(repeat)
         self.external = external  # events recorded while a HIP graph is being captured
         self.pairs = []
         self.samples = []
@@ -35,7 +36,8 @@ class KernelProbe(object):
             return launch()
         a, b = L.Timer(), L.Timer()  # HIP events behind the C ABI (ococc_timer_*)
         a.record(self.external)  # torch's current stream == the stream handed to the C ABI (_lib.stream())
-        out = launch()
+        for _ in range(self.repeat):
+            out = launch()
         b.record(self.external)
         self.pairs.append((a, b))
         return out
@@ -46,14 +48,14 @@ class KernelProbe(object):
             self.samples.append(a.elapsed_ms(b))
 
     def count(self):
-        return len(self.samples) if self.external else len(self.pairs)
+        return (len(self.samples) if self.external else len(self.pairs)) * self.repeat
 
     def mean_ms(self):
         if self.external:
-            return sum(self.samples) / len(self.samples) if self.samples else None
+            return sum(self.samples) / len(self.samples) / self.repeat if self.samples else None
         if not self.pairs:
             return None
-        return sum(a.elapsed_ms(b) for a, b in self.pairs) / len(self.pairs)
+        return sum(a.elapsed_ms(b) for a, b in self.pairs) / len(self.pairs) / self.repeat
 
 
 _probe = None
