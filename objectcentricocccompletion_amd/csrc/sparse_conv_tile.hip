@@ -29,7 +29,9 @@
 // block-by-block path and stalled their round): 128 -> 64 channels 29.7 us against 50.1 us for the
 // streamed-weights kernel; 64 -> 32 19.7 us and 32 -> 64 21.1 us against 21.3 / 21.2 us for the
 // resident-weights kernel; 64 -> 128 (256-row tiles, two rounds of workgroups, spills) 65 us against 40 us.
-// With one workgroup per CU every phase exposes its load latency; the host selects the kernel per shape
+// With one workgroup per CU every phase exposes its load latency: shapes up to 64 x 64 channels use 256-row tiles
+// with ONE block per offset gathered ahead (mean 7.5 rows per offset and tile), fit 128 registers, and run two
+// workgroups per CU (64 -> 32 16.5 us, 32 -> 64 17.6 us).  The host selects the kernel per shape
 // (spconv/ops.py), or when told to.
 #include "common.hpp"
 
@@ -40,7 +42,7 @@ constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
 
 template <int KD, int NC, int T, bool OUT_BF16>
-__global__ void __launch_bounds__(kTileThreads, 1)
+__global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64 && KD <= 64) ? 4 : 1)
 subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn,
                       int kvol, int dense_k, const int32_t* __restrict__ table, int64_t n_out,
                       const float* __restrict__ bias, void* __restrict__ out_) {
@@ -50,7 +52,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;  // [T][LDT] f32 accumulators
   // the 16 (input row, tile row) pairs of the MFMA block a wave is about to multiply, per offset slot
-  constexpr int FB = 2;   // blocks per offset whose rows are gathered ahead (mean 15 rows per offset and tile: a second
+  constexpr int FB = (T <= 256 && NC <= 64 && KD <= 64) ? 1 : 2;  // blocks per offset whose rows are gathered ahead (mean 15 rows per offset and tile: a second
                           // block for a third of the offsets; past FB blocks an offset goes block by block)
   __shared__ int32_t sl_in[NW][MAXO][16 * FB];
   __shared__ uint16_t sl_row[NW][MAXO][16 * FB];
@@ -260,10 +262,9 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   }
 }
 
-template <int KD, int NC>
-int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
-                int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
-  constexpr int T = NC >= 128 ? 256 : 512;
+template <int KD, int NC, int T>
+int launch_tile_t(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
+                  int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
   constexpr size_t lds = (size_t)T * (NC + 4) * 4;
   const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, T), 8));
   if (out_dtype == OCOCC_BF16) {
@@ -279,6 +280,19 @@ int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
   }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
+}
+
+template <int KD, int NC>
+int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
+                int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
+  if constexpr (NC >= 128)
+    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+  else if constexpr (KD <= 64) {
+    // 256-row tiles, one block per offset gathered ahead: <= 128 registers, so TWO workgroups share a CU and one's
+    // load latency hides behind the other's phases (64 -> 32: 19.2 -> 16.5 us, 32 -> 64: 21.1 -> 17.6 us)
+    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+  } else
+    return launch_tile_t<KD, NC, 512>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
 }
 
 template <int KD>

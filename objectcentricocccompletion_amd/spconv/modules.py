@@ -1,5 +1,6 @@
 """SparseModule / SparseSequential / ToDense -- host mirror of
 mmdet3d/ops/spconv/modules.py:44-214 (container logic only; no device code)."""
+import os
 from collections import OrderedDict
 
 from torch import nn
@@ -20,7 +21,7 @@ def is_spconv_module(module):
 # (ococc_sparse_conv_gather_gemm_ln_bf16).  Off by default: measured on configs[1] the fused epilogue costs
 # what the separate LN kernel costs (the workgroups of the conv kernel reach their epilogue together, so the
 # extra erf / statistics work is not hidden behind anyone's MFMA phase) -- 560 vs 551 us of kernels per step.
-FUSE_CONV_LN = False
+FUSE_CONV_LN = os.environ.get('OCOCC_FUSE_CONV_LN', '0') == '1'
 
 
 def _is_fusable_norm(module):
