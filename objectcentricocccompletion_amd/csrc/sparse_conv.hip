@@ -782,7 +782,7 @@ int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
     rc = launch_gather_gemm<KD, 64, (KD >= 128 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out,
                                                         out_dtype, stream, ln);
   else if (cs == 32)
-    rc = launch_gather_gemm<KD, 32, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
+    rc = launch_gather_gemm<KD, 32, (KD <= 16 ? 2 : 4)>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
   else if (cs == 16)
     rc = launch_gather_gemm<KD, 16, 4>(feat, wn, kvol, ncols, table, blockmask, n_out, bias, out, out_dtype, stream, ln);
   if (rc >= 0) return rc;
