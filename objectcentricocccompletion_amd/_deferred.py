@@ -8,14 +8,23 @@ them in one launch per kind before .backward() / autograd.grad() returns (inside
 simply lands behind the pass's last kernel).
 
 Handing out a buffer that is written later is only sound when nobody reads it before the flush.  `deferrable`
-admits exactly the parameters for which that holds -- an f32 leaf whose .grad is None (AccumulateGrad then keeps
+admits exactly the parameters for which that holds -- a single process, or dist.GradBuckets as the gradient
+exchange (see GRADS_READ_AFTER_BACKWARD); an f32 leaf whose .grad is None (AccumulateGrad then keeps
 the tensor it is given instead of adding to an existing one), no tensor or post-accumulate hooks, no
 create_graph, not already queued in this pass (a shared weight would be summed by the engine's input buffer) --
 and `_flush` re-checks the outcome: a .grad that is not the handed-out buffer (the engine cloned it) is
 overwritten with the finished values.  Everything else takes the immediate per-layer reduction.
 """
+import os
+
 import torch
 
+ENABLED = os.environ.get('OCOCC_DEFER_PARAM_REDUCE', '1') != '0'  # 0: always the per-layer reductions
+# Data-parallel wrappers that consume a gradient from a hook on its AccumulateGrad node (torch DDP's reducer: a C++
+# post hook, invisible from Python) would copy the unwritten buffer into their bucket.  With more than one rank the
+# queue therefore stays off until the code that owns the gradient exchange says it reads gradients only AFTER
+# backward() has returned -- dist.GradBuckets does (pack() / all_reduce() run behind the pass).
+GRADS_READ_AFTER_BACKWARD = False
 _flushers = {}   # kind -> fn(list of jobs)
 _jobs = {}       # kind -> [job, ...] of the running pass
 _grads = []      # (param, view of the buffer handed to autograd)
@@ -27,6 +36,12 @@ def register(kind, fn):
 
 
 def deferrable(*params):
+    if not ENABLED:
+        return False
+    if not GRADS_READ_AFTER_BACKWARD:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
     for p in params:
         if id(p) in _queued:
             _flush()  # second use of a parameter in one pass: finish what is pending, then reduce immediately

@@ -47,6 +47,10 @@ class GradBuckets(object):
     def __init__(self, params, bucket_bytes=32 << 20, wire_dtype=None):
         self.params = [p for p in params if p.requires_grad]
         self.wire_dtype = wire_dtype
+        # gradients are read by pack() / all_reduce(), i.e. after backward() returned: the end-of-backward
+        # parameter-gradient reductions (_deferred.py) are safe next to this exchange
+        from . import _deferred
+        _deferred.GRADS_READ_AFTER_BACKWARD = True
         self.buckets = []  # (flat buffer, [(param, offset, numel)])
         cur, cur_n = [], 0
         limit = max(1, bucket_bytes // 4)

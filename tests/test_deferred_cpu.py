@@ -111,3 +111,19 @@ def test_outside_backward_nothing_is_queued():
     w, _ = _setup()
     assert D.defer('cpu_test', (torch.zeros(4), torch.zeros(4)), [(w, torch.zeros(4))]) is False
     assert D.pending() == 0
+
+
+def test_multi_rank_needs_the_gradient_exchange_to_opt_in(monkeypatch):
+    """With > 1 rank a hook-driven exchange (torch DDP) would read the unwritten buffer: the queue stays off until
+    dist.GradBuckets (which reads gradients after backward) is the exchange."""
+    import torch.distributed as dist
+    w, x = _setup()
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a: 2)
+    monkeypatch.setattr(D, 'GRADS_READ_AFTER_BACKWARD', False)
+    _Mul.apply(x, w).sum().backward()
+    assert _LOG == [] and torch.equal(w.grad, x.sum(0).detach())
+    monkeypatch.setattr(D, 'GRADS_READ_AFTER_BACKWARD', True)
+    w.grad = None
+    _Mul.apply(x, w).sum().backward()
+    assert _LOG == [1] and torch.equal(w.grad, x.sum(0).detach())
