@@ -191,6 +191,19 @@ def dtype_code(dt):
     raise OcoccError(f'unsupported dtype {dt}; the kernels take float32 or bfloat16')
 
 
+_CONSTS = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """A small read-only constant on `device`, uploaded once per (values, device, dtype): building it per call
+    (torch.tensor(list, device=...)) is a pageable host-to-device copy, i.e. a host synchronisation, every time."""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(key[0], dtype=dtype, device=device)
+    return t
+
+
 def workspace(nbytes, device):
     """Caller-owned scratch buffer (the C ABI never allocates)."""
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)

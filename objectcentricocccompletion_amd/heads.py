@@ -26,6 +26,20 @@ from .sir import SIRLayer
 from .sst.sst_ops import build_mlp, unique_with_inverse
 
 
+def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx):
+    """Row numbers into pos_data for SparseHeadMixin.filter_pos_assigned_but_empty_rois."""
+    rb = roi_batch_idx.long()
+    pb = pos_batch_idx.long()
+    srb, order_r = torch.sort(rb, stable=True)
+    spb, order_p = torch.sort(pb, stable=True)
+    n = rb.numel()
+    # position of every RoI among the RoIs of its sample = sorted position - first sorted position of the sample
+    local = torch.arange(n, device=rb.device) - torch.searchsorted(srb, srb)
+    sel = torch.nonzero(filtered_pos_mask[order_r]).reshape(-1)          # the one read-back (output size)
+    at = torch.searchsorted(spb, srb[sel]) + local[sel]                    # sorted position inside pos_data
+    return order_p[at]
+
+
 class SparseHeadMixin(object):
     """Helpers OccBBoxHead / OccAutoEncoder take from FullySparseBboxHead."""
 
@@ -48,13 +62,20 @@ class SparseHeadMixin(object):
         return new_feature
 
     def filter_pos_assigned_but_empty_rois(self, pos_data, pos_batch_idx, filtered_pos_mask, roi_batch_idx):
-        """fsd_bbox_head.py:442-455."""
-        real_bsz = int(roi_batch_idx.max().item()) + 1
-        out = []
-        for b in range(real_bsz):
-            keep = torch.nonzero(filtered_pos_mask[roi_batch_idx == b]).reshape(-1)
-            out.append(pos_data[pos_batch_idx == b][keep])
-        return torch.cat(out, 0)
+        """fsd_bbox_head.py:442-455: per sample b, the rows of `pos_data` that belong to b, picked at the in-sample
+        positions where `filtered_pos_mask` (over the RoIs of b) is set; samples concatenated in order.  The
+        reference loops over the samples with three boolean-mask indexings (= three host read-backs) each; here
+        the row numbers come from two stable sorts and one `nonzero`, and are reused while the same three index
+        tensors are passed again (the loss filters four tensors with them)."""
+        key = (pos_batch_idx, filtered_pos_mask, roi_batch_idx)
+        cached = getattr(self, '_filter_rows_cache', None)
+        if cached is not None and all(a is b for a, b in zip(cached[0], key)) \
+                and cached[1] == tuple(t._version for t in key):
+            rows = cached[2]
+        else:
+            rows = _filter_rows(*key)
+            self._filter_rows_cache = (key, tuple(t._version for t in key), rows)
+        return pos_data[rows]
 
     def get_class_wise_box_weights(self, weights, gt_labels, cfg):
         class_wise_weight = cfg.get('class_wise_box_weights', None)
@@ -75,13 +96,11 @@ class SparseHeadMixin(object):
         all_gt = torch.cat([pos_gt_labels, pos_gt_labels.new_full((num_samples - num_pos,), -1)], 0)
         all_label = ious.new_zeros(num_samples)
         for i in range(self.num_classes):
-            m = all_gt == i
-            this = ious[m]
-            pos = this > pos_thrs[i]
-            interval = (~pos) & ~(this < neg_thrs[i])
-            lab = pos.float()
-            lab[interval] = (this[interval] - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i])
-            all_label[m] = lab
+            # (elementwise selects instead of the reference's boolean-mask assignments: same values, no read-back)
+            pos = ious > pos_thrs[i]
+            interval = (~pos) & ~(ious < neg_thrs[i])
+            lab = torch.where(interval, (ious - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i]), pos.to(ious.dtype))
+            all_label = torch.where(all_gt == i, lab, all_label)
         label_weights = (all_label >= 0).float()
         cw = cfg.get('class_wise_cls_weights', None)
         if cw is not None:
@@ -618,7 +637,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         reg_mask[0:pos_gt_bboxes.size(0)] = 1
         bbox_weights = self.get_class_wise_box_weights((reg_mask > 0).float(), pos_labels, cfg)
         occ_reg_mask = torch.zeros_like(reg_mask)
-        if reg_mask.bool().any():
+        if pos_gt_bboxes.size(0) > 0 and reg_mask.numel() > 0:  # == reg_mask.bool().any(), known on the host
             gt_ct = pos_gt_bboxes.clone().detach()
             roi_center = pos_bboxes[..., 0:3]
             roi_ry = pos_bboxes[..., 6] % (2 * np.pi)
@@ -627,9 +646,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             gt_ct[..., 0:3] = rotation_3d_in_axis(gt_ct[..., 0:3].unsqueeze(1), -(roi_ry + np.pi / 2), axis=2).squeeze(1)
             ry = gt_ct[..., 6] % (2 * np.pi)
             opposite = (ry > np.pi * 0.5) & (ry < np.pi * 1.5)
-            ry[opposite] = (ry[opposite] + np.pi) % (2 * np.pi)
-            flag = ry > np.pi
-            ry[flag] = ry[flag] - np.pi * 2
+            ry = torch.where(opposite, (ry + np.pi) % (2 * np.pi), ry)
+            ry = torch.where(ry > np.pi, ry - np.pi * 2, ry)
             gt_ct[..., 6] = torch.clamp(ry, min=-np.pi / 2, max=np.pi / 2)
             anchor = pos_bboxes.clone().detach()
             anchor[:, 0:3] = 0
@@ -641,9 +659,9 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
                 num_gt = pos_gt_bboxes.size(0)
                 n_occ = min(num_occ_per_tracklet, num_gt) if num_occ_per_tracklet > 0 else num_gt
                 roi_local_xyz = smp_pos[None, ...].repeat(n_occ, 1, 1)
-                sel = torch.arange(num_gt, device=pos_bboxes.device)[-n_occ:]
-                gt_smp, roi_smp = pos_gt_bboxes[sel], pos_bboxes[sel]
-                occ_reg_mask[:num_gt][sel] = 1
+                # the last n_occ of the num_gt positives (arange(num_gt)[-n_occ:] upstream; n_occ >= 1 here)
+                gt_smp, roi_smp = pos_gt_bboxes[num_gt - n_occ:num_gt], pos_bboxes[num_gt - n_occ:num_gt]
+                occ_reg_mask[num_gt - n_occ:num_gt] = 1
                 if transform_occ:
                     roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, gt_smp[:, 6], axis=2)
                     roi_local_xyz += gt_smp[..., None, 0:3]

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .._lib import const_tensor
 from ..norm import layer_norm_act
 from ..sst.sst_ops import build_mlp
 from . import occ_ops
@@ -32,8 +33,8 @@ class PosEncode(nn.Module):
     def forward(self, x):
         assert x.size(-1) == 3
         if self.use_norm:
-            lo = torch.tensor(self.norm_bound[:3], device=x.device)
-            hi = torch.tensor(self.norm_bound[3:], device=x.device)
+            lo = const_tensor(self.norm_bound[:3], x.device)
+            hi = const_tensor(self.norm_bound[3:], x.device)
             x = (x - lo) / (hi - lo) * 2.0 - 1.0
         ori_shape = x.shape[:-1] + (-1,)
         x = x.reshape(-1, 1, 3)

@@ -3,6 +3,8 @@ occupancy grid (generate_dense_voxel_centers :5-50, quantize_points :53-93,
 jitter_voxel_center :96-100).  Elementwise index math on small tensors."""
 import torch
 
+from .._lib import const_tensor
+
 
 def generate_dense_voxel_centers(bbox_sizes, voxel_size, scale_wlh=[1.0, 1.0, 1.0],
                                  offset_wlh=[0.0, 0.0, 0.0], as_volume=False):
@@ -29,7 +31,8 @@ def quantize_points(points, rois, rois_points_idx, voxel_size, scale_wlh=[1.0, 1
     """Voxel index floor((p + size/2) / voxel) of box-frame points, the volume centred on the
     (enlarged) RoI of each point; with to_center the centre of that voxel (occ_ops.py:53-93)."""
     sizes = rois[:, 4:7]
-    sizes = sizes * sizes.new_tensor(scale_wlh).view(1, 3) + sizes.new_tensor(offset_wlh).view(1, 3)
+    sizes = sizes * const_tensor(scale_wlh, sizes.device, sizes.dtype).view(1, 3) \
+        + const_tensor(offset_wlh, sizes.device, sizes.dtype).view(1, 3)
     min_bound = (-sizes / 2)[rois_points_idx.long()]
     voxel_coors = torch.floor((points - min_bound) / voxel_size).to(torch.long)
     if to_center:

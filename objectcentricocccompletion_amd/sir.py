@@ -9,6 +9,7 @@ LN(+GELU) -> ococc_layernorm_act_*, scatter max/mean -> ococc_segment_reduce_f32
 import torch
 from torch import nn
 
+from ._lib import const_tensor
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import (build_mlp, fuse_norm_act, get_activation_layer, scatter_v2,
                           unique_with_inverse)
@@ -84,7 +85,7 @@ class SIRLayer(nn.Module):
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None,
                 return_inv=False, return_both=False, unq_inv_once=None, new_coors_once=None):
-        xyz_normalizer = torch.tensor(self.xyz_normalizer, device=features.device, dtype=features.dtype)
+        xyz_normalizer = const_tensor(self.xyz_normalizer, features.device, features.dtype)
         features_ls = [torch.cat([features[:, :3] / xyz_normalizer[None, :], features[:, 3:]], dim=1)]
         if self.with_shortcut:
             shortcut = features[:, 3:]
