@@ -42,17 +42,17 @@ constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
 
 template <int KD, int NC, int T, bool OUT_BF16>
-__global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64 && KD <= 64) ? 4 : 1)
+__global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64) ? 4 : 1)
 subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn,
                       int kvol, int dense_k, const int32_t* __restrict__ table, int64_t n_out,
                       const float* __restrict__ bias, void* __restrict__ out_) {
   constexpr int KSTEPS = KD / 32, NB = NC / 16, LDT = NC + 4, U = T / 64;
-  constexpr int NW = kTileWaves, MAXO = kTileOffsetsPerWave, DB = T / 16 / NW;  // DB: dense blocks per wave
+  constexpr int NW = kTileWaves, MAXO = (T <= 256 && KD >= 128) ? 2 : kTileOffsetsPerWave, DB = T / 16 / NW;  // DB: dense blocks per wave
   static_assert(KD % 32 == 0 && NC % 16 == 0 && T % (16 * NW) == 0, "tile kernel shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;  // [T][LDT] f32 accumulators
   // the 16 (input row, tile row) pairs of the MFMA block a wave is about to multiply, per offset slot
-  constexpr int FB = (T <= 256 && NC <= 64 && KD <= 64) ? 1 : 2;  // blocks per offset whose rows are gathered ahead (mean 15 rows per offset and tile: a second
+  constexpr int FB = (T <= 256 && NC <= 64) ? 1 : 2;  // blocks per offset whose rows are gathered ahead (mean 15 rows per offset and tile: a second
                           // block for a third of the offsets; past FB blocks an offset goes block by block)
   __shared__ int32_t sl_in[NW][MAXO][16 * FB];
   __shared__ uint16_t sl_row[NW][MAXO][16 * FB];
@@ -189,7 +189,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       }
     // weight fragments: two sets (the next offset's arrive during this one's work) where the registers allow,
     // else one set, re-requested right behind the MFMAs that read it
-    constexpr int WB = (NB * KSTEPS * 4 * 2 + MAXO * FB * KSTEPS * 4 <= 200) ? 2 : 1;
+    constexpr int WB = (NB * KSTEPS * 4 * 2 + MAXO * FB * KSTEPS * 4 <= ((T <= 256 && NC <= 64) ? 80 : 200)) ? 2 : 1;
     if (cnt[0] > 0) load_w(w[0], kk[0]);
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
@@ -291,8 +291,11 @@ int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
     // 256-row tiles, one block per offset gathered ahead: <= 128 registers, so TWO workgroups share a CU and one's
     // load latency hides behind the other's phases (64 -> 32: 19.2 -> 16.5 us, 32 -> 64: 21.1 -> 17.6 us)
     return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
-  } else
+  } else {
+    // (128 input channels at 256 rows: fits 128 registers only with two offsets per wave and pass and one set of
+    // weight fragments -- 30.6 us against 29.5 us for the 512-row tile at one workgroup per CU)
     return launch_tile_t<KD, NC, 512>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+  }
 }
 
 template <int KD>
