@@ -286,6 +286,15 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
 int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                 int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
                                 const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
+/* The same kernel with the LayerNorm (+ GELU) that follows the convolution in the reference's
+ * make_sparse_convmodule block (mmdet3d/ops/sparse_block.py:216-289: conv -> LN(eps) -> GELU) applied in the
+ * epilogue, where the finished f32 row sits in LDS: conv_out [n_out, ncols] bf16 (what the LN backward needs), y =
+ * act(LN(conv_out)) bf16, mean_rstd [n_out, 2] f32.  The norm sees the bf16-rounded conv output, as the separate
+ * ococc_layernorm_act_fwd would.  Shapes up to 64 x 64 channels; OCOCC_EUNSUPPORTED otherwise. */
+int ococc_sparse_conv_tile_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
+                                   int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
+                                   const float* gamma, const float* beta, float eps, int32_t act,
+                                   uint16_t* conv_out, uint16_t* y, float* mean_rstd, ococc_stream_t stream);
 
 /* weights [kvol, cin, cout] (the reference layout (kD,kH,kW,Cin,Cout),
  * spconv/conv.py:98-99) in f32 or bf16 ->

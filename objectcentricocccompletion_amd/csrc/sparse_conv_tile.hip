@@ -41,11 +41,25 @@ constexpr int kTileThreads = 512;
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
 
-template <int KD, int NC, int T, bool OUT_BF16>
+// LayerNorm (+ GELU) of the enclosing conv -> norm -> act block in the epilogue: the finished f32 row sits in LDS, so
+// the statistics cost three lane exchanges and the separate LN launch (one read of the conv output) disappears.
+// As in the unfused pair of kernels the norm sees the bf16-rounded conv output.
+struct TileLn {
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int act;           // 0 none, 1 GELU(erf)
+  uint16_t* y;       // [n_out, NC] bf16
+  float* mean_rstd;  // [n_out, 2]
+};
+__device__ __forceinline__ float tile_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float tile_round_bf16(float v) { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); }
+
+template <int KD, int NC, int T, bool OUT_BF16, bool LN = false>
 __global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64) ? 4 : 1)
 subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn,
                       int kvol, int dense_k, const int32_t* __restrict__ table, int64_t n_out,
-                      const float* __restrict__ bias, void* __restrict__ out_) {
+                      const float* __restrict__ bias, void* __restrict__ out_, TileLn ln) {
   constexpr int KSTEPS = KD / 32, NB = NC / 16, LDT = NC + 4, U = T / 64;
   constexpr int NW = kTileWaves, MAXO = (T <= 256 && KD >= 128) ? 2 : kTileOffsetsPerWave, DB = T / 16 / NW;  // DB: dense blocks per wave
   static_assert(KD % 32 == 0 && NC % 16 == 0 && T % (16 * NW) == 0, "tile kernel shape");
@@ -242,12 +256,12 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     __syncthreads();
   }
 
-  // ---- epilogue: tile -> global, 8 channels (16 bytes of bf16) per thread ----
+  // ---- epilogue: tile -> global, 8 channels (16 bytes of bf16) per thread; a row is NC / 8 consecutive lanes ----
   for (int i = threadIdx.x; i < T * (NC / 8); i += kTileThreads) {
     const int r = i / (NC / 8), c8 = i % (NC / 8);
     const int64_t row = row0 + r;
-    if (row >= n_out) continue;
-    const f32x4 v0 = *(const f32x4*)(tile + r * LDT + c8 * 8), v1 = *(const f32x4*)(tile + r * LDT + c8 * 8 + 4);
+    if (row >= n_out) continue;  // (whole rows leave together: the lane exchanges below stay inside a row)
+    f32x4 v0 = *(const f32x4*)(tile + r * LDT + c8 * 8), v1 = *(const f32x4*)(tile + r * LDT + c8 * 8 + 4);
     if (OUT_BF16) {
       u32x4 q;
       q.x = (uint32_t)ococc_f32_to_bf16(v0.x) | ((uint32_t)ococc_f32_to_bf16(v0.y) << 16);
@@ -259,24 +273,75 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       *(f32x4*)((float*)out_ + row * NC + c8 * 8) = v0;
       *(f32x4*)((float*)out_ + row * NC + c8 * 8 + 4) = v1;
     }
+    if constexpr (LN) {
+      float z[8];
+      float rs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        z[j] = tile_round_bf16(v0[j]);
+        z[4 + j] = tile_round_bf16(v1[j]);
+        rs += z[j] + z[4 + j];
+      }
+#pragma unroll
+      for (int d = 1; d < NC / 8; d <<= 1) rs += __shfl_xor(rs, d, 64);
+      const float mean = rs * (1.f / NC);
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dlt = z[j] - mean;
+        sq += dlt * dlt;
+      }
+#pragma unroll
+      for (int d = 1; d < NC / 8; d <<= 1) sq += __shfl_xor(sq, d, 64);
+      const float rstd = rsqrtf(sq * (1.f / NC) + ln.eps);
+      const f32x4 g0 = *(const f32x4*)(ln.gamma + c8 * 8), g1 = *(const f32x4*)(ln.gamma + c8 * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(ln.beta + c8 * 8), b1 = *(const f32x4*)(ln.beta + c8 * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t0 = (z[j] - mean) * rstd * g0[j] + b0[j];
+        const float t1 = (z[4 + j] - mean) * rstd * g1[j] + b1[j];
+        z[j] = ln.act == 1 ? tile_gelu(t0) : t0;
+        z[4 + j] = ln.act == 1 ? tile_gelu(t1) : t1;
+      }
+      u32x4 q;
+      q.x = (uint32_t)ococc_f32_to_bf16(z[0]) | ((uint32_t)ococc_f32_to_bf16(z[1]) << 16);
+      q.y = (uint32_t)ococc_f32_to_bf16(z[2]) | ((uint32_t)ococc_f32_to_bf16(z[3]) << 16);
+      q.z = (uint32_t)ococc_f32_to_bf16(z[4]) | ((uint32_t)ococc_f32_to_bf16(z[5]) << 16);
+      q.w = (uint32_t)ococc_f32_to_bf16(z[6]) | ((uint32_t)ococc_f32_to_bf16(z[7]) << 16);
+      *(u32x4*)(ln.y + row * NC + c8 * 8) = q;
+      if (c8 == 0) {
+        ln.mean_rstd[row * 2] = mean;
+        ln.mean_rstd[row * 2 + 1] = rstd;
+      }
+    }
   }
 }
 
 template <int KD, int NC, int T>
 int launch_tile_t(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
-                  int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
+                  int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream,
+                  const TileLn* ln = nullptr) {
   constexpr size_t lds = (size_t)T * (NC + 4) * 4;
   const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, T), 8));
-  if (out_dtype == OCOCC_BF16) {
+  if (ln) {
+    if constexpr (NC <= 64 && KD <= 64) {
+      auto fn = subm_tile_conv_kernel<KD, NC, T, true, true>;
+      OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
+                         table, n_out, bias, out, *ln);
+    } else {
+      return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused LayerNorm epilogue: shapes up to 64 x 64 channels");
+    }
+  } else if (out_dtype == OCOCC_BF16) {
     auto fn = subm_tile_conv_kernel<KD, NC, T, true>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
-                       table, n_out, bias, out);
+                       table, n_out, bias, out, TileLn{});
   } else {
     auto fn = subm_tile_conv_kernel<KD, NC, T, false>;
     OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
-                       table, n_out, bias, out);
+                       table, n_out, bias, out, TileLn{});
   }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
@@ -284,31 +349,32 @@ int launch_tile_t(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kv
 
 template <int KD, int NC>
 int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
-                int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
+                int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream,
+                const TileLn* ln = nullptr) {
   if constexpr (NC >= 128)
-    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
   else if constexpr (KD <= 64) {
     // 256-row tiles, one block per offset gathered ahead: <= 128 registers, so TWO workgroups share a CU and one's
     // load latency hides behind the other's phases (64 -> 32: 19.2 -> 16.5 us, 32 -> 64: 21.1 -> 17.6 us)
-    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    return launch_tile_t<KD, NC, 256>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
   } else {
     // (128 input channels at 256 rows: fits 128 registers only with two offsets per wave and pass and one set of
     // weight fragments -- 30.6 us against 29.5 us for the 512-row tile at one workgroup per CU)
-    return launch_tile_t<KD, NC, 512>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    return launch_tile_t<KD, NC, 512>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
   }
 }
 
 template <int KD>
 int dispatch_tile_nc(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, int dense_k,
                      const int32_t* table, int64_t n_out, const float* bias, void* out, int out_dtype,
-                     hipStream_t stream) {
+                     hipStream_t stream, const TileLn* ln = nullptr) {
   switch (ncols) {
-    case 32: return launch_tile<KD, 32>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
-    case 64: return launch_tile<KD, 64>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 32: return launch_tile<KD, 32>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
+    case 64: return launch_tile<KD, 64>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
     case 128:
       // (128 x 128: two sets of weight fragments alone are 256 registers)
       if constexpr (KD <= 64)
-        return launch_tile<KD, 128>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream);
+        return launch_tile<KD, 128>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
       else
         return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "128 x 128 channels: use ococc_sparse_conv_gather_gemm_bf16");
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "ncols must be 32/64/128");
@@ -317,11 +383,10 @@ int dispatch_tile_nc(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int
 
 }  // namespace
 
-extern "C" int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
-                                           int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
-                                           int64_t n_out, const float* bias, void* out, int32_t out_dtype,
-                                           ococc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+int tile_entry(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol, int32_t ncols,
+               const int32_t* table, int32_t dense_k, int64_t n_out, const float* bias, void* out, int32_t out_dtype,
+               hipStream_t stream, const TileLn* ln) {
   OCOCC_REQUIRE(n_in >= 0 && n_out >= 0, "negative row count");
   OCOCC_REQUIRE(kvol >= 1, "kernel volume must be >= 1");
   OCOCC_REQUIRE(dense_k >= -1 && dense_k < kvol, "dense_k must be -1 or an offset index");
@@ -331,9 +396,30 @@ extern "C" int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, i
   OCOCC_REQUIRE(feat || n_in == 0, "null feat");
   OCOCC_REQUIRE(n_in * kd * 2 < 0xffffff00ll, "feat too large for the 32-bit buffer offsets of the gathers");
   switch (kd) {
-    case 32: return dispatch_tile_nc<32>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
-    case 64: return dispatch_tile_nc<64>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
-    case 128: return dispatch_tile_nc<128>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream);
+    case 32: return dispatch_tile_nc<32>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
+    case 64: return dispatch_tile_nc<64>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
+    case 128: return dispatch_tile_nc<128>(feat, n_in, wn, kvol, ncols, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 32/64/128");
   }
+}
+}  // namespace
+
+extern "C" int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                           int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
+                                           int64_t n_out, const float* bias, void* out, int32_t out_dtype,
+                                           ococc_stream_t stream_) {
+  return tile_entry(feat, n_in, kd, wn, kvol, ncols, table, dense_k, n_out, bias, out, out_dtype,
+                    (hipStream_t)stream_, nullptr);
+}
+
+extern "C" int ococc_sparse_conv_tile_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                              int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
+                                              int64_t n_out, const float* gamma, const float* beta, float eps,
+                                              int32_t act, uint16_t* conv_out, uint16_t* y, float* mean_rstd,
+                                              ococc_stream_t stream_) {
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(n_out == 0 || (gamma && beta && y && mean_rstd), "null pointer");
+  const TileLn ln{gamma, beta, eps, act, y, mean_rstd};
+  return tile_entry(feat, n_in, kd, wn, kvol, ncols, table, dense_k, n_out, nullptr, conv_out, OCOCC_BF16,
+                    (hipStream_t)stream_, &ln);
 }

@@ -72,6 +72,13 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
+    def _ln_wanted(self, indice_pairs, indice_pair_num, num_out):
+        from . import modules as _m
+        from . import ops as _ops
+        kind = _ops.ln_fusion_kind(indice_pairs, indice_pair_num, num_out, self.inverse, self.subm,
+                                   self.in_channels, self.out_channels)
+        return _m.FUSE_CONV_LN or (kind == 'tile' and _m.FUSE_TILE_CONV_LN)
+
     def _ln_fusable(self, features):
         import torch
         from . import ops as _ops
@@ -131,7 +138,8 @@ class SparseConvolution(SparseModule):
                                                  indice_pair_num, outids.shape[0], self.inverse,
                                                  self.subm)
         else:
-            if _ln is not None and self.bias is None and self._ln_fusable(features):
+            if _ln is not None and self.bias is None and self._ln_fusable(features) and self._ln_wanted(
+                    indice_pairs, indice_pair_num, outids.shape[0]):
                 # norm (+ GELU) of the enclosing make_sparse_convmodule, fused into the conv epilogue
                 out_features = Fsp.indice_conv_ln(features, self.weight, _ln.weight, _ln.bias, indice_pairs,
                                                   indice_pair_num, outids.shape[0], _ln.eps,

@@ -22,11 +22,16 @@ def is_spconv_module(module):
 # what the separate LN kernel costs (the workgroups of the conv kernel reach their epilogue together, so the
 # extra erf / statistics work is not hidden behind anyone's MFMA phase) -- 560 vs 551 us of kernels per step.
 FUSE_CONV_LN = os.environ.get('OCOCC_FUSE_CONV_LN', '0') == '1'
+# The tile kernel (csrc/sparse_conv_tile.hip) is the exception: its epilogue has the whole f32 row in LDS, the
+# statistics are three lane exchanges, and the layer's separate LN launch (10.8 us on the 32 -> 64 layer of
+# configs[1]) disappears.  On by default for the layers that run on that kernel.
+FUSE_TILE_CONV_LN = os.environ.get('OCOCC_FUSE_TILE_CONV_LN', '1') == '1'
 
 
 def _is_fusable_norm(module):
     from ..norm import LayerNorm
-    return FUSE_CONV_LN and isinstance(module, LayerNorm) and module.fused_act in ('none', 'gelu')
+    return (FUSE_CONV_LN or FUSE_TILE_CONV_LN) and isinstance(module, LayerNorm) \
+        and module.fused_act in ('none', 'gelu')
 
 
 class SparseSequential(SparseModule):

@@ -404,6 +404,20 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     return out if nc == cout else out[:, :cout].contiguous()
 
 
+def _tile_ln_shape(cin, cout):
+    return cin in (32, 64) and cout in (32, 64)  # instantiations of ococc_sparse_conv_tile_ln_bf16
+
+
+def ln_fusion_kind(indice_pairs, indice_pair_num, num_activate_out, inverse, subm, cin, cout):
+    """Which kernel a conv -> LayerNorm(+GELU) block would fuse into: 'tile' (the compact-then-multiply kernel has
+    the finished f32 row in LDS: the epilogue is nearly free and the separate LN launch disappears) or 'stationary'
+    (the output-stationary kernels: measured no faster than the two launches, opt-in)."""
+    if not subm or not _tile_ln_shape(cin, cout):
+        return 'stationary'
+    rb, _ = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd', int(num_activate_out), subm)
+    return 'tile' if _use_tile_kernel(rb, cin, cout) else 'stationary'
+
+
 def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indice_pair_num, num_activate_out,
                    inverse=False, subm=False, _saved=None):
     """indice_conv with the LayerNorm(+GELU) that follows it in make_sparse_convmodule fused into the
@@ -416,15 +430,22 @@ def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indic
     rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd',
                                           int(num_activate_out), subm)
     x = _to_bf16_padded(features, cin)
-    wn = _prep_weights(filters, 0, cin, cout)
+    tile = subm and _tile_ln_shape(cin, cout) and _use_tile_kernel(rb, cin, cout)
+    wn = _prep_weights(filters, 4 if tile else 0, cin, cout)
     conv_out = torch.empty((rows, cout), dtype=torch.bfloat16, device=x.device)
     y = torch.empty_like(conv_out)
     stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
     g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
     kvol = wn.shape[0]
-    rc = L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
-                                                     L.ptr(mask), rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
-                                                     L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
+    if tile:
+        rc = L.lib.ococc_sparse_conv_tile_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
+                                                  kvol // 2, rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
+                                                  L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
+    else:
+        rc = L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout,
+                                                         L.ptr(table), L.ptr(mask), rows, L.ptr(g32), L.ptr(b32),
+                                                         float(eps), int(act), L.ptr(conv_out), L.ptr(y),
+                                                         L.ptr(stats), L.stream())
     if rc == -3:  # OCOCC_EUNSUPPORTED: no fused kernel for this shape
         return None
     L.check(rc, 'sparse_conv_gather_gemm_ln')

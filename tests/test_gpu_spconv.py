@@ -374,8 +374,8 @@ def test_fused_conv_ln_gelu_matches_unfused(dev, cin, cout):
     dout = torch.randn(idx.shape[0], cout, generator=g).to(dev).bfloat16()
     res = []
     for fused in (True, False):
-        orig = spm.FUSE_CONV_LN
-        spm.FUSE_CONV_LN = fused
+        orig, orig_tile = spm.FUSE_CONV_LN, spm.FUSE_TILE_CONV_LN
+        spm.FUSE_CONV_LN = spm.FUSE_TILE_CONV_LN = fused
         try:
             x = feats.clone().requires_grad_(True)
             block.zero_grad(set_to_none=True)
@@ -383,7 +383,7 @@ def test_fused_conv_ln_gelu_matches_unfused(dev, cin, cout):
             y.backward(dout)
             res.append((y.detach().float(), x.grad.float(), [p.grad.float().clone() for p in block.parameters()]))
         finally:
-            spm.FUSE_CONV_LN = orig
+            spm.FUSE_CONV_LN, spm.FUSE_TILE_CONV_LN = orig, orig_tile
     (yf, gxf, gpf), (yu, gxu, gpu) = res
     assert float((yf - yu).abs().max()) <= 2e-2 * float(yu.abs().max())      # bf16 outputs: <= 1-2 ulp apart
     assert float((yf - yu).abs().mean()) <= 1e-3 * float(yu.abs().max())

@@ -92,3 +92,91 @@ def test_density_hint_selects_the_kernel(dev):
     assert ops._use_tile_kernel(rb, 128, 64) and not ops._use_tile_kernel(rb, 64, 32)
     ops.set_rulebook_density(pairs, 11.0)
     assert not ops._use_tile_kernel(rb, 128, 64)
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 64), (64, 32), (32, 32), (64, 64)])
+@pytest.mark.parametrize('act', [0, 1])
+def test_tile_kernel_layernorm_epilogue(dev, cin, cout, act):
+    """ococc_sparse_conv_tile_ln_bf16 = ococc_sparse_conv_tile_bf16 followed by ococc_layernorm_act_fwd: the conv
+    output bit for bit, the statistics to f32 rounding, the activated output within one bf16 step; rows past the
+    last full tile and a row count that is no multiple of anything."""
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.spconv import ops
+    shape = [12, 10, 11]
+    coors = _scene(dev, 5, shape, 0.05, seed=3 * cin + cout)
+    n = coors.shape[0]
+    _, pairs, num = ops.get_indice_pairs(coors, 5, shape, 3, subm=True)
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.1).to(dev)
+    x = torch.randn(n, cin, generator=g).to(dev).bfloat16()
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    beta = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    ops.SPARSE_TILE_CONV = True
+    try:
+        conv = ops.indice_conv(x, w, pairs, num, n, False, True)
+        fused = ops.indice_conv_ln(x, w, gamma, beta, 1e-3, act, pairs, num, n, False, True)
+    finally:
+        ops.SPARSE_TILE_CONV = None
+    assert fused is not None
+    conv_out, y, stats = fused
+    assert torch.equal(conv_out, conv)
+    y_ref = torch.empty_like(conv)
+    stats_ref = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(conv), n, cout, L.ptr(gamma), L.ptr(beta), 1e-3, act, L.ptr(y_ref),
+                                          L.ptr(stats_ref), L.BF16, L.stream()), 'ln')
+    torch.cuda.synchronize()
+    assert float((stats - stats_ref).abs().max()) <= 1e-4 * float(stats_ref.abs().max())
+    d = (y.float() - y_ref.float()).abs()
+    assert float(d.max()) <= 2e-2 * float(y_ref.float().abs().max())          # <= one bf16 step at the top value
+    assert float((d > 0).float().mean()) < 0.02                                # and only where a rounding tie flips
+    # refused outside its shapes
+    assert L.lib.ococc_sparse_conv_tile_ln_bf16(L.ptr(x), n, 128, L.ptr(x), 27, 64, L.ptr(x), 13, n, L.ptr(gamma),
+                                                L.ptr(beta), 1e-3, act, L.ptr(conv_out), L.ptr(y), L.ptr(stats),
+                                                L.stream()) == -3
+
+
+def test_block_fuses_layernorm_only_on_the_tile_kernel(dev):
+    """make_sparse_convmodule(SubMConv3d -> LN -> GELU): with the tile kernel selected the norm runs in the conv
+    epilogue (default), else as its own launch; both equal the unfused block (values and gradients)."""
+    from objectcentricocccompletion_amd.sparse_block import make_sparse_convmodule
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, ops
+    from objectcentricocccompletion_amd.spconv import modules as spm
+    torch.manual_seed(4)
+    shape = [12, 10, 11]
+    coors = _scene(dev, 4, shape, 0.05, seed=9)
+    n = coors.shape[0]
+    block = make_sparse_convmodule(32, 64, 3, 'k', padding=1, conv_type='SubMConv3d', act_type='gelu',
+                                   norm_cfg=dict(type='LN', eps=1e-3)).to(dev)
+    feats = torch.randn(n, 32, device=dev).bfloat16()
+    dout = torch.randn(n, 64, device=dev).bfloat16()
+    calls = []
+    real = ops.indice_conv_ln
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    res = {}
+    orig = (spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN)
+    ops.indice_conv_ln = spy
+    try:
+        for name, tile, fuse in (('tile_fused', True, True), ('tile_unfused', True, False), ('stationary', False, True)):
+            ops.SPARSE_TILE_CONV, spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN = tile, fuse, False
+            del calls[:]
+            xin = feats.clone().requires_grad_(True)
+            block.zero_grad(set_to_none=True)
+            y = block(SparseConvTensor(xin, coors, shape, 4)).features
+            y.backward(dout)
+            torch.cuda.synchronize()
+            res[name] = (len(calls), y.detach().float(), xin.grad.float(), [p.grad.float().clone() for p in block.parameters()])
+    finally:
+        ops.indice_conv_ln = real
+        ops.SPARSE_TILE_CONV = None
+        spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN = orig
+    assert res['tile_fused'][0] == 1 and res['tile_unfused'][0] == 0 and res['stationary'][0] == 0
+    _, yu, gxu, gpu = res['tile_unfused']
+    _, yf, gxf, gpf = res['tile_fused']
+    assert float((yf - yu).abs().max()) <= 2e-2 * float(yu.abs().max())
+    assert float((gxf - gxu).abs().max()) <= 2e-2 * float(gxu.abs().max())
+    for a, b in zip(gpf, gpu):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
