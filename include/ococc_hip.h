@@ -464,9 +464,11 @@ int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc
  * configs/ococc/ococcnet.py:468-470).  params / grads / exp_avg / exp_avg_sq are HOST arrays of
  * num_tensors (<= 48) device pointers to contiguous f32 tensors of numel[i] elements.  `step` is a
  * DEVICE float holding the number of steps taken so far: the kernel uses step + 1 for the bias
- * corrections; with bump_step != 0 a one-thread kernel queued behind it stores step + 1 (pass 0 on all
+ * corrections; with bump_step = 1 a one-thread kernel queued behind it stores step + 1 (pass 0 on all
  * but the last call when one optimizer step needs several calls), so the sequence can be replayed from
- * a captured HIP graph.
+ * a captured HIP graph.  bump_step = 2: `step` points to {float count; uint32 ticket}, ticket zero before
+ * the first call; launches of up to 2048 workgroups (2 M elements) then store count + 1 from their last
+ * workgroup instead of a second launch (larger ones fall back to the one-thread kernel).
  * ------------------------------------------------------------------------------------------- */
 int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
                     void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel, float lr,

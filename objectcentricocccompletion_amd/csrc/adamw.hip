@@ -12,6 +12,7 @@ namespace {
 
 constexpr int kMaxTensors = 48;
 constexpr int kElemsPerBlock = 256 * 4;
+constexpr int kTicketMaxBlocks = 2048;
 
 struct AdamPack {
   float* p[kMaxTensors];
@@ -25,10 +26,12 @@ struct AdamPack {
 
 __global__ void __launch_bounds__(256)
 adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float wd,
-             const float* __restrict__ step) {
-  // the step count is bumped by a one-thread kernel queued behind this one (a last-block-done ticket
-  // would serialise one same-address atomic per workgroup: ~0.5 ms for the 66 M parameters of OcOccNet)
-  const float t = *step + 1.f;
+             float* step, uint32_t* ticket) {
+  // The step count is bumped either by a one-thread kernel queued behind this one, or -- `ticket` given, small
+  // launches only -- by the LAST workgroup to finish: every workgroup has read the old count by the time it
+  // takes its ticket, so the store cannot be seen by this launch.  (One same-address atomic per workgroup:
+  // nothing for the 300 workgroups of the encoder, ~0.5 ms for the 66 M parameters of OcOccNet, hence the choice.)
+  const float t = *(const volatile float*)step + 1.f;
   // binary search of this block's tensor (the table sits in kernel-argument memory: every probe is a
   // dependent scalar load, so a linear walk over 48 entries costs microseconds per block)
   int lo = 0, hi = pk.count - 1;
@@ -77,6 +80,16 @@ adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float w
       p[i] = pj; m[i] = mj; v[i] = vj;
     }
   }
+  if (ticket) {
+    __syncthreads();  // (every thread of the workgroup is past its read of *step: it sits in front of the barrier above)
+    if (threadIdx.x == 0) {
+      const uint32_t got = atomicAdd(ticket, 1u);
+      if (got == gridDim.x - 1) {
+        *ticket = 0;  // ready for the next launch (stream order)
+        *step = t;
+      }
+    }
+  }
 }
 
 __global__ void adamw_bump_kernel(float* step) { *step += 1.f; }
@@ -90,6 +103,7 @@ extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const v
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE(num_tensors >= 0, "negative tensor count");
   OCOCC_REQUIRE(step, "step must be a device pointer");
+  OCOCC_REQUIRE(bump_step >= 0 && bump_step <= 2, "bump_step must be 0, 1 or 2");
   if (num_tensors == 0) return OCOCC_OK;
   OCOCC_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, "null pointer table");
   OCOCC_REQUIRE(num_tensors <= kMaxTensors, "at most 48 tensors per call (split the parameter list)");
@@ -111,10 +125,12 @@ extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const v
   if (cnt == 0) return OCOCC_OK;
   pk.first_block[cnt] = blocks;
   pk.count = cnt;
+  // bump_step 2: `step` points to {float count; uint32 ticket (zero)}; the last workgroup stores count + 1
+  const bool in_kernel = bump_step == 2 && blocks <= kTicketMaxBlocks;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, pk, lr, beta1, beta2, eps,
-                     weight_decay, (const float*)step);
+                     weight_decay, step, in_kernel ? (uint32_t*)(step + 1) : (uint32_t*)nullptr);
   OCOCC_CHECK_LAUNCH();
-  if (bump_step) {
+  if (bump_step && !in_kernel) {
     hipLaunchKernelGGL(adamw_bump_kernel, dim3(1), dim3(1), 0, stream, step);
     OCOCC_CHECK_LAUNCH();
   }

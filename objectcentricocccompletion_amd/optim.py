@@ -29,7 +29,7 @@ class AdamW(torch.optim.Optimizer):
                 st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         if 'step_dev' not in group:
             dev = group['params'][0].device
-            group['step_dev'] = torch.zeros(1, dtype=torch.float32, device=dev)
+            group['step_dev'] = torch.zeros(2, dtype=torch.float32, device=dev)  # {count, ticket of the kernel}
 
     def init_state(self):
         """Allocate the moment buffers and the device step counter now (call before capturing
@@ -68,7 +68,7 @@ class AdamW(torch.optim.Optimizer):
                     arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
                     (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']), float(b1),
                     float(b2), float(group['eps']), float(group['weight_decay']), group['step_dev'].data_ptr(),
-                    int(last), L.stream()), 'adamw')
+                    2 if last else 0, L.stream()), 'adamw')
             for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
                 torch.autograd.graph.increment_version(p)
         return loss
