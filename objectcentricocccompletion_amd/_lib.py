@@ -164,7 +164,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device (the raw accessor: building a torch.cuda.Stream
+    object per kernel launch cost ~11 us of host time, 1.4 ms per OcOccNet step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
