@@ -14,6 +14,10 @@ the tensor it is given instead of adding to an existing one), no tensor or post-
 create_graph, not already queued in this pass (a shared weight would be summed by the engine's input buffer) --
 and `_flush` re-checks the outcome: a .grad that is not the handed-out buffer (the engine cloned it) is
 overwritten with the finished values.  Everything else takes the immediate per-layer reduction.
+
+Not covered: a parameter used twice in one pass WITH a nested backward (reentrant activation checkpointing) between
+its two uses -- the nested pass's flush forgets that the first use is still waiting in the engine's input buffer.
+Set OCOCC_DEFER_PARAM_REDUCE=0 for such models.
 """
 import os
 
