@@ -189,3 +189,45 @@ def test_tile_conv_adjoint_identities_full_size(dev, scene, cin, cout):
     lhs = float((y.double() * dy.double()).sum())
     rhs = float((x.double() * dx.double()).sum())
     assert abs(lhs - rhs) <= 2e-2 * max(abs(lhs), abs(rhs), 1.0) + 1e-2 * float(y.abs().max()) * n ** 0.5
+
+
+def test_tile_conv_layernorm_epilogue_full_size(dev, scene):
+    """The 32 -> 64 layer of the benchmark with LayerNorm + GELU in the tile kernel's epilogue, at full size:
+    run-to-run identical, conv output identical to the plain tile kernel, every output row normalised (the
+    pre-activation recomputed from the returned statistics has zero mean / unit variance per row), and the
+    statistics equal to those of the separate LayerNorm kernel."""
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.spconv import ops
+    from objectcentricocccompletion_amd.voxel.scatter_points import grid_unique
+    _, _, _, coors = scene
+    uc, _, _ = grid_unique(coors, [B] + SHAPE)
+    n = uc.shape[0]
+    _, pairs, num = ops.get_indice_pairs(uc, B, SHAPE, 3, subm=True)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 32, generator=g).to(dev).bfloat16()
+    w = (torch.randn(3, 3, 3, 32, 64, generator=g) * 0.05).to(dev)
+    gamma = torch.ones(64, device=dev)
+    beta = torch.zeros(64, device=dev)
+    ops.SPARSE_TILE_CONV = True
+    try:
+        conv = ops.indice_conv(x, w, pairs, num, n, False, True)
+        a = ops.indice_conv_ln(x, w, gamma, beta, 1e-3, 0, pairs, num, n, False, True)
+        b = ops.indice_conv_ln(x, w, gamma, beta, 1e-3, 0, pairs, num, n, False, True)
+    finally:
+        ops.SPARSE_TILE_CONV = None
+    for t, u in zip(a, b):
+        assert torch.equal(t, u)
+    conv_out, y, stats = a
+    assert torch.equal(conv_out, conv)
+    z = (conv_out.float() - stats[:, :1]) * stats[:, 1:]              # act = none, gamma = 1, beta = 0: z == y
+    assert float(z.mean(1).abs().max()) <= 1e-4
+    var = z.var(1, unbiased=False)
+    nz = conv_out.float().var(1, unbiased=False) > 1e-2              # (rows of ~zero variance are dominated by eps)
+    assert float((var[nz] - 1).abs().max()) <= 0.1
+    assert float((y.float() - z).abs().max()) <= 2e-2 * float(z.abs().max())
+    ref_y = torch.empty_like(conv)
+    ref_stats = torch.empty_like(stats)
+    L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(conv), n, 64, L.ptr(gamma), L.ptr(beta), 1e-3, 0, L.ptr(ref_y),
+                                          L.ptr(ref_stats), L.BF16, L.stream()), 'ln')
+    torch.cuda.synchronize()
+    assert float((stats - ref_stats).abs().max()) <= 1e-4 * float(ref_stats.abs().max())
