@@ -44,8 +44,10 @@ PMC_JSON = 'r01_pmc_gather_gemm_stream_64_128.json'
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed steps (default 500 for the 0.35 ms submconv step -- a 17 ms timed region of 50 steps '
+                         'moved by 10 %% with one scheduling hiccup of the host -- and 50 for the other workloads)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default 20 / 10)')
     ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
     ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -58,7 +60,12 @@ def parse():
                     help='use the N>1 launch plan (fwd+bwd graph, eager all-reduce, optimizer graph) at N=1 too')
     ap.add_argument('--no-graph', action='store_true',
                     help='launch every kernel eagerly from Python instead of replaying the captured HIP graph')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 500 if args.workload == 'submconv' else 50
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == 'submconv' else 10
+    return args
 
 
 def cpu_baseline(sample_grids, points, model):

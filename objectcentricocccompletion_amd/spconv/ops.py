@@ -410,8 +410,11 @@ def _tile_ln_shape(cin, cout):
 
 def ln_fusion_kind(indice_pairs, indice_pair_num, num_activate_out, inverse, subm, cin, cout):
     """Which kernel a conv -> LayerNorm(+GELU) block would fuse into: 'tile' (the compact-then-multiply kernel has
-    the finished f32 row in LDS: the epilogue is nearly free and the separate LN launch disappears) or 'stationary'
-    (the output-stationary kernels: measured no faster than the two launches, opt-in)."""
+    the finished f32 row in LDS: the epilogue is nearly free and the separate LN launch disappears), 'first' (the
+    16 -> 32 input layer, measured ahead fused) or 'stationary' (the other output-stationary kernels: measured no
+    faster than the two launches, opt-in)."""
+    if (cin, cout) == (16, 32):
+        return 'first'  # the resident-weights kernel at two 16-row blocks per wave: 19.9 us against 15.5 + 7.4 us
     if not subm or not _tile_ln_shape(cin, cout):
         return 'stationary'
     rb, _ = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd', int(num_activate_out), subm)
