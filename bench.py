@@ -466,6 +466,16 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     sp_ops.set_probe(None)
+    # host cost of queueing one step on an idle device (one hipGraphLaunch, or the eager launch sequence): when it
+    # approaches ms_per_step the number above is the host's, not the GPU's
+    host_us = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        step()
+        host_us.append((time.perf_counter() - h0) * 1e6)
+    torch.cuda.synchronize()
+    host_us = sorted(host_us)[len(host_us) // 2]
     if use_graph:
         sp_ops.set_probe(probe)
         for _ in range(min(args.steps, 20)):
@@ -503,6 +513,7 @@ def main():
                             'channels 16-32-64-128, LN+GELU, bf16 features',
                 'grids_per_gpu': B, 'points_per_grid': P, 'active_voxels': n_vox,
                 'rulebook_pairs': n_pairs, 'parallelism': f'dp{world}', 'launch': graph_note,
+                'host_us_to_queue_one_step': round(host_us, 1),
             },
             'roofline': {
                 'kernel': 'gather_gemm_stream_kernel<64,128,true> (SubMConv3d 64->128 forward: gathers X[.,64], writes Y[.,128])',
