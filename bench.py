@@ -530,7 +530,7 @@ def main():
                             'eager steps after the timed graph replays, 8 back-to-back launches per event pair',
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier)
             res['cpu_baseline'] = cpu_baseline(4, P, model)
         print(json.dumps(res), flush=True)
     if world > 1:
