@@ -390,3 +390,59 @@ def test_fused_conv_ln_gelu_matches_unfused(dev, cin, cout):
     assert float((gxf - gxu).abs().max()) <= 2e-2 * float(gxu.abs().max())
     for a, b in zip(gpf, gpu):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
+
+
+# ---------------------------------------------------------------- vectors from the reference's own geometry.h
+def _golden_rulebook(golden_dir, name):
+    import os
+    g = np.load(os.path.join(golden_dir, 'rulebook.npz'))
+    idx, num = g[name + '_indices'], g[name + '_num']
+    pairs = np.full((len(num), 2, len(idx)), -1, np.int32)
+    o = 0
+    for k, c in enumerate(num):
+        pairs[k, 0, :c] = g[name + '_pairs_in'][o:o + c]
+        pairs[k, 1, :c] = g[name + '_pairs_out'][o:o + c]
+        o += c
+    return g, idx, pairs, num
+
+
+@pytest.mark.parametrize('name', ['bench40', 'bench80', 'shuffled', 'dilated', 'k133'])
+def test_subm_rulebook_equals_reference_geometry_h(dev, golden_dir, name):
+    """ops.get_indice_pairs(subm=True) == spconv::getIndicePairsSubM (geometry.h:247-297, compiled from the
+    reference by oracle/Makefile; tests/golden/rulebook.npz): counts, pairs, pair ORDER and the -1 fill."""
+    from objectcentricocccompletion_amd.spconv import ops
+    g, idx, ep, en = _golden_rulebook(golden_dir, name)
+    outids, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), int(g[name + '_batch']),
+                                              g[name + '_shape'].tolist(), g[name + '_ksize'].tolist(), 1, 0,
+                                              g[name + '_dilation'].tolist(), 0, subm=True)
+    assert np.array_equal(num.cpu().numpy(), en)
+    assert np.array_equal(pairs.cpu().numpy(), ep)
+    assert torch.equal(outids.cpu(), torch.from_numpy(idx))
+
+
+@pytest.mark.parametrize('name', ['down_k3s2p1', 'down_k2s2p0', 'down_aniso', 's1p0', 'up_k3s2p1', 'up_k2s2p0'])
+def test_regular_rulebook_equals_reference_geometry_h(dev, golden_dir, name):
+    """SparseConv3d / SparseConvTranspose3d rulebooks == getIndicePairsConv / DeConv (geometry.h:144-245): same
+    active outputs, same pairs per offset in the same order; output rows numbered sorted (as the reference's GPU
+    path does through torch::_unique, spconv_ops.h:130) instead of by first appearance (its CPU path)."""
+    from objectcentricocccompletion_amd.spconv import ops
+    g, idx, ep, en = _golden_rulebook(golden_dir, name)
+    tr = bool(g[name + '_transpose'])
+    eo = g[name + '_out_indices']
+    opad = [0, 0, 0]
+    if tr:  # recover the out_padding the generator used from the stored out_shape
+        base = ops.get_deconv_output_size(g[name + '_shape'].tolist(), g[name + '_ksize'].tolist(),
+                                          g[name + '_stride'].tolist(), g[name + '_padding'].tolist(), [1, 1, 1], opad)
+        opad = [int(a - b) for a, b in zip(g[name + '_out_shape'].tolist(), base)]
+    outids, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), int(g[name + '_batch']),
+                                              g[name + '_shape'].tolist(), g[name + '_ksize'].tolist(),
+                                              g[name + '_stride'].tolist(), g[name + '_padding'].tolist(),
+                                              g[name + '_dilation'].tolist(), opad, subm=False, transpose=tr)
+    order, perm = _match_sorted(eo)
+    assert np.array_equal(outids.cpu().numpy(), eo[order])
+    assert np.array_equal(num.cpu().numpy(), en)
+    p = pairs.cpu().numpy()
+    for k in range(len(en)):
+        assert np.array_equal(p[k, 0, :en[k]], ep[k, 0, :en[k]])
+        assert np.array_equal(p[k, 1, :en[k]], perm[ep[k, 1, :en[k]]])
+        assert (p[k, :, en[k]:] == -1).all()
