@@ -26,6 +26,11 @@ namespace {
 struct Geom {
   int32_t batch, D, H, W;
   int32_t kd, kh, kw;
+  // generic path (template KS = 0): table entry k = (kz,ky,kx) of row at q is the row at q + start + k * step.
+  // Plain sub-manifold: start = -k/2, step = 1.  Dilated sub-manifold (geometry.h:24-85 with the stride 1 /
+  // padding k/2 the reference forces, spconv_ops.h:66-83): gather side start = -k/2, step = +dilation; scatter side
+  // start = +k/2, step = -dilation -- NOT mirror images of each other unless dilation = 1.
+  int32_t sz, sy, sx, tz, ty, tx;
 };
 
 __device__ __forceinline__ int32_t rank_of(const uint32_t* __restrict__ bitmap,
@@ -88,9 +93,9 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
   int32_t b = -1, z0 = 0, y0 = 0, x0 = 0;
   if (o < n) {
     b = indices[o * 4];
-    z0 = indices[o * 4 + 1] - kd / 2;
-    y0 = indices[o * 4 + 2] - kh / 2;
-    x0 = indices[o * 4 + 3] - kw / 2;
+    z0 = indices[o * 4 + 1] + (KS ? -(KS / 2) : g.sz);
+    y0 = indices[o * 4 + 2] + (KS ? -(KS / 2) : g.sy);
+    x0 = indices[o * 4 + 3] + (KS ? -(KS / 2) : g.sx);
   }
   const bool row_ok = (unsigned)b < (unsigned)g.batch;
   uint32_t mask = 0;
@@ -98,11 +103,12 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
   // add per offset; a negative corner coordinate makes base meaningless but those offsets are masked out
   const int32_t base = row_ok ? ((b * g.D + z0) * g.H + y0) * g.W + x0 : 0;
   auto lookup = [&](int kz, int ky, int kx) -> int32_t {
-    const int32_t z = z0 + kz, y = y0 + ky, x = x0 + kx;
+    const int32_t oz = KS ? kz : kz * g.tz, oy = KS ? ky : ky * g.ty, ox = KS ? kx : kx * g.tx;
+    const int32_t z = z0 + oz, y = y0 + oy, x = x0 + ox;
     int32_t v = -1;
     if (row_ok && (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H &&
         (unsigned)x < (unsigned)g.W) {
-      const int32_t cell = base + (kz * g.H + ky) * g.W + kx;
+      const int32_t cell = base + (oz * g.H + oy) * g.W + ox;
       const int32_t r = rank_of(bitmap, prefix, cell);
       if (r >= 0) v = perm ? perm[r] - 1 : r;  // perm holds row + 1 (0 = empty)
     }
@@ -186,7 +192,8 @@ neighbour_table_kernel(const int32_t* __restrict__ indices, int64_t n, Geom g,
 // one workgroup per offset: exclusive scan of the per-block counts (in place) and the pair count of
 // the reference-format rulebook, indice_num[k] = total of offset kvol-1-k (geometry.h:247-297 order)
 __global__ void __launch_bounds__(256)
-block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t* __restrict__ indice_num) {
+block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t* __restrict__ indice_num,
+                     int flip = 1) {
   __shared__ uint32_t wsum[4];
   const int k = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,18 +219,20 @@ block_offsets_kernel(uint32_t* __restrict__ blk, int64_t nblk, int kvol, int32_t
     carry += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && indice_num) indice_num[kvol - 1 - k] = (int32_t)carry;
+  if (threadIdx.x == 0 && indice_num) indice_num[flip ? kvol - 1 - k : k] = (int32_t)carry;
 }
 
 // pairs[k][0][pos] = j, pairs[k][1][pos] = nbr_t[K-1-k][j]  for valid entries
 __global__ void __launch_bounds__(256)
 compact_pairs_kernel(const int32_t* __restrict__ nbr_t, const uint32_t* __restrict__ blk_off,
                      int64_t n, int kvol, const int32_t* __restrict__ indice_num,
-                     int32_t* __restrict__ pairs, int fill_tails) {
-  // grid (row blocks of 256, kvol): same blocking as neighbour_table_kernel, order preserving
+                     int32_t* __restrict__ pairs, int fill_tails, int flip = 1) {
+  // grid (row blocks of 256, kvol): same blocking as neighbour_table_kernel, order preserving.
+  // flip: the table is the gather side and the scatter side is its mirror image (plain sub-manifold);
+  // !flip: the table already is the scatter side (row j -> its output at offset k)
   __shared__ uint32_t wsum[4];
   const int k = blockIdx.y;
-  const int src = kvol - 1 - k;
+  const int src = flip ? kvol - 1 - k : k;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   // the unused tail of offset k reads -1 (ops.py:46-106 returns a -1 filled tensor); thread j owns slot j
@@ -439,9 +448,14 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
   OCOCC_REQUIRE(n >= 0, "n < 0");
   OCOCC_REQUIRE(make_layout(n, batch_size, host_shape, host_ksize, &L),
                 "need batch>=1, shape>=1, odd kernel sizes, batch*D*H*W < 2^31");
+  int32_t dil[3] = {1, 1, 1};
   if (host_dilation)
-    OCOCC_REQUIRE(host_dilation[0] == 1 && host_dilation[1] == 1 && host_dilation[2] == 1,
-                  "sub-manifold dilation != 1 is not supported");
+    for (int i = 0; i < 3; ++i) {
+      OCOCC_REQUIRE(host_dilation[i] >= 1, "dilation < 1");
+      dil[i] = host_dilation[i];
+    }
+  const bool dilated = dil[0] != 1 || dil[1] != 1 || dil[2] != 1;
+  OCOCC_REQUIRE(!dilated || !grid_bitmap, "the sorted-grid entry point is for dilation 1");
   const int kvol = host_ksize[0] * host_ksize[1] * host_ksize[2];
   OCOCC_REQUIRE(!blockmask || kvol <= 32, "blockmask needs kernel volume <= 32");
   if (n == 0) {
@@ -458,7 +472,8 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
   const int32_t* perm = nullptr;  // identity when the caller's rows are already in cell order
   uint32_t* blk = (uint32_t*)(ws + L.off_pos);
   Geom g{batch_size, host_shape[0], host_shape[1], host_shape[2],
-         host_ksize[0], host_ksize[1], host_ksize[2]};
+         host_ksize[0], host_ksize[1], host_ksize[2],
+         -(host_ksize[0] / 2), -(host_ksize[1] / 2), -(host_ksize[2] / 2), dil[0], dil[1], dil[2]};
   const int64_t nblk = ococc_cdiv(n, 256);
 
   if (!grid_bitmap) {
@@ -482,6 +497,29 @@ int subm_rulebook_impl(const int32_t* indices, int64_t n, int32_t batch_size, co
   }
   uint32_t* cnt = indice_pairs ? blk : nullptr;
   if (cnt && kvol > 64) OCOCC_HIP(hipMemsetAsync(blk, 0, (int64_t)kvol * nblk * 4, stream));
+  if (dilated) {
+    // The reference keeps padding = k/2 whatever the dilation, so the scatter side (input j -> outputs at
+    // p + k/2 - m * dilation) is not the mirror image of the gather side.  Pass 1: scatter-side table into nbr_t,
+    // compacted into the reference-format pairs (same ascending-j order as the CPU functor).  Pass 2: nbr_t is
+    // overwritten with the gather-side table the convolution reads.
+    if (indice_pairs) {
+      Geom gs = g;
+      gs.sz = host_ksize[0] / 2; gs.sy = host_ksize[1] / 2; gs.sx = host_ksize[2] / 2;
+      gs.tz = -dil[0]; gs.ty = -dil[1]; gs.tx = -dil[2];
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream,
+                         indices, n, gs, bitmap, prefix, perm, nbr_t, (uint32_t*)nullptr, cnt);
+      OCOCC_CHECK_LAUNCH();
+      hipLaunchKernelGGL(block_offsets_kernel, dim3(kvol), dim3(256), 0, stream, blk, nblk, kvol, indice_num, 0);
+      OCOCC_CHECK_LAUNCH();
+      hipLaunchKernelGGL(compact_pairs_kernel, dim3((unsigned)nblk, kvol), dim3(256), 0, stream, nbr_t, blk, n,
+                         kvol, indice_num, indice_pairs, fill_tails, 0);
+      OCOCC_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<0>), dim3((unsigned)nblk), dim3(256), 0, stream,
+                       indices, n, g, bitmap, prefix, perm, nbr_t, blockmask, (uint32_t*)nullptr);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   if (g.kd == 3 && g.kh == 3 && g.kw == 3)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(neighbour_table_kernel<3>), dim3((unsigned)nblk), dim3(256), 0, stream,
                        indices, n, g, bitmap, prefix, perm, nbr_t, blockmask, cnt);

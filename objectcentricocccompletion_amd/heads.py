@@ -123,6 +123,31 @@ class SparseHeadMixin(object):
         return boxes
 
 
+    def get_bboxes_from_tracklet(self, rois, cls_score, bbox_pred, valid_roi_mask, class_labels, class_pred, img_metas,
+                                 gt_rois=None, cfg=None):
+        """fsd_bbox_head.py:994-1073: per sample (boxes [n,7], sigmoid scores, labels, non-empty mask); empty RoIs are
+        kept and flagged, the caller decides.  test_cfg switches: identical_decode (return the proposals and their
+        scores), replace_center / replace_size / replace_yaw (oracle experiments with the matched GT boxes)."""
+        assert rois.size(0) == cls_score.size(0) == bbox_pred.size(0)
+        tc = self.test_cfg or {}
+        scores = cls_score.sigmoid()
+        if tc.get('identical_decode', False):
+            boxes, scores = rois[:, 1:], class_pred
+        else:
+            boxes = self.decode_from_rois(rois, bbox_pred)
+        for key, dst, src in (('replace_center', slice(0, 3), slice(1, 4)), ('replace_size', slice(3, 6), slice(4, 7)),
+                              ('replace_yaw', slice(6, 7), slice(7, 8))):
+            if tc.get(key, False):
+                m = gt_rois[:, 0].bool()
+                boxes[m, dst] = gt_rois[m, src]
+        batch = rois[..., 0]
+        out = []
+        for b in range(int(batch.max().item() + 1)):
+            m = batch == b
+            out.append((boxes[m], scores[m].view(-1), class_labels[m], valid_roi_mask[m]))
+        return out
+
+
 @HEADS.register_module()
 class OccAutoEncoder(nn.Module, SparseHeadMixin):
     """Point encoder (SIR) + implicit occupancy decoder (occ_ae_head.py:28-264)."""

@@ -627,6 +627,6 @@ def collate_tracklets(samples, device):
     if 'gt_tracklet_candidates' in samples[0]:
         batch['gt_tracklet_candidates'] = [[trk_to(c) for c in s['gt_tracklet_candidates']] for s in samples]
     if 'occ_labels' in samples[0]:
-        batch['gt_occs'] = [[o.to(device).float() for o in s['occ_labels']] for s in samples]
-        batch['gt_occ_scores'] = [[sc.reshape(1).to(device).float() for sc in s['occ_labels_scores']] for s in samples]
+        batch['occ_labels'] = [[o.to(device).float() for o in s['occ_labels']] for s in samples]
+        batch['occ_labels_scores'] = [[sc.reshape(1).to(device).float() for sc in s['occ_labels_scores']] for s in samples]
     return batch

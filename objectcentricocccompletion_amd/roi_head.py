@@ -136,22 +136,35 @@ class TrackletRoIHeadOCC(nn.Module):
         boxes, masks = zip(*[gt.concated_boxes_from_ts(trk.ts_list) for trk, gt in zip(tracklets, gt_tracklets)])
         return torch.cat([torch.cat(masks, 0)[:, None].float(), torch.cat(boxes, 0)], 1)
 
-    def simple_test(self, pts_xyz, pts_feats, pts_batch_inds, pts_frame_inds, img_metas, tracklet_list,
-                    gt_tracklet_candidates=None, gt_occ_list=None, gt_occ_scores_list=None, **kwargs):
-        """One tracklet at a time (batch size 1, as the reference asserts :547): refined boxes and,
-        with test_occ_iou, per-RoI occupancy intersection / union counts."""
-        assert len(tracklet_list) == 1
+    def simple_test(self, pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, img_metas, tracklet_list,
+                    gt_candidates_list=None, gt_occs_list=None, gt_occ_scores_list=None, **kwargs):
+        """One tracklet at a time (batch size 1, as the reference asserts): ``[dict(out_tracklets=[refined
+        tracklet], inters, unions, gt_boxes)]`` (tracklet_roi_head_occ.py:492-610).  The refined tracklet is a
+        copy of the proposal updated through Tracklet.update_from_prediction (RoIs without points keep their
+        proposal box and score); with test_occ_iou the per-RoI occupancy intersection / union counts follow."""
+        assert len(tracklet_list) == 1, 'only support batch size 1'
+        gt_rois = gt_occ_list = gt_occ_score_list = None
+        if gt_candidates_list is not None:
+            gts, gt_occ_list, gt_occ_score_list = self._select_one2one_candidates(
+                tracklet_list, gt_candidates_list, gt_occs_list, gt_occ_scores_list)
+            gt_rois = self.get_gt_rois(tracklet_list, gts)
         rois, roi_frame_inds, cls_preds, labels_3d = self.tracklets2rois(tracklet_list)
-        res = self._bbox_forward(pts_xyz, pts_feats, pts_batch_inds, pts_frame_inds, rois, cls_preds, roi_frame_inds)
-        boxes = self.bbox_head.decode_from_rois(rois, res['bbox_pred'])
-        out = dict(boxes_3d=boxes, scores_3d=res['cls_score'].sigmoid().view(-1), labels_3d=labels_3d,
-                   valid_roi_mask=res['nonempty_roi_mask'])
-        if self.test_cfg.get('test_occ_iou', False) and gt_tracklet_candidates is not None:
-            gts, occs, _ = self._select_one2one_candidates(tracklet_list, gt_tracklet_candidates, gt_occ_list,
-                                                           gt_occ_scores_list)
-            if occs[0] is not None and len(gts[0]) > 0:
-                gt_rois = self.get_gt_rois(tracklet_list, gts)
-                out.update(self.test_occ(rois, gt_rois, res['fused_roi_feats'], [occs[0]]))
+        res = self._bbox_forward(pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, rois, cls_preds, roi_frame_inds)
+        decoded = self.bbox_head.get_bboxes_from_tracklet(rois, res['cls_score'], res['bbox_pred'],
+                                                          res['nonempty_roi_mask'], labels_3d, cls_preds, img_metas,
+                                                          gt_rois=gt_rois, cfg=self.test_cfg)
+        out_tracklets = []
+        for i, trk in enumerate(tracklet_list):
+            new = trk.clone()
+            boxes, scores, labels, valid = decoded[i]
+            if self.test_cfg.get('tta', None) is not None:
+                boxes = self.inverse_aug(new, boxes, img_metas[i])
+            new.update_from_prediction(boxes, scores, labels, valid, to_ego=True)
+            out_tracklets.append(new)
+        out = dict(out_tracklets=out_tracklets)
+        if self.test_cfg.get('test_occ_iou', False):
+            out.update(self.test_occ(rois, res['fused_roi_feats'], gt_rois, gt_occ_list, gt_occ_score_list, pts_xyz,
+                                     pts_batch_idx, pts_frame_inds, roi_frame_inds))
         return [out]
 
     @staticmethod
@@ -172,29 +185,45 @@ class TrackletRoIHeadOCC(nn.Module):
         return holder.boxes
 
     @torch.no_grad()
-    def test_occ(self, occ_rois, gt_rois, fused_roi_feats, gt_occ_list):
-        """Chunked decoding of all GT voxels in every matched RoI frame; integer inter / union per
-        RoI (:394-486).  The decoder is called with (features, points, RoI index) -- no
-        [chunk,K,1536] copies."""
-        match = gt_rois[:, 0].bool() if gt_rois[:, 0].dtype != torch.bool else gt_rois[:, 0]
-        chunk = self.test_cfg.get('iou_chunk_size', -1)
-        chunk = int(match.sum()) if chunk == -1 else chunk
-        pred_boxes, gt_boxes_all, feats = occ_rois[match][:, 1:], gt_rois[match][:, 1:], fused_roi_feats[match]
+    def test_occ(self, rois, fused_roi_feats, gt_rois, gt_occ_list, gt_occ_score_list, pts_xyz=None,
+                 pts_batch_idx=None, pts_frame_inds=None, roi_frame_inds=None):
+        """Occupancy IoU counts of one tracklet (tracklet_roi_head_occ.py:268-486): every known GT voxel is
+        decoded in every RoI that has a GT box at its timestamp, in chunks of test_cfg.iou_chunk_size RoIs;
+        integer inter / union per RoI.  Nothing is counted without occupancy labels, without a matched frame,
+        or when the label confidence is under occ_label_thresh.  The decoder is called with (features, points,
+        RoI index) -- no [chunk,K,1536] copies.  test_cfg.test_baseline (:289-393) rasterises the points
+        accumulated up to each frame instead of decoding."""
+        empty = dict(inters=[], unions=[], gt_boxes=[])
+        if gt_rois is None or gt_occ_list is None or gt_occ_list[0] is None:
+            return empty
+        match = gt_rois[:, 0] == 1
+        if not bool(match.any()) or float(gt_occ_score_list[0]) < self.bbox_head.occ_label_thresh:
+            return empty
         occ_xyz, occ_label = gt_occ_list[0][..., :3], (gt_occ_list[0][..., 3] == 1).long()
         K = occ_xyz.size(0)
+
+        def to_roi_frame(xyz, gb, pb):
+            if not self.test_cfg.get('transform_to_gt', True):
+                return xyz
+            xyz = rotation_3d_in_axis(xyz, gb[:, 6], axis=2)       # GT box frame -> ego frame
+            xyz += gb[..., None, 0:3]
+            xyz[..., 2] += gb[:, None, 5] / 2                      # labels sit at voxel gravity centres
+            xyz -= pb[..., None, :3]                               # ego frame -> RoI frame
+            xyz[..., 2] -= pb[:, None, 5] / 2
+            return rotation_3d_in_axis(xyz, -(pb[:, 6]), axis=2)
+
+        if self.test_cfg.get('test_baseline', False):
+            return self._test_occ_accumulated_points(rois, gt_rois, match, occ_xyz, occ_label, to_roi_frame, pts_xyz,
+                                                     pts_batch_idx, pts_frame_inds, roi_frame_inds)
+        chunk = self.test_cfg.get('iou_chunk_size', -1)
+        chunk = int(match.numel()) if chunk == -1 else chunk
+        pred_boxes, gt_boxes_all, feats = rois[match][:, 1:], gt_rois[match][:, 1:], fused_roi_feats[match]
         decoder = self.bbox_head.occ_ae_head.occ_decoder
         inters, unions, gt_boxes = [], [], []
         for f, pb, gb in zip(torch.split(feats, chunk), torch.split(pred_boxes, chunk), torch.split(gt_boxes_all, chunk)):
             n = gb.size(0)
-            xyz = occ_xyz[None].repeat(n, 1, 1)
+            xyz = to_roi_frame(occ_xyz[None].repeat(n, 1, 1), gb, pb)
             lab = occ_label[None].repeat(n, 1)
-            if self.test_cfg.get('transform_to_gt', True):
-                xyz = rotation_3d_in_axis(xyz, gb[:, 6], axis=2)
-                xyz += gb[..., None, 0:3]
-                xyz[..., 2] += gb[:, None, 5] / 2
-                xyz -= pb[..., None, :3]
-                xyz[..., 2] -= pb[:, None, 5] / 2
-                xyz = rotation_3d_in_axis(xyz, -(pb[:, 6]), axis=2)
             if self.test_cfg.get('ignore_outside_occ', False):
                 half = pb[:, None, 3:6] / 2
                 inside = (xyz >= -half).all(-1) & (xyz <= half).all(-1)
@@ -205,6 +234,36 @@ class TrackletRoIHeadOCC(nn.Module):
             inters.append(((cls == 1) & (lab == 1)).sum(1).cpu())
             unions.append(((cls == 1) | (lab == 1)).sum(1).cpu())
             gt_boxes.append(gb.cpu())
+        return dict(inters=inters, unions=unions, gt_boxes=gt_boxes)
+
+    def _test_occ_accumulated_points(self, rois, gt_rois, match, occ_xyz, occ_label, to_roi_frame, pts_xyz,
+                                     pts_batch_idx, pts_frame_inds, roi_frame_inds):
+        """The point-accumulation baseline (:289-393): the occupancy of RoI i is the set of 0.2 m cells of its own
+        box hit by the pooled points of RoIs 0..i, each in its own RoI frame."""
+        inds, roi_inds, info = self.roi_extractor(pts_xyz[:, :3], pts_batch_idx, pts_frame_inds, rois[:, :8],
+                                                  roi_frame_inds)
+        local = rotation_3d_in_axis(info['local_xyz'][None], info['local_xyz'].new_tensor([torch.pi / 2]), axis=2)[0]
+        vs = self.bbox_head.occ_ae_head.voxel_size
+        inters, unions, gt_boxes = [], [], []
+        for i in torch.nonzero(match).view(-1).tolist():
+            gb, pb = gt_rois[i, 1:], rois[i, 1:]
+            q = to_roi_frame(occ_xyz[None].clone(), gb[None], pb[None])[0]
+            size = pb[3:6]
+            dims = torch.ceil(size / vs).to(torch.int32)
+            cells = lambda p: torch.floor((p + size[None] / 2) / vs).to(torch.long)
+            inb = lambda c: (c >= 0).all(1) & (c < dims[None]).all(1)
+            pc = cells(local[roi_inds <= i])
+            pc = pc[inb(pc)]
+            qc = cells(q)
+            qin = inb(qc)
+            pred = torch.zeros_like(occ_label)
+            if bool(qin.any()):
+                grid = torch.zeros(tuple(int(d) for d in dims), dtype=torch.bool, device=q.device)
+                grid[pc[:, 0], pc[:, 1], pc[:, 2]] = True
+                pred[qin] = grid[qc[qin, 0], qc[qin, 1], qc[qin, 2]].long()
+            inters.append(((pred == 1) & (occ_label == 1)).sum(-1, keepdim=True).cpu())
+            unions.append(((pred == 1) | (occ_label == 1)).sum(-1, keepdim=True).cpu())
+            gt_boxes.append(gb[None])
         return dict(inters=inters, unions=unions, gt_boxes=gt_boxes)
 
 
@@ -228,17 +287,39 @@ class TrackletDetectorOCC(nn.Module):
         batch = torch.cat([torch.full((p.size(0),), i, dtype=torch.long, device=p.device) for i, p in enumerate(points)])
         return xyz.contiguous(), feats.contiguous(), batch, torch.cat(pts_frame_inds, 0).long()
 
-    def forward_train(self, points, pts_frame_inds, img_metas, tracklet, gt_tracklet_candidates, gt_occs=None,
-                      gt_occ_scores=None, **kwargs):
-        xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
-        return self.roi_head.forward_train(xyz, feats, batch, frames, img_metas, tracklet, gt_tracklet_candidates,
-                                           gt_occs, gt_occ_scores)
+    @staticmethod
+    def fake_points_for_empty_input(tensors):
+        """After PointsRangeFilter a sample can arrive without points: give it one zero row
+        (tracklet_detector_occ.py:299-311)."""
+        return [t.new_zeros((1,) + tuple(t.shape[1:])) if len(t) == 0 else t for t in tensors]
 
-    def simple_test(self, points, pts_frame_inds, img_metas, tracklet, gt_tracklet_candidates=None, gt_occs=None,
-                    gt_occ_scores=None, **kwargs):
+    def forward_train(self, points, pts_frame_inds=None, img_metas=None, tracklet=None, gt_tracklet_candidates=None,
+                      occ_labels=None, occ_labels_scores=None):
+        """tracklet_detector_occ.py:96-147 (argument names = the keys Collect3D emits, ococcnet.py:247-254)."""
+        points = self.fake_points_for_empty_input(points)
+        pts_frame_inds = self.fake_points_for_empty_input(pts_frame_inds)
         xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
-        return self.roi_head.simple_test(xyz, feats, batch, frames, img_metas, tracklet, gt_tracklet_candidates,
-                                         gt_occs, gt_occ_scores)
+        return self.roi_head.forward_train(pts_xyz=xyz, pts_feats=feats, pts_batch_idx=batch, pts_frame_inds=frames,
+                                           img_metas=img_metas, tracklet_list=tracklet,
+                                           gt_candidates_list=gt_tracklet_candidates, gt_occs_list=occ_labels,
+                                           gt_occ_scores_list=occ_labels_scores)
+
+    def simple_test(self, points, img_metas, pts_frame_inds, tracklet, gt_tracklet_candidates=None, occ_labels=None,
+                    occ_labels_scores=None, rescale=False, **kwargs):
+        """tracklet_detector_occ.py:149-198."""
+        points = self.fake_points_for_empty_input(points)
+        pts_frame_inds = self.fake_points_for_empty_input(pts_frame_inds)
+        xyz, feats, batch, frames = self._cat_points(points, pts_frame_inds)
+        return self.roi_head.simple_test(pts_xyz=xyz, pts_feats=feats, pts_batch_idx=batch, pts_frame_inds=frames,
+                                         img_metas=img_metas, tracklet_list=tracklet,
+                                         gt_candidates_list=gt_tracklet_candidates, gt_occs_list=occ_labels,
+                                         gt_occ_scores_list=occ_labels_scores)
+
+    def forward_test(self, points, img_metas, img=None, **kwargs):
+        """tracklet_detector_occ.py:313-345: with test_cfg.tta the arguments are lists over augmentations."""
+        if self.test_cfg is not None and self.test_cfg.get('tta', None) is not None:
+            return self.aug_test(points, img_metas, **kwargs)
+        return self.simple_test(points, img_metas, **kwargs)
 
     def aug_test(self, points, img_metas, pts_frame_inds, tracklet, rescale=False):
         """Test-time augmentation (tracklet_detector_occ.py:200-221): points / metas / frame indices / tracklets
@@ -249,20 +330,17 @@ class TrackletDetectorOCC(nn.Module):
         tta = self.roi_head.test_cfg['tta']
         per_aug = []
         for p, meta, inds, trks in zip(points, img_metas, pts_frame_inds, tracklet):
-            res = self.simple_test(p, inds, meta, trks)
             outs = []
-            for i, trk in enumerate(trks):
-                t = trk.clone()
-                boxes = self.roi_head.inverse_aug(t, res[i]['boxes_3d'][:, :7].clone(), meta[i])
-                t.boxes, t.scores = boxes, res[i]['scores_3d'].clone()
-                outs.append(t)
+            for i, trk in enumerate(trks):  # simple_test refines one tracklet per call and undoes the augmentation
+                r = self.simple_test([p[i]], [meta[i]], [inds[i]], [trk])[0]
+                outs.append(r['out_tracklets'][0])
             per_aug.append(outs)
         bsz = len(points[0])
         return [Tracklet.merge_augs([per_aug[k][i] for k in range(len(points))], tta, points[0][0].device)
                 for i in range(bsz)]
 
     def forward(self, return_loss=True, **kwargs):
-        return self.forward_train(**kwargs) if return_loss else self.simple_test(**kwargs)
+        return self.forward_train(**kwargs) if return_loss else self.forward_test(**kwargs)
 
 
 def occupancy_iou_metrics(results):

@@ -165,11 +165,17 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
                                                 L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num),
                                                 L.ptr(ws), ws.numel(), L.stream()),
                 'subm_rulebook_build')
-    rb = RulebookTables(True, kvol)
+    dilated = any(int(d) != 1 for d in dilation)
+    # (a dilated sub-manifold rulebook of the reference is not its own mirror image -- it keeps padding = k/2 --
+    # so it is handled like a user-supplied one: the input-gradient table is derived from the pairs on demand)
+    rb = RulebookTables(not dilated, kvol)
     if DEFAULT_PAIRS_PER_ROW is not None:
         rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+    if dilated and n > 0:
+        _own_row_offset(rb, num, nbr_t, mask, n)
     rb.tables[(False, 'fwd')] = (nbr_t, mask, n)
-    rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights
+    if not dilated:
+        rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights
     pairs._ococc = rb
     return indices, pairs, num
 
@@ -191,8 +197,41 @@ def _tables_for(indice_pairs, indice_pair_num, inverse, direction, rows, subm):
                                                     kvol, indice_pairs.size(2), side, rows,
                                                     L.ptr(table), L.ptr(mask), L.stream()),
                 'rulebook_pairs_to_table')
+        if subm and not rb.subm and rows > 0:
+            _own_row_offset(rb, indice_pair_num, table, mask, rows)
         rb.tables[key] = (table, mask, rows)
     return rb, rb.tables[key]
+
+
+def _own_row_offset(rb, indice_pair_num, table, mask, rows):
+    """indiceConv evaluates ONE offset of a subM layer as "own row" and never from the rulebook: the offset with
+    the most pairs (indicePairMaxOffset, spconv_ops.h:273-278,300-303,320-322; backward :393-399).  For a regular
+    sub-manifold rulebook that is the centre and its pairs are (j, j) anyway; for a dilated one (padding stays
+    k/2) or a hand-made one it is whatever offset wins, so it is read back here -- once per rulebook, for rulebooks
+    that are not our own dilation-1 ones (the reference reads indice_num back on every call)."""
+    if getattr(rb, 'own_row_offset', None) is None:
+        rb.own_row_offset = int(torch.argmax(indice_pair_num))  # first maximum, as std::max_element
+    c = rb.own_row_offset
+    table[c] = torch.arange(rows, dtype=torch.int32, device=table.device)
+    if mask is not None and c < 32:
+        mask |= (1 << c) if c < 31 else -(1 << 31)
+
+
+def _subm_wgrad_pairs(rb, indice_pairs, indice_pair_num):
+    """The pair lists the weight gradient of a subM layer contracts over when the rulebook is not one of ours with
+    dilation 1: the offset with the most pairs pairs every row with itself (spconv_ops.h:393-399), whatever the
+    rulebook holds."""
+    hit = getattr(rb, 'wgrad_pairs', None)
+    if hit is None:
+        kvol, _, cap = indice_pairs.shape
+        if getattr(rb, 'own_row_offset', None) is None:
+            rb.own_row_offset = int(torch.argmax(indice_pair_num))
+        c = rb.own_row_offset
+        pairs, num = indice_pairs.clone(), indice_pair_num.clone()
+        pairs[c] = torch.arange(cap, dtype=torch.int32, device=pairs.device)[None, :]
+        num[c] = cap
+        hit = rb.wgrad_pairs = (pairs, num)
+    return hit
 
 
 def _round_kd(c):
@@ -481,8 +520,13 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         kvol = indice_pairs.size(0)
         cap = indice_pairs.size(2)
         pairs = indice_pairs
+        rb0 = getattr(indice_pairs, '_ococc', None)
+        if subm and cap == n_in and cap > 0 and (rb0 is None or not rb0.subm):
+            if rb0 is None:
+                rb0 = indice_pairs._ococc = RulebookTables(False, kvol)
+            pairs, indice_pair_num = _subm_wgrad_pairs(rb0, indice_pairs, indice_pair_num)
         if inverse:  # wgrad pairs x rows with dy rows: swap the two pair rows
-            pairs = indice_pairs.flip(1).contiguous()
+            pairs = pairs.flip(1).contiguous()
 
         def run():
             nbytes = L.lib.ococc_sparse_conv_wgrad_workspace_bytes(kvol, cap, kd_in, kd_out)

@@ -45,4 +45,4 @@ def synthetic_training_batch(num_tracklets, frames=32, pts_per_frame=64, occ_que
         occs.append([torch.cat([q, lab], 1).to(device)])
         occ_scores.append([torch.tensor([0.9], device=device)])
     return dict(points=points, pts_frame_inds=pts_frames, img_metas=None, tracklet=trks,
-                gt_tracklet_candidates=cands, gt_occs=occs, gt_occ_scores=occ_scores)
+                gt_tracklet_candidates=cands, occ_labels=occs, occ_labels_scores=occ_scores)

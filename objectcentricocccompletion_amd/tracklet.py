@@ -164,6 +164,43 @@ class Tracklet(object):
         self.boxes = out
         self.shared_pose = pose
 
+    def shared2ego(self, boxes=None):
+        """Boxes expressed in the tracklet's shared frame back into each frame's own ego frame
+        (LiDARTracklet.shared2ego, lidar_tracklet.py:449-492): centres through inv(pose_i) @ shared_pose, the yaw
+        from the transformed heading vector (sin, cos, 0).  The 4x4 inverses are taken on the host (f32 poses, a
+        handful per tracklet), as the reference does."""
+        src = self.boxes if boxes is None else boxes
+        tgt_pose = torch.stack([p.to(self.device) for p in self.pose_list], 0)
+        mm = torch.linalg.inv(tgt_pose.cpu()).to(self.device) @ self.shared_pose.to(self.device)
+        ones = src.new_ones((src.size(0), 1))
+        centre = torch.einsum('nij,nj->ni', mm.to(src.dtype), torch.cat([src[:, :3], ones], 1))[:, :3]
+        rot = mm.clone().to(src.dtype)
+        rot[:, :3, 3] = 0
+        hv = torch.stack([torch.sin(src[:, 6]), torch.cos(src[:, 6]), torch.zeros_like(src[:, 6])], 1)
+        hv = torch.einsum('nij,nj->ni', rot, torch.cat([hv, ones], 1))[:, :3]
+        return torch.cat([centre, src[:, 3:6], torch.atan2(hv[:, 0], hv[:, 1])[:, None]], 1)
+
+    def update_from_prediction(self, boxes, scores, labels, valid_mask, to_ego=True):
+        """Take over refined boxes / scores (LiDARTracklet.update_from_prediction, lidar_tracklet.py:403-447): frames
+        whose RoI was empty (valid_mask False) keep their own box and score; with to_ego both are expressed in the
+        per-frame ego frames, as the evaluation wants; an augmentation translation recorded on the tracklet is undone
+        first.  A tracklet without poses is already in one frame and is left there."""
+        assert len(boxes) == len(scores) == len(labels) == len(valid_mask) == len(self)
+        assert bool((labels == labels[0]).all())
+        self.type = int(labels[0])
+        boxes = boxes[:, :7].clone()
+        if getattr(self, 'translation_factor', None) is not None:
+            back = -torch.as_tensor(self.translation_factor, dtype=boxes.dtype, device=self.device).view(-1)[:3]
+            boxes[:, :3] += back
+            self.translate(back)
+        posed = getattr(self, 'pose_list', None) is not None and getattr(self, 'shared_pose', None) is not None
+        new = self.shared2ego(boxes) if (to_ego and posed) else boxes
+        old = self.shared2ego() if posed else self.boxes[:, :7]
+        keep = valid_mask.to(self.device).bool()
+        self.boxes = torch.where(keep[:, None], new.to(self.boxes.dtype), old)
+        self.scores = torch.where(keep, scores.to(self.scores.dtype), self.scores)
+        self.pose_list = None
+
     def select(self, keep):
         """Keep the frames with the given positions (LiDARTracklet.remove over its list fields, lidar_tracklet.py:106-118)."""
         keep = list(keep)

@@ -475,42 +475,60 @@ static int inside_quad(const double* qx, const double* qy, double px, double py)
   }
   return !(pos && neg);
 }
+/* area of the intersection of two rotated BEV rectangles given as (x, y, z, w, l, h, yaw) rows */
+static double bev_overlap_area(const float* a, const float* b) {
+  double ax[4], ay[4], bx[4], by[4], px[24], py[24];
+  int m = 0;
+  box_corners(a, ax, ay);
+  box_corners(b, bx, by);
+  for (int i = 0; i < 4; ++i) if (inside_quad(bx, by, ax[i], ay[i])) { px[m] = ax[i]; py[m++] = ay[i]; }
+  for (int i = 0; i < 4; ++i) if (inside_quad(ax, ay, bx[i], by[i])) { px[m] = bx[i]; py[m++] = by[i]; }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int i2 = (i + 1) & 3, j2 = (j + 1) & 3;
+      const double rx = ax[i2] - ax[i], ry = ay[i2] - ay[i], sx = bx[j2] - bx[j], sy = by[j2] - by[j];
+      const double den = rx * sy - ry * sx;
+      if (fabs(den) < 1e-14) continue;
+      const double u = ((bx[j] - ax[i]) * sy - (by[j] - ay[i]) * sx) / den;
+      const double v = ((bx[j] - ax[i]) * ry - (by[j] - ay[i]) * rx) / den;
+      if (u >= 0 && u <= 1 && v >= 0 && v <= 1) { px[m] = ax[i] + u * rx; py[m++] = ay[i] + u * ry; }
+    }
+  double area = 0.0;
+  if (m >= 3) {
+    double gx = 0, gy = 0;
+    for (int i = 0; i < m; ++i) { gx += px[i]; gy += py[i]; }
+    gx /= m; gy /= m;
+    for (int i = 1; i < m; ++i)  /* insertion sort by angle */
+      for (int j = i; j > 0 && atan2(py[j] - gy, px[j] - gx) < atan2(py[j - 1] - gy, px[j - 1] - gx); --j) {
+        double tx = px[j], ty = py[j]; px[j] = px[j - 1]; py[j] = py[j - 1]; px[j - 1] = tx; py[j - 1] = ty;
+      }
+    for (int i = 0; i < m; ++i) { const int j = (i + 1) % m; area += px[i] * py[j] - px[j] * py[i]; }
+    area = fabs(area) * 0.5;
+  }
+  return area;
+}
+
 void oracle_aligned_iou3d(const float* b1, const float* b2, int64_t n, float* iou) {
   for (int64_t t = 0; t < n; ++t) {
     const float* a = b1 + t * 7;
     const float* b = b2 + t * 7;
-    double ax[4], ay[4], bx[4], by[4], px[24], py[24];
-    int m = 0;
-    box_corners(a, ax, ay);
-    box_corners(b, bx, by);
-    for (int i = 0; i < 4; ++i) if (inside_quad(bx, by, ax[i], ay[i])) { px[m] = ax[i]; py[m++] = ay[i]; }
-    for (int i = 0; i < 4; ++i) if (inside_quad(ax, ay, bx[i], by[i])) { px[m] = bx[i]; py[m++] = by[i]; }
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
-        const int i2 = (i + 1) & 3, j2 = (j + 1) & 3;
-        const double rx = ax[i2] - ax[i], ry = ay[i2] - ay[i], sx = bx[j2] - bx[j], sy = by[j2] - by[j];
-        const double den = rx * sy - ry * sx;
-        if (fabs(den) < 1e-14) continue;
-        const double u = ((bx[j] - ax[i]) * sy - (by[j] - ay[i]) * sx) / den;
-        const double v = ((bx[j] - ax[i]) * ry - (by[j] - ay[i]) * rx) / den;
-        if (u >= 0 && u <= 1 && v >= 0 && v <= 1) { px[m] = ax[i] + u * rx; py[m++] = ay[i] + u * ry; }
-      }
-    double area = 0.0;
-    if (m >= 3) {
-      double gx = 0, gy = 0;
-      for (int i = 0; i < m; ++i) { gx += px[i]; gy += py[i]; }
-      gx /= m; gy /= m;
-      for (int i = 1; i < m; ++i)  /* insertion sort by angle */
-        for (int j = i; j > 0 && atan2(py[j] - gy, px[j] - gx) < atan2(py[j - 1] - gy, px[j - 1] - gx); --j) {
-          double tx = px[j], ty = py[j]; px[j] = px[j - 1]; py[j] = py[j - 1]; px[j - 1] = tx; py[j - 1] = ty;
-        }
-      for (int i = 0; i < m; ++i) { const int j = (i + 1) % m; area += px[i] * py[j] - px[j] * py[i]; }
-      area = fabs(area) * 0.5;
-    }
+    const double area = bev_overlap_area(a, b);
     double top = fmin((double)a[2] + a[5], (double)b[2] + b[5]), bot = fmax((double)a[2], (double)b[2]);
     double oh = top - bot; if (oh < 0) oh = 0;
     const double inter = area * oh, v1 = (double)a[3] * a[4] * a[5], v2 = (double)b[3] * b[4] * b[5];
     double den = v1 + v2 - inter; if (den < 1e-8) den = 1e-8;
     iou[t] = (float)(inter / den);
+  }
+}
+
+/* TorchEx boxes_overlap_1to1 contract (call site lidar_box3d.py:429-434): rows (x1, y1, x2, y2, yaw) as
+ * xywhr2xyxyr makes them (structures/utils.py:85-103) -> BEV intersection area of the i-th pair. */
+void oracle_bev_overlap_1to1(const float* r1, const float* r2, int64_t n, float* area) {
+  for (int64_t t = 0; t < n; ++t) {
+    const float* p = r1 + t * 5;
+    const float* q = r2 + t * 5;
+    const float a[7] = {(p[0] + p[2]) * 0.5f, (p[1] + p[3]) * 0.5f, 0.f, p[2] - p[0], p[3] - p[1], 1.f, p[4]};
+    const float b[7] = {(q[0] + q[2]) * 0.5f, (q[1] + q[3]) * 0.5f, 0.f, q[2] - q[0], q[3] - q[1], 1.f, q[4]};
+    area[t] = (float)bev_overlap_area(a, b);
   }
 }

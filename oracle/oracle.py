@@ -202,6 +202,14 @@ def aligned_iou3d(boxes1, boxes2):
     return out
 
 
+def bev_overlap_1to1(xyxyr1, xyxyr2):
+    """TorchEx boxes_overlap_1to1 contract (lidar_box3d.py:429-434) -> BEV intersection area [n] f32."""
+    b1, b2 = _f(xyxyr1), _f(xyxyr2)
+    out = np.zeros((b1.shape[0],), np.float32)
+    L().oracle_bev_overlap_1to1(_p(b1), _p(b2), i64(b1.shape[0]), _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ floating point helpers
 def bf16_round(a):
     """round-to-nearest-even float32 -> bfloat16 -> float32 (numpy)."""

@@ -60,3 +60,55 @@ def synth_tracklets(num_tracklets=2, frames=32, pts_per_frame=60, seed=0, first_
                 pts_batch=np.concatenate(pts_batch).astype(np.int64)[perm],
                 pts_frame=np.concatenate(pts_frame).astype(np.int64)[perm],
                 pts_attr=np.concatenate(attrs).astype(np.float32)[perm])
+
+
+def synth_training_scene(seed=0, frames=16, pts_per_frame=48, occ_queries=64):
+    """Four proposal tracklets with their GT candidates, decorated points and occupancy labels -- the inputs of
+    TrackletRoIHeadOCC.forward_train / simple_test -- as plain numpy, so that the golden generator can wrap them
+    in the reference's LiDARTracklet and the tests in the product's Tracklet.  Covers: two candidates (far /
+    near), a candidate missing timestamps (negative RoIs), a frame without points (empty RoI), an occupancy
+    label score under occ_label_thresh, and a tracklet without any candidate."""
+    rng = np.random.default_rng(seed)
+    samples = []
+    for b in range(4):
+        w, l, h = rng.uniform(1.8, 2.2), rng.uniform(4.2, 5.0), rng.uniform(1.5, 1.9)
+        x0, y0, z0 = rng.uniform(-40, 40), rng.uniform(-40, 40), rng.uniform(-1.5, -0.5)
+        heading = rng.uniform(-np.pi, np.pi)
+        t = np.arange(frames)
+        boxes = np.stack([x0 + t * np.cos(heading), y0 + t * np.sin(heading), np.full(frames, z0), np.full(frames, w),
+                          np.full(frames, l), np.full(frames, h), heading + rng.normal(0, 0.02, frames)], 1).astype(np.float32)
+        scores = rng.uniform(0.3, 1.0, frames).astype(np.float32)
+        ts = [1500000000000000 + 100000 * (1000 * b + 7 * i) for i in range(frames)]  # Waymo microsecond stamps (> 1e10, lidar_tracklet.py:180)
+        pts, fr = [], []
+        for i in range(frames):
+            if b == 1 and i == 3:
+                continue  # a frame without points: an empty RoI that is assigned a GT box
+            loc = (rng.random((pts_per_frame, 3)) - 0.5) * (np.array([l, w, h]) + 0.9)
+            yaw = boxes[i, 6]
+            c, s = np.cos(yaw), np.sin(yaw)
+            xyz = np.stack([boxes[i, 0] + loc[:, 0] * c - loc[:, 1] * s, boxes[i, 1] + loc[:, 0] * s + loc[:, 1] * c,
+                            boxes[i, 2] + h / 2 + loc[:, 2]], 1)
+            deco = np.concatenate([rng.random((pts_per_frame, 2)), np.full((pts_per_frame, 1), yaw / np.pi),
+                                   np.tile(boxes[i, 3:6] / 10, (pts_per_frame, 1)), np.full((pts_per_frame, 1), scores[i])], 1)
+            pts.append(np.concatenate([xyz, deco], 1))
+            fr.append(np.full(pts_per_frame, i))
+        pts, fr = np.concatenate(pts).astype(np.float32), np.concatenate(fr).astype(np.int64)
+        perm = rng.permutation(len(pts))
+        noise = np.array([0.1, 0.1, 0.05, 0.05, 0.05, 0.05, 0.02]) * (3.0 if b == 2 else 1.0)
+        near = (boxes + rng.normal(0, 1, boxes.shape) * noise).astype(np.float32)
+        far = near.copy()
+        far[:, :2] += 1.5
+        occ = lambda: np.concatenate([(rng.random((occ_queries, 3)) - 0.5) * [l, w, h],
+                                      rng.integers(0, 3, (occ_queries, 1))], 1).astype(np.float32)
+        if b == 0:
+            cands = [(far, ts, occ(), 0.9), (near, ts, occ(), 0.8)]
+        elif b == 1:
+            keep = [i for i in range(frames) if i % 5 != 2]  # candidate missing some timestamps
+            cands = [(near[keep], [ts[i] for i in keep], occ(), 0.95)]
+        elif b == 2:
+            cands = [(near, ts, occ(), 0.3)]  # label score under occ_label_thresh = 0.4
+        else:
+            cands = []
+        samples.append(dict(points=pts[perm], pts_frame_inds=fr[perm], boxes=boxes, scores=scores, ts=ts,
+                            candidates=cands))
+    return samples

@@ -234,7 +234,7 @@ def test_detector_train_and_test_end_to_end(dev):
     points, frames, trks, cands, occs, occ_scores = _synthetic_batch(dev)
     model.train()
     losses = model(return_loss=True, points=points, pts_frame_inds=[f.clone() for f in frames], img_metas=None,
-                   tracklet=trks, gt_tracklet_candidates=cands, gt_occs=occs, gt_occ_scores=occ_scores)
+                   tracklet=trks, gt_tracklet_candidates=cands, occ_labels=occs, occ_labels_scores=occ_scores)
     for k in ('loss_rcnn_cls', 'loss_rcnn_bbox', 'loss_rcnn_occ', 'acc', 'precision_posbox', 'recall_posbox',
               'num_pos_rois', 'num_occupied', 'recall_pos', 'precision_neg'):
         assert k in losses and bool(torch.isfinite(losses[k]).all()), k
@@ -246,9 +246,9 @@ def test_detector_train_and_test_end_to_end(dev):
     with torch.no_grad():
         for b in range(len(points)):
             r = model(return_loss=False, points=[points[b]], pts_frame_inds=[frames[b]], img_metas=None,
-                      tracklet=[trks[b]], gt_tracklet_candidates=[cands[b]], gt_occs=[occs[b]],
-                      gt_occ_scores=[occ_scores[b]])
-            assert r[0]['boxes_3d'].shape == (len(trks[b]), 7) and 'inters' in r[0]
+                      tracklet=[trks[b]], gt_tracklet_candidates=[cands[b]], occ_labels=[occs[b]],
+                      occ_labels_scores=[occ_scores[b]])
+            assert r[0]['out_tracklets'][0].boxes.shape == (len(trks[b]), 7) and 'inters' in r[0]
             i, u = torch.cat(r[0]['inters']), torch.cat(r[0]['unions'])
             assert i.dtype == torch.long and bool((i <= u).all()) and bool((u > 0).all())
             results.append(r[0])
@@ -436,16 +436,18 @@ def test_tta_iou_clamped_merge_and_aug_test(dev):
     t_flip = trks[0].clone()
     t_flip.flip('horizontal')
     with torch.no_grad():
-        single = model.simple_test([points[0]], [frames[0]], [dict()], [trks[0]])[0]
-        flipped = model.simple_test([p_flip], [frames[0]], [dict(pcd_horizontal_flip=True)], [t_flip])[0]
+        model.roi_head.test_cfg['tta'] = None                   # plain refinement of each view, no inverse transform
+        single = model.simple_test([points[0]], [dict()], [frames[0]], [trks[0]])[0]['out_tracklets'][0]
+        flipped = model.simple_test([p_flip], [dict(pcd_horizontal_flip=True)], [frames[0]], [t_flip])[0]['out_tracklets'][0]
+        model.roi_head.test_cfg['tta'] = dict(merge='max')
         merged = model.aug_test([[points[0]], [p_flip]], [[dict()], [dict(pcd_horizontal_flip=True)]],
                                 [[frames[0]], [frames[0]]], [[trks[0]], [t_flip]])
     assert len(merged) == 1 and merged[0].boxes.shape == (8, 7)
-    back = Tracklet(flipped['boxes_3d'][:, :7].clone(), list(range(8)))
+    back = Tracklet(flipped.boxes[:, :7].clone(), list(range(8)))
     back.flip('horizontal')
-    s0, s1 = single['scores_3d'], flipped['scores_3d']
+    s0, s1 = single.scores, flipped.scores
     pick = (s1 > s0)[:, None]                                   # 'max': per frame the better-scoring augmentation
-    exp = torch.where(pick, back.boxes, single['boxes_3d'][:, :7])
+    exp = torch.where(pick, back.boxes, single.boxes[:, :7])
     assert torch.allclose(merged[0].boxes, exp, atol=1e-5)
     assert torch.allclose(merged[0].scores, torch.maximum(s0, s1))
     assert torch.equal(trks[0].boxes, _synthetic_batch(dev, B=1, L=8)[2][0].boxes)   # inputs untouched

@@ -1,0 +1,140 @@
+"""GPU parity of the training / evaluation path of TrackletRoIHeadOCC against the REFERENCE's own
+TrackletRoIHeadOCC run on the same seeded scene with the same name-hashed weights
+(tests/golden/ococc_train.npz, oracle/gen_golden_train.py):
+
+  A2   _select_one2one_candidates / TrackletAssigner / _assign_and_sample
+  A13  the loss dict of forward_train (every key) and the parameter gradients behind it
+  A14  simple_test: refined tracklets and the test_occ inter / union integers
+
+The scene is regenerated from its seed (oracle/synth.synth_training_scene); the .npz holds the reference's
+outputs only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'ococc_train.npz'), allow_pickle=False)
+
+
+@pytest.fixture(scope='module')
+def model(dev):
+    from objectcentricocccompletion_amd import heads, point_pool, roi_head  # noqa: F401 (register)
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    m = DETECTORS.build(ococcnet_model_cfg())
+    bh = m.roi_head.bbox_head
+    bh.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in bh.state_dict().items()}, seed=0))
+    return m.to(dev).eval()   # eval: dropout off, as in the generator
+
+
+def _scene(dev):
+    from objectcentricocccompletion_amd.tracklet import Tracklet
+    samples = synth.synth_training_scene(seed=0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    points = [T(s['points']) for s in samples]
+    frames = [T(s['pts_frame_inds']) for s in samples]
+    trks = [Tracklet(T(s['boxes']), s['ts'], T(s['scores']), type=0) for s in samples]
+    cands = [[Tracklet(T(cb), cts, type=0) for (cb, cts, _, _) in s['candidates']] for s in samples]
+    occs = [[T(o) for (_, _, o, _) in s['candidates']] for s in samples]
+    occ_scores = [[torch.tensor([sc], dtype=torch.float32, device=dev) for (_, _, _, sc) in s['candidates']]
+                  for s in samples]
+    return samples, points, frames, trks, cands, occs, occ_scores
+
+
+def test_assign_and_sample_equals_reference(dev, gold, model):
+    samples, points, frames, trks, cands, occs, occ_scores = _scene(dev)
+    batch_idx = torch.cat([torch.full((len(p),), i, dtype=torch.long, device=dev) for i, p in enumerate(points)])
+    fi = torch.cat(frames).clone()
+    torch.manual_seed(123)
+    res = model.roi_head._assign_and_sample(trks, cands, occs, occ_scores, batch_idx, fi)
+    assert len(res) == 4
+    for b, r in enumerate(res):
+        g = lambda k: gold[f'assign_{k}_{b}']
+        assert np.array_equal(r.pos_inds.cpu().numpy(), g('pos_inds'))
+        assert np.array_equal(r.neg_inds.cpu().numpy(), g('neg_inds'))
+        assert np.array_equal(r.bboxes.cpu().numpy(), g('bboxes'))                   # copies of the inputs: exact
+        assert np.array_equal(r.bboxes_frame_inds.cpu().numpy(), g('frame_inds'))    # incl. the random shift
+        assert np.allclose(r.iou.cpu().numpy(), g('iou'), atol=2e-5)                  # aligned IoU, HIP kernel
+        assert np.array_equal(r.scores.cpu().numpy(), g('scores'))
+        assert r.pos_gt_bboxes.shape == g('pos_gt_bboxes').shape                       # (0, 7) without a candidate
+        assert np.array_equal(r.pos_gt_bboxes.cpu().numpy(), g('pos_gt_bboxes'))
+        assert np.array_equal(r.pos_gt_labels.cpu().numpy(), g('pos_gt_labels'))
+    assert np.array_equal(fi.cpu().numpy(), gold['assign_pts_frame_inds'])             # shifted in place, as upstream
+    # the scene exercises what it claims to
+    assert len(res[1].neg_inds) > 0 and len(res[3].pos_inds) == 0 and len(res[0].neg_inds) == 0
+
+
+LOSS_KEYS = ['loss_rcnn_cls', 'num_pos_rois', 'num_neg_rois', 'loss_rcnn_bbox', 'num_occupied', 'num_free',
+             'loss_rcnn_occ', 'recall_neg', 'recall_pos', 'precision_neg', 'precision_pos', 'acc', 'precision_posbox',
+             'recall_posbox', 'precision_negbox', 'recall_negbox']
+
+
+def test_forward_train_losses_and_gradients_equal_reference(dev, gold, model):
+    samples, points, frames, trks, cands, occs, occ_scores = _scene(dev)
+    torch.manual_seed(123)
+    model.zero_grad(set_to_none=True)
+    losses = model(return_loss=True, points=points, pts_frame_inds=[f.clone() for f in frames], img_metas=None,
+                   tracklet=trks, gt_tracklet_candidates=cands, occ_labels=occs, occ_labels_scores=occ_scores)
+    assert sorted(losses.keys()) == sorted(LOSS_KEYS)
+    for k in LOSS_KEYS:
+        got, exp = losses[k].detach().float().cpu().numpy().reshape(-1), gold['loss_' + k].reshape(-1)
+        assert got.shape == exp.shape, k
+        if k.startswith('num_'):
+            assert np.array_equal(got, exp), k
+        elif k == 'loss_rcnn_occ':                    # reduction='none': one BCE term per query point
+            assert np.allclose(got, exp, rtol=1e-4, atol=2e-4), (k, np.abs(got - exp).max())
+        else:
+            assert np.allclose(got, exp, rtol=1e-4, atol=1e-5), (k, got, exp)
+    total = losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()
+    total.backward()
+    params = dict(model.roi_head.bbox_head.named_parameters())
+    names, norms = [str(n) for n in gold['grad_names']], gold['grad_norms']
+    assert sorted(names) == sorted(params.keys())      # registration order differs, names do not
+    worst = 0.0
+    for n, e in zip(names, norms):
+        g = params[n].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        worst = max(worst, abs(got - e) / max(e, 1e-6 * float(norms.max())))
+        assert abs(got - e) <= 2e-3 * e + 1e-6 * float(norms.max()), (n, got, e)
+    for k in gold.files:
+        if k.startswith('grad_') and k not in ('grad_names', 'grad_norms'):
+            g, e = params[k[5:]].grad.cpu().numpy(), gold[k]
+            assert np.abs(g - e).max() <= 2e-3 * np.abs(e).max() + 1e-7, (k, np.abs(g - e).max(), np.abs(e).max())
+    model.zero_grad(set_to_none=True)
+    print(f'worst relative gradient-norm error over {len(names)} parameters: {worst:.2e}')
+
+
+@pytest.mark.parametrize('b', [0, 1, 2])
+def test_simple_test_tracklets_and_occupancy_counts_equal_reference(dev, gold, model, b):
+    samples, points, frames, trks, cands, occs, occ_scores = _scene(dev)
+    t = trks[b]
+    eye = torch.eye(4, device=dev)
+    t.pose_list, t.shared_pose = [eye.clone() for _ in range(len(t))], eye.clone()
+    before = t.boxes.clone()
+    with torch.no_grad():
+        r = model(return_loss=False, points=[points[b]], img_metas=[dict()], pts_frame_inds=[frames[b]], tracklet=[t],
+                  gt_tracklet_candidates=[cands[b]], occ_labels=[occs[b]], occ_labels_scores=[occ_scores[b]])[0]
+    assert sorted(r.keys()) == ['gt_boxes', 'inters', 'out_tracklets', 'unions']
+    ot = r['out_tracklets'][0]
+    assert torch.equal(t.boxes, before)                                    # the proposal is refined on a copy
+    assert np.allclose(ot.boxes.cpu().numpy(), gold[f'test_boxes_{b}'], rtol=1e-4, atol=2e-4)
+    assert np.allclose(ot.scores.cpu().numpy(), gold[f'test_scores_{b}'], rtol=1e-4, atol=1e-5)
+    cat = lambda xs, empty: torch.cat(xs).numpy() if len(xs) else empty
+    inters, unions = cat(r['inters'], np.zeros(0, np.int64)), cat(r['unions'], np.zeros(0, np.int64))
+    assert inters.dtype == np.int64
+    assert np.array_equal(inters, gold[f'test_inters_{b}'])               # integer counts: exact
+    assert np.array_equal(unions, gold[f'test_unions_{b}'])
+    assert np.allclose(cat(r['gt_boxes'], np.zeros((0, 7), np.float32)), gold[f'test_gt_boxes_{b}'], atol=1e-6)
+    if b == 2:   # label confidence 0.3 < occ_label_thresh: nothing is counted
+        assert len(r['inters']) == 0
+    if b == 1:   # the candidate misses timestamps: those frames are not counted; frame 3 has no points and keeps its box
+        assert len(inters) == len(samples[1]['candidates'][0][1])
+        assert np.allclose(ot.boxes[3].cpu().numpy(), samples[1]['boxes'][3], atol=1e-6)

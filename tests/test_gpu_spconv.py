@@ -446,3 +446,28 @@ def test_regular_rulebook_equals_reference_geometry_h(dev, golden_dir, name):
         assert np.array_equal(p[k, 0, :en[k]], ep[k, 0, :en[k]])
         assert np.array_equal(p[k, 1, :en[k]], perm[ep[k, 1, :en[k]]])
         assert (p[k, :, en[k]:] == -1).all()
+
+
+@pytest.mark.parametrize('dil', [(2, 2, 2), (1, 2, 3)])
+def test_dilated_subm_conv_vs_oracle(dev, dil):
+    """SubMConv3d(dilation != 1): the reference keeps padding = k/2 (spconv_ops.h:66-83), so the rulebook is not
+    symmetric, and indiceConv treats the offset with the most pairs as "own row" (spconv_ops.h:273-303).  Rulebook
+    bit-exact, forward / dgrad / wgrad against the oracle's indiceConv restatement."""
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(31)
+    B, shape, cin, cout = 2, (9, 11, 13), 16, 32
+    idx = _voxels(rng, B, shape, 0.3, True)
+    n = len(idx)
+    _, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), 3, 1, 0, list(dil), 0, subm=True)
+    ep, en = O.subm_rulebook(idx, B, shape, (3, 3, 3), dil)
+    assert np.array_equal(num.cpu().numpy(), en) and np.array_equal(pairs.cpu().numpy(), ep)
+    x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+    w = O.bf16_round(rng.standard_normal((3, 3, 3, cin, cout)).astype(np.float32) * 0.2)
+    dy = O.bf16_round(rng.standard_normal((n, cout)).astype(np.float32))
+    xt, wt, dyt = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    y = ops.indice_conv(xt, wt, pairs, num, n, False, True)
+    assert np.allclose(y.cpu().numpy(), O.indice_conv(x, w, ep, en, n, subm=True), **TOL)
+    din, dw = ops.indice_conv_backward(xt, wt, dyt, pairs, num, False, True)
+    edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
+    assert np.allclose(din.cpu().numpy(), edin, **TOL)
+    assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * max(1.0, float(np.abs(edw).max())))
