@@ -87,6 +87,42 @@ def main():
         centers = mods['occ_ops'].quantize_points(pts_info['local_xyz'], rois, roi_inds, 0.2, to_center=True)
         pe = head.occ_ae_head.occ_decoder.pos_encode(qxyz[:4])
         tpe = head.pos_enc(frames.view(2, -1).t().float())
+    # tracklets of unequal length through transformer_forward_various_length (ococc_bbox_head.py:911-995):
+    # tracklet 0 keeps its 32 frames, tracklet 1 keeps 20, rows in random order
+    g2 = torch.Generator().manual_seed(17)
+    keep = torch.cat([torch.arange(32), 32 + torch.randperm(32, generator=g2)[:20]])
+    vl_index = keep[torch.randperm(len(keep), generator=g2)]
+    with torch.no_grad():
+        vl = head.transformer_forward_various_length(rois[vl_index], frames[vl_index], fcf[vl_index],
+                                                     nonempty[vl_index])
+    out['vl_index'], out['vl_out'] = vl_index.numpy(), vl.numpy()
+
+    # backward of one SIRLayer (voxel_encoder.py:764-832: both segment-max argmax routes, the gather-back of the
+    # voxel feature, three LN+GELU pairs) and of the decoder (occ_base.py:120-139), SURVEY G1 / G4: gradients of
+    # fixed random projections of the outputs w.r.t. inputs and parameters
+    xg, fg = x_in.clone().requires_grad_(True), f_cluster.clone().requires_grad_(True)
+    pfg, vfg = blk(xg, roi_inds, fg)
+    wp, wv = torch.randn(pfg.shape, generator=g), torch.randn(vfg.shape, generator=g)
+    blk.zero_grad()
+    ((pfg * wp).sum() + (vfg * wv).sum()).backward()
+    out['sir_wp'], out['sir_wv'] = wp.numpy(), wv.numpy()
+    out['sir_grad_x'], out['sir_grad_fcluster'] = xg.grad.numpy(), fg.grad.numpy()
+    for n, p_ in blk.named_parameters():
+        out['sir_grad__' + n] = p_.grad.numpy().copy()
+    blk.zero_grad()
+    dec = head.occ_ae_head.occ_decoder
+    fr = res['fused_roi_feats'].clone().requires_grad_(True)
+    lg = dec.occ_forward(fr[:, None, :].repeat(1, K, 1), qxyz)
+    wl = torch.randn(lg.shape, generator=g)
+    dec.zero_grad()
+    (lg * wl).sum().backward()
+    out['dec_wl'], out['dec_grad_feats'] = wl.numpy(), fr.grad.numpy()
+    for n, p_ in dec.named_parameters():   # the two 4 MB matrices as norm + leading rows only
+        gq = p_.grad.numpy()
+        out['dec_gradnorm__' + n] = np.float64(np.linalg.norm(gq.astype(np.float64)))
+        out['dec_grad__' + n] = gq.copy() if gq.size <= 70000 else gq[:32].copy()
+    dec.zero_grad()
+
     for k in ('fused_roi_feats', 'ori_roi_feats', 'cls_score', 'bbox_pred'):
         out['out_' + k] = res[k].numpy()
     out['out_nonempty_roi_mask'] = res['nonempty_roi_mask'].numpy()

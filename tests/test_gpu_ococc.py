@@ -500,3 +500,65 @@ def test_dataset_to_detector_end_to_end(dev, tmp_path):
         assert bool(torch.isfinite(losses[k]).all()), k
     assert float(losses['num_pos_rois']) > 0                     # the near GT candidate was matched, frame by frame
     (losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()).backward()
+
+
+def test_sir_layer_and_decoder_backward_vs_reference_golden(dev, gold, head):
+    """gradients of one SIRLayer (voxel_encoder.py:764-832) and of the OccDecoder
+    (occ_base.py:120-139) w.r.t. inputs and parameters against the imported reference's autograd."""
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
+    _, _, _, roi_inds, _, _ = _inputs(gold, dev)
+    blk = head.block_list[1]
+    x, fc = T('sir_x').requires_grad_(True), T('sir_fcluster').requires_grad_(True)
+    head.zero_grad(set_to_none=True)
+    pf, vf = blk(x, roi_inds, fc)
+    ((pf * T('sir_wp')).sum() + (vf * T('sir_wv')).sum()).backward()
+    assert rel_err(x.grad.cpu(), gold['sir_grad_x']) < 1e-3
+    assert rel_err(fc.grad.cpu(), gold['sir_grad_fcluster']) < 1e-3
+    for n, p in blk.named_parameters():
+        assert rel_err(p.grad.cpu(), gold['sir_grad__' + n]) < 1e-3, n
+    head.zero_grad(set_to_none=True)
+
+    dec = head.occ_ae_head.occ_decoder
+    feats = T('out_fused_roi_feats').requires_grad_(True)
+    xyz = T('dec_xyz')
+    R, K, _ = xyz.shape
+    idx = torch.arange(R, device=dev).repeat_interleave(K)
+    for form in ('factorised', 'reference-shaped'):
+        head.zero_grad(set_to_none=True)
+        feats.grad = None
+        if form == 'factorised':
+            lg = dec(feats, xyz.reshape(-1, 3), idx).view(R, K, 1)
+        else:
+            lg = dec.occ_forward(feats[:, None, :].repeat(1, K, 1), xyz)
+        (lg * T('dec_wl')).sum().backward()
+        assert rel_err(feats.grad.cpu(), gold['dec_grad_feats']) < 2e-3, form
+        for n, p in dec.named_parameters():
+            g = p.grad.cpu().numpy()
+            e = gold['dec_grad__' + n]
+            assert rel_err(g if g.size <= 70000 else g[:32], e) < 2e-3, (form, n)   # the two 4 MB matrices: leading rows + norm
+            assert abs(np.linalg.norm(g.astype(np.float64)) - float(gold['dec_gradnorm__' + n])) < 2e-3 * float(gold['dec_gradnorm__' + n]), (form, n)
+    head.zero_grad(set_to_none=True)
+
+
+def test_transformer_various_length_vs_reference_golden(dev, gold, head):
+    """Tracklets of unequal length (train_cfg.fixed_length=False): padding to the longest, key-padding mask,
+    causal mask, per-tracklet frame order restored (ococc_bbox_head.py:911-995)."""
+    pts_xyz, pts_feats, info, roi_inds, rois, frames = _inputs(gold, dev)
+    idx = torch.from_numpy(gold['vl_index']).to(dev)
+    fcf = torch.from_numpy(gold['out_final_cluster_feats']).to(dev)
+    mask = torch.from_numpy(gold['out_nonempty_roi_mask']).to(dev)
+    with torch.no_grad():
+        out = head.transformer_forward_various_length(rois[idx], frames[idx], fcf[idx], mask[idx])
+    assert out.shape == (52, 1536)
+    assert rel_err(out.cpu(), gold['vl_out']) < REL
+    # and the dispatcher takes this path in training mode when the config says so
+    head.train()
+    old = head.train_cfg.get('fixed_length', True)
+    try:
+        head.train_cfg['fixed_length'] = False
+        torch.manual_seed(0)
+        o2 = head.transformer_forward(rois[idx], frames[idx], fcf[idx], mask[idx])
+        assert o2.shape == (52, 1536) and bool(torch.isfinite(o2).all())
+    finally:
+        head.train_cfg['fixed_length'] = old
+        head.eval()
