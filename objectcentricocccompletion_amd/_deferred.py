@@ -2,22 +2,24 @@
 
 The weight-gradient slab sums of the sparse convolutions and the dgamma/dbeta sums of the LayerNorm layers feed
 nothing before the optimizer, and each is a launch of a few dozen blocks: run per layer they cost ~5-8 us apiece
-at one wave of work.  Here a layer's backward computes only its partial sums, hands autograd a view of the (still
-unwritten) gradient buffer, and registers the reduction; the autograd engine's final callback finishes all of
-them in one launch per kind before .backward() / autograd.grad() returns (inside a HIP-graph capture the launch
-simply lands behind the pass's last kernel).
+at one wave of work.  Here a layer's backward computes only its partial sums and registers the reduction; the
+autograd engine's final callback finishes all of them in one launch per kind before .backward() returns (inside a
+HIP-graph capture the launch simply lands behind the pass's last kernel).
 
-Handing out a buffer that is written later is only sound when nobody reads it before the flush.  `deferrable`
-admits exactly the parameters for which that holds -- a single process, or dist.GradBuckets as the gradient
-exchange (see GRADS_READ_AFTER_BACKWARD); an f32 leaf whose .grad is None (AccumulateGrad then keeps
-the tensor it is given instead of adding to an existing one), no tensor or post-accumulate hooks, no
-create_graph, not already queued in this pass (a shared weight would be summed by the engine's input buffer) --
-and `_flush` re-checks the outcome: a .grad that is not the handed-out buffer (the engine cloned it) is
-overwritten with the finished values.  Everything else takes the immediate per-layer reduction.
+The queued gradient never travels through the autograd engine: the layer's backward returns None for the
+parameter, and the flush itself puts the finished tensor into ``.grad`` -- assigns it when ``.grad`` is None, adds it
+otherwise.  Whatever else contributes to the same parameter in the pass (a weight-decay term written into the loss,
+a weight tied to a dense op, a second use of the layer, gradients accumulated over several passes) reaches ``.grad``
+through the engine's own AccumulateGrad as usual and is summed with ours, in that order; nothing ever reads a
+buffer before it is written.
 
-Not covered: a parameter used twice in one pass WITH a nested backward (reentrant activation checkpointing) between
-its two uses -- the nested pass's flush forgets that the first use is still waiting in the engine's input buffer.
-Set OCOCC_DEFER_PARAM_REDUCE=0 for such models.
+`deferrable` admits a parameter only when the running pass is one that accumulates into ``.grad`` for it
+(`torch._C._will_engine_execute_node` on its AccumulateGrad node: True for .backward(), an error for
+torch.autograd.grad(..., [p]), which wants the value handed back through the engine) and when nobody watches the
+engine's hand-over: no tensor hooks, no post-accumulate hooks, no create_graph, and -- with more than one rank --
+only when the gradient exchange reads ``.grad`` after backward() has returned (dist.GradBuckets does; torch DDP's
+reducer hooks AccumulateGrad from C++ and would miss our contribution).  Everything else takes the immediate
+per-layer reduction, which returns the gradient the ordinary way.
 """
 import os
 
@@ -25,18 +27,27 @@ import torch
 
 ENABLED = os.environ.get('OCOCC_DEFER_PARAM_REDUCE', '1') != '0'  # 0: always the per-layer reductions
 # Data-parallel wrappers that consume a gradient from a hook on its AccumulateGrad node (torch DDP's reducer: a C++
-# post hook, invisible from Python) would copy the unwritten buffer into their bucket.  With more than one rank the
+# post hook, invisible from Python) never see a gradient that bypasses the engine.  With more than one rank the
 # queue therefore stays off until the code that owns the gradient exchange says it reads gradients only AFTER
 # backward() has returned -- dist.GradBuckets does (pack() / all_reduce() run behind the pass).
 GRADS_READ_AFTER_BACKWARD = False
 _flushers = {}   # kind -> fn(list of jobs)
 _jobs = {}       # kind -> [job, ...] of the running pass
-_grads = []      # (param, view of the buffer handed to autograd)
-_queued = set()  # id(param) of the running pass
+_grads = []      # (param, finished-at-flush buffer)
 
 
 def register(kind, fn):
     _flushers[kind] = fn
+
+
+def _accumulates_into_grad(p):
+    """True when the running backward pass will execute p's AccumulateGrad node (p.grad gets the result)."""
+    with torch.enable_grad():
+        node = p.view_as(p).grad_fn.next_functions[0][0]
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except RuntimeError:  # autograd.grad(..., inputs=[p]) captures the gradient instead / no pass is running
+        return False
 
 
 def deferrable(*params):
@@ -46,24 +57,22 @@ def deferrable(*params):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return False
-    for p in params:
-        if id(p) in _queued:
-            _flush()  # second use of a parameter in one pass: finish what is pending, then reduce immediately
-            return False
-    if torch.is_grad_enabled():
+    if torch.is_grad_enabled():  # create_graph: the gradient itself must stay differentiable
         return False
     for p in params:
-        if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and p.grad is None
-                and p.dtype == torch.float32 and p.is_contiguous()):
+        if not (isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and p.dtype == torch.float32
+                and p.is_contiguous() and (p.grad is None or (p.grad.dtype == torch.float32 and p.grad.is_contiguous()))):
             return False
         if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+            return False
+        if not _accumulates_into_grad(p):
             return False
     return True
 
 
 def defer(kind, job, grads):
-    """Queue `job` for the kind's flusher; `grads` = [(param, view handed to autograd), ...].  False outside a
-    backward pass (nothing queued)."""
+    """Queue `job` for the kind's flusher; `grads` = [(param, buffer the job will have written), ...].  True: the
+    caller's backward must return None for these parameters.  False outside a backward pass (nothing queued)."""
     try:  # (one callback per job: a pass that raised never ran its callbacks, so "first of the pass" is unknowable;
         # the second and later calls of a pass find the queues empty)
         torch.autograd.Variable._execution_engine.queue_callback(_flush)
@@ -71,9 +80,7 @@ def defer(kind, job, grads):
         return False
     _jobs.setdefault(kind, []).append(job)
     for p, v in grads:
-        # (an alias, not `v` itself: a second owner of the tensor autograd is handed makes AccumulateGrad clone it)
         _grads.append((p, v.detach()))
-        _queued.add(id(p))
     return True
 
 
@@ -85,11 +92,12 @@ def _flush():
     global _jobs, _grads
     jobs, grads = _jobs, _grads
     _jobs, _grads = {}, []
-    _queued.clear()
     for kind, items in jobs.items():
         if items:
             _flushers[kind](items)
     for p, v in grads:
-        g = p.grad
-        if g is not None and g.data_ptr() != v.data_ptr():
-            g.copy_(v.reshape(g.shape))
+        v = v.reshape(p.shape)
+        if p.grad is None:
+            p.grad = v
+        else:  # accumulation over passes, another differentiable use of p in this pass, or a second queued use
+            p.grad.add_(v)

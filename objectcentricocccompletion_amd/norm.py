@@ -42,6 +42,8 @@ class _LayerNormAct(Function):
         dy2 = dy.reshape(-1, c).to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
         dgamma, dbeta = layernorm_act_backward(x2, dy2, w32, b32, stats, ctx.act, dx, weight, bias)
+        if dgamma is None:  # queued: weight.grad / bias.grad receive the sums when the pass ends (_deferred)
+            return dx.reshape(ctx.shape), None, None, None, None
         return dx.reshape(ctx.shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
 
 
@@ -62,12 +64,13 @@ _deferred.register('ln', _flush_param_reduce)
 
 
 def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=None):
-    """dx into `dx`; -> (dgamma, dbeta) f32 [c].  With the parameters given and an autograd backward pass running,
-    only the per-block partial sums are computed now and the two sums join the pass's end-of-backward launch
-    (_deferred); otherwise they are reduced right behind the kernel."""
+    """dx into `dx`; -> (dgamma, dbeta) f32 [c].  With the parameters given (by our autograd Functions) and a
+    backward pass running that accumulates into their .grad, only the per-block partial sums are computed now, the
+    two sums join the pass's end-of-backward launch and reach .grad there (_deferred): (None, None) is returned.
+    Otherwise they are reduced right behind the kernel."""
     n, c = x2.shape
     dgb = torch.empty((2, c), dtype=torch.float32, device=x2.device)  # overwritten by the kernel
-    dgamma, dbeta = dgb[0], dgb[1]  # views: what autograd is handed is never the queue's own reference
+    dgamma, dbeta = dgb[0], dgb[1]
     dt = L.dtype_code(x2.dtype)
     ws = L.workspace(L.lib.ococc_layernorm_act_bwd_workspace_bytes(n, c), x2.device)
     defer = False
@@ -79,7 +82,7 @@ def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=
                                           int(act), L.ptr(dx), None if defer else L.ptr(dgamma),
                                           None if defer else L.ptr(dbeta), dt, L.ptr(ws), ws.numel(), L.stream()),
             'layernorm_act_bwd')
-    return dgamma, dbeta
+    return (None, None) if defer else (dgamma, dbeta)
 
 
 def layer_norm_act(x, weight, bias, eps=1e-5, act='none'):

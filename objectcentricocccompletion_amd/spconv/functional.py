@@ -22,7 +22,7 @@ class _IndiceConvBase(Function):
         input_bp, filters_bp = ops.indice_conv_backward(
             features, filters, grad_output.contiguous(), indice_pairs, indice_pair_num,
             cls.INVERSE, cls.SUBM, _x_bf16=x_bf16, need_input_grad=ctx.needs_input_grad[0],
-            need_filter_grad=ctx.needs_input_grad[1])
+            need_filter_grad=ctx.needs_input_grad[1], _autograd=True)
         return input_bp, filters_bp, None, None, None
 
 
@@ -96,9 +96,9 @@ class _IndiceConvLN(Function):
         dgamma, dbeta = layernorm_act_backward(conv_out, dy2, g32, b32, stats, act, dconv, gamma, beta)
         input_bp, filters_bp = ops.indice_conv_backward(
             features, filters, dconv, indice_pairs, indice_pair_num, inverse, subm, _x_bf16=x_bf16,
-            need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1])
-        return (input_bp, filters_bp, dgamma.to(wdtype), dbeta.to(wdtype), None, None, None, None, None, None,
-                None)
+            need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1], _autograd=True)
+        return (input_bp, filters_bp, None if dgamma is None else dgamma.to(wdtype),
+                None if dbeta is None else dbeta.to(wdtype), None, None, None, None, None, None, None)
 
 
 def indice_conv_ln(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out, eps, act,

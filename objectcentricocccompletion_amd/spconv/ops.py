@@ -506,8 +506,10 @@ def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, nu
 
 
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False,
-                         subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True):
-    """ops.py:142-160 -> (input_bp [n_in,Cin], filters_bp like filters)."""
+                         subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True, _autograd=False):
+    """ops.py:142-160 -> (input_bp [n_in,Cin], filters_bp like filters).  ``_autograd`` (set by our autograd
+    Functions only): the weight gradient may join the end-of-backward reduction queue (_deferred), in which case
+    filters_bp is None here and ``filters.grad`` receives it when the pass ends."""
     L.require_device(features, filters, out_bp, indice_pairs)
     cin, cout = filters.shape[-2], filters.shape[-1]
     n_in, n_out = features.size(0), out_bp.size(0)
@@ -535,15 +537,15 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             out = dw[:, :cin, :cout].reshape(filters.shape)  # a view: splitting kvol never copies
             # Inside an autograd backward pass only the slabs are computed now; the slab reductions of all layers
             # go into ONE launch queued to the end of the pass (_deferred): dW feeds nothing before that.
-            defer = (_overlap is None and cap > 0 and n_in > 0 and n_out > 0 and cin == kd_in and cout == kd_out
-                     and _deferred.deferrable(filters)
+            defer = (_autograd and _overlap is None and cap > 0 and n_in > 0 and n_out > 0 and cin == kd_in
+                     and cout == kd_out and _deferred.deferrable(filters)
                      and _deferred.defer('wgrad', (ws, indice_pair_num, int(kvol), kd_in * kd_out, dw),
                                          [(filters, out)]))
             L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
                                                        L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
                                                        None if defer else L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
                     'sparse_conv_wgrad')
-            return out.to(filters.dtype)
+            return None if defer else out.to(filters.dtype)
 
         if _overlap is not None:
             # the weight gradient feeds nothing until the optimizer: run it on a side stream next to the

@@ -31,8 +31,9 @@ class _Mul(torch.autograd.Function):
         val = (g * x).sum(0)
         buf = torch.full((2, w.numel()), float('nan'))
         out = buf[0]
-        if not (D.deferrable(w) and D.defer('cpu_test', (out.detach(), val), [(w, out)])):
-            out.copy_(val)
+        if D.deferrable(w) and D.defer('cpu_test', (out.detach(), val), [(w, out)]):
+            return g * w, None     # queued: w.grad receives it when the pass ends
+        out.copy_(val)
         return g * w, out
 
 
@@ -51,11 +52,36 @@ def test_fresh_grad_is_handed_out_buffer_and_one_flush_per_pass():
     assert torch.equal(w2.grad, (x * w).sum(0).detach())
 
 
-def test_accumulation_takes_the_immediate_path():
+def test_accumulation_over_two_passes():
     w, x = _setup()
     _Mul.apply(x, w).sum().backward()
-    _Mul.apply(x, w).sum().backward()  # .grad exists: in-place add would read an unwritten buffer
-    assert _LOG == [1]
+    _Mul.apply(x, w).sum().backward()  # .grad exists: the flush adds the finished sum to it
+    assert _LOG == [1, 1]
+    assert torch.allclose(w.grad, 2 * x.sum(0).detach())
+
+
+def test_parameter_with_another_differentiable_use_in_the_same_pass():
+    """loss = layer(x).sum() + an explicit L2 term on the same weight: the engine delivers the L2 part
+    through AccumulateGrad, the queue adds the layer's part at the end of the pass -- nothing is lost, whichever
+    comes first, with or without a gradient from an earlier pass."""
+    for prior in (False, True):
+        w, x = _setup()
+        if prior:
+            w.grad = torch.ones(4)
+        (_Mul.apply(x, w).sum() + w.pow(2).sum()).backward()
+        exp = x.sum(0).detach() + 2 * w.detach() + (1.0 if prior else 0.0)
+        assert _LOG == [1] and torch.allclose(w.grad, exp), (prior, w.grad, exp)
+        was = D.ENABLED
+        try:
+            D.ENABLED = False
+            w2 = torch.nn.Parameter(w.detach().clone())
+            (_Mul.apply(x, w2).sum() + w2.pow(2).sum()).backward()
+        finally:
+            D.ENABLED = was
+        assert torch.allclose(w.grad, w2.grad + (1.0 if prior else 0.0))
+    # a weight tied to a dense op
+    w, x = _setup()
+    (_Mul.apply(x, w).sum() + (x.detach() @ w).sum()).backward()
     assert torch.allclose(w.grad, 2 * x.sum(0).detach())
 
 
@@ -83,28 +109,15 @@ def test_hooks_and_create_graph_take_the_immediate_path():
     assert _LOG == [] and torch.allclose(w2.grad, x2.sum(0))
 
 
-def test_cloned_gradient_is_repaired():
-    """A second owner of the returned tensor makes AccumulateGrad clone it (stale copy): the flush overwrites it."""
+def test_backward_with_inputs_and_unneeded_parameter():
+    """backward(inputs=[w]) accumulates into w.grad like a plain backward (queued); backward(inputs=[x]) does not
+    touch w at all (the layer is told so through needs_input_grad and nothing may be queued for it)."""
     w, x = _setup()
-    keep = []
-
-    class _Keep(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, x, w):
-            ctx.save_for_backward(x, w)
-            return x * w
-
-        @staticmethod
-        def backward(ctx, g):
-            x, w = ctx.saved_tensors
-            out = torch.full((w.numel(),), float('nan'))
-            keep.append(out)
-            assert D.deferrable(w) and D.defer('cpu_test', (out, (g * x).sum(0)), [(w, out)])
-            return g * w, out
-
-    _Keep.apply(x, w).sum().backward()
-    assert w.grad.data_ptr() != keep[0].data_ptr()
-    assert torch.equal(w.grad, x.sum(0).detach())
+    _Mul.apply(x, w).sum().backward(inputs=[w])
+    assert _LOG == [1] and torch.equal(w.grad, x.sum(0).detach()) and x.grad is None
+    w, x = _setup()
+    _Mul.apply(x, w).sum().backward(inputs=[x])
+    assert _LOG == [] and w.grad is None and torch.equal(x.grad, w.detach().expand(3, 4))
 
 
 def test_outside_backward_nothing_is_queued():

@@ -90,6 +90,51 @@ def test_gradient_accumulation_over_two_passes(dev):
         spm.FUSE_CONV_LN = orig
 
 
+def test_weight_with_an_explicit_regulariser_in_the_loss(dev):
+    """loss = stack(x) + sum(w^2) over the conv and LayerNorm parameters.  The regulariser's part comes
+    through the engine, the layers' part through the end-of-backward queue; the sum must equal the per-layer path
+    (OCOCC_DEFER_PARAM_REDUCE=0)."""
+    from objectcentricocccompletion_amd import _deferred as D
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor
+    from objectcentricocccompletion_amd.spconv import modules as spm
+    orig = spm.FUSE_CONV_LN
+    try:
+        blocks = _stack(dev, (16, 32, 64), False)
+        idx, feats, dout = _inputs(dev, 16, 64)
+
+        def run():
+            blocks.zero_grad(set_to_none=True)
+            t = SparseConvTensor(feats.clone().requires_grad_(True), idx, [10, 12, 9], 2)
+            for blk in blocks:
+                t = blk(t)
+            reg = sum(p.pow(2).sum() for p in blocks.parameters())
+            ((t.features.float() * dout.float()).sum() + 0.5 * reg).backward()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in blocks.parameters()]
+
+        seen = []
+        real = dict(D._flushers)
+        for kind, fn in real.items():
+            D._flushers[kind] = (lambda jobs, kind=kind, fn=fn: (seen.append(kind), fn(jobs))[1])
+        try:
+            late = run()
+        finally:
+            D._flushers.update(real)
+        assert sorted(seen) == ['ln', 'wgrad']            # the queue was in use
+        was = D.ENABLED
+        try:
+            D.ENABLED = False
+            now = run()
+        finally:
+            D.ENABLED = was
+        for p, a, b in zip(blocks.parameters(), late, now):
+            assert torch.isfinite(a).all()
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())   # (w + dW) vs (dW + w): one rounding
+            assert float((a - p.detach()).abs().max()) > 0                      # the layer's part is in there
+    finally:
+        spm.FUSE_CONV_LN = orig
+
+
 def test_layernorm_module_shared_and_autograd_grad(dev):
     """One LayerNorm used twice in a pass (the engine sums both contributions before AccumulateGrad) and
     autograd.grad() on its parameters, against torch's f32 LayerNorm."""
