@@ -58,6 +58,10 @@ def parse():
                     help='ococcnet workload: keep the occupancy-decoder MLP in f32 (default: bf16 GEMMs, f32 accumulate)')
     ap.add_argument('--split-graph', action='store_true',
                     help='use the N>1 launch plan (fwd+bwd graph, eager all-reduce, optimizer graph) at N=1 too')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='compute the NEXT batch\'s geometry on a forked stream of the step\'s graph instead of at the head of '
+                         'its own step (graph.PipelinedStep; measured no faster: the geometry kernels contend with the '
+                         'convolutions they run beside, 0.346-0.360 vs 0.335 ms/step)')
     ap.add_argument('--no-graph', action='store_true',
                     help='launch every kernel eagerly from Python instead of replaying the captured HIP graph')
     args = ap.parse_args()
@@ -415,9 +419,36 @@ def main():
     probe = sp_ops.KernelProbe(kd=PROBE_KD, ncols=PROBE_NC, repeat=8 if use_graph else 1)
 
     graph_note = 'eager launches'
+    pipelined = False
     if use_graph:
         try:
-            if world == 1 and not args.split_graph:
+            if world == 1 and not args.split_graph and args.pipeline:
+                # the geometry of the NEXT batch (voxelise, scatter-mean, rulebook: points only, no weights) is
+                # recorded on a forked stream of the same graph and runs beside the convolutions (graph.PipelinedStep)
+                from objectcentricocccompletion_amd.graph import PipelinedStep
+
+                def train_on(geom):
+                    opt.zero_grad(set_to_none=True)
+                    out = model(geometry=geom)
+                    out.features.backward(d_cap)
+                    opt.step()
+                    return out
+
+                if os.environ.get('OCOCC_PIPE_FORK', 'head') == 'backward':
+                    def fwd_only(geom):
+                        opt.zero_grad(set_to_none=True)
+                        return model(geometry=geom)
+
+                    def bwd_opt(out):
+                        out.features.backward(d_cap)
+                        opt.step()
+                        return out
+                    g_pipe = PipelinedStep(lambda: model.geometry(xyz, feats, bidx, B, static=True), bwd_opt, forward=fwd_only)
+                else:
+                    g_pipe = PipelinedStep(lambda: model.geometry(xyz, feats, bidx, B, static=True), train_on)
+                step = g_pipe.replay
+                pipelined = True
+            elif world == 1 and not args.split_graph:
                 g_all = GraphedStep(whole_step, warmup=3)
 
                 def step():
@@ -443,7 +474,13 @@ def main():
                     buckets.reduce()
                     g_opt.replay()
                     return out
-            graph_note = 'one hipGraphLaunch per step' if world == 1 and not args.split_graph else 'two HIP graphs + eager RCCL all-reduce'
+            if pipelined:
+                graph_note = ('one hipGraphLaunch per step; the next batch\'s geometry (voxelise, scatter-mean, rulebook) '
+                              'runs on a forked stream of the same graph')
+            elif world == 1 and not args.split_graph:
+                graph_note = 'one hipGraphLaunch per step'
+            else:
+                graph_note = 'two HIP graphs + eager RCCL all-reduce'
         except Exception as e:  # noqa: BLE001 -- report and fall back to eager launches, never to another device
             print(f'[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
             use_graph = False

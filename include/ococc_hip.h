@@ -165,6 +165,34 @@ int ococc_voxelize_scatter_mean_f32(const float* points, int32_t num_point_featu
                                     ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * B1 + B2 + B3 for a batch of per-object grids in three launches: the outputs of
+ * ococc_voxelize_scatter_mean_f32 (replaces Voxelization dynamic + DynamicScatter mean,
+ * ops/voxel/voxelize.py:10-113, ops/voxel/scatter_points.py:53-107) AND of the 3x3x3 dilation-1
+ * ococc_subm_rulebook_build_sorted on those voxels (replaces getIndicePair<3> with subM,
+ * ops/spconv/include/spconv/spconv_ops.h:27-104 / geometry.h:247-297), bit for bit, in the
+ * fixed-capacity form (every one of `capacity` rows is written; rows past *num_voxels carry -1
+ * coordinates, count 0, zero features, -1 neighbours; indice_pairs[k][.][indice_num[k]..] is left
+ * unwritten, as with fill_pair_tails = 0).
+ * Preconditions beyond those of the two entry points: batch_idx is non-decreasing (points arrive
+ * grouped by object grid; anything else sets *status = 1 and drops the offending points), the cells of
+ * one grid are a multiple of 32 and at most 512 Ki (bitmap + prefix of one grid live in LDS),
+ * capacity = min(n, batch * cells).  slices (1..8): workgroups per grid in the emit launch.
+ * nbr_t [27, capacity] int32, blockmask [ceil(capacity/16)] u32, indice_pairs [27, 2, capacity] int32,
+ * indice_num [27] int32.  The workspace starts with the grid_unique layout (bitmap | prefix), as the
+ * voxelize_scatter workspace does.
+ * ------------------------------------------------------------------------ */
+int64_t ococc_object_grid_geometry_workspace_bytes(int64_t n, int32_t batch_size, const int32_t host_grid_zyx[3],
+                                                   int32_t slices);
+int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
+                                   int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
+                                   const float host_coors_range[6], int32_t batch_size,
+                                   const int32_t host_grid_zyx[3], int32_t slices, int32_t* voxel_coors,
+                                   int64_t capacity, int32_t* inv, int32_t* counts, float* voxel_feats,
+                                   uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status, int32_t* nbr_t,
+                                   uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
+                                   int64_t workspace_bytes, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * visibility ray test of the GT-occupancy annotation
  * replaces point_cloud_to_range_image_idx (tools/occ/occ_annotate.py:141-207) and the gather /
  * compare / max-over-frames-and-sensors around it in OccAnnotator.annotate_trk (:488-556).

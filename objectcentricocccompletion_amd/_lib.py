@@ -35,6 +35,10 @@ SIGNATURES = {
     'ococc_grid_unique_i32': (c_i32, [c_vp, c_i64, c_i32, _I4, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),
     'ococc_voxelize_scatter_workspace_bytes': (c_i64, [c_i64, c_i32, _I3]),
+    'ococc_object_grid_geometry_workspace_bytes': (c_i64, [c_i64, c_i32, _I3, c_i32]),
+    'ococc_object_grid_geometry_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3, c_i32,
+                                               c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_i64, c_vp]),
     'ococc_voxelize_scatter_mean_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3,
                                                 c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_occ_visibility_f64': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
@@ -213,6 +217,57 @@ def const_tensor(values, device, dtype=torch.float32):
     return t
 
 
+_plan = None  # the BufferPlan in force (None: plain torch.empty)
+
+
+def empty(shape, dtype, device):
+    """torch.empty, or the next buffer of the BufferPlan in force."""
+    if _plan is not None:
+        return _plan.take(tuple(int(v) for v in shape), dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+class BufferPlan(object):
+    """Caller-owned output memory for a chain of ops whose wrappers allocate through L.empty / L.workspace.
+
+    The first ``with plan:`` block records every buffer the wrapped calls allocate; every later block hands the same
+    tensors back in the same order (the calls must repeat with the same shapes and dtypes -- checked).  With two plans
+    a captured HIP graph can write the geometry of the NEXT batch into one set of buffers while the training kernels
+    of the same graph read the other set (graph.PipelinedStep)."""
+
+    def __init__(self):
+        self.bufs, self.pos, self.recorded = [], 0, False
+
+    def take(self, shape, dtype, device):
+        if not self.recorded:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.bufs.append(t)
+            return t
+        if self.pos >= len(self.bufs):
+            raise OcoccError('BufferPlan: more allocations than in the recorded run')
+        t = self.bufs[self.pos]
+        self.pos += 1
+        if tuple(t.shape) != shape or t.dtype != dtype or t.device != torch.device(device):
+            raise OcoccError(f'BufferPlan: allocation {self.pos - 1} was {tuple(t.shape)} {t.dtype}, now {shape} {dtype}')
+        return t
+
+    def __enter__(self):
+        global _plan
+        if _plan is not None:
+            raise OcoccError('BufferPlan: plans do not nest')
+        self.pos = 0
+        _plan = self
+        return self
+
+    def __exit__(self, *exc):
+        global _plan
+        _plan = None
+        if exc[0] is None and self.recorded and self.pos != len(self.bufs):
+            raise OcoccError('BufferPlan: fewer allocations than in the recorded run')
+        self.recorded = True
+        return False
+
+
 def workspace(nbytes, device):
     """Caller-owned scratch buffer (the C ABI never allocates)."""
-    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+    return empty((max(int(nbytes), 1),), torch.uint8, device)

@@ -59,3 +59,54 @@ class GraphedStep(object):
         return self.out
 
     __call__ = replay
+
+
+class PipelinedStep(object):
+    """A training step whose input geometry is prepared one batch ahead, inside the same graph launch.
+
+    ``prepare()`` builds everything of the NEXT batch that depends on its points only (SubMOccEncoder.geometry:
+    voxelise, scatter-mean, rulebook -- a dozen short, latency-bound launches that feed nothing before the next
+    step); ``train(geometry)`` is forward + backward (+ optimizer) on the CURRENT batch.  Both are recorded into one
+    HIP graph, the geometry chain on a forked side stream, so it runs beside the convolutions instead of in front of
+    them.  Two such graphs alternate: graph i trains on geometry buffers i and writes buffers 1-i (L.BufferPlan gives
+    ``prepare`` the same caller-owned output memory every time), so a replay never writes what it reads.  The very
+    first geometry is computed eagerly here.  Same results as the un-pipelined step: the data flow is unchanged,
+    only the order in which independent kernels may run.
+
+    The reference has no counterpart; its data loader prefetches batches on the host, and its voxelisation and
+    rulebook run inside forward (ops/voxel/voxelize.py:10-113, ops/spconv/conv.py:146-172)."""
+
+    def __init__(self, prepare, train, warmup=2, forward=None):
+        """``forward`` (optional): train is split as train(forward(geometry)); the fork then sits BEHIND the forward
+        pass, i.e. the geometry chain runs beside the backward kernels only."""
+        from . import _lib as L
+        self.plans = (L.BufferPlan(), L.BufferPlan())
+        self.side = torch.cuda.Stream()
+        self.geo = [None, None]
+        for i in (0, 1):  # geometry of the first batch into set 0; set 1 records its buffers (overwritten by graph 0)
+            with self.plans[i], torch.no_grad():
+                self.geo[i] = prepare()
+        torch.cuda.synchronize()
+
+        def body(i):
+            def fn():
+                cur = torch.cuda.current_stream()
+                mid = forward(self.geo[i]) if forward is not None else self.geo[i]
+                self.side.wait_stream(cur)                      # fork
+                with torch.cuda.stream(self.side), self.plans[1 - i], torch.no_grad():
+                    self.geo[1 - i] = prepare()
+                out = train(mid)
+                cur.wait_stream(self.side)                      # join
+                return out
+            return fn
+
+        first = GraphedStep(body(0), warmup=warmup)
+        self.steps = (first, GraphedStep(body(1), warmup=warmup, pool=first.pool()))
+        self.turn = 0
+
+    def replay(self):
+        out = self.steps[self.turn].replay()
+        self.turn ^= 1
+        return out
+
+    __call__ = replay

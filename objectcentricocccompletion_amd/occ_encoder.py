@@ -13,15 +13,20 @@ from torch import nn
 from .sparse_block import make_sparse_convmodule
 from .spconv import SparseConvTensor
 from .spconv import ops as sp_ops
-from .voxel import dynamic_scatter, voxelization, voxelize_scatter_mean
+from .voxel import dynamic_scatter, object_grid_geometry, voxelization, voxelize_scatter_mean
 
 
 class SubMOccEncoder(nn.Module):
 
     def __init__(self, in_channels=16, channels=(32, 64, 128), voxel_size=(0.2, 0.2, 0.2),
                  point_cloud_range=(-4, -4, -4, 4, 4, 4), norm_cfg=dict(type='LN', eps=1e-3),
-                 act_type='gelu', feature_dtype=torch.bfloat16, fused_front_end=True):
+                 act_type='gelu', feature_dtype=torch.bfloat16, fused_front_end=True, grouped_points=True):
+        """``grouped_points``: the points of one object grid are contiguous in the input (batch_idx non-decreasing), as
+        the per-object pipelines deliver them; the fixed-capacity geometry then runs through the per-grid LDS kernels
+        (voxel.object_grid_geometry).  A batch that breaks the promise is reported through the status word of the
+        returned meta tensor and its stray points are dropped."""
         super().__init__()
+        self.grouped_points = bool(grouped_points)
         self.fused_front_end = bool(fused_front_end) and feature_dtype in (torch.bfloat16, torch.float32)
         self.voxel_size = list(voxel_size)
         self.point_cloud_range = list(point_cloud_range)
@@ -45,17 +50,48 @@ class SubMOccEncoder(nn.Module):
         coors = torch.cat([batch_idx.view(-1, 1).to(torch.int32), zyx], 1)
         return coors
 
-    def forward(self, points, feats, batch_idx, batch_size, static=False):
+    def geometry(self, points, feats, batch_idx, batch_size, static=False):
+        """Everything that depends on the points only, none of it on the weights: voxelise -> scatter-mean ->
+        SparseConvTensor -> the sub-manifold rulebook all conv layers share (indice_key 'subm1').  A training loop
+        can run this for batch t+1 on a second stream while batch t trains (graph.PipelinedStep): the chain is a
+        dozen short, latency-bound launches that fit beside the convolutions.  Returns the input SparseConvTensor
+        with the rulebook already in its indice_dict; pass it to forward(geometry=...)."""
+        key = self.conv_layers[0][0].indice_key
+        conv = self.conv_layers[0][0]
+        if (static and self.grouped_points and self.fused_front_end and list(conv.kernel_size) == [3, 3, 3]
+                and list(conv.dilation) == [1, 1, 1] and not (feats.requires_grad and torch.is_grad_enabled())):
+            res = object_grid_geometry(points, batch_idx, feats, self.voxel_size, self.point_cloud_range,
+                                       self.sparse_shape, batch_size, out_dtype=self.feature_dtype)
+            if res is not None:
+                vfeats, vcoors, _, _, meta, pairs, num = res
+                x = SparseConvTensor(vfeats, vcoors, self.sparse_shape, batch_size)
+                x.indice_dict[key] = (vcoors, vcoors, pairs, num, self.sparse_shape)
+                x.meta = meta
+                return x
+        x = self._front_end(points, feats, batch_idx, batch_size, static)
+        outids, pairs, num = sp_ops.get_indice_pairs(x.indices, batch_size, self.sparse_shape, conv.kernel_size,
+                                                     conv.stride, conv.padding, conv.dilation, conv.output_padding,
+                                                     True, False, grid=x.grid)
+        x.indice_dict[key] = (outids, x.indices, pairs, num, self.sparse_shape)
+        return x
+
+    def forward(self, points=None, feats=None, batch_idx=None, batch_size=None, static=False, geometry=None):
         """``static=True`` keeps every tensor at its fixed capacity (one row per point; unused
         voxel rows carry -1 coordinates, take part in no rulebook pair and must get a zero
         upstream gradient), so that the whole step has no device read-back and can be captured
-        in a HIP graph (graph.GraphedStep)."""
+        in a HIP graph (graph.GraphedStep).  ``geometry``: the result of self.geometry() for this batch."""
         # all conv weights to their bf16 kernel layouts in one launch (forward operands, and the dgrad
         # operands of the layers whose input needs a gradient)
         grad = torch.is_grad_enabled()
         items = [(layer[0].weight, 0) for layer in self.conv_layers]
         items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
         sp_ops.prepare_weights(items)
+        x = geometry if geometry is not None else self.geometry(points, feats, batch_idx, batch_size, static)
+        for layer in self.conv_layers:
+            x = layer(x)
+        return x
+
+    def _front_end(self, points, feats, batch_idx, batch_size, static):
         if self.fused_front_end:
             # voxelize -> cat -> DynamicScatter(mean) -> cast in one C-ABI call (7 launches instead of 15)
             vfeats, vcoors, _, _, _ = voxelize_scatter_mean(
@@ -66,10 +102,7 @@ class SubMOccEncoder(nn.Module):
             vfeats, vcoors = dynamic_scatter(feats, coors, 'mean',
                                              grid_shape=[batch_size] + self.sparse_shape, static=static)
             vfeats = vfeats.to(self.feature_dtype)
-        x = SparseConvTensor(vfeats, vcoors, self.sparse_shape, batch_size)
-        for layer in self.conv_layers:
-            x = layer(x)
-        return x
+        return SparseConvTensor(vfeats, vcoors, self.sparse_shape, batch_size)
 
 
 def synthetic_object_grids(num_grids, points_per_grid, in_channels=16, half_extent=4.0, seed=0,

@@ -7,7 +7,6 @@ import math
 
 import numpy as np
 import torch
-from torch.nn import init
 from torch.nn.parameter import Parameter
 
 from . import functional as Fsp
@@ -17,60 +16,54 @@ from .structure import SparseConvTensor
 from ..registry import CONV_LAYERS
 
 
-def _calculate_fan_in_and_fan_out_hwio(tensor):
-    """conv.py:28-45 (weights are stored ...,Cin,Cout)."""
-    dimensions = tensor.ndimension()
-    if dimensions < 2:
-        raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 dimensions')
-    if dimensions == 2:
-        return tensor.size(-2), tensor.size(-1)
-    receptive = tensor[..., 0, 0].numel()
-    return tensor.size(-2) * receptive, tensor.size(-1) * receptive
+def _fans_hwio(weight):
+    """(fan_in, fan_out) of a [..., Cin, Cout] filter bank: channels times the number of kernel taps."""
+    taps = weight.numel() // (weight.shape[-2] * weight.shape[-1])
+    return weight.shape[-2] * taps, weight.shape[-1] * taps
+
+
+def _per_axis(value, ndim):
+    return [int(v) for v in value] if isinstance(value, (list, tuple)) else [int(value)] * ndim
 
 
 class SparseConvolution(SparseModule):
+    """Common body of the sparse / sub-manifold / inverse / transposed layers.  Attribute names, the constructor
+    signature and the (kD, kH, kW, Cin, Cout) weight layout are the reference's (conv.py:47-111): configs name the
+    arguments and state dicts name the parameters."""
 
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
                  dilation=1, groups=1, bias=True, subm=False, output_padding=0, transposed=False,
                  inverse=False, indice_key=None, fused_bn=False):
         super().__init__()
-        assert groups == 1
-
-        def _l(v):
-            return list(v) if isinstance(v, (list, tuple)) else [v] * ndim
-
-        kernel_size, stride, padding = _l(kernel_size), _l(stride), _l(padding)
-        dilation, output_padding = _l(dilation), _l(output_padding)
-        for d, s in zip(dilation, stride):
-            assert any([s == 1, d == 1]), "don't support this."
-        self.ndim = ndim
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.kernel_size = kernel_size
-        self.conv1x1 = np.prod(kernel_size) == 1
-        self.stride = stride
-        self.padding = padding
-        self.dilation = dilation
-        self.transposed = transposed
-        self.inverse = inverse
-        self.output_padding = output_padding
-        self.groups = groups
-        self.subm = subm
-        self.indice_key = indice_key
-        self.fused_bn = fused_bn
-        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
-        if bias:
-            self.bias = Parameter(torch.Tensor(out_channels))
-        else:
-            self.register_parameter('bias', None)
+        if groups != 1:
+            raise NotImplementedError('grouped sparse convolutions are not built (the reference asserts groups == 1)')
+        geom = dict(kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation,
+                    output_padding=output_padding)
+        for name, value in geom.items():
+            setattr(self, name, _per_axis(value, ndim))
+        if any(s != 1 and d != 1 for s, d in zip(self.stride, self.dilation)):
+            raise ValueError('stride and dilation cannot both differ from 1 along an axis')
+        self.ndim, self.groups = ndim, groups
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.subm, self.transposed, self.inverse = subm, transposed, inverse
+        self.indice_key, self.fused_bn = indice_key, fused_bn
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        if self.bias is not None:
-            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
-            bound = 1 / math.sqrt(fan_in)
-            init.uniform_(self.bias, -bound, bound)
+        """The reference's initial distribution (conv.py:103-111): Kaiming-uniform(a = sqrt 5) for the weights with
+        the fan-in torch derives from a [dim0, dim1, ...] reading of the tensor -- dim 1 times everything behind it,
+        which for this channels-last bank is kH * kW * Cin * Cout, not Cin * taps -- and a bias uniform in
+        +-1/sqrt(Cin * taps)."""
+        fan_w = self.weight[0].numel() if self.weight.dim() > 2 else self.weight.shape[-2]
+        bound = math.sqrt(2.0 / (1.0 + 5.0)) * math.sqrt(3.0 / fan_w)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                fan_in, _ = _fans_hwio(self.weight)
+                self.bias.uniform_(-1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
 
     def _ln_wanted(self, indice_pairs, indice_pair_num, num_out):
         from . import modules as _m
@@ -91,47 +84,46 @@ class SparseConvolution(SparseModule):
         """``_ln``: the LayerNorm module that follows this conv in a make_sparse_convmodule block; when the
         shape allows, it (and its fused GELU) run in the conv kernel's epilogue and the returned tensor is
         marked ``_ln_applied`` so that the container skips the norm."""
-        assert isinstance(input, SparseConvTensor)
-        features = input.features
-        indices = input.indices
-        spatial_shape = input.spatial_shape
-        batch_size = input.batch_size
-        if not self.subm:
-            if self.transposed:
-                out_spatial_shape = ops.get_deconv_output_size(
-                    spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation,
-                    self.output_padding)
-            else:
-                out_spatial_shape = ops.get_conv_output_size(
-                    spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation)
-        else:
-            out_spatial_shape = spatial_shape
-        if self.conv1x1:
-            features = torch.mm(input.features,
-                                self.weight.view(self.in_channels, self.out_channels).to(features.dtype))
+        if not isinstance(input, SparseConvTensor):
+            raise TypeError(f'{type(self).__name__} takes a SparseConvTensor, got {type(input).__name__}')
+        features, batch_size = input.features, input.batch_size
+
+        def wrap(feats, ids, shape):
+            out = SparseConvTensor(feats, ids, shape, batch_size, input.grid)
+            out.indice_dict = input.indice_dict
+            return out
+
+        if self.conv1x1:  # a 1^ndim kernel is a per-voxel Linear: no rulebook at all
+            feats = torch.mm(features, self.weight.view(self.in_channels, self.out_channels).to(features.dtype))
             if self.bias is not None:
-                features = features + self.bias.to(features.dtype)
-            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape,
-                                          input.batch_size)
-            out_tensor.indice_dict = input.indice_dict
-            out_tensor.grid = input.grid
-            return out_tensor
-        datas = input.find_indice_pair(self.indice_key)
+                feats = feats + self.bias.to(feats.dtype)
+            return wrap(feats, input.indices, input.spatial_shape)
+
+        # the rulebook: shared through indice_dict between layers that name the same indice_key
+        cached = input.find_indice_pair(self.indice_key)
         if self.inverse:
-            assert datas is not None and self.indice_key is not None
-            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = datas
-            assert indice_pairs.shape[0] == np.prod(self.kernel_size), \
-                'inverse conv must have same kernel size as its couple conv'
+            if cached is None:
+                raise KeyError(f'inverse conv: no rulebook cached under indice_key {self.indice_key!r}')
+            _, outids, indice_pairs, indice_pair_num, out_spatial_shape = cached  # the partner's INPUT side
+            if indice_pairs.shape[0] != int(np.prod(self.kernel_size)):
+                raise ValueError('an inverse conv needs the kernel size of the conv it undoes')
         else:
-            if self.indice_key is not None and datas is not None:
-                outids, _, indice_pairs, indice_pair_num, _ = datas
+            if self.subm:
+                out_spatial_shape = input.spatial_shape
+            elif self.transposed:
+                out_spatial_shape = ops.get_deconv_output_size(input.spatial_shape, self.kernel_size, self.stride,
+                                                               self.padding, self.dilation, self.output_padding)
+            else:
+                out_spatial_shape = ops.get_conv_output_size(input.spatial_shape, self.kernel_size, self.stride,
+                                                             self.padding, self.dilation)
+            if cached is not None:
+                outids, _, indice_pairs, indice_pair_num, _ = cached
             else:
                 outids, indice_pairs, indice_pair_num = ops.get_indice_pairs(
-                    indices, batch_size, spatial_shape, self.kernel_size, self.stride,
-                    self.padding, self.dilation, self.output_padding, self.subm, self.transposed,
-                    grid=input.grid)
-                input.indice_dict[self.indice_key] = (outids, indices, indice_pairs,
-                                                      indice_pair_num, spatial_shape)
+                    input.indices, batch_size, input.spatial_shape, self.kernel_size, self.stride, self.padding,
+                    self.dilation, self.output_padding, self.subm, self.transposed, grid=input.grid)
+                input.indice_dict[self.indice_key] = (outids, input.indices, indice_pairs, indice_pair_num,
+                                                      input.spatial_shape)
         if self.fused_bn:
             assert self.bias is not None
             out_features = ops.fused_indice_conv(features, self.weight, self.bias, indice_pairs,
@@ -144,9 +136,7 @@ class SparseConvolution(SparseModule):
                 out_features = Fsp.indice_conv_ln(features, self.weight, _ln.weight, _ln.bias, indice_pairs,
                                                   indice_pair_num, outids.shape[0], _ln.eps,
                                                   1 if _ln.fused_act == 'gelu' else 0, self.inverse, self.subm)
-                out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
-                out_tensor.indice_dict = input.indice_dict
-                out_tensor.grid = input.grid
+                out_tensor = wrap(out_features, outids, out_spatial_shape)
                 out_tensor._ln_applied = True
                 return out_tensor
             if self.subm:
@@ -160,10 +150,7 @@ class SparseConvolution(SparseModule):
                                                indice_pair_num, outids.shape[0])
             if self.bias is not None:
                 out_features = out_features + self.bias.to(out_features.dtype)
-        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
-        out_tensor.indice_dict = input.indice_dict
-        out_tensor.grid = input.grid
-        return out_tensor
+        return wrap(out_features, outids, out_spatial_shape)
 
 
 @CONV_LAYERS.register_module()

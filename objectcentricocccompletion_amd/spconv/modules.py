@@ -41,38 +41,31 @@ class SparseSequential(SparseModule):
 
     def __init__(self, *args, **kwargs):
         super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
-        else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            if name in self._modules:
-                raise ValueError('name exists.')
-            self.add_module(name, module)
+        named = args[0].items() if len(args) == 1 and isinstance(args[0], OrderedDict) else \
+            ((str(i), m) for i, m in enumerate(args))
+        for name, module in list(named) + list(kwargs.items()):
+            self.add(module, name)
         self._sparity_dict = {}
 
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError('index {} is out of range'.format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
+    def add(self, module, name=None):
+        """Append a child; unnamed children are numbered like nn.Sequential's."""
+        name = str(len(self._modules)) if name is None else name
+        if name in self._modules:
+            raise KeyError(f'a child named {name!r} exists')
+        self.add_module(name, module)
 
     def __len__(self):
         return len(self._modules)
 
+    def __getitem__(self, idx):
+        children = list(self._modules.values())
+        if not -len(children) <= idx < len(children):
+            raise IndexError(f'index {idx} is out of range')
+        return children[idx]
+
     @property
     def sparity_dict(self):
         return self._sparity_dict
-
-    def add(self, module, name=None):
-        if name is None:
-            name = str(len(self._modules))
-            if name in self._modules:
-                raise KeyError('name exists')
-        self.add_module(name, module)
 
     def forward(self, input):
         mods = list(self._modules.items())

@@ -142,10 +142,10 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
         raise L.OcoccError('get_indice_pairs: unsupported geometry (odd kernel sizes, '
                            'batch*D*H*W < 2^31 required)')
     ws = L.workspace(nbytes, dev)
-    nbr_t = torch.empty((kvol, n), dtype=torch.int32, device=dev)
-    mask = torch.empty(((n + 15) // 16,), dtype=torch.int32, device=dev) if kvol <= 32 else None
-    pairs = torch.empty((kvol, 2, n), dtype=torch.int32, device=dev)
-    num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+    nbr_t = L.empty((kvol, n), torch.int32, dev)
+    mask = L.empty(((n + 15) // 16,), torch.int32, dev) if kvol <= 32 else None
+    pairs = L.empty((kvol, 2, n), torch.int32, dev)
+    num = L.empty((kvol,), torch.int32, dev)
     grid = getattr(indices, '_ococc_grid', None)
     if (grid is not None and grid[3] == (int(batch_size),) + tuple(int(v) for v in spatial_shape)
             and all(int(d) == 1 for d in dilation)):
@@ -168,16 +168,23 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     dilated = any(int(d) != 1 for d in dilation)
     # (a dilated sub-manifold rulebook of the reference is not its own mirror image -- it keeps padding = k/2 --
     # so it is handled like a user-supplied one: the input-gradient table is derived from the pairs on demand)
-    rb = RulebookTables(not dilated, kvol)
-    if DEFAULT_PAIRS_PER_ROW is not None:
-        rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+    rb = attach_subm_tables(pairs, nbr_t, mask, n, kvol, symmetric=not dilated)
     if dilated and n > 0:
         _own_row_offset(rb, num, nbr_t, mask, n)
-    rb.tables[(False, 'fwd')] = (nbr_t, mask, n)
-    if not dilated:
-        rb.tables[(False, 'bwd')] = (nbr_t, mask, n)  # symmetric: same table, offset-flipped weights
-    pairs._ococc = rb
     return indices, pairs, num
+
+
+def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True):
+    """Hang the device-side companions of a sub-manifold rulebook (offset-major gather table, 16-row block masks) on
+    its indice_pairs tensor, where indice_conv / indice_conv_backward look for them."""
+    rb = RulebookTables(symmetric, kvol)
+    if DEFAULT_PAIRS_PER_ROW is not None:
+        rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+    rb.tables[(False, 'fwd')] = (nbr_t, mask, rows)
+    if symmetric:
+        rb.tables[(False, 'bwd')] = (nbr_t, mask, rows)  # symmetric: same table, offset-flipped weights
+    pairs._ococc = rb
+    return rb
 
 
 def _tables_for(indice_pairs, indice_pair_num, inverse, direction, rows, subm):

@@ -1,55 +1,53 @@
-"""SparseConvTensor -- same fields and methods as mmdet3d/ops/spconv/structure.py:21-69."""
-import numpy as np
+"""SparseConvTensor: the active voxels of a batch of grids.  Field and method names follow the reference's
+container (mmdet3d/ops/spconv/structure.py:21-69) because configs, blocks and checkpoints address them."""
+import math
+
 import torch
 
 
 def scatter_nd(indices, updates, shape):
-    """structure.py:5-18: dense tensor with `updates` written at `indices` (no repeats)."""
-    ret = torch.zeros(*shape, dtype=updates.dtype, device=updates.device)
-    ndim = indices.shape[-1]
-    output_shape = list(indices.shape[:-1]) + shape[indices.shape[-1]:]
-    flat = indices.view(-1, ndim)
-    slices = [flat[:, i] for i in range(ndim)] + [Ellipsis]
-    ret[slices] = updates.view(*output_shape)
-    return ret
+    """Dense tensor of `shape` holding `updates` at the integer coordinates `indices` [..., k] (k leading dims of
+    `shape`; coordinates must not repeat), zero elsewhere.  One index_put."""
+    k = indices.shape[-1]
+    dense = updates.new_zeros(tuple(shape))
+    coords = indices.reshape(-1, k).long().unbind(1)
+    dense.index_put_(coords, updates.reshape((-1,) + tuple(shape[k:])))
+    return dense
 
 
 class SparseConvTensor(object):
+    """features [N, C]; indices [N, 1 + ndim] int32 rows (batch, z, y, x); the grid extent; and ``indice_dict``, the
+    rulebooks already built on this geometry, keyed by the layers' ``indice_key``.  ``grid`` is kept for
+    call-compatibility with the reference (its pre-allocated dense index grid); the product never needs one."""
 
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
         self.features = features
-        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.indices = indices.int() if indices.dtype != torch.int32 else indices
         self.spatial_shape = spatial_shape
         self.batch_size = batch_size
-        self.indice_dict = {}
         self.grid = grid
+        self.indice_dict = {}
+
+    def find_indice_pair(self, key):
+        return self.indice_dict.get(key) if key is not None else None
 
     @property
     def spatial_size(self):
-        return np.prod(self.spatial_shape)
-
-    def find_indice_pair(self, key):
-        if key is None:
-            return None
-        return self.indice_dict.get(key, None)
-
-    def dense(self, channels_first=True):
-        output_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
-        res = scatter_nd(self.indices.long(), self.features, output_shape)
-        if not channels_first:
-            return res
-        ndim = len(self.spatial_shape)
-        trans = list(range(0, ndim + 1))
-        trans.insert(1, ndim + 1)
-        return res.permute(*trans).contiguous()
-
-    def replace_feature(self, new_features):
-        """spconv 2.x style functional update (sparse_block.py:13-19 probes for it)."""
-        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,
-                               self.grid)
-        out.indice_dict = self.indice_dict
-        return out
+        return math.prod(int(s) for s in self.spatial_shape)
 
     @property
     def sparity(self):
-        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+        """Fraction of the batch's cells that are active (the reference spells it this way)."""
+        return self.indices.shape[0] / (self.spatial_size * self.batch_size)
+
+    def dense(self, channels_first=True):
+        """[B, C, *spatial] (or [B, *spatial, C]) with zeros at inactive cells."""
+        extent = (int(self.batch_size),) + tuple(int(s) for s in self.spatial_shape)
+        out = scatter_nd(self.indices, self.features, extent + (self.features.shape[1],))
+        return out.movedim(-1, 1).contiguous() if channels_first else out
+
+    def replace_feature(self, new_features):
+        """spconv 2.x style functional update (sparse_block.py:13-19 probes for it): same geometry, same rulebooks."""
+        twin = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, self.grid)
+        twin.indice_dict = self.indice_dict
+        return twin

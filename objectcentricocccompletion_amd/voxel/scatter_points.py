@@ -220,12 +220,12 @@ def voxelize_scatter_mean(points, batch_idx, feats, voxel_size, coors_range, gri
     if nbytes < 0:
         raise L.OcoccError(f'voxelize_scatter_mean: grid {dims} too large for the bitmap plan')
     ws = L.workspace(nbytes, dev)
-    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-    inv = torch.empty((n,), dtype=torch.int32, device=dev)
-    counts = torch.empty((cap,), dtype=torch.int32, device=dev)
-    out = torch.empty((cap, c), dtype=torch.float32, device=dev)
-    out16 = torch.empty((cap, c), dtype=torch.bfloat16, device=dev) if want16 else None
-    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    coors = L.empty((cap, 4), torch.int32, dev)
+    inv = L.empty((n,), torch.int32, dev)
+    counts = L.empty((cap,), torch.int32, dev)
+    out = L.empty((cap, c), torch.float32, dev)
+    out16 = L.empty((cap, c), torch.bfloat16, dev) if want16 else None
+    meta = L.empty((2,), torch.int32, dev)
     L.check(L.lib.ococc_voxelize_scatter_mean_f32(
         L.ptr(pts), pts.size(1), L.ptr(bidx), n, L.ptr(fts), c, L.f3(voxel_size), L.f6(coors_range),
         int(batch_size), L.i3(grid_zyx), L.ptr(coors), cap, L.ptr(inv), L.ptr(counts), L.ptr(out), L.ptr(out16),
@@ -243,6 +243,55 @@ def voxelize_scatter_mean(points, batch_idx, feats, voxel_size, coors_range, gri
     coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), bool(static))
     inv._ococc_counts = counts
     return vfeats, coors, inv, counts, meta
+
+
+def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid_zyx, batch_size,
+                         out_dtype=torch.float32, slices=8):
+    """voxelize_scatter_mean(static=True) followed by spconv.ops.get_indice_pairs(3x3x3 sub-manifold) on its rows, in
+    three launches (ococc_object_grid_geometry_f32) instead of ten, for points that arrive GROUPED BY GRID (batch_idx
+    non-decreasing).  Same tensors, same values: returns (voxel_feats, voxel_coors, inv, counts, meta, indice_pairs,
+    indice_pair_num); the pair tensor carries the gather tables the convolutions read, the coordinates the grid tag,
+    exactly as the two separate calls leave them.  None when the shape is outside the kernel's plan (cells per grid
+    not a multiple of 32 or above 512 Ki): the caller then takes the general path."""
+    from ..spconv import ops as sp_ops
+    L.require_device(points, batch_idx, feats)
+    want16 = out_dtype == torch.bfloat16
+    assert want16 or out_dtype == torch.float32
+    assert points.dtype == torch.float32 and feats.dtype == torch.float32
+    pts, fts = points.detach().contiguous(), feats.detach().contiguous()
+    bidx = (batch_idx if batch_idx.dtype == torch.int32 else batch_idx.to(torch.int32)).contiguous()
+    n, c = fts.shape
+    dev = fts.device
+    grid_zyx = [int(v) for v in grid_zyx]
+    dims = [int(batch_size)] + grid_zyx
+    cap = min(n, dims[0] * dims[1] * dims[2] * dims[3])
+    nbytes = L.lib.ococc_object_grid_geometry_workspace_bytes(n, int(batch_size), L.i3(grid_zyx), int(slices))
+    if nbytes < 0 or n == 0:
+        return None
+    ws = L.workspace(nbytes, dev)
+    coors = L.empty((cap, 4), torch.int32, dev)
+    inv = L.empty((n,), torch.int32, dev)
+    counts = L.empty((cap,), torch.int32, dev)
+    out = L.empty((cap, c), torch.float32, dev)
+    out16 = L.empty((cap, c), torch.bfloat16, dev) if want16 else None
+    meta = L.empty((2,), torch.int32, dev)
+    nbr_t = L.empty((27, cap), torch.int32, dev)
+    mask = L.empty(((cap + 15) // 16,), torch.int32, dev)
+    pairs = L.empty((27, 2, cap), torch.int32, dev)
+    num = L.empty((27,), torch.int32, dev)
+    L.check(L.lib.ococc_object_grid_geometry_f32(
+        L.ptr(pts), pts.size(1), L.ptr(bidx), n, L.ptr(fts), c, L.f3(voxel_size), L.f6(coors_range), int(batch_size),
+        L.i3(grid_zyx), int(slices), L.ptr(coors), cap, L.ptr(inv), L.ptr(counts), L.ptr(out), L.ptr(out16),
+        meta.data_ptr(), meta.data_ptr() + 4, L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num), L.ptr(ws), ws.numel(),
+        L.stream()), 'object_grid_geometry')
+    vfeats = out16 if want16 else out
+    bo, po = L.c_i64(), L.c_i64()
+    L.check(L.lib.ococc_grid_unique_workspace_layout(4, L.i4(dims), bo, po), 'grid_unique_layout')
+    coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), True)
+    inv._ococc_counts = counts
+    sp_ops.attach_subm_tables(pairs, nbr_t, mask, cap, 27)
+    pairs._ococc_keepalive = ws
+    return vfeats, coors, inv, counts, meta, pairs, num
 
 
 class DynamicScatter(nn.Module):

@@ -18,7 +18,7 @@ for r in rows:
         # bench.py's roofline probe: 20 eager steps after the timed region launch this kernel 8x back to back
         per=float(r['AverageNs'])/1e3; calls=1.0; tag='*'; note=True
     tot+=per
-    if per>6: print(f"{r['Name'][:86]:86s} {calls:5.1f}{tag}{float(r['AverageNs'])/1e3:7.1f} {per:7.1f}")
+    if per>float(__import__("os").environ.get("PROF_MIN_US","6")): print(f"{r['Name'][:86]:86s} {calls:5.1f}{tag}{float(r['AverageNs'])/1e3:7.1f} {per:7.1f}")
 print('steps',n,'kernel us/step',round(tot,1))
 if note: print('* once per step; the other launches in the trace are the roofline probe (8 back-to-back launches per event pair, after the timed region)')
 PY
