@@ -140,7 +140,7 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
                        GeoParams g, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ local_prefix,
                        int32_t* __restrict__ code_of, int32_t* __restrict__ table, int64_t* __restrict__ seg,
                        uint32_t* __restrict__ blockmask, int64_t mask_words, int32_t* __restrict__ inv,
-                       int32_t* __restrict__ status) {
+                       int32_t* __restrict__ bad_flags) {
   extern __shared__ uint32_t smem[];
   uint32_t* bm = smem;             // [words]
   uint32_t* pf = smem + g.words;   // [words]
@@ -264,7 +264,7 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
     for (int j = 0; j < 16; ++j) tot += s_cnt[ls][k][j];
     table[((int64_t)b * g.slices + sl) * kCols + k] = tot;
   }
-  if (threadIdx.x == 0 && s_bad) *status = 1;
+  if (threadIdx.x == 0) bad_flags[blockIdx.x] = s_bad;  // (gathered into *status by the next launch: no memset)
   STAMP(4);
 }
 
@@ -272,8 +272,14 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
 __global__ void __launch_bounds__(64)
 geometry_bases_kernel(const int32_t* __restrict__ table, int64_t entries, int32_t* __restrict__ bases,
                       int32_t* __restrict__ totals, int32_t* __restrict__ indice_num, int32_t* __restrict__ num_voxels,
-                      int64_t cap) {
+                      int64_t cap, const int32_t* __restrict__ bad_flags, int nflags, int32_t* __restrict__ status) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 27) {  // status = any workgroup of the first launch saw a point outside its grid's segment
+    int bad = 0;
+    for (int i = lane; i < nflags; i += 64) bad |= bad_flags[i];
+    const unsigned long long m = __ballot(bad != 0);
+    if (lane == 0) *status = m ? 1 : 0;
+  }
   int32_t carry = 0;
   for (int64_t e0 = 0; e0 < entries; e0 += 64 * 8) {  // 8 entries per lane and round: their loads are independent
     int32_t v[8], sum = 0;
@@ -645,7 +651,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
 }
 
 struct GeoLayout {
-  int64_t words_total, off_bitmap, off_prefix, off_code, off_lpre, off_table, off_bases, off_totals, off_seg, total;
+  int64_t words_total, off_bitmap, off_prefix, off_code, off_lpre, off_table, off_bases, off_totals, off_seg, off_bad, total;
 };
 
 inline bool make_geo_layout(int64_t n, int32_t batch, const int32_t* grid_zyx, int32_t slices, GeoLayout* L,
@@ -675,7 +681,8 @@ inline bool make_geo_layout(int64_t n, int32_t batch, const int32_t* grid_zyx, i
   L->off_bases = L->off_table + ococc_align_up(entries * kCols * 4, 256);
   L->off_totals = L->off_bases + ococc_align_up(entries * kCols * 4, 256);
   L->off_seg = L->off_totals + 256;
-  L->total = L->off_seg + ococc_align_up((int64_t)batch * 16, 256);
+  L->off_bad = L->off_seg + ococc_align_up((int64_t)batch * 16, 256);
+  L->total = L->off_bad + ococc_align_up((int64_t)batch * kMaxSlices * 4, 256);
   return true;
 }
 
@@ -739,20 +746,20 @@ extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_p
   int32_t* bases = (int32_t*)(ws + L.off_bases);
   int32_t* totals = (int32_t*)(ws + L.off_totals);
   int64_t* seg = (int64_t*)(ws + L.off_seg);
+  int32_t* bad_flags = (int32_t*)(ws + L.off_bad);
   const size_t lds = (size_t)g.words * 8;
   const int64_t mask_words = ococc_cdiv(capacity, 16);
-  OCOCC_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), stream));
   if (lds > 48 * 1024) {
     OCOCC_HIP(hipFuncSetAttribute((const void*)grid_mark_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OCOCC_HIP(hipFuncSetAttribute((const void*)grid_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   hipLaunchKernelGGL(grid_mark_count_kernel, dim3(batch_size * g.asplit), dim3(kThreads), lds, stream, points,
                      (int)num_point_features, batch_idx, n, g, bitmap, lpre, code_of, table, seg, blockmask, mask_words,
-                     inv, status);
+                     inv, bad_flags);
   OCOCC_CHECK_LAUNCH();
   const int64_t entries = (int64_t)batch_size * slices;
   hipLaunchKernelGGL(geometry_bases_kernel, dim3(kCols), dim3(64), 0, stream, table, entries, bases, totals,
-                     indice_num, num_voxels, capacity);
+                     indice_num, num_voxels, capacity, bad_flags, (int)(batch_size * g.asplit), status);
   OCOCC_CHECK_LAUNCH();
   const int emit_blocks = (int)entries;
   // worst case every row is padding; the padding workgroups index rows from the device-side total

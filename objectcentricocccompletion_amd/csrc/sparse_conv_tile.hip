@@ -37,6 +37,14 @@
 
 namespace {
 
+#ifdef OCOCC_TILE_STAMPS
+// diagnostic build only (tools/probe/tile_stamps.py): wall-clock stamps per workgroup and phase into a buffer of their own
+__device__ long long* t_stamps = nullptr;
+#define TSTAMP(slot) do { if (threadIdx.x == 0 && t_stamps) t_stamps[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TSTAMP(slot) do { } while (0)
+#endif
+
 constexpr int kTileThreads = 512;
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
@@ -71,6 +79,8 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   __shared__ int32_t sl_in[NW][MAXO][16 * FB];
   __shared__ uint16_t sl_row[NW][MAXO][16 * FB];
   __shared__ int s_cnt[NW];
+  __shared__ uint32_t s_owner[T];  // row -> tag of the wave whose addition is next (see the additions below)
+  __shared__ int s_more[2];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,6 +90,9 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   const int64_t row0 = (int64_t)wg * T;
   if (row0 >= n_out) return;
 
+  TSTAMP(0);
+  for (int i = threadIdx.x; i < T; i += kTileThreads) s_owner[i] = 0u;
+  uint32_t claim = 0;
   for (int i = threadIdx.x; i < T * (NC / 4); i += kTileThreads) {
     const int r = i / (NC / 4), c4 = i % (NC / 4);
     *(f32x4*)(tile + r * LDT + c4 * 4) = bias ? *(const f32x4*)(bias + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -150,6 +163,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     return cnt;
   };
   __syncthreads();
+  TSTAMP(1);
 
   bf16x8 w[2][NB][KSTEPS];
   // ---- the dense offset: row r of the tile is slot r; waves own disjoint 16-row blocks, loads batched ----
@@ -172,6 +186,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     }
   }
   __syncthreads();
+  TSTAMP(2);
 
   // ---- the other offsets: in pass p, round j, wave v takes the (p*MAXO + j)*NW + v -th of them ----
   const int nk = kvol - (dense_k >= 0 ? 1 : 0);
@@ -188,6 +203,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
 #pragma unroll
       for (int j = 0; j < MAXO; ++j) cnt[j] = compact16(e[j], j, 0, 16 * FB);
     }
+    if (pass == 0) TSTAMP(3);
     // (the lists are written and read by the same wave: LDS keeps a wave's operations in order)
     bf16x8 x[MAXO][FB][KSTEPS];
     int32_t in[MAXO][FB];
@@ -205,6 +221,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     // else one set, re-requested right behind the MFMAs that read it
     constexpr int WB = (NB * KSTEPS * 4 * 2 + MAXO * FB * KSTEPS * 4 <= ((T <= 256 && NC <= 64) ? 80 : 200)) ? 2 : 1;
     if (cnt[0] > 0) load_w(w[0], kk[0]);
+    if (pass == 0) TSTAMP(4);
 #pragma unroll
     for (int j = 0; j < MAXO; ++j) {
       if (WB == 2 && j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0) load_w(w[(j + 1) & 1], kk[(j + 1) % MAXO]);
@@ -214,20 +231,47 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
         if (16 * f < cnt[j]) mma(acc[f], w[WB == 2 ? (j & 1) : 0], x[j][f]);
       if (WB == 1 && j + 1 < MAXO && cnt[(j + 1) % MAXO] > 0 && cnt[j] <= 16 * FB) load_w(w[0], kk[(j + 1) % MAXO]);
       if (lane == 0) s_cnt[wave] = cnt[j];
+      if (pass == 0 && j == 0) TSTAMP(5);
       __syncthreads();
+      if (pass == 0 && j == 0) TSTAMP(6);
       int most = s_cnt[0];
 #pragma unroll
       for (int t = 1; t < NW; ++t) most = s_cnt[t] > most ? s_cnt[t] : most;
-      // additions into the shared tile in wave order (offsets ascend with the wave index inside a round)
+      // Additions into the shared tile.  The sum order per output element stays "ascending offset" (= ascending wave
+      // inside a round), but the eight waves no longer take turns: two waves of a round rarely hit the same row (a row
+      // has 0.76 sparse contributions in all), so every wave claims its rows first -- LDS atomic max of a tag that grows
+      // with the claim round and, inside one, is largest for the LOWEST wave -- and the waves whose claims stood add
+      // together.  A wave that lost a row to an earlier offset claims again in the next claim round, after the winner's
+      // addition: the order of the additions to any one row is exactly the serial one, the result bit for bit the same.
+      {
+        bool pend[FB];
 #pragma unroll
-      for (int t = 0; t < NW; ++t) {
-        if (wave == t) {
+        for (int f = 0; f < FB; ++f) pend[f] = in[j][f] >= 0;
+        for (;;) {
+          ++claim;
+          const uint32_t tag = ((uint32_t)claim << 8) | (uint32_t)(255 - wave);
 #pragma unroll
           for (int f = 0; f < FB; ++f)
-            if (in[j][f] >= 0) add_block(acc[f], rowl[j][f]);
+            if (pend[f] && kg == 0) atomicMax(&s_owner[rowl[j][f]], tag);
+          if (threadIdx.x == 0) s_more[claim & 1] = 0;
+          __syncthreads();
+          bool lost = false;
+#pragma unroll
+          for (int f = 0; f < FB; ++f)
+            if (pend[f]) {
+              if (s_owner[rowl[j][f]] == tag) {
+                add_block(acc[f], rowl[j][f]);
+                pend[f] = false;
+              } else {
+                lost = true;
+              }
+            }
+          if (lost) s_more[claim & 1] = 1;  // benign race: every writer stores 1
+          __syncthreads();
+          if (!s_more[claim & 1]) break;  // (the flag of this claim round is cleared again two rounds later)
         }
-        __syncthreads();
       }
+      if (pass == 0 && j == 0) TSTAMP(7);
       // offsets with more than 16 FB rows (dense neighbourhoods): the remaining blocks one by one
       for (int b = FB; b * 16 < most; ++b) {
         const bool have = b * 16 < cnt[j];
@@ -256,6 +300,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     __syncthreads();
   }
 
+  TSTAMP(8);
   // ---- epilogue: tile -> global, 8 channels (16 bytes of bf16) per thread; a row is NC / 8 consecutive lanes ----
   for (int i = threadIdx.x; i < T * (NC / 8); i += kTileThreads) {
     const int r = i / (NC / 8), c8 = i % (NC / 8);
@@ -315,6 +360,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       }
     }
   }
+  TSTAMP(9);
 }
 
 template <int KD, int NC, int T>
@@ -403,6 +449,12 @@ int tile_entry(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* w
   }
 }
 }  // namespace
+
+#ifdef OCOCC_TILE_STAMPS
+extern "C" int ococc_tile_set_stamps(long long* dev_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(t_stamps), &dev_buffer, sizeof(dev_buffer)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
                                            int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
