@@ -6,5 +6,8 @@ from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg, ococ
 model = ococcnet_model_cfg()
 train_pipeline = ococcnet_train_pipeline()
 data = dict(samples_per_gpu=4, workers_per_gpu=4)
-optimizer = dict(type='AdamW', lr=1e-6, weight_decay=0.01)          # configs/ococc/ococcnet.py: lr, AdamW
+# configs/_base_/schedules/cosine_2x.py:2-15 merged with configs/ococc/ococcnet.py:468-470 (lr override)
+optimizer = dict(type='AdamW', lr=1e-6, betas=(0.9, 0.999), weight_decay=0.05,
+                 paramwise_cfg=dict(custom_keys={'norm': dict(decay_mult=0.)}))
+lr_config = dict(policy='cyclic', target_ratio=(100, 1e-3), cyclic_times=1, step_ratio_up=0.1)
 optimizer_config = dict(grad_clip=dict(max_norm=10, norm_type=2))

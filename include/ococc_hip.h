@@ -502,6 +502,14 @@ int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const*
                     void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel, float lr,
                     float beta1, float beta2, float eps, float weight_decay, float* step,
                     int32_t bump_step, ococc_stream_t stream);
+/* The same update with the learning rate read from device memory at run time (one float): a learning-rate schedule
+ * (the reference's cyclic policy, configs/_base_/schedules/cosine_2x.py:10-15, applied per iteration by mmcv's
+ * CyclicLrUpdaterHook) then takes effect between replays of a captured HIP graph, where a scalar launch argument
+ * would stay frozen at its capture-time value. */
+int ococc_adamw_lr_dev_f32(int32_t num_tensors, void* const* params, const void* const* grads,
+                           void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                           const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                           float* step, int32_t bump_step, ococc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stream timers (HIP events) for the measurement harness (bench.py roofline line).  No reference

@@ -25,8 +25,11 @@ struct AdamPack {
 };
 
 __global__ void __launch_bounds__(256)
-adamw_kernel(AdamPack pk, float lr, float beta1, float beta2, float eps, float wd,
+adamw_kernel(AdamPack pk, float lr_arg, const float* __restrict__ lr_dev, float beta1, float beta2, float eps, float wd,
              float* step, uint32_t* ticket) {
+  // the learning rate either rides in the launch arguments or is read from device memory: a schedule can then
+  // change it between replays of a captured HIP graph (a kernel argument is frozen into the graph node)
+  const float lr = lr_dev ? *lr_dev : lr_arg;
   // The step count is bumped either by a one-thread kernel queued behind this one, or -- `ticket` given, small
   // launches only -- by the LAST workgroup to finish: every workgroup has read the old count by the time it
   // takes its ticket, so the store cannot be seen by this launch.  (One same-address atomic per workgroup:
@@ -96,11 +99,10 @@ __global__ void adamw_bump_kernel(float* step) { *step += 1.f; }
 
 }  // namespace
 
-extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
-                               void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
-                               float lr, float beta1, float beta2, float eps, float weight_decay,
-                               float* step, int32_t bump_step, ococc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+int adamw_launch(int32_t num_tensors, void* const* params, const void* const* grads, void* const* exp_avg,
+                 void* const* exp_avg_sq, const int64_t* numel, float lr, const float* lr_dev, float beta1, float beta2,
+                 float eps, float weight_decay, float* step, int32_t bump_step, hipStream_t stream) {
   OCOCC_REQUIRE(num_tensors >= 0, "negative tensor count");
   OCOCC_REQUIRE(step, "step must be a device pointer");
   OCOCC_REQUIRE(bump_step >= 0 && bump_step <= 2, "bump_step must be 0, 1 or 2");
@@ -127,7 +129,7 @@ extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const v
   pk.count = cnt;
   // bump_step 2: `step` points to {float count; uint32 ticket (zero)}; the last workgroup stores count + 1
   const bool in_kernel = bump_step == 2 && blocks <= kTicketMaxBlocks;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, pk, lr, beta1, beta2, eps,
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, stream, pk, lr, lr_dev, beta1, beta2, eps,
                      weight_decay, step, in_kernel ? (uint32_t*)(step + 1) : (uint32_t*)nullptr);
   OCOCC_CHECK_LAUNCH();
   if (bump_step && !in_kernel) {
@@ -135,4 +137,22 @@ extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const v
     OCOCC_CHECK_LAUNCH();
   }
   return OCOCC_OK;
+}
+}  // namespace
+
+extern "C" int ococc_adamw_f32(int32_t num_tensors, void* const* params, const void* const* grads,
+                               void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               float* step, int32_t bump_step, ococc_stream_t stream_) {
+  return adamw_launch(num_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, nullptr, beta1, beta2, eps,
+                      weight_decay, step, bump_step, (hipStream_t)stream_);
+}
+
+extern "C" int ococc_adamw_lr_dev_f32(int32_t num_tensors, void* const* params, const void* const* grads,
+                                      void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
+                                      const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                                      float* step, int32_t bump_step, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(lr_dev, "lr_dev must be a device pointer");
+  return adamw_launch(num_tensors, params, grads, exp_avg, exp_avg_sq, numel, 0.f, lr_dev, beta1, beta2, eps,
+                      weight_decay, step, bump_step, (hipStream_t)stream_);
 }

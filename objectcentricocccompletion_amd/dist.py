@@ -4,8 +4,8 @@ ranks, ONE bucketed gradient all-reduce per step -- what the reference gets from
 tools/dist_train.sh:11-12 + mmcv's MMDistributedDataParallel.
 
 xGMI is point to point (7 links x ~153 GB/s per GPU), so the 66.55 M gradients go out as a few
-large flat buckets (default 32 MiB elements-aligned, bf16 on the wire optional) instead of
-per-parameter messages; the two 4-byte avg-factor reductions of the loss ride in
+large flat buckets (32 MiB, bf16 on the wire for the 66.55 M-parameter model, optionally launched from gradient
+hooks so that they overlap the backward pass) instead of per-parameter messages; the two 4-byte avg-factor reductions of the loss ride in
 losses.reduce_mean."""
 import os
 
@@ -39,21 +39,42 @@ def shard_range(num_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class GradBuckets(object):
-    """Flat gradient buckets: parameters are packed once (in reverse registration order, the
-    order backward produces them) into contiguous buffers; ``all_reduce()`` copies the grads in,
-    averages them across ranks with one collective per bucket and copies them back."""
+# gradient volume (elements) from which the wire format defaults to bf16: the 66.55 M-parameter OcOccNet sends 266 MB
+# per step in f32, i.e. ~3 ms through one ~153 GB/s xGMI link in a ring; the 115 k-parameter encoder of
+# configs[1] is latency bound either way and keeps f32
+BF16_WIRE_FROM = 8 << 20
 
-    def __init__(self, params, bucket_bytes=32 << 20, wire_dtype=None):
+
+class GradBuckets(object):
+    """Flat gradient buckets: parameters are packed once (in reverse registration order, the order backward produces
+    them) into contiguous buffers and averaged across ranks with one collective per bucket.
+
+    Two ways to drive it:
+      * after the pass -- ``all_reduce()`` (= ``pack()``, ``reduce()``, ``unpack()``; the three pieces can be recorded
+        into HIP graphs around the one eager RCCL call, as bench.py does);
+      * ``overlap=True`` -- a post-accumulate-grad hook per parameter copies each gradient into its bucket as soon as
+        autograd has produced it and launches the bucket's all-reduce when the last of its gradients has arrived, so
+        the collectives of the late layers run beside the backward pass of the early ones (what the reference gets
+        from MMDistributedDataParallel's reducer, apis/seq_training_apis.py:146-150); ``finish()`` after backward()
+        waits for them and writes the averages back.
+    ``wire_dtype``: dtype on the wire; default bf16 from 8 Mi gradient elements up, else the parameters' dtype."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, wire_dtype='auto', overlap=False):
         self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        if wire_dtype == 'auto':
+            wire_dtype = torch.bfloat16 if total >= BF16_WIRE_FROM else None
         self.wire_dtype = wire_dtype
-        # gradients are read by pack() / all_reduce(), i.e. after backward() returned: the end-of-backward
-        # parameter-gradient reductions (_deferred.py) are safe next to this exchange
+        self.overlap = bool(overlap)
         from . import _deferred
-        _deferred.GRADS_READ_AFTER_BACKWARD = True
+        # after-the-pass mode reads gradients once backward() has returned: the end-of-backward parameter-gradient
+        # reductions (_deferred.py) are safe next to it.  The hooks of overlap mode watch the engine's hand-over, so
+        # every hooked parameter takes the immediate per-layer reduction by itself (_deferred.deferrable).
+        _deferred.GRADS_READ_AFTER_BACKWARD = not self.overlap
         self.buckets = []  # (flat buffer, [(param, offset, numel)])
         cur, cur_n = [], 0
-        limit = max(1, bucket_bytes // 4)
+        elem = 2 if wire_dtype in (torch.bfloat16, torch.float16) else 4
+        limit = max(1, bucket_bytes // elem)
         for p in reversed(self.params):
             if cur and cur_n + p.numel() > limit:
                 self._close(cur, cur_n)
@@ -62,6 +83,14 @@ class GradBuckets(object):
             cur_n += p.numel()
         if cur:
             self._close(cur, cur_n)
+        self._works = []
+        if self.overlap:
+            self._pending = [len(items) for _, items in self.buckets]
+            self._where = {}
+            for bi, (_, items) in enumerate(self.buckets):
+                for p, off, n in items:
+                    self._where[id(p)] = (bi, off, n)
+                    p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _close(self, items, n):
         p0 = items[0][0]
@@ -71,6 +100,39 @@ class GradBuckets(object):
     def _active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    # ---- overlap mode -------------------------------------------------------------------------------------
+    def _on_grad(self, p):
+        if not self._active():
+            return
+        bi, off, n = self._where[id(p)]
+        flat = self.buckets[bi][0]
+        flat[off:off + n].view_as(p).copy_(p.grad)
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._works.append((bi, dist.all_reduce(flat, async_op=True)))
+
+    def finish(self):
+        """Overlap mode, after backward(): launch the buckets that are still waiting for a gradient (parameters that
+        took no part in the pass count as zero), wait for all collectives, write the averages into ``.grad``."""
+        if not self._active():
+            return
+        launched = {bi for bi, _ in self._works}
+        for bi, (flat, items) in enumerate(self.buckets):
+            if bi in launched:
+                continue
+            for p, off, n in items:  # a bucket that did not complete is packed whole here
+                if p.grad is None:
+                    flat[off:off + n].zero_()
+                else:
+                    flat[off:off + n].view_as(p).copy_(p.grad)
+            self._works.append((bi, dist.all_reduce(flat, async_op=True)))
+        for _, w in self._works:
+            w.wait()
+        self._works = []
+        self._pending = [len(items) for _, items in self.buckets]
+        self.unpack()
+
+    # ---- after-the-pass mode ------------------------------------------------------------------------------
     def pack(self):
         """Gradients -> flat buckets (one fused copy per bucket).  Device work only: may be recorded at the end
         of a forward+backward HIP graph."""
@@ -112,6 +174,8 @@ class GradBuckets(object):
                 torch._foreach_copy_(dst, src)
 
     def all_reduce(self):
+        if self.overlap:
+            return self.finish()
         self.pack()
         self.reduce()
         self.unpack()

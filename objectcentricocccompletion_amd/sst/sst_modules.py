@@ -343,6 +343,10 @@ class WindowMultiheadAttention(nn.Module):
 
     def __init__(self, embed_dim, num_heads, dropout=0.0, cosine=False, tau_min=0.01, non_shared_tau=False):
         super().__init__()
+        if dropout != 0:
+            raise NotImplementedError('attention-probability dropout is not built into the window-attention kernel; the '
+                                      'reference SST configs use dropout=0.0 (sst_basic_block_v2.py:41-75 passes it to '
+                                      'nn.MultiheadAttention)')
         self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))

@@ -35,8 +35,28 @@ def _worker(rank, world, port, q):
     loss = ((model(x_all[lo:hi]) - y_all[lo:hi]) ** 2).sum() / 8 * world
     loss.backward()
     buckets = od.GradBuckets(model.parameters(), bucket_bytes=256)   # forces several buckets
-    assert len(buckets.buckets) > 1
+    assert len(buckets.buckets) > 1 and buckets.wire_dtype is None     # small model: f32 on the wire
     buckets.all_reduce()
+    after_pass = [p.grad.clone() for p in model.parameters()]
+    # overlap mode: the same gradients, exchanged from post-accumulate-grad hooks while backward is still running
+    # (one parameter takes no part in the pass: its bucket completes in finish())
+    twin = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
+    twin.load_state_dict(model.state_dict())
+    unused = torch.nn.Parameter(torch.ones(5))
+    ob = od.GradBuckets(list(twin.parameters()) + [unused], bucket_bytes=256, overlap=True)
+    (((twin(x_all[lo:hi]) - y_all[lo:hi]) ** 2).sum() / 8 * world).backward()
+    launched_in_pass = len(ob._works)
+    ob.finish()
+    overlap_equal = all(torch.allclose(a, p.grad, atol=1e-7) for a, p in zip(after_pass, twin.parameters()))
+    overlap_ok = overlap_equal and launched_in_pass >= 1 and float(unused.grad.abs().sum()) == 0.0
+    # bf16 on the wire (what the 66.55 M-parameter model defaults to): same averages to bf16 precision
+    big = od.GradBuckets(model.parameters(), wire_dtype=torch.bfloat16)
+    for p, gq in zip(model.parameters(), after_pass):
+        p.grad = gq.clone()
+    big.all_reduce()   # gradients already equal on both ranks: the average must reproduce them within a bf16 rounding
+    bf16_ok = all(torch.allclose(p.grad, gq, rtol=1e-2, atol=1e-3) for p, gq in zip(model.parameters(), after_pass))
+    for p, gq in zip(model.parameters(), after_pass):
+        p.grad = gq
     avg = reduce_mean(torch.tensor([float(rank + 1)]))
     # NaiveSyncBatchNorm1d (mmdet3d/ops/norm.py:28-100): statistics over both ranks' rows
     from objectcentricocccompletion_amd.norm import NaiveSyncBatchNorm1d
@@ -49,7 +69,8 @@ def _worker(rank, world, port, q):
     # plain numpy payloads: torch tensors travel through shared-memory handles that die with the sender
     q.put((rank, [p.grad.numpy().copy() for p in model.parameters()],
            [p.detach().numpy().copy() for p in model.parameters()], float(avg), (lo, hi),
-           yb.detach().numpy().copy(), xh.grad.numpy().copy(), bn.running_mean.numpy().copy()))
+           yb.detach().numpy().copy(), xh.grad.numpy().copy(), bn.running_mean.numpy().copy(), bool(overlap_ok),
+           bool(bf16_ok)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -65,7 +86,9 @@ def test_world_size_2_bucketed_allreduce_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, g0, w0, a0, s0, y0, gx0, rm0), (_, g1, w1, a1, s1, y1, gx1, rm1) = out
+    (_, g0, w0, a0, s0, y0, gx0, rm0, ov0, bf0), (_, g1, w1, a1, s1, y1, gx1, rm1, ov1, bf1) = out
+    assert ov0 and ov1, 'overlap-mode gradients differ from the after-the-pass exchange'
+    assert bf0 and bf1, 'bf16 wire buckets'
     g0, w0, g1, w1 = ([torch.from_numpy(a) for a in t] for t in (g0, w0, g1, w1))
     assert s0 == (0, 4) and s1 == (4, 8) and a0 == a1 == 1.5
     for a, b in zip(w0, w1):
@@ -102,3 +125,11 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_wire_dtype_defaults_to_bf16_for_the_big_model():
+    from objectcentricocccompletion_amd.dist import BF16_WIRE_FROM, GradBuckets
+    small = GradBuckets([torch.nn.Parameter(torch.zeros(1000))])
+    big = GradBuckets([torch.nn.Parameter(torch.zeros(BF16_WIRE_FROM))])
+    assert small.wire_dtype is None and big.wire_dtype == torch.bfloat16
+    assert big.buckets[0][0].dtype == torch.bfloat16 and len(big.buckets) == 1

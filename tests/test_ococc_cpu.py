@@ -164,3 +164,25 @@ def test_verbatim_reference_config_builds_through_the_registry(gold):
     # building twice from one loaded config must give the same network (the reference mutates its config lists)
     again = DETECTORS.build(config.fromfile(_REF_CFG).model)
     assert sum(p.numel() for p in again.parameters()) == 66553173
+
+
+def test_cyclic_lr_policy_and_paramwise_groups():
+    """The two pieces of mmcv the reference's schedule needs (configs/_base_/schedules/cosine_2x.py:2-15), restated in
+    optim.py: CyclicLrUpdaterHook's cosine segments and DefaultOptimizerConstructor's custom_keys."""
+    import math
+    from objectcentricocccompletion_amd.optim import cyclic_lr, param_groups_from_cfg
+    n = 1000
+    assert cyclic_lr(1e-6, 0, n) == pytest.approx(1e-6)                       # starts at the base rate
+    assert cyclic_lr(1e-6, 100, n) == pytest.approx(1e-4)                     # x100 after the first tenth
+    assert cyclic_lr(1e-6, 50, n) == pytest.approx(1e-6 * (100 + 0.5 * (1 - 100) * (math.cos(math.pi * 0.5) + 1)))
+    assert 1e-9 <= cyclic_lr(1e-6, n - 1, n) < 1.5e-9                        # x1e-3 at the end of the cycle
+    assert all(cyclic_lr(1e-6, i, n) >= cyclic_lr(1e-6, i + 1, n) for i in range(100, n - 1))
+    head = _build_head()
+    groups = param_groups_from_cfg(head.named_parameters(), 0.05, dict(custom_keys={'norm': dict(decay_mult=0.)}))
+    by_decay = {g['weight_decay']: g['params'] for g in groups}
+    names = {id(p): n_ for n_, p in head.named_parameters()}
+    assert set(by_decay) == {0.0, 0.05}
+    assert all('norm' in names[id(p)] for p in by_decay[0.0]) and not any('norm' in names[id(p)] for p in by_decay[0.05])
+    assert any('vfe_layers.0.norm' in names[id(p)] for p in by_decay[0.0])   # DynamicVFELayerV2's LayerNorm
+    assert any('.1.0.weight' in names[id(p)] or '.0.1.weight' in names[id(p)] for p in by_decay[0.05])  # build_mlp's LN keeps decay
+    assert sum(len(g['params']) for g in groups) == 269
