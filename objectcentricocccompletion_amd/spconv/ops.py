@@ -422,6 +422,53 @@ def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
     return out
 
 
+# The kernels contract over at most 128 channels and write at most 128 columns per launch.  Wider layers (the
+# reference's indiceConv has no limit, spconv_ops.h:260-456) run as panels: the contraction in 128-channel slices whose
+# f32 partial outputs are summed, the columns in 128-wide slices side by side.
+_PANEL = 128
+
+
+def _panels(c):
+    return [(lo, min(lo + _PANEL, c)) for lo in range(0, c, _PANEL)]
+
+
+def _indice_conv_panels(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse, subm, bias, _saved):
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    xf = features.float()
+    cols = []
+    for q0, q1 in _panels(cout):
+        acc = None
+        for p0, p1 in _panels(cin):
+            part = indice_conv(xf[:, p0:p1].contiguous(), filters[..., p0:p1, q0:q1].contiguous(), indice_pairs,
+                               indice_pair_num, num_activate_out, inverse, subm)
+            acc = part if acc is None else acc.add_(part)
+        cols.append(acc)
+    out = torch.cat(cols, 1)
+    if bias is not None:
+        out = out + bias.float()
+    if _saved is not None:
+        _saved['x_bf16'] = features.to(torch.bfloat16).contiguous()
+    return out.to(features.dtype)
+
+
+def _indice_conv_backward_panels(features, filters, out_bp, indice_pairs, indice_pair_num, inverse, subm,
+                                 need_input_grad, need_filter_grad):
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    xf, dyf = features.float(), out_bp.float()
+    din = torch.zeros_like(xf) if need_input_grad else None
+    dw = torch.zeros(filters.shape, dtype=torch.float32, device=filters.device) if need_filter_grad else None
+    for p0, p1 in _panels(cin):
+        for q0, q1 in _panels(cout):
+            gi, gw = indice_conv_backward(xf[:, p0:p1].contiguous(), filters[..., p0:p1, q0:q1].contiguous(),
+                                          dyf[:, q0:q1].contiguous(), indice_pairs, indice_pair_num, inverse, subm,
+                                          need_input_grad=need_input_grad, need_filter_grad=need_filter_grad)
+            if need_input_grad:
+                din[:, p0:p1] += gi
+            if need_filter_grad:
+                dw[..., p0:p1, q0:q1] = gw
+    return (din.to(features.dtype) if need_input_grad else None), (dw.to(filters.dtype) if need_filter_grad else None)
+
+
 def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
                 inverse=False, subm=False, bias=None, _saved=None):
     """ops.py:109-125.  features [n_in,Cin] (f32 or bf16), filters [kD,kH,kW,Cin,Cout];
@@ -429,6 +476,9 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     L.require_device(features, filters, indice_pairs)
     cin, cout = filters.shape[-2], filters.shape[-1]
     assert features.shape[1] == cin
+    if cin > _PANEL or cout > _PANEL:
+        return _indice_conv_panels(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse, subm,
+                                   bias, _saved)
     rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd',
                                           int(num_activate_out), subm)
     kd = _round_kd(cin)
@@ -519,6 +569,9 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     filters_bp is None here and ``filters.grad`` receives it when the pass ends."""
     L.require_device(features, filters, out_bp, indice_pairs)
     cin, cout = filters.shape[-2], filters.shape[-1]
+    if cin > _PANEL or cout > _PANEL:
+        return _indice_conv_backward_panels(features, filters, out_bp, indice_pairs, indice_pair_num, inverse, subm,
+                                            need_input_grad, need_filter_grad)
     n_in, n_out = features.size(0), out_bp.size(0)
     kd_in, kd_out = _round_kd(cin), _round_kd(cout)
     dy = _to_bf16_padded(out_bp, kd_out)

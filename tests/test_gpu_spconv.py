@@ -513,3 +513,29 @@ def test_occupancy_encoder_vs_oracle_restatement(dev, fused_front_end, tile):
                            ('dbeta', layer[1].bias.grad, ref['grads'][li][2])):
             g = g.cpu().numpy().astype(np.float64)
             assert np.abs(g - e).max() <= 2e-4 * np.abs(e).max(), (li, name, np.abs(g - e).max() / np.abs(e).max())
+
+
+@pytest.mark.parametrize('cin,cout', [(192, 64), (64, 320), (256, 144)])
+def test_wide_channels_run_as_panels_vs_oracle(dev, cin, cout):
+    """More than 128 input or output channels (the reference's indiceConv has no limit): contraction and columns in
+    128-wide panels, same bar against the oracle; module level too (autograd through SubMConv3d)."""
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, SubMConv3d, ops
+    rng = np.random.default_rng(cin + cout)
+    idx, x, w, dy, pairs, num, ep, en = _conv_case(rng, dev, 2, (10, 11, 12), 0.15, cin, cout)
+    n = len(idx)
+    xt, wt, dyt = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    y = ops.indice_conv(xt, wt, pairs, num, n, False, True)
+    assert np.allclose(y.cpu().numpy(), O.indice_conv(x, w, ep, en, n, subm=True), rtol=1e-4, atol=5e-4)
+    din, dw = ops.indice_conv_backward(xt, wt, dyt, pairs, num, False, True)
+    edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
+    assert np.allclose(din.cpu().numpy(), edin, rtol=1e-4, atol=5e-4)
+    assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * max(1.0, float(np.abs(edw).max())))
+    conv = SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key='w').to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(wt)
+    xin = xt.clone().requires_grad_(True)
+    out = conv(SparseConvTensor(xin, torch.from_numpy(idx).to(dev), [10, 11, 12], 2)).features
+    out.backward(dyt)
+    assert np.allclose(out.detach().cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert np.allclose(xin.grad.cpu().numpy(), din.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert np.allclose(conv.weight.grad.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-5)
