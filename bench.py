@@ -146,10 +146,27 @@ def bench_ococcnet(args, world, rank, dev):
         opt.step()
         return total
 
+    # roofline probe: the occupancy decoder's forward (the FLOP hot spot, SURVEY.md 8a A11: per query point
+    # 2 x (60 x 512 + 512 x 1024 + 1024 x 1024 + 1024) = 3.21 MFLOP with the first layer factorised per RoI, plus
+    # 2 x 1536 x 512 once per RoI), HIP events on the stream its GEMMs are launched on (torch's current stream)
+    decoder = model.roi_head.bbox_head.occ_ae_head.occ_decoder
+    dec_events, dec_shapes = [], []
+    real_forward = decoder.forward
+
+    def timed_forward(feats, xyz, idx, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real_forward(feats, xyz, idx, *a, **k)
+        e1.record()
+        dec_events.append((e0, e1))
+        dec_shapes.append((feats.shape[0], xyz.shape[0]))
+        return out
+
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
+    decoder.forward = timed_forward
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -158,12 +175,19 @@ def bench_ococcnet(args, world, rank, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    decoder.forward = real_forward
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # kernel time of one step (device-side): HIP events around a step with the queue already full
+    torch.cuda.synchronize()
     if rank == 0:
-        print(json.dumps({
+        dec_ms = sum(a.elapsed_time(b) for a, b in dec_events) / max(len(dec_events), 1)
+        rois, queries = dec_shapes[0] if dec_shapes else (0, 0)
+        flops = queries * 2.0 * (60 * 512 + 512 * 1024 + 1024 * 1024 + 1024) + rois * 2.0 * 1536 * 512
+        peak = 157.3 if args.f32_decoder else 2500.0
+        res = {
             'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * B * L * args.steps / dt, 1),
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
@@ -172,8 +196,53 @@ def bench_ococcnet(args, world, rank, dev):
             'config': {'workload': f'configs[2]: full ococcnet.py model (66.55 M parameters), {B} tracklets x {L} '
                                    f'frames = {B * L} object grids/GPU/step, 64 points/frame, K=512 occupancy '
                                    'queries, fwd+bwd+AdamW, all-reduce of 266 MB gradients at N>1',
-                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}'},
-            'roofline': None, 'cpu_baseline': None}), flush=True)
+                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}', 'launch': 'eager (host-bound at 4 tracklets: '
+                       '~2.5 k launches per step; --tracklets 64 leaves that regime)'},
+            'roofline': {'kernel': 'OccDecoder forward (MLP 60|1536 -> 512 -> 1024 -> 1024 -> 1 over all query points, '
+                                   'library GEMMs + fused LN/GELU kernels)',
+                         'bound': 'mfma', 'achieved': round(flops / (dec_ms * 1e-3) / 1e12, 2) if dec_ms else None,
+                         'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(flops / (dec_ms * 1e-3) / 1e12 / peak, 4) if dec_ms else None, 'traffic': None,
+                         'algorithmic_flops_per_launch': flops, 'avg_launch_ms': round(dec_ms, 4),
+                         'launches_timed': len(dec_events), 'query_points': queries, 'rois': rois},
+            'cpu_baseline': None}
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline_ococcnet(L)
+        print(json.dumps(res), flush=True)
+
+
+def cpu_baseline_ococcnet(frames):
+    """The product's module graph for the same step on the host cores, with its HIP leaf operators swapped for torch /
+    oracle restatements (oracle/cpu_port.py, fp32, torch CPU, every core): ONE tracklet per step (a quarter of the
+    GPU batch; the CPU path is linear in the tracklets), fwd + bwd + AdamW; baseline only."""
+    from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
+    from oracle import cpu_port
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = cpu_port.build_detector_cpu(seed_weights=False).train()
+    model.roi_head.train_cfg['random_shift_frame_inds'] = False
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-6)
+    batch = synthetic_training_batch(1, frames, pts_per_frame=64, occ_queries=512, seed=0, device='cpu')
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **batch)
+        (losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()).backward()
+        opt.step()
+
+    with cpu_port.cpu_ops():
+        step()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 2 or time.perf_counter() - t0 < 10.0:
+            step()
+            reps += 1
+            if time.perf_counter() - t0 > 30.0:
+                break
+        dt = (time.perf_counter() - t0) / reps
+    return {'value': round(frames / dt, 2), 'unit': 'object-grids/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 tracklet x {frames} frames ({frames} object grids) per step, fwd+bwd+AdamW in fp32, {reps} '
+                      f'repetitions, torch {torch.__version__.split("+")[0]} CPU with {cores} threads, oracle/cpu_port.py'}
 
 
 def bench_sst(args, world, rank, dev):

@@ -49,21 +49,54 @@ class TrackletRoIHeadOCC(nn.Module):
         return dict(self._bbox_forward_train(pts_xyz, pts_feats, pts_batch_idx, pts_frame_inds, samples)['loss_bbox'])
 
     def _select_one2one_candidates(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list):
-        """Per proposal tracklet: the GT candidate with most frames of IoU > candidate_thresh."""
+        """Per proposal tracklet: the GT candidate with most frames of IoU > candidate_thresh
+        (tracklet_roi_head_occ.py:993-1030).  The reference walks tracklets and candidates and reads one count back per
+        pair; here the timestamp matching of the whole batch is done on the host first, ALL (proposal box, candidate
+        box) pairs go through one aligned-IoU launch, the counts come back in one read, and the per-frame IoUs of the
+        chosen candidates are left with the proposals for the assigner (Tracklet.self_ious)."""
+        from .tracklet import aligned_iou_3d, host_index
         cfg = self.train_cfg if self.train_cfg is not None else self.test_cfg
         thr = cfg.get('candidate_thresh', 0.5)
+        dev = tracklet_list[0].device
+        p_off, c_off, i1, i2, seg, spans = 0, 0, [], [], [], []   # spans[(t, c)] = (start, end, own frame indices)
+        c_boxes = []
+        for t, (trk, cands) in enumerate(zip(tracklet_list, candidates_list)):
+            for c, cand in enumerate(cands):
+                a, b = trk.common_frames(cand)
+                spans.append((t, c, len(i1), len(i1) + len(a), a))
+                i1 += [p_off + v for v in a]
+                i2 += [c_off + v for v in b]
+                seg += [len(spans) - 1] * len(a)
+                c_boxes.append(cand.boxes[:, :7])
+                c_off += len(cand)
+            p_off += len(trk)
+        counts, ious = [0] * len(spans), None
+        if i1:
+            P = torch.cat([t.boxes[:, :7] for t in tracklet_list], 0)
+            C = torch.cat(c_boxes, 0)
+            ious = aligned_iou_3d(P[host_index(i1, dev)], C[host_index(i2, dev)])
+            hits = torch.zeros(len(spans), device=dev).index_add_(0, host_index(seg, dev), (ious > thr).float())
+            counts = [int(v) for v in hits.tolist()]          # the one read-back of the selection
+        best = {}
+        for k, (t, c, lo, hi, own) in enumerate(spans):
+            if t not in best or counts[k] > counts[best[t]]:   # first maximum, as torch.argmax
+                best[t] = k
         out_trks, out_occs, out_scores = [], [], []
-        for trk, cands, occs, scores in zip(tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list):
+        for t, (trk, cands, occs, scores) in enumerate(zip(tracklet_list, candidates_list, gt_occs_list or [None] * len(tracklet_list),
+                                                            gt_occ_scores_list or [None] * len(tracklet_list))):
             if len(cands) == 0:
                 out_trks.append(trk.new_empty())
                 out_occs.append(None)
                 out_scores.append(None)
                 continue
-            aff = torch.tensor([int((trk.intersection_ious(c) > thr).sum()) for c in cands])
-            k = int(torch.argmax(aff))
-            out_trks.append(cands[k])
-            out_occs.append(occs[k])
-            out_scores.append(scores[k])
+            _, c, lo, hi, own = spans[best[t]]
+            out_trks.append(cands[c])
+            out_occs.append(occs[c] if occs is not None else None)
+            out_scores.append(scores[c] if scores is not None else None)
+            over = trk.boxes.new_zeros(len(trk))
+            if hi > lo:
+                over = ious[lo:hi] if own == list(range(len(trk))) else over.index_copy(0, host_index(own, dev), ious[lo:hi])
+            trk._self_iou_cache = {id(cands[c]): over}
         return out_trks, out_occs, out_scores
 
     def _assign_and_sample(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list, pts_batch_idx,

@@ -22,6 +22,15 @@ def aligned_iou_3d(boxes1, boxes2):
     return out
 
 
+def host_index(values, device, dtype=torch.long):
+    """A small index list built on the host -> device tensor WITHOUT a device synchronisation (torch.tensor(list,
+    device=...) is a pageable copy and waits for the stream): staged through pinned memory, copied asynchronously."""
+    t = torch.tensor(values, dtype=dtype)
+    if torch.device(device).type == 'cpu' or t.numel() == 0:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def _median_lower_upper_mean(x):
     """numpy.median along dim 0 (for an even count: the mean of the two middle values; torch.median
     would return the lower one)."""
@@ -69,23 +78,33 @@ class Tracklet(object):
         other = set(trk.ts_list)
         return [ts for ts in self.ts_list if ts in other]
 
+    def common_frames(self, trk):
+        """Host-side matching of timestamps: (own frame indices, the other tracklet's frame indices)."""
+        inter = self.ts_intersection(trk)
+        return [self.ts2index[t] for t in inter], [trk.ts2index[t] for t in inter]
+
     def intersection_ious(self, trk):
         """IoU of the boxes the two tracklets have at common timestamps (lidar_tracklet.py:290-299)."""
-        inter = self.ts_intersection(trk)
-        if len(inter) == 0:
+        i1, i2 = self.common_frames(trk)
+        if len(i1) == 0:
             return self.boxes.new_zeros(0)
-        i1 = torch.tensor([self.ts2index[t] for t in inter], device=self.device)
-        i2 = torch.tensor([trk.ts2index[t] for t in inter], device=self.device)
-        return aligned_iou_3d(self.boxes[i1], trk.boxes[i2])
+        if i1 == i2 and len(i1) == len(self) == len(trk):   # same frames in the same order: no gather at all
+            return aligned_iou_3d(self.boxes, trk.boxes)
+        return aligned_iou_3d(self.boxes[host_index(i1, self.device)], trk.boxes[host_index(i2, self.device)])
 
     def self_ious(self, trk):
-        """Per own box: IoU with the other tracklet's box of the same timestamp, 0 if none (:278-288)."""
+        """Per own box: IoU with the other tracklet's box of the same timestamp, 0 if none (:278-288).  The RoI head
+        computes these for a whole batch in one launch and leaves them in ``_self_iou_cache`` (roi_head.py)."""
+        hit = getattr(self, '_self_iou_cache', {}).get(id(trk))
+        if hit is not None:
+            return hit
         out = self.boxes.new_zeros(len(self))
-        inter = self.ts_intersection(trk)
-        if len(inter) == 0:
+        i1, _ = self.common_frames(trk)
+        if len(i1) == 0:
             return out
-        idx = torch.tensor([self.ts2index[t] for t in inter], device=self.device, dtype=torch.long)
-        out[idx] = self.intersection_ious(trk)
+        if len(i1) == len(self):
+            return self.intersection_ious(trk) if i1 == list(range(len(self))) else out.index_copy(0, host_index(i1, self.device), self.intersection_ious(trk))
+        out[host_index(i1, self.device)] = self.intersection_ious(trk)
         return out
 
     # ---- in-place geometric transforms: LiDARTracklet.flip / translate / scale / rotate
@@ -269,16 +288,22 @@ class Tracklet(object):
 
 
 class AssignResult(object):
-    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None, gt_inds_host=None):
         self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+        self.gt_inds_host = gt_inds_host   # the same indices as a Python list when the assigner built them on the host
 
 
 class SamplingResult(object):
     """PseudoSampler output (every box kept): positives first, then negatives."""
 
     def __init__(self, assign_result, bboxes, gt_bboxes):
-        self.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
-        self.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        host = assign_result.gt_inds_host
+        if host is not None:   # (timestamp matching happens on the host: no nonzero(), no read-back)
+            self.pos_inds = host_index([i for i, g in enumerate(host) if g > 0], bboxes.device)
+            self.neg_inds = host_index([i for i, g in enumerate(host) if g == 0], bboxes.device)
+        else:
+            self.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+            self.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
         self.pos_bboxes, self.neg_bboxes = bboxes[self.pos_inds], bboxes[self.neg_inds]
         self.num_gts = gt_bboxes.shape[0]
         self.pos_assigned_gt_inds = assign_result.gt_inds[self.pos_inds] - 1
@@ -306,10 +331,10 @@ class TrackletAssigner(object):
         assigned_labels = torch.full((num_bboxes,), -1, dtype=torch.long, device=device)
         scores = trk_pd.concated_scores().detach()
         if num_gts == 0 or num_bboxes == 0:
-            gt_inds = torch.full((num_bboxes,), -1, dtype=torch.long, device=device)
-            if num_gts == 0:
-                gt_inds[:] = 0
-            res = AssignResult(num_gts, gt_inds, torch.zeros((num_bboxes,), device=device), assigned_labels)
+            fill = 0 if num_gts == 0 else -1
+            gt_inds = torch.full((num_bboxes,), fill, dtype=torch.long, device=device)
+            res = AssignResult(num_gts, gt_inds, torch.zeros((num_bboxes,), device=device), assigned_labels,
+                               gt_inds_host=[fill] * num_bboxes)
             res.scores = scores
             return res
         overlaps = trk_pd.self_ious(trk_gt)
@@ -317,8 +342,8 @@ class TrackletAssigner(object):
         if self.object_centric:
             ov = overlaps.tolist()
             idx = [j if ov[i] > self.iou_thr else 0 for i, j in enumerate(idx)]
-        gt_inds = torch.tensor(idx, dtype=torch.long, device=device)
-        assigned_labels[gt_inds > 0] = trk_gt.type
-        res = AssignResult(num_gts, gt_inds, overlaps, assigned_labels)
+        gt_inds = host_index(idx, device)
+        assigned_labels = torch.where(gt_inds > 0, torch.full_like(assigned_labels, trk_gt.type), assigned_labels)
+        res = AssignResult(num_gts, gt_inds, overlaps, assigned_labels, gt_inds_host=idx)
         res.scores = scores
         return res

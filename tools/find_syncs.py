@@ -21,7 +21,7 @@ cfg['train_cfg']['random_shift_frame_inds'] = False
 model = DETECTORS.build(cfg).to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
 opt = AdamW(params, lr=1e-6)
-batch = synthetic_training_batch(4, 32, pts_per_frame=64, occ_queries=512, seed=0, device=dev)
+batch = synthetic_training_batch(int(os.environ.get('TRACKLETS', '4')), 32, pts_per_frame=64, occ_queries=512, seed=0, device=dev)
 
 
 def step():
