@@ -363,6 +363,7 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   TSTAMP(9);
 }
 
+
 template <int KD, int NC, int T>
 int launch_tile_t(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int dense_k, const int32_t* table,
                   int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream,

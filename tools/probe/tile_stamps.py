@@ -13,8 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, 'objectcentricocccompletion_amd', 'csrc')
 so = '/tmp/libtile_stamps.so'
-subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-DOCOCC_TILE_STAMPS',
-                os.path.join(csrc, 'sparse_conv_tile.hip'), os.path.join(csrc, 'capi.hip'), '-o', so], check=True)
+subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-DOCOCC_TILE_STAMPS']
+               + os.environ.get('TILE_DEFS', '').split() +
+               [os.path.join(csrc, 'sparse_conv_tile.hip'), os.path.join(csrc, 'capi.hip'), '-o', so], check=True)
 lib = ctypes.CDLL(so)
 from objectcentricocccompletion_amd import _lib as L  # noqa: E402
 from objectcentricocccompletion_amd.spconv import ops  # noqa: E402
@@ -56,9 +57,23 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print(f'tile conv {kd} -> {nc}: us per launch', round(e0.elapsed_time(e1) / 20 * 1e3, 1))
+# the contraction itself, f32 on the device: out[o] = sum_k x[table[k][o]] @ w[k]
+tb = table.view(27, n).long()
+ref = torch.zeros(n, nc, device=dev)
+wf = w.view(27, kd, nc).bfloat16().float()
+for k in range(27):
+    m = tb[k] >= 0
+    ref[m] += x[tb[k][m]].float() @ wf[k]
+err = (out.float() - ref).abs().max().item()
+print('max |out - f32 reference|', err, 'of', ref.abs().max().item(), '(bf16 output rounding: 2^-9 relative)')
 st = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64) / 100.0
 st = st[st[:, 0] > 0]
-names = ['tile init', 'dense offset', 'pass0: table cols + ranks', 'pass0: gathers issued + w', 'pass0 j0: MFMA', 'pass0 j0: barrier wait',
+if len(st) == 0:
+    sys.exit(0)
+if nc >= 128:
+    names = ['zero masks, dense rows requested', 'table columns + ranks', 'gathers issued + barrier', 'chunk 0: dense product', 'chunk 0: produce', 'chunk 0: barrier', 'chunk 0: pull', 'chunk 0: barrier 2', 'chunk 0 store + other chunks']
+else:
+    names = ['tile init', 'dense offset', 'pass0: table cols + ranks', 'pass0: gathers issued + w', 'pass0 j0: MFMA', 'pass0 j0: barrier wait',
          'pass0 j0: ordered adds', 'rest of the passes', 'epilogue']
 print({nm: round(float(np.median(st[:, i + 1] - st[:, i])), 2) for i, nm in enumerate(names)})
 print('workgroups', len(st), 'median lifetime', round(float(np.median(st[:, 9] - st[:, 0])), 2), 'first start -> last end', round(float(st[:, 9].max() - st[:, 0].min()), 2))
