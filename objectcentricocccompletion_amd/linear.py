@@ -1,0 +1,52 @@
+"""nn.Linear for the per-point layers of the RoI encoder (same parameters, same state-dict keys).
+
+The SIR layers and their MLPs (voxel_encoder.py:686-832, sst_ops.py:333-360) apply Linear(16..144 -> 3..144) to every
+point of the batch: 1.3e5 rows at 64 tracklets.  Their weight gradient dW = dY^T X is then a GEMM with a tiny output and
+a contraction 1e5 long; the library runs it as one 32x32 macro-tile per output block (measured on MI355X: 340-380 us
+per layer, 47 such GEMMs = 19 ms of a 157 ms step).  Here the rows are cut into slices of 4096, the slices contracted
+as ONE batched GEMM and the partial products summed (fixed order): 35-65 us (tools/probe/tall_wgrad.py).  Forward and
+input gradient are the ordinary GEMMs."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+TALL_ROWS = 16384   # from this many rows on (and <= 256 features) the sliced weight gradient is used
+_SLICE = 4096
+
+
+def sliced_wgrad(gy, x, rows=_SLICE):
+    """dY^T X -> [out, in], contraction over the rows in slices of ``rows`` (+ a remainder)."""
+    n, cout = gy.shape
+    cin = x.shape[1]
+    s = n // rows
+    out = (gy[:s * rows].view(s, rows, cout).transpose(1, 2) @ x[:s * rows].view(s, rows, cin)).sum(0)
+    if s * rows < n:
+        out = out + gy[s * rows:].t() @ x[s * rows:]
+    return out
+
+
+class _TallLinear(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gw = sliced_wgrad(gy, x) if ctx.needs_input_grad[1] else None
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class Linear(nn.Linear):
+
+    def forward(self, x):
+        if (x.dim() == 2 and x.size(0) >= TALL_ROWS and max(self.in_features, self.out_features) <= 256
+                and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled()):
+            return _TallLinear.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)

@@ -13,6 +13,7 @@ from ._lib import const_tensor
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import (build_mlp, fuse_norm_act, get_activation_layer, scatter_v2,
                           unique_with_inverse)
+from .linear import Linear
 from .voxel.scatter_points import gather_rows
 
 
@@ -24,7 +25,7 @@ class DynamicVFELayerV2(nn.Module):
         super().__init__()
         self.fp16_enabled = False
         self.norm = build_norm_layer(norm_cfg, out_channels)[1]
-        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        self.linear = Linear(in_channels, out_channels, bias=False)
         self.act = get_activation_layer(act, out_channels)
         self.norm, self.act = fuse_norm_act(self.norm, self.act)
         self.dropout = nn.Dropout(p=dropout) if dropout > 0 else None

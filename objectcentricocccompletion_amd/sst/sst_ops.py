@@ -91,6 +91,9 @@ def fuse_norm_act(norm_layer, act_layer):
     return norm_layer, act_layer
 
 
+from ..linear import Linear  # noqa: E402 (nn.Linear with a sliced weight gradient for 1e5-row inputs)
+
+
 def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias=False, dropout=0):
     """sst_ops.py:333-360: Sequential of Sequential(Linear, norm, act[, Dropout]) blocks; with
     is_head the last entry is a bare Linear(bias=True).  Keys: <i>.0.weight, <i>.1.{weight,bias}."""
@@ -102,10 +105,10 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias
         act_layer = get_activation_layer(act, c)
         norm_layer = build_norm_layer(norm_cfg, c)[1]
         if i == len(hidden_dims) - 1 and is_head:
-            layer_list.append(nn.Linear(last_channel, c, bias=True))
+            layer_list.append(Linear(last_channel, c, bias=True))
         else:
             norm_layer, act_layer = fuse_norm_act(norm_layer, act_layer)
-            sq = [nn.Linear(last_channel, c, bias=bias), norm_layer, act_layer]
+            sq = [Linear(last_channel, c, bias=bias), norm_layer, act_layer]
             if dropout > 0:
                 sq.append(nn.Dropout(dropout))
             layer_list.append(nn.Sequential(*sq))

@@ -77,6 +77,7 @@ def cpu_ops():
     patches = [(norm, 'layer_norm_act', _layer_norm_act), (layers, 'layer_norm_act', _layer_norm_act),
                (occ_base, 'layer_norm_act', _layer_norm_act), (sst_ops, 'grid_unique', _grid_unique),
                (sst_ops, 'segment_reduce', _segment_reduce), (sir, 'gather_rows', _gather_rows),
+               (occ_base, 'gather_rows', _gather_rows),
                (point_pool, 'dynamic_point_pool_mixed', _dynamic_point_pool_mixed),
                (tracklet, 'aligned_iou_3d', _aligned_iou_3d), (_lib, 'require_device', lambda *a, **k: None)]
     saved = [(m, n, getattr(m, n)) for m, n, _ in patches]

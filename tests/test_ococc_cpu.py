@@ -186,3 +186,25 @@ def test_cyclic_lr_policy_and_paramwise_groups():
     assert any('vfe_layers.0.norm' in names[id(p)] for p in by_decay[0.0])   # DynamicVFELayerV2's LayerNorm
     assert any('.1.0.weight' in names[id(p)] or '.0.1.weight' in names[id(p)] for p in by_decay[0.05])  # build_mlp's LN keeps decay
     assert sum(len(g['params']) for g in groups) == 269
+
+
+def test_tall_linear_matches_nn_linear():
+    """linear.Linear: same forward, input / weight / bias gradients as nn.Linear when the sliced weight gradient is on."""
+    import torch
+    from objectcentricocccompletion_amd import linear
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(24, 40)
+    lin = linear.Linear(24, 40)
+    lin.load_state_dict(ref.state_dict())
+    assert list(lin.state_dict()) == list(ref.state_dict())
+    x = torch.randn(linear.TALL_ROWS + 4096 + 77, 24, requires_grad=True)   # slices + a remainder
+    x2 = x.detach().clone().requires_grad_(True)
+    g = torch.randn(x.size(0), 40)
+    lin(x).backward(g)
+    ref(x2).backward(g)
+    assert torch.equal(lin(x), ref(x2))
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+    small = torch.randn(100, 24, requires_grad=True)   # below the threshold: the stock path
+    assert lin(small).grad_fn.name() != '_TallLinearBackward'
