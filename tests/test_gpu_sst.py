@@ -231,3 +231,76 @@ def test_encoder_layer_use_bn_option(dev, gold):
     assert abs(float(y.mean())) < 1e-3 and abs(float(y.var(0).mean()) - 1.0) < 5e-2     # batch-normalised output
     y.pow(2).mean().backward()
     assert bool(torch.isfinite(x.grad).all()) and float(enc.norm1.running_mean.abs().sum()) > 0
+
+
+def test_sst_at_the_configs4_grid_shape(dev):
+    """configs[4] geometry (80 x 80 x 64 cells at 0.1 m, windows 8x8x8, drop levels 30 / 60 / 100, d_model 128, 8 heads,
+    two shifted blocks) on 4 object grids of 8200 points: size-independent properties of the window bookkeeping, the
+    attention core against f64 torch attention on the windows the input layer really produced (all three padded
+    lengths), and equivariance of the whole backbone under a permutation of the voxel order."""
+    from objectcentricocccompletion_amd.occ_encoder import synthetic_object_grids
+    from objectcentricocccompletion_amd.sst import flat2window_v2, window2flat_v2
+    from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2, SSTv2, _WindowAttnCore
+    from objectcentricocccompletion_amd.voxel import dynamic_scatter, voxelization
+    G, P = 4, 8200
+    xyz, feats, bidx = synthetic_object_grids(G, P, seed=5, device=dev)
+    xyz[:, 2] *= 0.8
+    zyx = voxelization(xyz, [0.1, 0.1, 0.1], [-4, -4, -3.2, 4, 4, 3.2], -1, -1)
+    vfeats, vcoors = dynamic_scatter(feats, torch.cat([bidx.view(-1, 1).to(torch.int32), zyx], 1), 'mean',
+                                     grid_shape=[G, 64, 80, 80])
+    n = vfeats.shape[0]
+    assert n > 7000 * G                       # ~8 000 active voxels per grid, as configs[4] states
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 128, generator=g).to(dev)
+    layer = SSTInputLayerV2(DROP, WINDOW, (80, 80, 64), shuffle_voxels=False, debug=True, mute=True).eval()
+    info = layer(x, vcoors.long())
+    kept = info['voxel_feats'].shape[0]
+    assert 0 < kept <= n
+    H, D = 8, 16
+    for i in range(2):
+        ind, masks = info[f'flat2win_inds_shift{i}'], info[f'key_mask_shift{i}']
+        level = info[f'voxel_drop_level_shift{i}']
+        assert level.numel() == kept and int(level.min()) >= 0 and int(level.max()) <= 2
+        # every kept voxel sits in exactly one slot of one window of its drop level; no window over its capacity
+        back = window2flat_v2(flat2window_v2(info['voxel_feats'], ind), ind)
+        assert torch.equal(back, info['voxel_feats'])
+        total = 0
+        for lv, m in masks.items():
+            tokens = (~m).sum(1)
+            assert m.shape[1] == DROP[lv]['max_tokens'] and int(tokens.max()) <= DROP[lv]['max_tokens'] and int(tokens.min()) >= 1
+            lo, hi = DROP[lv]['drop_range']
+            total += int(tokens.sum())
+            assert int((level == lv).sum()) == int(tokens.sum())
+            valid = (~m).long()
+            assert bool((valid[:, 1:] <= valid[:, :-1]).all())      # valid tokens are a prefix of the window
+            # the attention core at this level's padded length and the real key lengths (first 64 windows)
+            T, nW = m.shape[1], min(64, m.shape[0])
+            key_len = tokens[:nW].int()
+            q, k, v = (torch.randn(nW, T, H * D, generator=g).to(dev).bfloat16().float().requires_grad_(True) for _ in range(3))
+            pad = torch.arange(T, device=dev)[None, :] >= key_len[:, None]
+            dout = torch.randn(nW, T, H * D, generator=g).to(dev).bfloat16().float() * (~pad)[:, :, None]
+            out = _WindowAttnCore.apply(q, k, v, key_len, H)
+            out.backward(dout)
+            qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+            s = torch.einsum('wthd,wshd->whts', qr.view(nW, T, H, D), kr.view(nW, T, H, D)) * D ** -0.5
+            ref = torch.einsum('whts,wshd->wthd', torch.softmax(s.masked_fill(pad[:, None, None, :], float('-inf')), -1),
+                               vr.view(nW, T, H, D)).reshape(nW, T, H * D)
+            ref.backward(dout.double())
+            assert float(((out.detach().double() - ref.detach()) * (~pad)[:, :, None]).abs().max()) < 3e-2   # bf16 P and V
+            for got, exp in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+                assert float((got.double() - exp).abs().max()) < 3e-2 * float(exp.abs().max())
+        assert total == kept
+    # the backbone does not care in which order the voxels arrive
+    model = SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, dropout=0.0, activation='gelu',
+                  num_attached_conv=0, to_bev=False, layer_cfg=dict(compute_dtype=torch.bfloat16))
+    model.load_state_dict(synth.synth_state_dict({k_: tuple(v_.shape) for k_, v_ in model.state_dict().items()}, seed=7))
+    model = model.to(dev).eval()
+    layer = SSTInputLayerV2(DROP, WINDOW, (80, 80, 64), shuffle_voxels=False, debug=False, mute=True).eval()
+    if kept == n:   # (nothing dropped at this density: outputs are per input voxel)
+        perm = torch.randperm(n, generator=g).to(dev)
+        with torch.no_grad():
+            a = model(layer(x, vcoors.long()))[0]['voxel_feats'].float()
+            b = model(layer(x[perm], vcoors.long()[perm]))[0]['voxel_feats'].float()
+        assert a.shape == (n, 128) and bool(torch.isfinite(a).all())
+        # same windows, tokens in another order inside them: sums in another order, bf16 intermediates
+        assert float((a[perm] - b).abs().max()) < 3e-2 * float(a.abs().max())
