@@ -619,7 +619,118 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
     # ------------------------------------------------------------------ targets
     def get_targets(self, sampling_results, rcnn_train_cfg, concat=True, transform_occ=True,
                     num_occ_per_tracklet=-1):
-        """ococc_bbox_head.py:1045-1163 (concat=True form)."""
+        """ococc_bbox_head.py:1045-1163 (concat=True form).  The reference computes the targets tracklet by tracklet
+        (``_get_target_single``, ~60 tiny launches each) and concatenates; every step of that is row-wise, so here the
+        rows of all tracklets are concatenated FIRST and the arithmetic runs once (``_get_targets_batched``): same
+        values, a few dozen launches per batch.  Tracklets whose occupancy samples differ in number fall back to the
+        per-tracklet form."""
+        ks = {tuple(r.occ_labels.shape) for r in sampling_results if len(r.pos_gt_bboxes) > 0}
+        if len(ks) <= 1 and all(r.occ_labels is not None for r in sampling_results if len(r.pos_gt_bboxes) > 0):
+            return self._get_targets_batched(sampling_results, rcnn_train_cfg, transform_occ, num_occ_per_tracklet)
+        return self._get_targets_per_tracklet(sampling_results, rcnn_train_cfg, transform_occ, num_occ_per_tracklet)
+
+    def _get_targets_batched(self, sampling_results, cfg, transform_occ, num_occ_per_tracklet):
+        from .tracklet import host_index
+        dev = sampling_results[0].iou.device
+        n_i = [int(r.iou.size(0)) for r in sampling_results]           # samples per tracklet (host numbers)
+        p_i = [int(r.pos_gt_bboxes.size(0)) for r in sampling_results]  # of which positives: the first p_i rows
+        N, P = sum(n_i), sum(p_i)
+        ious = torch.cat([r.iou for r in sampling_results], 0)
+        pos_gt_labels = torch.cat([r.pos_gt_labels for r in sampling_results], 0)
+        pos_bboxes = torch.cat([r.pos_bboxes for r in sampling_results], 0)
+        pos_gt_bboxes = torch.cat([r.pos_gt_bboxes for r in sampling_results], 0)
+        if pos_gt_bboxes.size(1) in (9, 10):
+            pos_bboxes, pos_gt_bboxes = pos_bboxes[:, :7], pos_gt_bboxes[:, :7]
+        starts = [sum(n_i[:t]) for t in range(len(n_i))]
+        pos_rows = host_index([starts[t] + j for t in range(len(n_i)) for j in range(p_i[t])], dev)
+        all_gt = torch.full((N,), -1, dtype=pos_gt_labels.dtype, device=dev).index_copy(0, pos_rows, pos_gt_labels)
+        label, label_weights = self._soft_label(ious, all_gt, cfg)
+        reg_mask = torch.zeros(N, dtype=torch.long, device=dev).index_fill(0, pos_rows, 1)
+        bbox_weights = (reg_mask > 0).float()
+        cw = cfg.get('class_wise_box_weights', None)
+        if cw is not None:
+            for i in range(self.num_classes):
+                bbox_weights = torch.where(all_gt == i, bbox_weights * cw[i], bbox_weights)
+        occ_reg_mask = torch.zeros_like(reg_mask)
+        bbox_target_batch_idx = host_index([t for t in range(len(n_i)) for _ in range(p_i[t])], dev, torch.int32)
+        if P > 0:
+            bbox_targets = self._canonical_box_targets(pos_bboxes, pos_gt_bboxes)
+            n_occ = [(min(num_occ_per_tracklet, p) if num_occ_per_tracklet > 0 else p) for p in p_i]
+            pstart = [sum(p_i[:t]) for t in range(len(p_i))]
+            sel_trk = [t for t in range(len(p_i)) for _ in range(n_occ[t])]
+            sel_pos = host_index([pstart[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])], dev)
+            occ_rows = host_index([starts[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])], dev)
+            occ_reg_mask = occ_reg_mask.index_fill(0, occ_rows, 1)
+            live = [t for t in range(len(p_i)) if p_i[t] > 0]
+            slot = {t: k for k, t in enumerate(live)}
+            occ_all = torch.stack([sampling_results[t].occ_labels for t in live], 0)      # [B', K, 4]
+            assert occ_all.dim() == 3 and occ_all.size(2) == 4
+            scores_all = torch.stack([sampling_results[t].occ_scores.reshape(-1)[0] for t in live], 0).float()
+            sel_slot = host_index([slot[t] for t in sel_trk], dev)
+            with torch.no_grad():
+                gt_smp, roi_smp = pos_gt_bboxes[sel_pos], pos_bboxes[sel_pos]
+                picked = occ_all[sel_slot]
+                roi_local_xyz, gt_occ = picked[..., 0:3], picked[..., 3:4]
+                if transform_occ:
+                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, gt_smp[:, 6], axis=2)
+                    roi_local_xyz += gt_smp[..., None, 0:3]
+                    roi_local_xyz[..., 2] += gt_smp[:, None, 5] / 2   # voxel centres are gravity centred
+                    roi_local_xyz -= roi_smp[..., None, :3]
+                    roi_local_xyz[..., 2] -= roi_smp[:, None, 5] / 2
+                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, -(roi_smp[:, 6]), axis=2)
+                occ_score = scores_all[sel_slot]
+            occ_target_batch_idx = host_index(sel_trk, dev, torch.int32)
+            pos_gt_bboxes_occ = gt_smp
+        else:
+            bbox_targets = pos_gt_bboxes.new_empty((0, 7))
+            roi_local_xyz = pos_gt_bboxes.new_zeros(0, 0, 3)
+            occ_score, gt_occ = pos_gt_bboxes.new_zeros(0), pos_gt_bboxes.new_zeros(0, 1)
+            occ_target_batch_idx = torch.zeros(0, dtype=torch.int32, device=dev)
+            pos_gt_bboxes_occ = pos_gt_bboxes.new_empty((0, 7))
+        label_weights = label_weights / torch.clamp(label_weights.sum(), min=1.0)
+        bbox_weights = bbox_weights / torch.clamp(bbox_weights.sum(), min=1.0)
+        return (label, bbox_targets, bbox_target_batch_idx, pos_gt_bboxes, pos_gt_labels, reg_mask, label_weights,
+                bbox_weights, roi_local_xyz, gt_occ, occ_score, occ_reg_mask, occ_target_batch_idx, pos_gt_bboxes_occ)
+
+    def _soft_label(self, ious, all_gt, cfg):
+        """get_multi_class_soft_label on rows whose class (-1 = not a positive) is already laid out."""
+        pos_thrs, neg_thrs = cfg['cls_pos_thr'], cfg['cls_neg_thr']
+        if isinstance(pos_thrs, float):
+            pos_thrs, neg_thrs = [pos_thrs] * self.num_classes, [neg_thrs] * self.num_classes
+        all_label = ious.new_zeros(ious.size(0))
+        for i in range(self.num_classes):
+            pos = ious > pos_thrs[i]
+            interval = (~pos) & ~(ious < neg_thrs[i])
+            lab = torch.where(interval, (ious - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i]), pos.to(ious.dtype))
+            all_label = torch.where(all_gt == i, lab, all_label)
+        label_weights = (all_label >= 0).float()
+        cw = cfg.get('class_wise_cls_weights', None)
+        if cw is not None:
+            for i in range(self.num_classes):
+                label_weights = torch.where(all_gt == i, label_weights * cw[i], label_weights)
+        return all_label, label_weights
+
+    def _canonical_box_targets(self, pos_bboxes, pos_gt_bboxes):
+        """GT boxes in the canonical frame of their RoIs -> coder deltas (ococc_bbox_head.py:1190-1222)."""
+        gt_ct = pos_gt_bboxes.clone().detach()
+        roi_center = pos_bboxes[..., 0:3]
+        roi_ry = pos_bboxes[..., 6] % (2 * np.pi)
+        gt_ct[..., 0:3] -= roi_center
+        gt_ct[..., 6] -= roi_ry
+        gt_ct[..., 0:3] = rotation_3d_in_axis(gt_ct[..., 0:3].unsqueeze(1), -(roi_ry + np.pi / 2), axis=2).squeeze(1)
+        ry = gt_ct[..., 6] % (2 * np.pi)
+        opposite = (ry > np.pi * 0.5) & (ry < np.pi * 1.5)
+        ry = torch.where(opposite, (ry + np.pi) % (2 * np.pi), ry)
+        ry = torch.where(ry > np.pi, ry - np.pi * 2, ry)
+        gt_ct[..., 6] = torch.clamp(ry, min=-np.pi / 2, max=np.pi / 2)
+        anchor = pos_bboxes.clone().detach()
+        anchor[:, 0:3] = 0
+        anchor[:, 6] = 0
+        return self.bbox_coder.encode(anchor, gt_ct)
+
+    def _get_targets_per_tracklet(self, sampling_results, rcnn_train_cfg, transform_occ=True, num_occ_per_tracklet=-1):
+        """The reference's loop, kept for batches whose tracklets carry different numbers of occupancy samples (and as
+        the statement the batched form is tested against)."""
         per = [self._get_target_single(r.pos_bboxes, r.pos_gt_bboxes, r.iou, r.pos_gt_labels, r.occ_labels,
                                        r.occ_scores, cfg=rcnn_train_cfg, transform_occ=transform_occ,
                                        num_occ_per_tracklet=num_occ_per_tracklet) for r in sampling_results]
@@ -663,21 +774,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         bbox_weights = self.get_class_wise_box_weights((reg_mask > 0).float(), pos_labels, cfg)
         occ_reg_mask = torch.zeros_like(reg_mask)
         if pos_gt_bboxes.size(0) > 0 and reg_mask.numel() > 0:  # == reg_mask.bool().any(), known on the host
-            gt_ct = pos_gt_bboxes.clone().detach()
-            roi_center = pos_bboxes[..., 0:3]
-            roi_ry = pos_bboxes[..., 6] % (2 * np.pi)
-            gt_ct[..., 0:3] -= roi_center
-            gt_ct[..., 6] -= roi_ry
-            gt_ct[..., 0:3] = rotation_3d_in_axis(gt_ct[..., 0:3].unsqueeze(1), -(roi_ry + np.pi / 2), axis=2).squeeze(1)
-            ry = gt_ct[..., 6] % (2 * np.pi)
-            opposite = (ry > np.pi * 0.5) & (ry < np.pi * 1.5)
-            ry = torch.where(opposite, (ry + np.pi) % (2 * np.pi), ry)
-            ry = torch.where(ry > np.pi, ry - np.pi * 2, ry)
-            gt_ct[..., 6] = torch.clamp(ry, min=-np.pi / 2, max=np.pi / 2)
-            anchor = pos_bboxes.clone().detach()
-            anchor[:, 0:3] = 0
-            anchor[:, 6] = 0
-            bbox_targets = self.bbox_coder.encode(anchor, gt_ct)
+            bbox_targets = self._canonical_box_targets(pos_bboxes, pos_gt_bboxes)
             assert occ_label.dim() == 2 and occ_label.size(1) == 4
             smp_pos, gt_occ = occ_label[:, 0:3], occ_label[:, 3:4]
             with torch.no_grad():

@@ -62,3 +62,29 @@ def test_simple_test_on_cpu_port_equals_reference(gold, model, b):
     assert np.allclose(ot.boxes.numpy(), gold[f'test_boxes_{b}'], rtol=1e-4, atol=2e-4)
     assert np.array_equal(torch.cat(r['inters']).numpy(), gold[f'test_inters_{b}'])
     assert np.array_equal(torch.cat(r['unions']).numpy(), gold[f'test_unions_{b}'])
+
+
+def test_batched_targets_equal_the_per_tracklet_loop(model):
+    """get_targets: rows of all tracklets concatenated first (the product's path) against the reference-shaped loop over
+    tracklets, on the scene with negatives, a frame without a match and a tracklet without a candidate -- bit for bit."""
+    samples, points, frames, trks, cands, occs, occ_scores = _scene()
+    head = model.roi_head.bbox_head
+    seen = {}
+
+    def spy(results, cfg, concat=True, transform_occ=True, num_occ_per_tracklet=-1):
+        seen['batched'] = head._get_targets_batched(results, cfg, transform_occ, num_occ_per_tracklet)
+        seen['loop'] = head._get_targets_per_tracklet(results, cfg, transform_occ, num_occ_per_tracklet)
+        return seen['batched']
+
+    head.get_targets = spy
+    try:
+        torch.manual_seed(123)
+        with cpu_port.cpu_ops():
+            model(return_loss=True, points=points, pts_frame_inds=[f.clone() for f in frames], img_metas=None, tracklet=trks,
+                  gt_tracklet_candidates=cands, occ_labels=occs, occ_labels_scores=occ_scores)
+    finally:
+        del head.get_targets
+    assert len(seen['batched']) == len(seen['loop']) == 14
+    for i, (a, b) in enumerate(zip(seen['batched'], seen['loop'])):
+        assert a.shape == b.shape and a.dtype == b.dtype, (i, a.shape, b.shape, a.dtype, b.dtype)
+        assert torch.equal(a, b), i
