@@ -323,6 +323,20 @@ int ococc_sparse_conv_tile_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t k
                                    int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
                                    const float* gamma, const float* beta, float eps, int32_t act,
                                    uint16_t* conv_out, uint16_t* y, float* mean_rstd, ococc_stream_t stream);
+/* The same kernel as the input-gradient pass of layer L+1 (feat = d conv_out of layer L+1, wn = its dgrad operand,
+ * table = its gather-side table for the backward direction) with the LayerNorm (+ GELU) BACKWARD of the block in
+ * front (layer L: conv -> LN -> act, sparse_block.py:216-289) applied in the epilogue: the finished row is the
+ * gradient of layer L's block OUTPUT; with layer L's saved conv output block_conv_out [n_out, ncols] bf16, its
+ * statistics mean_rstd [n_out, 2] and gamma / beta, d_conv_out [n_out, ncols] bf16 = the gradient of layer L's CONV
+ * output leaves instead (bit-identical to ococc_layernorm_act_bwd on the bf16 dgrad output), plus one row of
+ * partial sums [d gamma | d beta] per workgroup into partials [partial_rows, 2 ncols] f32 (every row written;
+ * ococc_layernorm_param_reduce_multi or a column sum finishes them).  ncols in {32, 64}. */
+int64_t ococc_sparse_conv_tile_lnbwd_partial_rows(int64_t n_out, int32_t kd, int32_t ncols);
+int ococc_sparse_conv_tile_lnbwd_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
+                                      int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
+                                      const uint16_t* block_conv_out, const float* mean_rstd, const float* gamma,
+                                      const float* beta, int32_t act, uint16_t* d_conv_out, float* partials,
+                                      int64_t partial_rows, ococc_stream_t stream);
 
 /* weights [kvol, cin, cout] (the reference layout (kD,kH,kW,Cin,Cout),
  * spconv/conv.py:98-99) in f32 or bf16 ->

@@ -63,6 +63,9 @@ SIGNATURES = {
                                             c_i32, c_vp]),
     'ococc_sparse_conv_tile_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,
                                                c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_sparse_conv_tile_lnbwd_partial_rows': (c_i64, [c_i64, c_i32, c_i32]),
+    'ococc_sparse_conv_tile_lnbwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,
+                                                  c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_sparse_conv_gather_gemm_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp,
                                                    c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
     'ococc_sparse_conv_gather_gemm_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64,

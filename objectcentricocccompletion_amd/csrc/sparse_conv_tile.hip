@@ -59,11 +59,24 @@ struct TileLn {
   int act;           // 0 none, 1 GELU(erf)
   uint16_t* y;       // [n_out, NC] bf16
   float* mean_rstd;  // [n_out, 2]
+  // LayerNorm BACKWARD epilogue (LNB instantiations, the dgrad of the NEXT layer): y = this layer's conv output (read),
+  // mean_rstd = its saved statistics (read), partials = [gridDim.x][2 NC] per-workgroup sums for d gamma | d beta
+  float* partials;
 };
 __device__ __forceinline__ float tile_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
 __device__ __forceinline__ float tile_round_bf16(float v) { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); }
+// d GELU(z) / dz, the arithmetic of layernorm_act.hip (Abramowitz & Stegun 7.1.26; one exponential for erf and density)
+__device__ __forceinline__ float tile_gelu_grad(float z) {
+  const float x = fabsf(z) * 0.70710678118654752440f;
+  const float e = __expf(-x * x);
+  const float t = __frcp_rn(1.f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float half_tail = 0.5f * poly * e;
+  const float cdf = z >= 0.f ? 1.f - half_tail : half_tail;
+  return cdf + z * 0.39894228040143267794f * e;
+}
 
-template <int KD, int NC, int T, bool OUT_BF16, bool LN = false>
+template <int KD, int NC, int T, bool OUT_BF16, bool LN = false, bool LNB = false>
 __global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64) ? 4 : 1)
 subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn,
                       int kvol, int dense_k, const int32_t* __restrict__ table, int64_t n_out,
@@ -88,7 +101,11 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   // XCD-aware: workgroups are dealt round-robin to the 8 XCDs; give each a contiguous eighth of the tiles
   const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int64_t row0 = (int64_t)wg * T;
-  if (row0 >= n_out) return;
+  if (row0 >= n_out) {
+    if constexpr (LNB)   // (a padding workgroup still owns a row of the partial sums)
+      for (int i = threadIdx.x; i < 2 * NC; i += kTileThreads) ln.partials[(int64_t)blockIdx.x * 2 * NC + i] = 0.f;
+    return;
+  }
 
   TSTAMP(0);
   for (int i = threadIdx.x; i < T; i += kTileThreads) s_owner[i] = 0u;
@@ -301,6 +318,95 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
   }
 
   TSTAMP(8);
+  if constexpr (LNB) {
+    // ---- epilogue of a dgrad whose output is the gradient of a conv -> LayerNorm -> act block's OUTPUT: the block's
+    // LayerNorm (+ GELU) backward happens here, on the finished f32 row, and the gradient of the block's conv output
+    // leaves instead (the separate LN-backward launch read this row back and wrote that one).  Arithmetic and its
+    // order are those of ln_act_bwd_vec_kernel (the incoming gradient rounded to bf16 first, as the unfused pair
+    // sees it): the rows are bit-identical; the per-workgroup sums for d gamma / d beta are grouped differently.
+    constexpr int LPRC = NC / 8;
+    const int c8 = threadIdx.x % LPRC;  // (kTileThreads is a multiple of LPRC: a thread keeps its channels)
+    float g[8], b[8], dg[8], db[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g[j] = ln.gamma[c8 * 8 + j];
+      b[j] = ln.beta[c8 * 8 + j];
+      dg[j] = db[j] = 0.f;
+    }
+    // the block's conv output and statistics for ALL of this thread's rows are requested at once (one exposed
+    // latency instead of one per row: at one workgroup per CU nothing else hides it)
+    constexpr int IT = T * LPRC / kTileThreads;
+    static_assert(T * LPRC % kTileThreads == 0, "rows per thread");
+    u32x4 xin_[IT];
+    float mean_[IT], rstd_[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int64_t row = row0 + (it * kTileThreads + threadIdx.x) / LPRC;
+      const int64_t rc = row < n_out ? row : n_out - 1;
+      xin_[it] = *(const u32x4*)(ln.y + rc * NC + c8 * 8);
+      mean_[it] = ln.mean_rstd[rc * 2];
+      rstd_[it] = ln.mean_rstd[rc * 2 + 1];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = (it * kTileThreads + threadIdx.x) / LPRC;
+      const int64_t row = row0 + r;
+      if (row >= n_out) continue;  // (whole rows leave together)
+      const f32x4 v0 = *(const f32x4*)(tile + r * LDT + c8 * 8), v1 = *(const f32x4*)(tile + r * LDT + c8 * 8 + 4);
+      const u32x4 xin = xin_[it];
+      const float mean = mean_[it], rstd = rstd_[it];
+      float xv[8], dzg[8];
+      xv[0] = __uint_as_float(xin.x << 16); xv[1] = __uint_as_float(xin.x & 0xffff0000u);
+      xv[2] = __uint_as_float(xin.y << 16); xv[3] = __uint_as_float(xin.y & 0xffff0000u);
+      xv[4] = __uint_as_float(xin.z << 16); xv[5] = __uint_as_float(xin.z & 0xffff0000u);
+      xv[6] = __uint_as_float(xin.w << 16); xv[7] = __uint_as_float(xin.w & 0xffff0000u);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xv[j] = (xv[j] - mean) * rstd;  // xhat
+        float dz = tile_round_bf16(j < 4 ? v0[j] : v1[j - 4]);
+        if (ln.act == 1) dz *= tile_gelu_grad(xv[j] * g[j] + b[j]);
+        dg[j] += dz * xv[j];
+        db[j] += dz;
+        dzg[j] = dz * g[j];
+        s1 += dzg[j];
+        s2 += dzg[j] * xv[j];
+      }
+#pragma unroll
+      for (int d = LPRC >> 1; d >= 1; d >>= 1) {
+        s1 += __shfl_xor(s1, d, 64);
+        s2 += __shfl_xor(s2, d, 64);
+      }
+      s1 *= (1.f / NC);
+      s2 *= (1.f / NC);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[j] - s1 - xv[j] * s2);
+      u32x4 q;
+      q.x = (uint32_t)ococc_f32_to_bf16(o[0]) | ((uint32_t)ococc_f32_to_bf16(o[1]) << 16);
+      q.y = (uint32_t)ococc_f32_to_bf16(o[2]) | ((uint32_t)ococc_f32_to_bf16(o[3]) << 16);
+      q.z = (uint32_t)ococc_f32_to_bf16(o[4]) | ((uint32_t)ococc_f32_to_bf16(o[5]) << 16);
+      q.w = (uint32_t)ococc_f32_to_bf16(o[6]) | ((uint32_t)ococc_f32_to_bf16(o[7]) << 16);
+      *(u32x4*)((uint16_t*)out_ + row * NC + c8 * 8) = q;
+    }
+    __syncthreads();  // the tile is read; its memory now carries the column sums of the thread groups
+    constexpr int GROUPS = kTileThreads / LPRC;
+    static_assert(GROUPS * 2 * NC <= T * LDT, "column sums fit the tile");
+    float* mine = tile + (threadIdx.x / LPRC) * 2 * NC;
+    *(f32x4*)(mine + c8 * 8) = f32x4{dg[0], dg[1], dg[2], dg[3]};
+    *(f32x4*)(mine + c8 * 8 + 4) = f32x4{dg[4], dg[5], dg[6], dg[7]};
+    *(f32x4*)(mine + NC + c8 * 8) = f32x4{db[0], db[1], db[2], db[3]};
+    *(f32x4*)(mine + NC + c8 * 8 + 4) = f32x4{db[4], db[5], db[6], db[7]};
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NC; i += kTileThreads) {
+      float sum = 0.f;
+#pragma unroll 4
+      for (int gq = 0; gq < GROUPS; ++gq) sum += tile[gq * 2 * NC + i];
+      ln.partials[(int64_t)blockIdx.x * 2 * NC + i] = sum;
+    }
+    TSTAMP(9);
+    return;
+  }
   // ---- epilogue: tile -> global, 8 channels (16 bytes of bf16) per thread; a row is NC / 8 consecutive lanes ----
   for (int i = threadIdx.x; i < T * (NC / 8); i += kTileThreads) {
     const int r = i / (NC / 8), c8 = i % (NC / 8);
@@ -370,7 +476,16 @@ int launch_tile_t(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kv
                   const TileLn* ln = nullptr) {
   constexpr size_t lds = (size_t)T * (NC + 4) * 4;
   const dim3 grid((unsigned)ococc_align_up(ococc_cdiv(n_out, T), 8));
-  if (ln) {
+  if (ln && ln->partials) {
+    if constexpr (NC <= 64) {
+      auto fn = subm_tile_conv_kernel<KD, NC, T, true, false, true>;
+      OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(fn, grid, dim3(kTileThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, dense_k,
+                         table, n_out, bias, out, *ln);
+    } else {
+      return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused LayerNorm backward epilogue: up to 64 output columns");
+    }
+  } else if (ln) {
     if constexpr (NC <= 64 && KD <= 64) {
       auto fn = subm_tile_conv_kernel<KD, NC, T, true, true>;
       OCOCC_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -472,7 +587,32 @@ extern "C" int ococc_sparse_conv_tile_ln_bf16(const uint16_t* feat, int64_t n_in
                                               ococc_stream_t stream_) {
   OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
   OCOCC_REQUIRE(n_out == 0 || (gamma && beta && y && mean_rstd), "null pointer");
-  const TileLn ln{gamma, beta, eps, act, y, mean_rstd};
+  const TileLn ln{gamma, beta, eps, act, y, mean_rstd, nullptr};
   return tile_entry(feat, n_in, kd, wn, kvol, ncols, table, dense_k, n_out, nullptr, conv_out, OCOCC_BF16,
+                    (hipStream_t)stream_, &ln);
+}
+
+namespace {
+// rows of the tile the launcher picks for a shape (launch_tile above)
+inline int tile_rows_for(int kd, int ncols) { return (ncols >= 128 || kd <= 64) ? 256 : 512; }
+}  // namespace
+
+extern "C" int64_t ococc_sparse_conv_tile_lnbwd_partial_rows(int64_t n_out, int32_t kd, int32_t ncols) {
+  if (n_out < 0 || (kd != 32 && kd != 64 && kd != 128) || (ncols != 32 && ncols != 64)) return -1;
+  return ococc_align_up(ococc_cdiv(n_out > 0 ? n_out : 1, tile_rows_for(kd, ncols)), 8);
+}
+
+extern "C" int ococc_sparse_conv_tile_lnbwd_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                                 int32_t kvol, int32_t ncols, const int32_t* table, int32_t dense_k,
+                                                 int64_t n_out, const uint16_t* block_conv_out,
+                                                 const float* mean_rstd, const float* gamma, const float* beta,
+                                                 int32_t act, uint16_t* d_conv_out, float* partials,
+                                                 int64_t partial_rows, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(ncols == 32 || ncols == 64, "fused LayerNorm backward: 32 or 64 output columns");
+  OCOCC_REQUIRE(n_out == 0 || (gamma && beta && block_conv_out && mean_rstd && d_conv_out && partials), "null pointer");
+  OCOCC_REQUIRE(partial_rows >= ococc_sparse_conv_tile_lnbwd_partial_rows(n_out, kd, ncols), "partials too small");
+  const TileLn ln{gamma, beta, 0.f, act, const_cast<uint16_t*>(block_conv_out), const_cast<float*>(mean_rstd), partials};
+  return tile_entry(feat, n_in, kd, wn, kvol, ncols, table, dense_k, n_out, nullptr, d_conv_out, OCOCC_BF16,
                     (hipStream_t)stream_, &ln);
 }

@@ -13,6 +13,7 @@ from torch import nn
 from .sparse_block import make_sparse_convmodule
 from .spconv import SparseConvTensor
 from .spconv import ops as sp_ops
+from .spconv.functional import chain_ln_backward
 from .voxel import dynamic_scatter, object_grid_geometry, voxelization, voxelize_scatter_mean
 
 
@@ -87,8 +88,11 @@ class SubMOccEncoder(nn.Module):
         items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
         sp_ops.prepare_weights(items)
         x = geometry if geometry is not None else self.geometry(points, feats, batch_idx, batch_size, static)
-        for layer in self.conv_layers:
-            x = layer(x)
+        # (a plain stack: every block's output goes into the next block's convolution and nowhere else, so each
+        # LayerNorm backward may run inside the next layer's input-gradient kernel)
+        with chain_ln_backward():
+            for layer in self.conv_layers:
+                x = layer(x)
         return x
 
     def _front_end(self, points, feats, batch_idx, batch_size, static):

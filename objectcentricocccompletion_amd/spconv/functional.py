@@ -4,6 +4,34 @@ from torch.autograd import Function
 from . import ops
 
 
+class LnBackwardLink(object):
+    """What the dgrad of the NEXT conv layer needs to run this block's LayerNorm backward in its epilogue, and where it
+    leaves the result.  Created by ``indice_conv_ln`` when a chain of blocks is declared (``chain_ln_backward``)."""
+    __slots__ = ('conv_out', 'stats', 'g32', 'b32', 'act', 'fused', 'partials', 'rows', 'expect')
+
+    def __init__(self):
+        self.conv_out = self.stats = self.g32 = self.b32 = self.partials = self.expect = None
+        self.act, self.fused, self.rows = 0, False, 0
+
+
+class chain_ln_backward(object):
+    """Inside this context the output of a conv -> LN -> act block (``indice_conv_ln``) that goes STRAIGHT into the next
+    block's convolution, and nowhere else, has its LayerNorm backward fused into that convolution's input-gradient
+    kernel (ococc_sparse_conv_tile_lnbwd_bf16): the gradient that travels between the two autograd nodes is then the
+    gradient of the block's CONV output, not of its activation output -- hooks on the tensor in between would see
+    that.  The promise "nowhere else" is the caller's (occ_encoder.SubMOccEncoder: a plain stack); a second consumer
+    is detected in the backward pass (the incoming gradient is not the buffer the fused kernel wrote) and raises."""
+    active = False
+
+    def __enter__(self):
+        self._prev, chain_ln_backward.active = chain_ln_backward.active, True
+        return self
+
+    def __exit__(self, *exc):
+        chain_ln_backward.active = self._prev
+        return False
+
+
 class _IndiceConvBase(Function):
     INVERSE = False
     SUBM = False
@@ -14,6 +42,8 @@ class _IndiceConvBase(Function):
         out = ops.indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out,
                               cls.INVERSE, cls.SUBM, _saved=saved)
         ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters, saved['x_bf16'])
+        # (a conv -> LN -> act block in front, in a declared chain: see LnBackwardLink below)
+        ctx.link_in = getattr(features, '_ococc_ln_link', None) if chain_ln_backward.active else None
         return out
 
     @classmethod
@@ -22,7 +52,7 @@ class _IndiceConvBase(Function):
         input_bp, filters_bp = ops.indice_conv_backward(
             features, filters, grad_output.contiguous(), indice_pairs, indice_pair_num,
             cls.INVERSE, cls.SUBM, _x_bf16=x_bf16, need_input_grad=ctx.needs_input_grad[0],
-            need_filter_grad=ctx.needs_input_grad[1], _autograd=True)
+            need_filter_grad=ctx.needs_input_grad[1], _autograd=True, _ln_link=getattr(ctx, 'link_in', None))
         return input_bp, filters_bp, None, None, None
 
 
@@ -66,11 +96,12 @@ class SubMConvFunction(_IndiceConvBase):
 
 class _IndiceConvLN(Function):
     """conv -> LayerNorm -> act with the norm in the conv kernel's epilogue (forward) and the existing LN
-    backward kernel in front of indice_conv_backward (backward).  mode: (inverse, subm)."""
+    backward kernel in front of indice_conv_backward (backward) -- or, in a declared chain, inside the dgrad kernel of
+    the next layer (LnBackwardLink).  mode: (inverse, subm)."""
 
     @staticmethod
     def forward(ctx, features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out, eps, act,
-                inverse, subm):
+                inverse, subm, link_in, link_out):
         saved = {}
         res = ops.indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indice_pair_num,
                                  num_activate_out, inverse, subm, _saved=saved)
@@ -80,6 +111,10 @@ class _IndiceConvLN(Function):
         ctx.save_for_backward(indice_pairs, indice_pair_num, features, filters, saved['x_bf16'], conv_out, stats,
                               saved['g32'], saved['b32'], gamma, beta)
         ctx.meta = (int(act), bool(inverse), bool(subm), gamma.dtype)
+        ctx.link_in, ctx.link_out = link_in, link_out
+        if link_out is not None:
+            link_out.conv_out, link_out.stats, link_out.g32, link_out.b32 = conv_out, stats, saved['g32'], saved['b32']
+            link_out.act = int(act)
         return y
 
     @staticmethod
@@ -90,21 +125,50 @@ class _IndiceConvLN(Function):
             ctx.saved_tensors
         act, inverse, subm, wdtype = ctx.meta
         n, c = conv_out.shape
-        dy2 = dy.to(torch.bfloat16).contiguous()
-        dconv = torch.empty_like(conv_out)
-        from ..norm import layernorm_act_backward
-        dgamma, dbeta = layernorm_act_backward(conv_out, dy2, g32, b32, stats, act, dconv, gamma, beta)
+        mine = ctx.link_out
+        if mine is not None and mine.fused:
+            # the next layer's dgrad already ran this block's LN backward: dy IS d conv_out
+            if (dy.data_ptr(), dy._version) != mine.expect or dy.dtype != torch.bfloat16:
+                raise L.OcoccError('chain_ln_backward: the output of a conv -> LN -> act block had a second consumer '
+                                   '(its gradient is not the untouched buffer the fused dgrad kernel wrote)')
+            dconv = dy
+            from .. import _deferred
+            dgb = torch.empty((2, c), dtype=torch.float32, device=dy.device)
+            if gamma is not beta and _deferred.deferrable(gamma, beta) and \
+                    _deferred.defer('ln', (mine.partials, mine.rows, c, dgb), [(gamma, dgb[0]), (beta, dgb[1])]):
+                dgamma = dbeta = None
+            else:
+                from ..norm import _flush_param_reduce
+                _flush_param_reduce([(mine.partials, mine.rows, c, dgb)])
+                dgamma, dbeta = dgb[0], dgb[1]
+            mine.fused, mine.partials, mine.expect = False, None, None
+        else:
+            dy2 = dy.to(torch.bfloat16).contiguous()
+            dconv = torch.empty_like(conv_out)
+            from ..norm import layernorm_act_backward
+            dgamma, dbeta = layernorm_act_backward(conv_out, dy2, g32, b32, stats, act, dconv, gamma, beta)
         input_bp, filters_bp = ops.indice_conv_backward(
             features, filters, dconv, indice_pairs, indice_pair_num, inverse, subm, _x_bf16=x_bf16,
-            need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1], _autograd=True)
+            need_input_grad=ctx.needs_input_grad[0], need_filter_grad=ctx.needs_input_grad[1], _autograd=True,
+            _ln_link=ctx.link_in)
         return (input_bp, filters_bp, None if dgamma is None else dgamma.to(wdtype),
-                None if dbeta is None else dbeta.to(wdtype), None, None, None, None, None, None, None)
+                None if dbeta is None else dbeta.to(wdtype), None, None, None, None, None, None, None, None, None)
 
 
 def indice_conv_ln(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out, eps, act,
                    inverse=False, subm=False):
-    return _IndiceConvLN.apply(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out,
-                               eps, act, inverse, subm)
+    link_in = getattr(features, '_ococc_ln_link', None) if chain_ln_backward.active else None
+    link_out = LnBackwardLink() if (chain_ln_backward.active and torch_is_grad_enabled()) else None
+    y = _IndiceConvLN.apply(features, filters, gamma, beta, indice_pairs, indice_pair_num, num_activate_out,
+                            eps, act, inverse, subm, link_in, link_out)
+    if link_out is not None:
+        y._ococc_ln_link = link_out
+    return y
+
+
+def torch_is_grad_enabled():
+    import torch
+    return torch.is_grad_enabled()
 
 
 indice_conv = SparseConvFunction.apply

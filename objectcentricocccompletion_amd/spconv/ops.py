@@ -394,6 +394,11 @@ def set_rulebook_density(indice_pairs, pairs_per_row):
         rb.pairs_per_row = float(pairs_per_row)
 
 
+# LayerNorm backward of a block fused into the NEXT layer's dgrad (tile kernel) when the blocks form a declared chain
+# (functional.chain_ln_backward; occ_encoder.SubMOccEncoder declares one)
+FUSE_LN_BACKWARD = os.environ.get('OCOCC_FUSE_LN_BACKWARD', '1') == '1'
+
+
 def _use_tile_kernel(rb, kd, ncols):
     if (rb is None or not rb.subm or rb.kvol % 2 == 0 or kd not in (32, 64, 128) or ncols not in (32, 64, 128)
             or kd * ncols >= 128 * 128):
@@ -563,7 +568,8 @@ def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, nu
 
 
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False,
-                         subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True, _autograd=False):
+                         subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True, _autograd=False,
+                         _ln_link=None):
     """ops.py:142-160 -> (input_bp [n_in,Cin], filters_bp like filters).  ``_autograd`` (set by our autograd
     Functions only): the weight gradient may join the end-of-backward reduction queue (_deferred), in which case
     filters_bp is None here and ``filters.grad`` receives it when the pass ends."""
@@ -628,6 +634,22 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             mode = 5  # fragment-major order for the tile kernel
         wn = _prep_weights(filters, mode, kd_out, nc)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
+        if (_ln_link is not None and FUSE_LN_BACKWARD and mode == 5 and nc == cin and nc in (32, 64)
+                and out_dtype == torch.bfloat16 and _ln_link.conv_out is not None
+                and tuple(_ln_link.conv_out.shape) == (rows, nc)):
+            # the block in front (conv -> LN -> act) gets its LayerNorm backward in this kernel's epilogue: what
+            # leaves is the gradient of ITS conv output (functional.LnBackwardLink)
+            prows = int(L.lib.ococc_sparse_conv_tile_lnbwd_partial_rows(rows, kd_out, nc))
+            partials = L.empty((prows, 2 * nc), torch.float32, features.device)
+            gin = L.empty((rows, nc), torch.bfloat16, features.device)
+            kvol = wn.shape[0]
+            L.check(L.lib.ococc_sparse_conv_tile_lnbwd_bf16(
+                L.ptr(dy), dy.size(0), kd_out, L.ptr(wn), kvol, nc, L.ptr(table), kvol // 2, rows,
+                L.ptr(_ln_link.conv_out), L.ptr(_ln_link.stats), L.ptr(_ln_link.g32), L.ptr(_ln_link.b32),
+                int(_ln_link.act), L.ptr(gin), L.ptr(partials), prows, L.stream()), 'sparse_conv_tile_lnbwd')
+            _ln_link.fused, _ln_link.partials, _ln_link.rows = True, partials, prows
+            _ln_link.expect = (gin.data_ptr(), gin._version)   # (the engine may add a second consumer's gradient in place)
+            return gin, filters_bp
         if _probe is not None:
             gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None))
         else:

@@ -265,3 +265,63 @@ def test_tile_kernel_layernorm_epilogue_vs_oracle(dev, cin, cout, act):
     c64 = conv_out.astype(np.float64)
     mu, rstd = c64.mean(1), 1.0 / np.sqrt(c64.var(1) + 1e-3)
     assert np.allclose(stats[:, 0], mu, rtol=1e-5, atol=1e-6) and np.allclose(stats[:, 1], rstd, rtol=1e-5)
+
+
+@pytest.mark.parametrize('static', [False, True])
+def test_layernorm_backward_inside_the_next_layers_dgrad(dev, static):
+    """SubMOccEncoder declares its blocks a chain (functional.chain_ln_backward): the LayerNorm (+ GELU) backward of
+    block L runs in the epilogue of block L+1's input-gradient kernel (ococc_sparse_conv_tile_lnbwd_bf16).  Against the
+    same backward pass with the separate LN-backward launches: the conv-output gradients are bit-identical, hence the
+    weight gradients too; d gamma / d beta are sums of the same terms grouped by other workgroups (tolerance)."""
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    from objectcentricocccompletion_amd.spconv import ops
+    torch.manual_seed(0)
+    enc = SubMOccEncoder().to(dev).train()
+    xyz, feats, bidx = synthetic_object_grids(6, 700, seed=3, device=dev)
+    grads, outs, launches = {}, {}, {}
+    for fused in (False, True):
+        ops.FUSE_LN_BACKWARD, ops.SPARSE_TILE_CONV = fused, True   # (the compact-then-multiply kernels for every layer)
+        try:
+            for p in enc.parameters():
+                p.grad = None
+            out = enc(xyz, feats, bidx, 6, static=static)
+            f = out.features.float()
+            gen = torch.Generator(device=dev).manual_seed(5)
+            (f * torch.randn(f.shape, generator=gen, device=dev)).sum().backward()
+            outs[fused] = f.detach().clone()
+            grads[fused] = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+        finally:
+            ops.FUSE_LN_BACKWARD, ops.SPARSE_TILE_CONV = True, None
+    assert torch.equal(outs[False], outs[True])
+    for k in grads[False]:
+        a, b = grads[False][k], grads[True][k]
+        assert bool(torch.isfinite(b).all()), k
+        if k.endswith('0.weight'):           # conv weights: same d conv_out rows -> the same contraction
+            assert torch.equal(a, b), k
+        else:                                # LayerNorm gamma / beta of the three blocks
+            assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6), k
+    names = [k for k in grads[True] if not k.endswith('0.weight')]
+    assert len(names) == 6
+
+
+def test_ln_backward_link_refuses_a_second_consumer(dev):
+    """The fused form is only sound when a block's output feeds the next convolution alone; another use of the tensor
+    inside a declared chain is caught in the backward pass."""
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    from objectcentricocccompletion_amd.spconv.functional import chain_ln_backward
+    torch.manual_seed(0)
+    enc = SubMOccEncoder().to(dev).train()
+    xyz, feats, bidx = synthetic_object_grids(3, 500, seed=1, device=dev)
+    from objectcentricocccompletion_amd.spconv import ops
+    x = enc.geometry(xyz, feats, bidx, 3)
+    ops.SPARSE_TILE_CONV = True
+    try:
+        with chain_ln_backward():
+            a = enc.conv_layers[0](x)
+            b = enc.conv_layers[1](a)
+            c = enc.conv_layers[2](b)
+        with pytest.raises(L.OcoccError):
+            (c.features.float().sum() + b.features.float().sum()).backward()
+    finally:
+        ops.SPARSE_TILE_CONV = None
