@@ -10,10 +10,11 @@
 // dgamma/dbeta: per-lane running sums over the rows a workgroup owns, combined
 // through LDS, written to per-workgroup slabs and added in a fixed order.
 #include "common.hpp"
+#include "ln_math.hpp"
 
 namespace {
 
-constexpr int kBwdMaxBlocks = 512;  // one dgamma/dbeta slab per block; 8 blocks per CU keep the streams busy
+constexpr int kBwdMaxBlocks = 1024;  // one dgamma/dbeta slab per block; 4 blocks per CU = the 16 waves the registers allow
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 
@@ -36,14 +37,14 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 __device__ __forceinline__ float norm_cdf(float z, float* e_out) {
   const float x = fabsf(z) * kInvSqrt2;
   const float e = __expf(-x * x);
-  const float t = __frcp_rn(1.f + 0.3275911f * x);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);  // (v_rcp_f32; __frcp_rn expands to the 10-instruction IEEE division)
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float half_tail = 0.5f * poly * e;  // (1 - erf(x)) / 2
   *e_out = e;
   return z >= 0.f ? 1.f - half_tail : half_tail;
 }
-// forward: libm erff is cheaper here (post-LN |z| is mostly < 2, its no-exp polynomial branch)
-__device__ __forceinline__ float gelu(float z) { return 0.5f * z * (1.f + erff(z * kInvSqrt2)); }
+// forward: the same Phi, packed where the kernel walks channel pairs (ln_math.hpp)
+__device__ __forceinline__ float gelu(float z) { return ln_gelu1(z); }
 __device__ __forceinline__ float gelu_grad(float z) {
   float e;
   const float cdf = norm_cdf(z, &e);
@@ -182,51 +183,67 @@ ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __
                       uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
-  float g[8], b[8];
+  ln_f32x2 g[4], b[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { g[j] = gamma[li * 8 + j]; b[j] = beta[li * 8 + j]; }
-  for (int64_t r = (int64_t)blockIdx.x * RPB + rloc; r < n; r += (int64_t)gridDim.x * RPB) {
-    float v[8];
-    unpack8(*(const u32x4*)(x + r * C + li * 8), v);
-    float s = 0.f;
+  for (int p = 0; p < 4; ++p) {
+    g[p] = ln_f32x2{gamma[li * 8 + 2 * p], gamma[li * 8 + 2 * p + 1]};
+    b[p] = ln_f32x2{beta[li * 8 + 2 * p], beta[li * 8 + 2 * p + 1]};
+  }
+  // two rows per trip (both loads in flight), packed f32 arithmetic, GELU through ln_math.hpp
+  const int64_t stride = (int64_t)gridDim.x * RPB;
+  for (int64_t r0 = (int64_t)blockIdx.x * RPB + rloc; r0 < n; r0 += 2 * stride) {
+    const int64_t r1 = r0 + stride;
+    const bool two = r1 < n;
+    const int64_t rr[2] = {r0, two ? r1 : r0};
+    u32x4 xin[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-    const float mean = group_sum(s, LPR) * (1.f / C);
-    float sq = 0.f;
+    for (int u = 0; u < 2; ++u) xin[u] = *(const u32x4*)(x + rr[u] * C + li * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; sq += d * d; }
-    const float rstd = rsqrtf(group_sum(sq, LPR) * (1.f / C) + eps);
-    float o[8];
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      ln_f32x2 v[4];
+      ln_unpack8(xin[u], v);
+      const ln_f32x2 sv = (v[0] + v[1]) + (v[2] + v[3]);
+      const float mean = group_sum(sv.x + sv.y, LPR) * (1.f / C);
+      ln_f32x2 sq = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float z = (v[j] - mean) * rstd * g[j] + b[j];
-      o[j] = act == 1 ? gelu(z) : z;
-    }
-    *(u32x4*)(y + r * C + li * 8) = pack8(o);
-    if (mean_rstd && li == 0) {
-      mean_rstd[r * 2] = mean;
-      mean_rstd[r * 2 + 1] = rstd;
+      for (int p = 0; p < 4; ++p) {
+        v[p] = v[p] - mean;
+        sq += v[p] * v[p];
+      }
+      const float rstd = rsqrtf(group_sum(sq.x + sq.y, LPR) * (1.f / C) + eps);
+      u32x4 q;
+      uint32_t* qq = (uint32_t*)&q;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        ln_f32x2 z = (v[p] * rstd) * g[p] + b[p];
+        if (act == 1) z = ln_gelu2(z);
+        qq[p] = ln_pack2(z);
+      }
+      *(u32x4*)(y + rr[u] * C + li * 8) = q;
+      if (mean_rstd && li == 0) {
+        mean_rstd[rr[u] * 2] = mean;
+        mean_rstd[rr[u] * 2 + 1] = rstd;
+      }
     }
   }
 }
 
-template <int LPR>
-__global__ void __launch_bounds__(256)
-ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
-                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                      const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
-                      float* __restrict__ partials) {
+template <int LPR, bool GELU>
+__device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ mean_rstd, uint16_t* __restrict__ dx,
+                                                    float* __restrict__ partials) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
-  float g[8], b[8], dg[8], db[8];
+  ln_f32x2 g[4], b[4], dg[4], db[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    g[j] = gamma[li * 8 + j];
-    b[j] = beta[li * 8 + j];
-    dg[j] = db[j] = 0.f;
+  for (int p = 0; p < 4; ++p) {
+    g[p] = ln_f32x2{gamma[li * 8 + 2 * p], gamma[li * 8 + 2 * p + 1]};
+    b[p] = ln_f32x2{beta[li * 8 + 2 * p], beta[li * 8 + 2 * p + 1]};
+    dg[p] = db[p] = ln_f32x2{0.f, 0.f};
   }
-  // two rows per trip: both rows' loads are issued before either is consumed (the kernel is a stream of
-  // 16-byte loads at 8 waves per CU, so loads in flight per lane are what buys bandwidth)
+  // two rows per trip: both rows' loads are issued before either is consumed
   const int64_t stride = (int64_t)gridDim.x * RPB;
   for (int64_t r0 = (int64_t)blockIdx.x * RPB + rloc; r0 < n; r0 += 2 * stride) {
     const int64_t r1 = r0 + stride;
@@ -244,35 +261,22 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && !two) break;
-      float xv[8], dv[8], dzg[8];
-      unpack8(xin[u], xv);
-      unpack8(din[u], dv);
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xv[j] = (xv[j] - mean[u]) * rstd[u];  // xhat
-        float dz = dv[j];
-        if (act == 1) dz *= gelu_grad(xv[j] * g[j] + b[j]);
-        dg[j] += dz * xv[j];
-        db[j] += dz;
-        dzg[j] = dz * g[j];
-        s1 += dzg[j];
-        s2 += dzg[j] * xv[j];
-      }
+      ln_f32x2 xv[4], dv[4], dzg[4];
+      ln_unpack8(xin[u], xv);
+      ln_unpack8(din[u], dv);
+      float s1, s2;
+      ln_bwd_piece8<GELU>(xv, dv, mean[u], rstd[u], g, b, dg, db, dzg, s1, s2);
       s1 = group_sum(s1, LPR) * (1.f / C);
       s2 = group_sum(s2, LPR) * (1.f / C);
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd[u] * (dzg[j] - s1 - xv[j] * s2);
-      *(u32x4*)(dx + rr[u] * C + li * 8) = pack8(o);
+      *(u32x4*)(dx + rr[u] * C + li * 8) = ln_bwd_finish8(xv, dzg, rstd[u], s1, s2);
     }
   }
   extern __shared__ __attribute__((aligned(16))) float red[];  // [RPB][2*C]
   float* mine = red + rloc * 2 * C;
-  *(f32x4*)(mine + li * 8) = f32x4{dg[0], dg[1], dg[2], dg[3]};
-  *(f32x4*)(mine + li * 8 + 4) = f32x4{dg[4], dg[5], dg[6], dg[7]};
-  *(f32x4*)(mine + C + li * 8) = f32x4{db[0], db[1], db[2], db[3]};
-  *(f32x4*)(mine + C + li * 8 + 4) = f32x4{db[4], db[5], db[6], db[7]};
+  *(f32x4*)(mine + li * 8) = f32x4{dg[0].x, dg[0].y, dg[1].x, dg[1].y};
+  *(f32x4*)(mine + li * 8 + 4) = f32x4{dg[2].x, dg[2].y, dg[3].x, dg[3].y};
+  *(f32x4*)(mine + C + li * 8) = f32x4{db[0].x, db[0].y, db[1].x, db[1].y};
+  *(f32x4*)(mine + C + li * 8 + 4) = f32x4{db[2].x, db[2].y, db[3].x, db[3].y};
   __syncthreads();
   float* slab = partials + (int64_t)blockIdx.x * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
@@ -281,6 +285,15 @@ ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict
     for (int g = 0; g < RPB; ++g) s += red[g * 2 * C + i];
     slab[i] = s;
   }
+}
+template <int LPR>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                      const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
+                      float* __restrict__ partials) {
+  if (act == 1) ln_act_bwd_vec_body<LPR, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
+  else ln_act_bwd_vec_body<LPR, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
 }
 
 // Wide rows (C = 512 * VEC, e.g. the 1024-wide layers of the occupancy decoder): one wave per row, VEC

@@ -33,6 +33,7 @@
 // over pairs.  Partial sums are written to per-workgroup slabs and added in a
 // fixed order (deterministic, no float atomics).
 #include "common.hpp"
+#include "ln_math.hpp"
 #include <cstdlib>
 
 namespace {
@@ -57,7 +58,7 @@ struct LnArgs {
   float* mean_rstd;    // [n_out, 2]
 };
 
-__device__ __forceinline__ float conv_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float conv_gelu(float z) { return ln_gelu1(z); }  // (ln_math.hpp)
 __device__ __forceinline__ float round_bf16(float v) { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); }
 // sum over the 4 lanes (kg = 0..3) that share an output row
 __device__ __forceinline__ float row_sum4(float v) {

@@ -34,6 +34,7 @@
 // workgroups per CU (64 -> 32 16.5 us, 32 -> 64 17.6 us).  The host selects the kernel per shape
 // (spconv/ops.py), or when told to.
 #include "common.hpp"
+#include "ln_math.hpp"
 
 namespace {
 
@@ -63,18 +64,8 @@ struct TileLn {
   // mean_rstd = its saved statistics (read), partials = [gridDim.x][2 NC] per-workgroup sums for d gamma | d beta
   float* partials;
 };
-__device__ __forceinline__ float tile_gelu(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float tile_gelu(float z) { return ln_gelu1(z); }  // (ln_math.hpp: the GELU of every kernel here)
 __device__ __forceinline__ float tile_round_bf16(float v) { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); }
-// d GELU(z) / dz, the arithmetic of layernorm_act.hip (Abramowitz & Stegun 7.1.26; one exponential for erf and density)
-__device__ __forceinline__ float tile_gelu_grad(float z) {
-  const float x = fabsf(z) * 0.70710678118654752440f;
-  const float e = __expf(-x * x);
-  const float t = __frcp_rn(1.f + 0.3275911f * x);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float half_tail = 0.5f * poly * e;
-  const float cdf = z >= 0.f ? 1.f - half_tail : half_tail;
-  return cdf + z * 0.39894228040143267794f * e;
-}
 
 template <int KD, int NC, int T, bool OUT_BF16, bool LN = false, bool LNB = false>
 __global__ void __launch_bounds__(kTileThreads, (T <= 256 && NC <= 64) ? 4 : 1)
@@ -326,15 +317,14 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
     // sees it): the rows are bit-identical; the per-workgroup sums for d gamma / d beta are grouped differently.
     constexpr int LPRC = NC / 8;
     const int c8 = threadIdx.x % LPRC;  // (kTileThreads is a multiple of LPRC: a thread keeps its channels)
-    float g[8], b[8], dg[8], db[8];
+    ln_f32x2 g[4], b[4], dg[4], db[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      g[j] = ln.gamma[c8 * 8 + j];
-      b[j] = ln.beta[c8 * 8 + j];
-      dg[j] = db[j] = 0.f;
+    for (int p = 0; p < 4; ++p) {
+      g[p] = ln_f32x2{ln.gamma[c8 * 8 + 2 * p], ln.gamma[c8 * 8 + 2 * p + 1]};
+      b[p] = ln_f32x2{ln.beta[c8 * 8 + 2 * p], ln.beta[c8 * 8 + 2 * p + 1]};
+      dg[p] = db[p] = ln_f32x2{0.f, 0.f};
     }
-    // the block's conv output and statistics for ALL of this thread's rows are requested at once (one exposed
-    // latency instead of one per row: at one workgroup per CU nothing else hides it)
+    // the block's conv output and statistics for ALL of this thread's rows are requested at once
     constexpr int IT = T * LPRC / kTileThreads;
     static_assert(T * LPRC % kTileThreads == 0, "rows per thread");
     u32x4 xin_[IT];
@@ -353,50 +343,30 @@ subm_tile_conv_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, co
       const int64_t row = row0 + r;
       if (row >= n_out) continue;  // (whole rows leave together)
       const f32x4 v0 = *(const f32x4*)(tile + r * LDT + c8 * 8), v1 = *(const f32x4*)(tile + r * LDT + c8 * 8 + 4);
-      const u32x4 xin = xin_[it];
-      const float mean = mean_[it], rstd = rstd_[it];
-      float xv[8], dzg[8];
-      xv[0] = __uint_as_float(xin.x << 16); xv[1] = __uint_as_float(xin.x & 0xffff0000u);
-      xv[2] = __uint_as_float(xin.y << 16); xv[3] = __uint_as_float(xin.y & 0xffff0000u);
-      xv[4] = __uint_as_float(xin.z << 16); xv[5] = __uint_as_float(xin.z & 0xffff0000u);
-      xv[6] = __uint_as_float(xin.w << 16); xv[7] = __uint_as_float(xin.w & 0xffff0000u);
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xv[j] = (xv[j] - mean) * rstd;  // xhat
-        float dz = tile_round_bf16(j < 4 ? v0[j] : v1[j - 4]);
-        if (ln.act == 1) dz *= tile_gelu_grad(xv[j] * g[j] + b[j]);
-        dg[j] += dz * xv[j];
-        db[j] += dz;
-        dzg[j] = dz * g[j];
-        s1 += dzg[j];
-        s2 += dzg[j] * xv[j];
-      }
+      ln_f32x2 xv[4], dv[4], dzg[4];
+      ln_unpack8(xin_[it], xv);
+      dv[0] = ln_f32x2{tile_round_bf16(v0.x), tile_round_bf16(v0.y)};
+      dv[1] = ln_f32x2{tile_round_bf16(v0.z), tile_round_bf16(v0.w)};
+      dv[2] = ln_f32x2{tile_round_bf16(v1.x), tile_round_bf16(v1.y)};
+      dv[3] = ln_f32x2{tile_round_bf16(v1.z), tile_round_bf16(v1.w)};
+      float s1, s2;
+      if (ln.act == 1) ln_bwd_piece8<true>(xv, dv, mean_[it], rstd_[it], g, b, dg, db, dzg, s1, s2);
+      else ln_bwd_piece8<false>(xv, dv, mean_[it], rstd_[it], g, b, dg, db, dzg, s1, s2);
 #pragma unroll
       for (int d = LPRC >> 1; d >= 1; d >>= 1) {
         s1 += __shfl_xor(s1, d, 64);
         s2 += __shfl_xor(s2, d, 64);
       }
-      s1 *= (1.f / NC);
-      s2 *= (1.f / NC);
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[j] - s1 - xv[j] * s2);
-      u32x4 q;
-      q.x = (uint32_t)ococc_f32_to_bf16(o[0]) | ((uint32_t)ococc_f32_to_bf16(o[1]) << 16);
-      q.y = (uint32_t)ococc_f32_to_bf16(o[2]) | ((uint32_t)ococc_f32_to_bf16(o[3]) << 16);
-      q.z = (uint32_t)ococc_f32_to_bf16(o[4]) | ((uint32_t)ococc_f32_to_bf16(o[5]) << 16);
-      q.w = (uint32_t)ococc_f32_to_bf16(o[6]) | ((uint32_t)ococc_f32_to_bf16(o[7]) << 16);
-      *(u32x4*)((uint16_t*)out_ + row * NC + c8 * 8) = q;
+      *(u32x4*)((uint16_t*)out_ + row * NC + c8 * 8) = ln_bwd_finish8(xv, dzg, rstd_[it], s1 * (1.f / NC), s2 * (1.f / NC));
     }
     __syncthreads();  // the tile is read; its memory now carries the column sums of the thread groups
     constexpr int GROUPS = kTileThreads / LPRC;
     static_assert(GROUPS * 2 * NC <= T * LDT, "column sums fit the tile");
     float* mine = tile + (threadIdx.x / LPRC) * 2 * NC;
-    *(f32x4*)(mine + c8 * 8) = f32x4{dg[0], dg[1], dg[2], dg[3]};
-    *(f32x4*)(mine + c8 * 8 + 4) = f32x4{dg[4], dg[5], dg[6], dg[7]};
-    *(f32x4*)(mine + NC + c8 * 8) = f32x4{db[0], db[1], db[2], db[3]};
-    *(f32x4*)(mine + NC + c8 * 8 + 4) = f32x4{db[4], db[5], db[6], db[7]};
+    *(f32x4*)(mine + c8 * 8) = f32x4{dg[0].x, dg[0].y, dg[1].x, dg[1].y};
+    *(f32x4*)(mine + c8 * 8 + 4) = f32x4{dg[2].x, dg[2].y, dg[3].x, dg[3].y};
+    *(f32x4*)(mine + NC + c8 * 8) = f32x4{db[0].x, db[0].y, db[1].x, db[1].y};
+    *(f32x4*)(mine + NC + c8 * 8 + 4) = f32x4{db[2].x, db[2].y, db[3].x, db[3].y};
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * NC; i += kTileThreads) {
       float sum = 0.f;
