@@ -375,6 +375,14 @@ int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, c
                                  const int32_t* indice_num, int32_t kvol, int64_t pair_capacity,
                                  float* dw, void* workspace, int64_t workspace_bytes,
                                  ococc_stream_t stream);
+/* Both kinds of end-of-backward parameter-gradient sums in ONE launch: the weight-gradient slab sums of
+ * ococc_sparse_conv_wgrad_reduce_multi (first five tables) and the LayerNorm d gamma / d beta column sums of
+ * ococc_layernorm_param_reduce_multi (last five); same results as the two calls, bit for bit.  (No reference
+ * counterpart: indiceConvBackward and torch's native_layer_norm_backward reduce inside their own kernels.) */
+int ococc_backward_param_reduce_multi(int32_t wcount, const void* const* workspaces, const int32_t* const* indice_nums,
+                                      const int32_t* kvols, const int64_t* elems, float* const* dws, int32_t lcount,
+                                      const void* const* partials, const int32_t* rows, const int32_t* c,
+                                      void* const* dgamma, void* const* dbeta, ococc_stream_t stream);
 /* dw == NULL above stops after the per-work-item slabs (left in `workspace`); this call finishes up to 8 such
  * weight gradients in one launch: dw[i][k][e] = sum of the slabs of offset k, fixed order (deterministic).
  * elems[i] = cin * cout of layer i.  Used to move the reductions of a backward pass behind its last kernel. */

@@ -36,8 +36,16 @@ _jobs = {}       # kind -> [job, ...] of the running pass
 _grads = []      # (param, finished-at-flush buffer)
 
 
+_joint = {}      # (kind, kind) -> fn(jobs of the first, jobs of the second) or None when it does not apply
+
+
 def register(kind, fn):
     _flushers[kind] = fn
+
+
+def register_joint(kinds, fn):
+    """One launch for two kinds when both have jobs queued; `fn` returns False to leave them to their own flushers."""
+    _joint[tuple(kinds)] = fn
 
 
 def _accumulates_into_grad(p):
@@ -92,6 +100,9 @@ def _flush():
     global _jobs, _grads
     jobs, grads = _jobs, _grads
     _jobs, _grads = {}, []
+    for (a, b), fn in _joint.items():
+        if jobs.get(a) and jobs.get(b) and fn(jobs[a], jobs[b]):
+            jobs[a], jobs[b] = [], []
     for kind, items in jobs.items():
         if items:
             _flushers[kind](items)

@@ -11,6 +11,7 @@
 // through LDS, written to per-workgroup slabs and added in a fixed order.
 #include "common.hpp"
 #include "ln_math.hpp"
+#include "param_reduce.hpp"
 
 namespace {
 
@@ -401,61 +402,14 @@ ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restric
   for (int i = threadIdx.x; i < 2 * C; i += 256) slab[i] = (red[i] + red[2 * C + i]) + (red[4 * C + i] + red[6 * C + i]);
 }
 
-// 8 outputs per block, 32 lanes each: lane l adds partials l, l+32, ... (fixed order),
-// then a fixed-shape butterfly combines the 32 lanes -> deterministic.
-__device__ __forceinline__ void ln_param_reduce_block(const float* __restrict__ partials, int nblocks, int c,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int block) {
-  const int i = block * 8 + (threadIdx.x >> 5);
-  const int l = threadIdx.x & 31;
-  // eight running sums per lane (fixed combination order): one sum made the 16 strided loads of a lane a
-  // chain of dependent L2 round trips (6.8 us per call whatever the width)
-  float a[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = 0.f;
-  if (i < 2 * c) {
-    const float* src = partials + i;
-    int b = l;
-    for (; b + 32 * 7 < nblocks; b += 32 * 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += src[(int64_t)(b + 32 * u) * 2 * c];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (b + 32 * u < nblocks) a[u] += src[(int64_t)(b + 32 * u) * 2 * c];
-  }
-  float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);
-  if (l == 0 && i < 2 * c) {
-    if (i < c) {
-      if (dgamma) dgamma[i] = s;
-    } else {
-      if (dbeta) dbeta[i - c] = s;
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256)
 ln_param_reduce_kernel(const float* __restrict__ partials, int nblocks, int c,
                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
   ln_param_reduce_block(partials, nblocks, c, dgamma, dbeta, blockIdx.x);
 }
 
-// The reductions of several layers in one launch: layer j owns blocks [first[j], first[j+1]).
-constexpr int kLnMultiMax = 16;
-struct LnReducePack {
-  const float* partials[kLnMultiMax];
-  float* dgamma[kLnMultiMax];
-  float* dbeta[kLnMultiMax];
-  int rows[kLnMultiMax];
-  int c[kLnMultiMax];
-  int first[kLnMultiMax + 1];
-};
 __global__ void __launch_bounds__(256) ln_param_reduce_multi_kernel(LnReducePack p, int count) {
-  int j = 0;
-  while (j + 1 < count && (int)blockIdx.x >= p.first[j + 1]) ++j;
-  ln_param_reduce_block(p.partials[j], p.rows[j], p.c[j], p.dgamma[j], p.dbeta[j], (int)blockIdx.x - p.first[j]);
+  ln_param_reduce_multi_body(p, count, (int)blockIdx.x);
 }
 
 inline int pick_lpr(int c) {

@@ -34,6 +34,7 @@
 // fixed order (deterministic, no float atomics).
 #include "common.hpp"
 #include "ln_math.hpp"
+#include "param_reduce.hpp"
 #include <cstdlib>
 
 namespace {
@@ -1136,14 +1137,14 @@ struct ReducePack {
 // offset of a sparse grid) into units of 256 elements, one thread each -- 27 x fewer, fatter units than one block per
 // 16 elements of every offset (18 k blocks of which 26/27 summed 8 values: 23 us for three layers).
 constexpr int kReduceGrid = 1024;
-__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReducePack pk) {
+__device__ __forceinline__ void wgrad_reduce_multi_body(const ReducePack& pk, int first_unit, int unit_stride) {
   const int lane = threadIdx.x & 63;
   for (int t = 0; t < pk.count; ++t) {
     const int kvol = pk.kvol[t];
     const int64_t elems = pk.elems[t];
     const int deep_units = (int)((elems + 15) / 16), wide_units = (int)((elems + 255) / 256);
     // units per offset (kvol <= 64 here: one lane per offset; larger kernels fall back to deep units for all)
-    for (int unit = blockIdx.x;; unit += gridDim.x) {
+    for (int unit = first_unit;; unit += unit_stride) {
       int k = -1, local = 0, nsl = 0, sbase = 0;
       if (kvol <= 64) {
         // lane = offset: its slab count and (exclusive scan) the index of its first slab
@@ -1197,6 +1198,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReducePack pk) 
       }
     }
   }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReducePack pk) {
+  wgrad_reduce_multi_body(pk, (int)blockIdx.x, (int)gridDim.x);
+}
+// both kinds of end-of-backward sums in one launch: the first wgrad_grid workgroups walk the slab units, the ones
+// behind them sum the LayerNorm partial rows (the two launches were 15 + 8 us of mostly latency, one after the other)
+__global__ void __launch_bounds__(256) backward_reduce_multi_kernel(ReducePack pk, LnReducePack lp, int ln_count,
+                                                                    int wgrad_grid) {
+  if ((int)blockIdx.x >= wgrad_grid) {
+    ln_param_reduce_multi_body(lp, ln_count, (int)blockIdx.x - wgrad_grid);
+    return;
+  }
+  wgrad_reduce_multi_body(pk, (int)blockIdx.x, wgrad_grid);
 }
 
 inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
@@ -1357,6 +1372,50 @@ extern "C" int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int
   if (!dw) return OCOCC_OK;  // slabs only: the caller reduces later (ococc_sparse_conv_wgrad_reduce_multi)
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ococc_cdiv(elems, 16), kvol), dim3(256), 0,
                      stream, slabs, indice_num, (int)kvol, elems, dw);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_backward_param_reduce_multi(int32_t wcount, const void* const* workspaces,
+                                                const int32_t* const* indice_nums, const int32_t* kvols,
+                                                const int64_t* elems, float* const* dws, int32_t lcount,
+                                                const void* const* partials, const int32_t* rows, const int32_t* c,
+                                                void* const* dgamma, void* const* dbeta, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(wcount >= 1 && wcount <= kMaxReduce, "1..8 weight-gradient reductions per call");
+  OCOCC_REQUIRE(lcount >= 1 && lcount <= kLnMultiMax, "1..16 LayerNorm reductions per call");
+  OCOCC_REQUIRE(workspaces && indice_nums && kvols && elems && dws && partials && rows && c && dgamma && dbeta,
+                "null pointer table");
+  ReducePack pk;
+  int blocks = 0;
+  for (int i = 0; i < wcount; ++i) {
+    OCOCC_REQUIRE(workspaces[i] && indice_nums[i] && dws[i] && kvols[i] >= 1 && elems[i] >= 1, "bad reduction descriptor");
+    pk.slabs[i] = (const float*)workspaces[i];
+    pk.num[i] = indice_nums[i];
+    pk.dw[i] = dws[i];
+    pk.elems[i] = elems[i];
+    pk.kvol[i] = kvols[i];
+    pk.first_block[i] = blocks;
+    blocks += (int)ococc_cdiv(elems[i], 16) * kvols[i];
+  }
+  pk.first_block[wcount] = blocks;
+  pk.count = wcount;
+  const int wgrad_grid = blocks < kReduceGrid ? blocks : kReduceGrid;
+  LnReducePack lp;
+  int lblocks = 0;
+  for (int j = 0; j < lcount; ++j) {
+    OCOCC_REQUIRE(partials[j] && rows[j] >= 1 && c[j] >= 1, "bad layer");
+    lp.partials[j] = (const float*)partials[j];
+    lp.dgamma[j] = (float*)dgamma[j];
+    lp.dbeta[j] = (float*)dbeta[j];
+    lp.rows[j] = rows[j];
+    lp.c[j] = c[j];
+    lp.first[j] = lblocks;
+    lblocks += (2 * c[j] + 7) / 8;
+  }
+  lp.first[lcount] = lblocks;
+  hipLaunchKernelGGL(backward_reduce_multi_kernel, dim3(wgrad_grid + lblocks), dim3(256), 0, stream, pk, lp, (int)lcount,
+                     wgrad_grid);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -281,6 +281,25 @@ def _flush_wgrad_reduce(todo):
 _deferred.register('wgrad', _flush_wgrad_reduce)
 
 
+def _flush_wgrad_and_ln(wjobs, ljobs):
+    """The slab sums and the LayerNorm d gamma / d beta sums of a pass in one launch (jobs as in the two flushers)."""
+    import ctypes
+    if len(wjobs) > 8 or len(ljobs) > 16:
+        return False
+    n, k = len(wjobs), len(ljobs)
+    vpn, i32n, i64n, vpk, i32k = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n, ctypes.c_void_p * k, ctypes.c_int32 * k
+    L.check(L.lib.ococc_backward_param_reduce_multi(
+        n, vpn(*[c[0].data_ptr() for c in wjobs]), vpn(*[c[1].data_ptr() for c in wjobs]), i32n(*[c[2] for c in wjobs]),
+        i64n(*[c[3] for c in wjobs]), vpn(*[c[4].data_ptr() for c in wjobs]),
+        k, vpk(*[j[0].data_ptr() for j in ljobs]), i32k(*[j[1] for j in ljobs]), i32k(*[j[2] for j in ljobs]),
+        vpk(*[j[3][0].data_ptr() for j in ljobs]), vpk(*[j[3][1].data_ptr() for j in ljobs]), L.stream()),
+        'backward_param_reduce_multi')
+    return True
+
+
+_deferred.register_joint(('wgrad', 'ln'), _flush_wgrad_and_ln)
+
+
 class overlap_wgrad(object):
     """Context manager around a backward pass: weight gradients of the sparse convolutions are computed on a
     side stream, concurrently with the input-gradient chain; on exit the current stream waits for the side

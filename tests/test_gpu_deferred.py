@@ -62,13 +62,19 @@ def test_deferred_equals_immediate(dev, chans, fused):
         real = dict(D._flushers)
         for kind, fn in real.items():
             D._flushers[kind] = (lambda jobs, kind=kind, fn=fn: (seen.append((kind, len(jobs))), fn(jobs))[1])
+        real_joint = dict(D._joint)
+        for kinds, fn in real_joint.items():
+            D._joint[kinds] = (lambda a, b, kinds=kinds, fn=fn: (seen.append((kinds, len(a), len(b))), fn(a, b))[1])
         try:
             late = _run(blocks, idx, feats, dout)
         finally:
             D._flushers.update(real)
+            D._joint.update(real_joint)
         assert D.pending() == 0
         if chans == (16, 32, 64, 128):
-            assert sorted(seen) == [('ln', 3), ('wgrad', 3)]          # one launch per kind for the whole pass
+            # ONE launch for the whole pass: the slab sums of the three convs and the d gamma / d beta sums of the
+            # three LayerNorms together (ococc_backward_param_reduce_multi)
+            assert seen == [(('wgrad', 'ln'), 3, 3)]
         now = _run(blocks, idx, feats, dout, hooks=True)
         for a, b in zip(late, now):
             assert torch.isfinite(a).all() and torch.equal(a, b)
@@ -116,11 +122,15 @@ def test_weight_with_an_explicit_regulariser_in_the_loss(dev):
         real = dict(D._flushers)
         for kind, fn in real.items():
             D._flushers[kind] = (lambda jobs, kind=kind, fn=fn: (seen.append(kind), fn(jobs))[1])
+        real_joint = dict(D._joint)
+        for kinds, fn in real_joint.items():
+            D._joint[kinds] = (lambda a, b, kinds=kinds, fn=fn: (seen.extend(kinds), fn(a, b))[1])
         try:
             late = run()
         finally:
             D._flushers.update(real)
-        assert sorted(seen) == ['ln', 'wgrad']            # the queue was in use
+            D._joint.update(real_joint)
+        assert sorted(seen) == ['ln', 'wgrad']            # the queue was in use (both kinds, one joint launch)
         was = D.ENABLED
         try:
             D.ENABLED = False
