@@ -306,32 +306,45 @@ ln_act_fwd_wide_kernel(const uint16_t* __restrict__ x, int64_t n, const float* _
                        uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
   constexpr int C = 512 * VEC;
   const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
+  ln_f32x2 g[VEC][4], b[VEC][4];
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) {
+    const int ch = (u * 64 + li) * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      g[u][p] = ln_f32x2{gamma[ch + 2 * p], gamma[ch + 2 * p + 1]};
+      b[u][p] = ln_f32x2{beta[ch + 2 * p], beta[ch + 2 * p + 1]};
+    }
+  }
   for (int64_t r = (int64_t)blockIdx.x * 4 + rloc; r < n; r += (int64_t)gridDim.x * 4) {
-    float v[VEC][8];
-    float s = 0.f;
+    ln_f32x2 v[VEC][4];
+    ln_f32x2 sv = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < VEC; ++u) {
-      unpack8(*(const u32x4*)(x + r * C + (u * 64 + li) * 8), v[u]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[u][j];
+      ln_unpack8(*(const u32x4*)(x + r * C + (u * 64 + li) * 8), v[u]);
+      sv += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
     }
-    const float mean = group_sum(s, 64) * (1.f / C);
-    float sq = 0.f;
+    const float mean = group_sum(sv.x + sv.y, 64) * (1.f / C);
+    ln_f32x2 sq = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < VEC; ++u)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[u][j] - mean; sq += d * d; }
-    const float rstd = rsqrtf(group_sum(sq, 64) * (1.f / C) + eps);
+      for (int p = 0; p < 4; ++p) {
+        v[u][p] = v[u][p] - mean;
+        sq += v[u][p] * v[u][p];
+      }
+    const float rstd = rsqrtf(group_sum(sq.x + sq.y, 64) * (1.f / C) + eps);
 #pragma unroll
     for (int u = 0; u < VEC; ++u) {
-      const int ch = (u * 64 + li) * 8;
-      float o[8];
+      u32x4 q;
+      uint32_t* qq = (uint32_t*)&q;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float z = (v[u][j] - mean) * rstd * gamma[ch + j] + beta[ch + j];
-        o[j] = act == 1 ? gelu(z) : z;
+      for (int p = 0; p < 4; ++p) {
+        ln_f32x2 z = (v[u][p] * rstd) * g[u][p] + b[u][p];
+        if (act == 1) z = ln_gelu2(z);
+        qq[p] = ln_pack2(z);
       }
-      *(u32x4*)(y + r * C + ch) = pack8(o);
+      *(u32x4*)(y + r * C + (u * 64 + li) * 8) = q;
     }
     if (mean_rstd && li == 0) {
       mean_rstd[r * 2] = mean;
@@ -340,51 +353,50 @@ ln_act_fwd_wide_kernel(const uint16_t* __restrict__ x, int64_t n, const float* _
   }
 }
 
-template <int VEC>
-__global__ void __launch_bounds__(256)
-ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
-                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                       const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
-                       float* __restrict__ partials) {
+template <int VEC, bool GELU>
+__device__ __forceinline__ void ln_act_bwd_wide_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean_rstd, uint16_t* __restrict__ dx,
+                                                     float* __restrict__ partials) {
   constexpr int C = 512 * VEC;
   const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
-  float dg[VEC][8], db[VEC][8];
+  // gamma / beta of the lane's channels stay in registers; packed f32 arithmetic (ln_math.hpp)
+  ln_f32x2 g[VEC][4], b[VEC][4], dg[VEC][4], db[VEC][4];
 #pragma unroll
-  for (int u = 0; u < VEC; ++u)
+  for (int u = 0; u < VEC; ++u) {
+    const int ch = (u * 64 + li) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dg[u][j] = db[u][j] = 0.f;
+    for (int p = 0; p < 4; ++p) {
+      g[u][p] = ln_f32x2{gamma[ch + 2 * p], gamma[ch + 2 * p + 1]};
+      b[u][p] = ln_f32x2{beta[ch + 2 * p], beta[ch + 2 * p + 1]};
+      dg[u][p] = db[u][p] = ln_f32x2{0.f, 0.f};
+    }
+  }
   for (int64_t r = (int64_t)blockIdx.x * 4 + rloc; r < n; r += (int64_t)gridDim.x * 4) {
+    u32x4 xin[VEC], din[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      xin[u] = *(const u32x4*)(x + r * C + (u * 64 + li) * 8);
+      din[u] = *(const u32x4*)(dy + r * C + (u * 64 + li) * 8);
+    }
     const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
-    float xv[VEC][8], dzg[VEC][8];
+    ln_f32x2 xv[VEC][4], dzg[VEC][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int u = 0; u < VEC; ++u) {
-      const int ch = (u * 64 + li) * 8;
-      float dv[8];
-      unpack8(*(const u32x4*)(x + r * C + ch), xv[u]);
-      unpack8(*(const u32x4*)(dy + r * C + ch), dv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xv[u][j] = (xv[u][j] - mean) * rstd;
-        const float gm = gamma[ch + j];
-        float dz = dv[j];
-        if (act == 1) dz *= gelu_grad(xv[u][j] * gm + beta[ch + j]);
-        dg[u][j] += dz * xv[u][j];
-        db[u][j] += dz;
-        dzg[u][j] = dz * gm;
-        s1 += dzg[u][j];
-        s2 += dzg[u][j] * xv[u][j];
-      }
+      ln_f32x2 dv[4];
+      ln_unpack8(xin[u], xv[u]);
+      ln_unpack8(din[u], dv);
+      float t1, t2;
+      ln_bwd_piece8<GELU>(xv[u], dv, mean, rstd, g[u], b[u], dg[u], db[u], dzg[u], t1, t2);
+      s1 += t1;
+      s2 += t2;
     }
     s1 = group_sum(s1, 64) * (1.f / C);
     s2 = group_sum(s2, 64) * (1.f / C);
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd * (dzg[u][j] - s1 - xv[u][j] * s2);
-      *(u32x4*)(dx + r * C + (u * 64 + li) * 8) = pack8(o);
-    }
+    for (int u = 0; u < VEC; ++u)
+      *(u32x4*)(dx + r * C + (u * 64 + li) * 8) = ln_bwd_finish8(xv[u], dzg[u], rstd, s1, s2);
   }
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2*C]
   float* mine = red + rloc * 2 * C;
@@ -392,14 +404,25 @@ ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restric
   for (int u = 0; u < VEC; ++u) {
     const int ch = (u * 64 + li) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      mine[ch + j] = dg[u][j];
-      mine[C + ch + j] = db[u][j];
+    for (int p = 0; p < 4; ++p) {
+      mine[ch + 2 * p] = dg[u][p].x;
+      mine[ch + 2 * p + 1] = dg[u][p].y;
+      mine[C + ch + 2 * p] = db[u][p].x;
+      mine[C + ch + 2 * p + 1] = db[u][p].y;
     }
   }
   __syncthreads();
   float* slab = partials + (int64_t)blockIdx.x * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += 256) slab[i] = (red[i] + red[2 * C + i]) + (red[4 * C + i] + red[6 * C + i]);
+}
+template <int VEC>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
+                       float* __restrict__ partials) {
+  if (act == 1) ln_act_bwd_wide_body<VEC, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
+  else ln_act_bwd_wide_body<VEC, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
 }
 
 __global__ void __launch_bounds__(256)
