@@ -512,7 +512,26 @@ def main():
                     opt.step()
                     return out
 
-                if os.environ.get('OCOCC_PIPE_FORK', 'head') == 'backward':
+                if os.environ.get('OCOCC_PIPE_FORK', 'head') == 'tail':
+                    # fork BEHIND the backward pass: the next batch's geometry runs beside the end of the step --
+                    # parameter-gradient sums (held back from the end-of-backward callback), AdamW, next weight operands
+                    from objectcentricocccompletion_amd import _deferred
+                    model.prepare_weights(grad=True)
+
+                    def fwd_bwd_held(geom):
+                        opt.zero_grad(set_to_none=True)
+                        out = model(geometry=geom, weights_ready=True)
+                        with _deferred.hold():
+                            out.features.backward(d_cap)
+                        return out
+
+                    def end_of_step():
+                        _deferred.flush()
+                        opt.step()
+                        model.prepare_weights(grad=True)
+                    g_pipe = PipelinedStep(lambda: model.geometry(xyz, feats, bidx, B, static=True), fwd_bwd_held,
+                                           tail=end_of_step)
+                elif os.environ.get('OCOCC_PIPE_FORK', 'head') == 'backward':
                     def fwd_only(geom):
                         opt.zero_grad(set_to_none=True)
                         return model(geometry=geom)

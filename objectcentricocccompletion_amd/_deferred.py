@@ -96,8 +96,39 @@ def pending():
     return sum(len(v) for v in _jobs.values())
 
 
+_held = False
+
+
+class hold(object):
+    """Inside this context the end-of-backward callback leaves the queued reductions alone; the caller runs them with
+    ``flush()`` when it wants them (graph.PipelinedStep forks the next batch's geometry in between, so that it runs
+    beside the reductions and the optimizer)."""
+
+    def __enter__(self):
+        global _held
+        self._prev, _held = _held, True
+        return self
+
+    def __exit__(self, *exc):
+        global _held
+        _held = self._prev
+        return False
+
+
+def flush():
+    """Run the queued reductions now (only needed after a backward pass under ``hold()``)."""
+    global _held
+    was, _held = _held, False
+    try:
+        _flush()
+    finally:
+        _held = was
+
+
 def _flush():
     global _jobs, _grads
+    if _held:
+        return
     jobs, grads = _jobs, _grads
     _jobs, _grads = {}, []
     for (a, b), fn in _joint.items():

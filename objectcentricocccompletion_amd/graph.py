@@ -76,9 +76,12 @@ class PipelinedStep(object):
     The reference has no counterpart; its data loader prefetches batches on the host, and its voxelisation and
     rulebook run inside forward (ops/voxel/voxelize.py:10-113, ops/spconv/conv.py:146-172)."""
 
-    def __init__(self, prepare, train, warmup=2, forward=None):
+    def __init__(self, prepare, train, warmup=2, forward=None, tail=None):
         """``forward`` (optional): train is split as train(forward(geometry)); the fork then sits BEHIND the forward
-        pass, i.e. the geometry chain runs beside the backward kernels only."""
+        pass, i.e. the geometry chain runs beside the backward kernels only.
+        ``tail`` (optional): the fork sits behind train(geometry) and tail() runs on the main stream beside the
+        geometry chain -- for the short, low-occupancy end of a step (parameter-gradient sums, optimizer, weight
+        operands of the next step), which leaves most of the chip to the geometry kernels."""
         from . import _lib as L
         self.plans = (L.BufferPlan(), L.BufferPlan())
         self.side = torch.cuda.Stream()
@@ -91,6 +94,14 @@ class PipelinedStep(object):
         def body(i):
             def fn():
                 cur = torch.cuda.current_stream()
+                if tail is not None:
+                    out = train(self.geo[i])
+                    self.side.wait_stream(cur)                  # fork behind the backward pass
+                    with torch.cuda.stream(self.side), self.plans[1 - i], torch.no_grad():
+                        self.geo[1 - i] = prepare()
+                    tail()
+                    cur.wait_stream(self.side)                  # join
+                    return out
                 mid = forward(self.geo[i]) if forward is not None else self.geo[i]
                 self.side.wait_stream(cur)                      # fork
                 with torch.cuda.stream(self.side), self.plans[1 - i], torch.no_grad():

@@ -76,17 +76,24 @@ class SubMOccEncoder(nn.Module):
         x.indice_dict[key] = (outids, x.indices, pairs, num, self.sparse_shape)
         return x
 
-    def forward(self, points=None, feats=None, batch_idx=None, batch_size=None, static=False, geometry=None):
+    def prepare_weights(self, grad=None):
+        """All conv weights to their bf16 kernel layouts in one launch (forward operands, and the dgrad operands of the
+        layers whose input needs a gradient).  forward() does this itself unless told the operands are current."""
+        grad = torch.is_grad_enabled() if grad is None else grad
+        items = [(layer[0].weight, 0) for layer in self.conv_layers]
+        items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
+        sp_ops.prepare_weights(items)
+
+    def forward(self, points=None, feats=None, batch_idx=None, batch_size=None, static=False, geometry=None,
+                weights_ready=False):
         """``static=True`` keeps every tensor at its fixed capacity (one row per point; unused
         voxel rows carry -1 coordinates, take part in no rulebook pair and must get a zero
         upstream gradient), so that the whole step has no device read-back and can be captured
         in a HIP graph (graph.GraphedStep).  ``geometry``: the result of self.geometry() for this batch."""
-        # all conv weights to their bf16 kernel layouts in one launch (forward operands, and the dgrad
-        # operands of the layers whose input needs a gradient)
-        grad = torch.is_grad_enabled()
-        items = [(layer[0].weight, 0) for layer in self.conv_layers]
-        items += [(layer[0].weight, 1) for layer in self.conv_layers[1:]] if grad else []
-        sp_ops.prepare_weights(items)
+        # ``weights_ready``: prepare_weights() already ran for the current parameter values (a pipelined step does it
+        # behind the optimizer, beside the next batch's geometry)
+        if not weights_ready:
+            self.prepare_weights()
         x = geometry if geometry is not None else self.geometry(points, feats, batch_idx, batch_size, static)
         # (a plain stack: every block's output goes into the next block's convolution and nowhere else, so each
         # LayerNorm backward may run inside the next layer's input-gradient kernel)
