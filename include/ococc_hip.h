@@ -408,6 +408,20 @@ int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n, int32_t c,
                             const float* gamma, const float* beta, const float* mean_rstd,
                             int32_t act, void* dx, float* dgamma, float* dbeta, int32_t dtype,
                             void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+/* The same two kernels with the Dropout that follows the activation in build_mlp's Sequential(Linear, norm, act,
+ * Dropout) (mmdet3d/ops/sst/sst_ops.py:333-360; occ_dropout = 0.1 in configs/ococc/ococcnet.py) folded in: y =
+ * dropout(act(LN(x))).  The keep mask is a counter-based hash of (seed, element index), 16 bits per element against
+ * drop_threshold = round(p * 65536) (0: no dropout; kept values are scaled by 65536 / (65536 - drop_threshold)); the
+ * backward regenerates it from the same (drop_threshold, seed), no mask is stored.  bf16 rows of 8 * 2^k <= 512 or
+ * 1024 / 1536 / 2048 channels; OCOCC_EUNSUPPORTED otherwise.  (torch's own Philox stream cannot be reproduced by a
+ * different kernel anyway; the statistics are what is kept.) */
+int ococc_layernorm_act_dropout_fwd_bf16(const uint16_t* x, int64_t n, int32_t c, const float* gamma, const float* beta,
+                                         float eps, int32_t act, uint32_t drop_threshold, uint64_t seed, uint16_t* y,
+                                         float* mean_rstd, ococc_stream_t stream);
+int ococc_layernorm_act_dropout_bwd_bf16(const uint16_t* x, const uint16_t* dy, int64_t n, int32_t c,
+                                         const float* gamma, const float* beta, const float* mean_rstd, int32_t act,
+                                         uint32_t drop_threshold, uint64_t seed, uint16_t* dx, float* dgamma,
+                                         float* dbeta, void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
 /* dgamma == dbeta == NULL in ococc_layernorm_act_bwd: dx and the per-block partial sums only (the workspace
  * then holds ococc_layernorm_act_bwd_partial_rows(n, c, dtype) rows of [2c] f32 and must stay alive).
  * ococc_layernorm_param_reduce_multi finishes up to 16 such layers in ONE launch -- the host mirror queues it

@@ -82,6 +82,10 @@ SIGNATURES = {
     'ococc_layernorm_act_bwd_workspace_bytes': (c_i64, [c_i64, c_i32]),
     'ococc_layernorm_act_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp,
                                         c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
+    'ococc_layernorm_act_dropout_fwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_f32, c_i32, ctypes.c_uint32,
+                                                     ctypes.c_uint64, c_vp, c_vp, c_vp]),
+    'ococc_layernorm_act_dropout_bwd_bf16': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, ctypes.c_uint32,
+                                                     ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_layernorm_act_bwd_partial_rows': (c_i32, [c_i64, c_i32, c_i32]),
     'ococc_layernorm_param_reduce_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_point_pool_workspace_bytes': (c_i64, [c_i64, c_i64]),

@@ -181,7 +181,7 @@ template <int LPR>
 __global__ void __launch_bounds__(256)
 ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __restrict__ gamma,
                       const float* __restrict__ beta, float eps, int act,
-                      uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
+                      uint16_t* __restrict__ y, float* __restrict__ mean_rstd, LnDropout drop) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
   ln_f32x2 g[4], b[4];
@@ -219,6 +219,7 @@ ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __
       for (int p = 0; p < 4; ++p) {
         ln_f32x2 z = (v[p] * rstd) * g[p] + b[p];
         if (act == 1) z = ln_gelu2(z);
+        if (drop.thr) z = z * ln_dropout_mask2(drop, rr[u], li * 4 + p, C / 2);
         qq[p] = ln_pack2(z);
       }
       *(u32x4*)(y + rr[u] * C + li * 8) = q;
@@ -234,7 +235,7 @@ template <int LPR, bool GELU>
 __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ mean_rstd, uint16_t* __restrict__ dx,
-                                                    float* __restrict__ partials) {
+                                                    float* __restrict__ partials, const LnDropout& drop) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
   ln_f32x2 g[4], b[4], dg[4], db[4];
@@ -265,6 +266,10 @@ __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__
       ln_f32x2 xv[4], dv[4], dzg[4];
       ln_unpack8(xin[u], xv);
       ln_unpack8(din[u], dv);
+      if (drop.thr) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dv[p] = dv[p] * ln_dropout_mask2(drop, rr[u], li * 4 + p, C / 2);
+      }
       float s1, s2;
       ln_bwd_piece8<GELU>(xv, dv, mean[u], rstd[u], g, b, dg, db, dzg, s1, s2);
       s1 = group_sum(s1, LPR) * (1.f / C);
@@ -292,9 +297,9 @@ __global__ void __launch_bounds__(256)
 ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
                       const float* __restrict__ gamma, const float* __restrict__ beta,
                       const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
-                      float* __restrict__ partials) {
-  if (act == 1) ln_act_bwd_vec_body<LPR, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
-  else ln_act_bwd_vec_body<LPR, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
+                      float* __restrict__ partials, LnDropout drop) {
+  if (act == 1) ln_act_bwd_vec_body<LPR, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
+  else ln_act_bwd_vec_body<LPR, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
 }
 
 // Wide rows (C = 512 * VEC, e.g. the 1024-wide layers of the occupancy decoder): one wave per row, VEC
@@ -303,7 +308,7 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
 ln_act_fwd_wide_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __restrict__ gamma,
                        const float* __restrict__ beta, float eps, int act,
-                       uint16_t* __restrict__ y, float* __restrict__ mean_rstd) {
+                       uint16_t* __restrict__ y, float* __restrict__ mean_rstd, LnDropout drop) {
   constexpr int C = 512 * VEC;
   const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
   ln_f32x2 g[VEC][4], b[VEC][4];
@@ -342,6 +347,7 @@ ln_act_fwd_wide_kernel(const uint16_t* __restrict__ x, int64_t n, const float* _
       for (int p = 0; p < 4; ++p) {
         ln_f32x2 z = (v[u][p] * rstd) * g[u][p] + b[u][p];
         if (act == 1) z = ln_gelu2(z);
+        if (drop.thr) z = z * ln_dropout_mask2(drop, r, (u * 64 + li) * 4 + p, C / 2);
         qq[p] = ln_pack2(z);
       }
       *(u32x4*)(y + r * C + (u * 64 + li) * 8) = q;
@@ -357,7 +363,7 @@ template <int VEC, bool GELU>
 __device__ __forceinline__ void ln_act_bwd_wide_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean_rstd, uint16_t* __restrict__ dx,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, const LnDropout& drop) {
   constexpr int C = 512 * VEC;
   const int li = threadIdx.x & 63, rloc = threadIdx.x >> 6;
   // gamma / beta of the lane's channels stay in registers; packed f32 arithmetic (ln_math.hpp)
@@ -387,6 +393,10 @@ __device__ __forceinline__ void ln_act_bwd_wide_body(const uint16_t* __restrict_
       ln_f32x2 dv[4];
       ln_unpack8(xin[u], xv[u]);
       ln_unpack8(din[u], dv);
+      if (drop.thr) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dv[p] = dv[p] * ln_dropout_mask2(drop, r, (u * 64 + li) * 4 + p, C / 2);
+      }
       float t1, t2;
       ln_bwd_piece8<GELU>(xv[u], dv, mean, rstd, g[u], b[u], dg[u], db[u], dzg[u], t1, t2);
       s1 += t1;
@@ -420,9 +430,9 @@ __global__ void __launch_bounds__(256)
 ln_act_bwd_wide_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
                        const float* __restrict__ gamma, const float* __restrict__ beta,
                        const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
-                       float* __restrict__ partials) {
-  if (act == 1) ln_act_bwd_wide_body<VEC, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
-  else ln_act_bwd_wide_body<VEC, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials);
+                       float* __restrict__ partials, LnDropout drop) {
+  if (act == 1) ln_act_bwd_wide_body<VEC, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
+  else ln_act_bwd_wide_body<VEC, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
 }
 
 __global__ void __launch_bounds__(256)
@@ -479,10 +489,10 @@ inline int vec_blocks(int64_t n, int c, int cap) {
 
 template <typename T>
 int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
-               int act, T* y, float* mean_rstd, hipStream_t stream) {
+               int act, T* y, float* mean_rstd, hipStream_t stream, LnDropout drop = LnDropout{0u, 1.f, 0u, 0u}) {
   if (sizeof(T) == 2 && vec_ok(c)) {
     const int grid = vec_blocks(n, c, 4096);
-#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd)
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd, drop)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
@@ -490,12 +500,13 @@ int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* be
   }
   if (sizeof(T) == 2 && (c == 1024 || c == 1536 || c == 2048)) {
     const int grid = (int)(ococc_cdiv(n, 4) < 8192 ? ococc_cdiv(n, 4) : 8192);
-#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_wide_kernel<V>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd)
+#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_wide_kernel<V>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd, drop)
     if (c == 1024) CALLW(2); else if (c == 1536) CALLW(3); else CALLW(4);
 #undef CALLW
     OCOCC_CHECK_LAUNCH();
     return OCOCC_OK;
   }
+  if (drop.thr) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused dropout: bf16 rows of 16..512 (x8) or 1024/1536/2048 channels");
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = ococc_grid_1d(ococc_cdiv(n, 256 / lpr) * 256, 256);
@@ -524,10 +535,10 @@ inline int bwd_partial_rows(int64_t n, int c, bool two_byte) {
 template <typename T>
 int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, const float* beta,
                const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
-               hipStream_t stream) {
+               hipStream_t stream, LnDropout drop = LnDropout{0u, 1.f, 0u, 0u}) {
   if (sizeof(T) == 2 && vec_ok(c)) {
     const int grid = bwd_partial_rows(n, c, true);
-#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials, drop)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
@@ -539,7 +550,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
   }
   if (sizeof(T) == 2 && (c == 1024 || c == 1536 || c == 2048)) {
     const int grid = bwd_partial_rows(n, c, true);
-#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_wide_kernel<V>), dim3(grid), dim3(256), 4 * 2 * c * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials)
+#define CALLW(V) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_wide_kernel<V>), dim3(grid), dim3(256), 4 * 2 * c * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials, drop)
     if (c == 1024) CALLW(2); else if (c == 1536) CALLW(3); else CALLW(4);
 #undef CALLW
     OCOCC_CHECK_LAUNCH();
@@ -549,6 +560,7 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
     OCOCC_CHECK_LAUNCH();
     return OCOCC_OK;
   }
+  if (drop.thr) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused dropout: bf16 rows of 16..512 (x8) or 1024/1536/2048 channels");
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = bwd_blocks(n, lpr);
@@ -611,6 +623,45 @@ extern "C" int ococc_layernorm_act_bwd(const void* x, const void* dy, int64_t n,
                              (float*)dx, dgamma, dbeta, (float*)workspace, stream);
   return launch_bwd<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, n, c, gamma, beta, mean_rstd,
                               act, (uint16_t*)dx, dgamma, dbeta, (float*)workspace, stream);
+}
+
+namespace {
+inline LnDropout make_dropout(uint32_t keep_threshold, uint64_t seed) {
+  return LnDropout{keep_threshold, 65536.f / (65536.f - (float)keep_threshold), (uint32_t)seed, (uint32_t)(seed >> 32)};
+}
+}  // namespace
+
+extern "C" int ococc_layernorm_act_dropout_fwd_bf16(const uint16_t* x, int64_t n, int32_t c, const float* gamma,
+                                                    const float* beta, float eps, int32_t act,
+                                                    uint32_t drop_threshold, uint64_t seed, uint16_t* y,
+                                                    float* mean_rstd, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(n >= 0 && c >= 1, "bad sizes");
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(drop_threshold < 65536u, "drop_threshold = round(p * 65536) must be below 65536");
+  if (n == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(x && y && gamma && beta, "null pointer");
+  return launch_fwd<uint16_t>(x, n, c, gamma, beta, eps, act, y, mean_rstd, (hipStream_t)stream_,
+                              make_dropout(drop_threshold, seed));
+}
+
+extern "C" int ococc_layernorm_act_dropout_bwd_bf16(const uint16_t* x, const uint16_t* dy, int64_t n, int32_t c,
+                                                    const float* gamma, const float* beta, const float* mean_rstd,
+                                                    int32_t act, uint32_t drop_threshold, uint64_t seed, uint16_t* dx,
+                                                    float* dgamma, float* dbeta, void* workspace,
+                                                    int64_t workspace_bytes, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(n >= 0 && c >= 1, "bad sizes");
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(drop_threshold < 65536u, "drop_threshold = round(p * 65536) must be below 65536");
+  if (n == 0) {
+    if (dgamma) OCOCC_HIP(hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), stream));
+    if (dbeta) OCOCC_HIP(hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), stream));
+    return OCOCC_OK;
+  }
+  OCOCC_REQUIRE(x && dy && dx && gamma && beta && mean_rstd, "null pointer");
+  OCOCC_REQUIRE(workspace && workspace_bytes >= ococc_layernorm_act_bwd_workspace_bytes(n, c), "workspace too small");
+  return launch_bwd<uint16_t>(x, dy, n, c, gamma, beta, mean_rstd, act, dx, dgamma, dbeta, (float*)workspace, stream,
+                              make_dropout(drop_threshold, seed));
 }
 
 extern "C" int32_t ococc_layernorm_act_bwd_partial_rows(int64_t n, int32_t c, int32_t dtype) {

@@ -59,6 +59,27 @@ __device__ __forceinline__ ln_f32x2 ln_gelu2(ln_f32x2 z) {
 }
 __device__ __forceinline__ float ln_gelu1(float z) { return ln_gelu2(ln_f32x2{z, z}).x; }
 
+// Dropout behind the activation (build_mlp's Sequential(Linear, norm, act, Dropout), sst_ops.py:333-360), folded into
+// the LN kernels: the keep mask is a counter-based hash of (seed, element index) -- one 32-bit hash per channel pair,
+// 16 bits each against the threshold -- so the backward kernel regenerates it instead of reading a stored mask
+// (torch's dropout writes a byte mask and reads it back: 5.6 ms per step on the decoder's [1 M, 1024] activations).
+// thr = round(p * 65536) (0: no dropout), scale = 65536 / (65536 - thr).
+struct LnDropout {
+  uint32_t thr;
+  float scale;
+  uint32_t seed_lo, seed_hi;
+};
+__device__ __forceinline__ ln_f32x2 ln_dropout_mask2(const LnDropout& d, int64_t row, int pair, int pairs_per_row) {
+  uint32_t h = ((uint32_t)row * (uint32_t)pairs_per_row + (uint32_t)pair) ^ d.seed_lo;
+  h *= 0x9E3779B1u;
+  h ^= h >> 16;
+  h = (h + d.seed_hi + (uint32_t)(row >> 24)) * 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return ln_f32x2{(h & 0xffffu) >= d.thr ? d.scale : 0.f, (h >> 16) >= d.thr ? d.scale : 0.f};
+}
+
 __device__ __forceinline__ void ln_unpack8(const u32x4 v, ln_f32x2 (&f)[4]) {
   f[0] = ln_f32x2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
   f[1] = ln_f32x2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};

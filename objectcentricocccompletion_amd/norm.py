@@ -18,7 +18,7 @@ from .registry import NORM_LAYERS
 class _LayerNormAct(Function):
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, act):
+    def forward(ctx, x, weight, bias, eps, act, drop_thr=0, seed=0):
         L.require_device(x, weight, bias)
         shape = x.shape
         c = shape[-1]
@@ -28,11 +28,16 @@ class _LayerNormAct(Function):
         w32, b32 = weight.float().contiguous(), bias.float().contiguous()
         y = torch.empty_like(x2)
         stats = torch.empty((n, 2), dtype=torch.float32, device=x2.device)
-        L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(x2), n, c, L.ptr(w32), L.ptr(b32), float(eps),
-                                              int(act), L.ptr(y), L.ptr(stats), dt, L.stream()),
-                'layernorm_act_fwd')
+        if drop_thr:
+            L.check(L.lib.ococc_layernorm_act_dropout_fwd_bf16(L.ptr(x2), n, c, L.ptr(w32), L.ptr(b32), float(eps), int(act),
+                                                               int(drop_thr), int(seed), L.ptr(y), L.ptr(stats), L.stream()),
+                    'layernorm_act_dropout_fwd')
+        else:
+            L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(x2), n, c, L.ptr(w32), L.ptr(b32), float(eps),
+                                                  int(act), L.ptr(y), L.ptr(stats), dt, L.stream()),
+                    'layernorm_act_fwd')
         ctx.save_for_backward(x2, w32, b32, stats, weight, bias)
-        ctx.act, ctx.shape, ctx.wdtype = int(act), shape, weight.dtype
+        ctx.act, ctx.shape, ctx.wdtype, ctx.drop = int(act), shape, weight.dtype, (int(drop_thr), int(seed))
         return y.reshape(shape)
 
     @staticmethod
@@ -41,10 +46,10 @@ class _LayerNormAct(Function):
         n, c = x2.shape
         dy2 = dy.reshape(-1, c).to(x2.dtype).contiguous()
         dx = torch.empty_like(x2)
-        dgamma, dbeta = layernorm_act_backward(x2, dy2, w32, b32, stats, ctx.act, dx, weight, bias)
+        dgamma, dbeta = layernorm_act_backward(x2, dy2, w32, b32, stats, ctx.act, dx, weight, bias, drop=ctx.drop)
         if dgamma is None:  # queued: weight.grad / bias.grad receive the sums when the pass ends (_deferred)
-            return dx.reshape(ctx.shape), None, None, None, None
-        return dx.reshape(ctx.shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None
+            return dx.reshape(ctx.shape), None, None, None, None, None, None
+        return dx.reshape(ctx.shape), dgamma.to(ctx.wdtype), dbeta.to(ctx.wdtype), None, None, None, None
 
 
 def _flush_param_reduce(todo):
@@ -63,7 +68,7 @@ def _flush_param_reduce(todo):
 _deferred.register('ln', _flush_param_reduce)
 
 
-def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=None):
+def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=None, drop=(0, 0)):
     """dx into `dx`; -> (dgamma, dbeta) f32 [c].  With the parameters given (by our autograd Functions) and a
     backward pass running that accumulates into their .grad, only the per-block partial sums are computed now, the
     two sums join the pass's end-of-backward launch and reach .grad there (_deferred): (None, None) is returned.
@@ -78,6 +83,12 @@ def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=
             and _deferred.deferrable(weight, bias):
         rows = L.lib.ococc_layernorm_act_bwd_partial_rows(n, c, dt)
         defer = rows > 0 and _deferred.defer('ln', (ws, rows, c, dgb), [(weight, dgamma), (bias, dbeta)])
+    if drop[0]:   # the forward dropped activations behind the norm: the same mask, regenerated from (threshold, seed)
+        L.check(L.lib.ococc_layernorm_act_dropout_bwd_bf16(
+            L.ptr(x2), L.ptr(dy2), n, c, L.ptr(w32), L.ptr(b32), L.ptr(stats), int(act), int(drop[0]), int(drop[1]),
+            L.ptr(dx), None if defer else L.ptr(dgamma), None if defer else L.ptr(dbeta), L.ptr(ws), ws.numel(),
+            L.stream()), 'layernorm_act_dropout_bwd')
+        return (None, None) if defer else (dgamma, dbeta)
     L.check(L.lib.ococc_layernorm_act_bwd(L.ptr(x2), L.ptr(dy2), n, c, L.ptr(w32), L.ptr(b32), L.ptr(stats),
                                           int(act), L.ptr(dx), None if defer else L.ptr(dgamma),
                                           None if defer else L.ptr(dbeta), dt, L.ptr(ws), ws.numel(), L.stream()),
@@ -85,27 +96,61 @@ def layernorm_act_backward(x2, dy2, w32, b32, stats, act, dx, weight=None, bias=
     return (None, None) if defer else (dgamma, dbeta)
 
 
-def layer_norm_act(x, weight, bias, eps=1e-5, act='none'):
-    """y = act(LayerNorm(x)) over the last dim; act in {'none', 'gelu'} (exact erf GELU)."""
-    return _LayerNormAct.apply(x, weight, bias, eps, {'none': 0, None: 0, 'gelu': 1}[act])
+def _fusable_dropout(x, p):
+    c = x.shape[-1]
+    vec = c % 8 == 0 and 16 <= c <= 512 and ((c // 8) & (c // 8 - 1)) == 0
+    return (0.0 < p < 1.0 and x.dtype == torch.bfloat16 and (vec or c in (1024, 1536, 2048))
+            and not torch.cuda.is_current_stream_capturing())   # (the seed is a host number: one mask per capture)
+
+
+def layer_norm_act(x, weight, bias, eps=1e-5, act='none', dropout=0.0):
+    """y = dropout(act(LayerNorm(x))) over the last dim; act in {'none', 'gelu'} (exact erf GELU).  ``dropout`` > 0
+    (training): inside the kernels for bf16 rows (mask regenerated in the backward from a seed drawn from torch's
+    CPU generator), torch's dropout behind the kernel otherwise."""
+    code = {'none': 0, None: 0, 'gelu': 1}[act]
+    if dropout and _fusable_dropout(x, dropout):
+        thr = int(round(dropout * 65536))
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: reproducible under manual_seed, no sync
+        return _LayerNormAct.apply(x, weight, bias, eps, code, thr, seed)
+    y = _LayerNormAct.apply(x, weight, bias, eps, code)
+    return torch.nn.functional.dropout(y, dropout, True) if dropout else y
 
 
 @NORM_LAYERS.register_module('LN')
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm over the channel dim with the HIP kernel; ``fused_act='gelu'`` folds
     the following GELU into the same pass (set by the builders below when they see the
-    reference's norm -> GELU order)."""
+    reference's norm -> GELU order); ``fused_dropout`` = p of a Dropout that follows the activation (build_mlp sets
+    it and leaves a placeholder in the Sequential), applied in training mode only."""
 
-    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True, fused_act='none'):
+    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True, fused_act='none', fused_dropout=0.0):
         super().__init__(normalized_shape, eps=eps, elementwise_affine=elementwise_affine)
         assert len(self.normalized_shape) == 1 and elementwise_affine
         self.fused_act = fused_act
+        self.fused_dropout = float(fused_dropout)
 
     def forward(self, x):
-        return layer_norm_act(x, self.weight, self.bias, self.eps, self.fused_act)
+        return layer_norm_act(x, self.weight, self.bias, self.eps, self.fused_act,
+                              self.fused_dropout if self.training else 0.0)
 
     def extra_repr(self):
-        return super().extra_repr() + f', fused_act={self.fused_act}'
+        extra = f', fused_dropout={self.fused_dropout}' if self.fused_dropout else ''
+        return super().extra_repr() + f', fused_act={self.fused_act}' + extra
+
+
+class FoldedDropout(nn.Module):
+    """Placeholder at the position of an nn.Dropout whose work the LayerNorm in front does (keeps the child indices
+    of the reference's Sequential(Linear, norm, act, Dropout))."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        return x
+
+    def extra_repr(self):
+        return f'p={self.p} (inside the preceding LayerNorm kernel)'
 
 
 class _AllGatherSum(Function):

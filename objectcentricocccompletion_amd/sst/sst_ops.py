@@ -110,7 +110,13 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act='relu', bias
             norm_layer, act_layer = fuse_norm_act(norm_layer, act_layer)
             sq = [Linear(last_channel, c, bias=bias), norm_layer, act_layer]
             if dropout > 0:
-                sq.append(nn.Dropout(dropout))
+                from ..norm import FoldedDropout, LayerNorm
+                if isinstance(norm_layer, LayerNorm) and isinstance(act_layer, nn.Identity):
+                    # norm and activation are one kernel already; the dropout behind them joins it (no byte mask)
+                    norm_layer.fused_dropout = float(dropout)
+                    sq.append(FoldedDropout(dropout))
+                else:
+                    sq.append(nn.Dropout(dropout))
             layer_list.append(nn.Sequential(*sq))
         last_channel = c
     return nn.Sequential(*layer_list)

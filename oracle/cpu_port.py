@@ -20,9 +20,10 @@ import torch.nn.functional as F
 from . import oracle as O
 
 
-def _layer_norm_act(x, weight, bias, eps=1e-5, act='none'):
+def _layer_norm_act(x, weight, bias, eps=1e-5, act='none', dropout=0.0):
     y = F.layer_norm(x.float(), (x.shape[-1],), weight.float(), bias.float(), eps).to(x.dtype)
-    return F.gelu(y) if act == 'gelu' else y
+    y = F.gelu(y) if act == 'gelu' else y
+    return F.dropout(y, dropout, True) if dropout else y
 
 
 def _grid_unique(coors, dims=None, static=False):
