@@ -17,6 +17,7 @@ from torch import nn
 from .._lib import const_tensor
 from ..norm import layer_norm_act
 from ..sst.sst_ops import build_mlp
+from ..linear import tall_addmm
 from ..voxel.scatter_points import gather_rows
 from . import occ_ops
 
@@ -87,7 +88,7 @@ class OccDecoder(nn.Module):
         D = self.roi_feature_channels
         roi_part = torch.mm(self._ln(roi_features), lin.weight[:, :D].t())           # [K, H]
         # (rows of roi_part repeated per query point: backward is the HIP segment sum, not torch's sort-based index_add)
-        h = torch.addmm(gather_rows(roi_part, pts_roi_inds), self.pos_encode(smp_xyzs), lin.weight[:, D:].t())
+        h = tall_addmm(gather_rows(roi_part, pts_roi_inds), self.pos_encode(smp_xyzs), lin.weight[:, D:])
         if lin.bias is not None:
             h = h + lin.bias
         if self.compute_dtype is None:
