@@ -265,10 +265,42 @@ def _to_bf16_padded(t, cols):
     return out
 
 
+# The weight-gradient kernels of a backward pass feed nothing before the optimizer and are each a few hundred
+# latency-bound work items on a 2048-workgroup grid.  With WGRAD_AT_END the layers' backward only queues them; at the
+# end of the pass they are launched TOGETHER, one per stream (a fork / join inside a captured graph), so that the three
+# kernels of the encoder (20 + 14 + 10 us one after the other) share the chip; their slab sums follow in the one
+XX
+_wgrad_streams = {}
+
+
+def _run_queued_wgrads(todo):
+    late = [j for j in todo if len(j) > 5 and j[5] is not None]
+    if not late:
+        return
+    cur = torch.cuda.current_stream()
+    dev = torch.cuda.current_device()
+    sides = _wgrad_streams.setdefault(dev, [])
+    while len(sides) < len(late) - 1:
+        sides.append(torch.cuda.Stream())
+
+    def launch(job):
+        ws, _, _, _, _, (x, n_in, kd_in, dy, n_out, kd_out, pairs, num, kvol, cap) = job
+        L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out, L.ptr(pairs), L.ptr(num),
+                                                   kvol, cap, None, L.ptr(ws), ws.numel(), L.stream()), 'sparse_conv_wgrad')
+    for i, job in enumerate(late[1:]):
+        sides[i].wait_stream(cur)                     # fork
+        with torch.cuda.stream(sides[i]):
+            launch(job)
+    launch(late[0])
+    for i in range(len(late) - 1):
+        cur.wait_stream(sides[i])                     # join (the operands stay referenced by the jobs until after it)
+
+
 def _flush_wgrad_reduce(todo):
     """Finish the weight gradients whose slabs are waiting (one launch per 8 layers); jobs =
-    (workspace, indice_pair_num, kvol, kd_in * kd_out, dw)."""
+    (workspace, indice_pair_num, kvol, kd_in * kd_out, dw[, queued wgrad operands])."""
     import ctypes
+    _run_queued_wgrads(todo)
     for lo in range(0, len(todo), 8):
         ch = todo[lo:lo + 8]
         n = len(ch)
@@ -286,6 +318,7 @@ def _flush_wgrad_and_ln(wjobs, ljobs):
     import ctypes
     if len(wjobs) > 8 or len(ljobs) > 16:
         return False
+    _run_queued_wgrads(wjobs)
     n, k = len(wjobs), len(ljobs)
     vpn, i32n, i64n, vpk, i32k = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n, ctypes.c_void_p * k, ctypes.c_int32 * k
     L.check(L.lib.ococc_backward_param_reduce_multi(
@@ -622,10 +655,14 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             out = dw[:, :cin, :cout].reshape(filters.shape)  # a view: splitting kvol never copies
             # Inside an autograd backward pass only the slabs are computed now; the slab reductions of all layers
             # go into ONE launch queued to the end of the pass (_deferred): dW feeds nothing before that.
+            late = WGRAD_AT_END and _autograd   # the slabs themselves wait for the end of the pass as well
+            compute = (x, n_in, kd_in, dy, n_out, kd_out, pairs, indice_pair_num, kvol, cap) if late else None
             defer = (_autograd and _overlap is None and cap > 0 and n_in > 0 and n_out > 0 and cin == kd_in
                      and cout == kd_out and _deferred.deferrable(filters)
-                     and _deferred.defer('wgrad', (ws, indice_pair_num, int(kvol), kd_in * kd_out, dw),
+                     and _deferred.defer('wgrad', (ws, indice_pair_num, int(kvol), kd_in * kd_out, dw, compute),
                                          [(filters, out)]))
+            if defer and late:
+                return None
             L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out,
                                                        L.ptr(pairs), L.ptr(indice_pair_num), kvol, cap,
                                                        None if defer else L.ptr(dw), L.ptr(ws), ws.numel(), L.stream()),
