@@ -269,7 +269,11 @@ def _to_bf16_padded(t, cols):
 # latency-bound work items on a 2048-workgroup grid.  With WGRAD_AT_END the layers' backward only queues them; at the
 # end of the pass they are launched TOGETHER, one per stream (a fork / join inside a captured graph), so that the three
 # kernels of the encoder (20 + 14 + 10 us one after the other) share the chip; their slab sums follow in the one
-XX
+# reduction launch.  MEASURED SLOWER on ROCm 7.2 and therefore off by default: 0.337 vs 0.299 ms per step -- the
+# kernels do overlap (trace: 14 / 13 / 26 us side by side), but the fork costs 6-18 us before the side branches start and
+# the join 11 us before the reduction does, more than the 18 us the overlap saves.  (One merged kernel was tried as
+# well: the shapes' bodies inlined into one launch need 210 registers -- two workgroups per CU -- and 248 out of line.)
+WGRAD_AT_END = os.environ.get('OCOCC_WGRAD_AT_END', '0') == '1'
 _wgrad_streams = {}
 
 
