@@ -298,6 +298,48 @@ class _TokenLinear(torch.autograd.Function):
         return dx, dw.to(w.dtype), db
 
 
+class _QkvProjection(torch.autograd.Function):
+    """The in-projection of a window-attention layer on flat tokens: q | k from x + pos, v from x
+    (sst_basic_block_v2.py:41-75: ``q = k = src + pos; v = src`` into nn.MultiheadAttention), written by two GEMMs
+    straight into the column slices of ONE [V, 3E] buffer -- the layout the attention kernels read -- instead of two
+    results concatenated (a 150 us copy per layer at 260 k tokens, and the matching split copies in the backward).
+    Weight gradients as in _TokenLinear (token dimension cut into slabs), read from the column slices in place."""
+
+    @staticmethod
+    def forward(ctx, x, pos, w, b):
+        E = x.shape[1]
+        xp = x + pos
+        out = torch.empty((x.shape[0], 3 * E), dtype=x.dtype, device=x.device)
+        torch.addmm(b[:2 * E], xp, w[:2 * E].t(), out=out[:, :2 * E])
+        torch.addmm(b[2 * E:], x, w[2 * E:].t(), out=out[:, 2 * E:])
+        ctx.save_for_backward(x, xp, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, w = ctx.saved_tensors
+        E = x.shape[1]
+        g = g.contiguous()
+        g_qk, g_v = g[:, :2 * E], g[:, 2 * E:]
+        dx = dpos = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            d_xp = g_qk @ w[:2 * E]
+            dpos = d_xp if ctx.needs_input_grad[1] else None
+            dx = torch.addmm(d_xp, g_v, w[2 * E:]) if ctx.needs_input_grad[0] else None
+        n, s = x.shape[0], _TokenLinear.SLABS
+        m = (n // s) * s
+        dw = torch.zeros((3 * E, E), dtype=torch.float32, device=x.device)
+        if m:
+            gs = g[:m].view(s, m // s, 3 * E)
+            dw[:2 * E] += torch.bmm(gs[:, :, :2 * E].transpose(1, 2), xp[:m].view(s, m // s, E)).float().sum(0)
+            dw[2 * E:] += torch.bmm(gs[:, :, 2 * E:].transpose(1, 2), x[:m].view(s, m // s, E)).float().sum(0)
+        if m < n:
+            dw[:2 * E] += (g_qk[m:].t() @ xp[m:]).float()
+            dw[2 * E:] += (g_v[m:].t() @ x[m:]).float()
+        db = g.sum(0, dtype=torch.float32).to(g.dtype)
+        return dx, dpos, dw.to(w.dtype), db
+
+
 class _ScatterRows(torch.autograd.Function):
     """out[slot[i]] = feat[pos[i]] into a zero [rows, C] tensor; slot and pos are injective, so the
     backward is the mirror gather (no sort-based index_put backward)."""
@@ -392,13 +434,13 @@ class WindowMultiheadAttention(nn.Module):
         E, H = self.embed_dim, self.num_heads
         w, b = self.in_proj_weight.to(dtype), self.in_proj_bias.to(dtype)
         x16 = x.to(dtype)
-        qk = _TokenLinear.apply(x16 + pos_flat, w[:2 * E], b[:2 * E])
-        v = _TokenLinear.apply(x16, w[2 * E:], b[2 * E:])
         if self.tau is not None:
+            qk = _TokenLinear.apply(x16 + pos_flat, w[:2 * E], b[:2 * E])
+            v = _TokenLinear.apply(x16, w[2 * E:], b[2 * E:])
             q_, k_ = self._cosine_q_k(qk[:, :E], qk[:, E:])
             qkv = torch.cat([q_, k_, v], 1)
         else:
-            qkv = torch.cat([qk, v], 1)
+            qkv = _QkvProjection.apply(x16, pos_flat.to(dtype), w, b)   # q | k | v in one buffer, no concatenation
         covered = sum(int(m[0].numel()) for m in maps.values())
         if covered == x.shape[0]:   # every token sits in a window (always, after drop_voxel): gather kernels
             args = []
