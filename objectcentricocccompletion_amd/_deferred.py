@@ -96,6 +96,13 @@ def pending():
     return sum(len(v) for v in _jobs.values())
 
 
+def discard():
+    """Drop what is queued (a backward pass that raised never runs its end-of-pass callback: its jobs would otherwise
+    be finished by the NEXT pass, against buffers that no longer mean anything)."""
+    global _jobs, _grads
+    _jobs, _grads = {}, []
+
+
 _held = False
 
 

@@ -129,6 +129,8 @@ class _IndiceConvLN(Function):
         if mine is not None and mine.fused:
             # the next layer's dgrad already ran this block's LN backward: dy IS d conv_out
             if (dy.data_ptr(), dy._version) != mine.expect or dy.dtype != torch.bfloat16:
+                from .. import _deferred
+                _deferred.discard()   # (this pass ends here: its queued reductions must not run in the next one)
                 raise L.OcoccError('chain_ln_backward: the output of a conv -> LN -> act block had a second consumer '
                                    '(its gradient is not the untouched buffer the fused dgrad kernel wrote)')
             dconv = dy
