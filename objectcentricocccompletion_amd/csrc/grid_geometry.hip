@@ -47,7 +47,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kEmitThreads = 256;    // kernel B: one workgroup per (grid, row slice), several per CU
 constexpr int kEmitWaves = kEmitThreads / 64;
 constexpr int kCols = 28;            // 27 kernel offsets + the voxel count
-constexpr int kMaxSlices = 8;
+constexpr int kMaxSlices = 16;
 constexpr int kCodesPerThread = 8;   // point codes a thread of kernel B fetches in one round
 
 // workgroup barrier for data exchanged through LDS only: does not wait for the wave's global stores to land
@@ -717,7 +717,7 @@ extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_p
   OCOCC_REQUIRE(n >= 1 && capacity >= 1 && c >= 1 && num_point_features >= 3, "bad sizes");
   OCOCC_REQUIRE(host_voxel_size && host_coors_range, "null voxel_size / coors_range");
   OCOCC_REQUIRE(make_geo_layout(n, batch_size, host_grid_zyx, slices, &L, &gu),
-                "need batch >= 1, grid cells a multiple of 32 and <= 512 Ki per grid, batch * cells < 2^30, 1 <= slices <= 8");
+                "need batch >= 1, grid cells a multiple of 32 and <= 512 Ki per grid, batch * cells < 2^30, 1 <= slices <= 16");
   OCOCC_REQUIRE(num_voxels && status && status == num_voxels + 1, "num_voxels/status: one device int32[2]");
   OCOCC_REQUIRE(points && batch_idx && feats && voxel_coors && inv && counts && voxel_feats && nbr_t && blockmask &&
                     indice_pairs && indice_num, "null device pointer");

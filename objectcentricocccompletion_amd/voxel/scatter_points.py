@@ -5,6 +5,8 @@ the torch_scatter calls inside scatter_v2 (mmdet3d/ops/sst/sst_ops.py:171-174).
 Kernels: ococc_grid_unique_i32 (sorted unique rows + inverse + counts),
 ococc_segment_reduce_f32 / _bwd_f32.
 """
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -245,8 +247,14 @@ def voxelize_scatter_mean(points, batch_idx, feats, voxel_size, coors_range, gri
     return vfeats, coors, inv, counts, meta
 
 
+# Row slices (workgroups of the emit kernel) per grid: 0 = from the points per grid, so that a slice holds fewer rows
+# than the emit kernel's 256 threads (a slice with more takes a second round of the whole row loop: at 8 slices for
+# 2000 points a quarter of the workgroups did, and the kernel waited for them: 34.4 vs 28.8 us)
+GEOMETRY_SLICES = int(os.environ.get('OCOCC_GEO_SLICES', 0))
+
+
 def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid_zyx, batch_size,
-                         out_dtype=torch.float32, slices=8):
+                         out_dtype=torch.float32, slices=None):
     """voxelize_scatter_mean(static=True) followed by spconv.ops.get_indice_pairs(3x3x3 sub-manifold) on its rows, in
     three launches (ococc_object_grid_geometry_f32) instead of ten, for points that arrive GROUPED BY GRID (batch_idx
     non-decreasing).  Same tensors, same values: returns (voxel_feats, voxel_coors, inv, counts, meta, indice_pairs,
@@ -265,6 +273,8 @@ def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid
     grid_zyx = [int(v) for v in grid_zyx]
     dims = [int(batch_size)] + grid_zyx
     cap = min(n, dims[0] * dims[1] * dims[2] * dims[3])
+    if slices is None:
+        slices = GEOMETRY_SLICES or min(16, max(1, -(-points.size(0) // max(int(batch_size), 1) // 176)))
     nbytes = L.lib.ococc_object_grid_geometry_workspace_bytes(n, int(batch_size), L.i3(grid_zyx), int(slices))
     if nbytes < 0 or n == 0:
         return None

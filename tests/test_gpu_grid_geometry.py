@@ -34,12 +34,12 @@ CASES = [dict(B=64, per_grid=2000, shape=(40, 40, 40), vs=0.2, half=4.0),       
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('slices', [1, 4, 8])
+@pytest.mark.parametrize('slices', [1, 4, 8, 13, None])
 def test_fused_geometry_equals_general_path(dev, case, slices):
     from objectcentricocccompletion_amd.spconv import ops
     from objectcentricocccompletion_amd.voxel import object_grid_geometry, voxelize_scatter_mean
     B, shape, vs = case['B'], list(case['shape']), case['vs']
-    xyz, feats, bidx = _points(B, case['per_grid'], seed=B * 7 + slices, half=case['half'], ragged=case.get('ragged', False),
+    xyz, feats, bidx = _points(B, case['per_grid'], seed=B * 7 + (slices or 0), half=case['half'], ragged=case.get('ragged', False),
                                empty_grid=case.get('empty_grid'))
     rng = [-case['half']] * 2 + [-shape[0] * vs / 2] + [case['half']] * 2 + [shape[0] * vs / 2]
     xyz[:, 2] = xyz[:, 2] * (shape[0] * vs / 2) / case['half']
