@@ -177,11 +177,36 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
   return v;
 }
 
-template <int LPR>
+// 8 consecutive channels of a row as four f32 pairs: bf16 rows move 16 bytes per lane, f32 rows 32 (the SIR layers of
+// the RoI encoder run their Linear -> LN -> GELU stages in f32: 120 launches per step of configs[2])
+struct Ln8 {
+  u32x4 a, b;
+};
+template <typename T> __device__ __forceinline__ Ln8 ln_load8(const T* p);
+template <> __device__ __forceinline__ Ln8 ln_load8<uint16_t>(const uint16_t* p) { return Ln8{*(const u32x4*)p, u32x4{0u, 0u, 0u, 0u}}; }
+template <> __device__ __forceinline__ Ln8 ln_load8<float>(const float* p) { return Ln8{*(const u32x4*)p, *(const u32x4*)(p + 4)}; }
+template <typename T> __device__ __forceinline__ void ln_unpack8t(const Ln8& v, ln_f32x2 (&f)[4]);
+template <> __device__ __forceinline__ void ln_unpack8t<uint16_t>(const Ln8& v, ln_f32x2 (&f)[4]) { ln_unpack8(v.a, f); }
+template <> __device__ __forceinline__ void ln_unpack8t<float>(const Ln8& v, ln_f32x2 (&f)[4]) {
+  f[0] = ln_f32x2{__uint_as_float(v.a.x), __uint_as_float(v.a.y)};
+  f[1] = ln_f32x2{__uint_as_float(v.a.z), __uint_as_float(v.a.w)};
+  f[2] = ln_f32x2{__uint_as_float(v.b.x), __uint_as_float(v.b.y)};
+  f[3] = ln_f32x2{__uint_as_float(v.b.z), __uint_as_float(v.b.w)};
+}
+template <typename T> __device__ __forceinline__ void ln_store8(T* p, const ln_f32x2 (&f)[4]);
+template <> __device__ __forceinline__ void ln_store8<uint16_t>(uint16_t* p, const ln_f32x2 (&f)[4]) {
+  *(u32x4*)p = u32x4{ln_pack2(f[0]), ln_pack2(f[1]), ln_pack2(f[2]), ln_pack2(f[3])};
+}
+template <> __device__ __forceinline__ void ln_store8<float>(float* p, const ln_f32x2 (&f)[4]) {
+  *(f32x4*)p = f32x4{f[0].x, f[0].y, f[1].x, f[1].y};
+  *(f32x4*)(p + 4) = f32x4{f[2].x, f[2].y, f[3].x, f[3].y};
+}
+
+template <int LPR, typename T = uint16_t>
 __global__ void __launch_bounds__(256)
-ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __restrict__ gamma,
+ln_act_fwd_vec_kernel(const T* __restrict__ x, int64_t n, const float* __restrict__ gamma,
                       const float* __restrict__ beta, float eps, int act,
-                      uint16_t* __restrict__ y, float* __restrict__ mean_rstd, LnDropout drop) {
+                      T* __restrict__ y, float* __restrict__ mean_rstd, LnDropout drop) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
   ln_f32x2 g[4], b[4];
@@ -196,14 +221,14 @@ ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __
     const int64_t r1 = r0 + stride;
     const bool two = r1 < n;
     const int64_t rr[2] = {r0, two ? r1 : r0};
-    u32x4 xin[2];
+    Ln8 xin[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) xin[u] = *(const u32x4*)(x + rr[u] * C + li * 8);
+    for (int u = 0; u < 2; ++u) xin[u] = ln_load8<T>(x + rr[u] * C + li * 8);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && !two) break;
       ln_f32x2 v[4];
-      ln_unpack8(xin[u], v);
+      ln_unpack8t<T>(xin[u], v);
       const ln_f32x2 sv = (v[0] + v[1]) + (v[2] + v[3]);
       const float mean = group_sum(sv.x + sv.y, LPR) * (1.f / C);
       ln_f32x2 sq = {0.f, 0.f};
@@ -213,16 +238,15 @@ ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __
         sq += v[p] * v[p];
       }
       const float rstd = rsqrtf(group_sum(sq.x + sq.y, LPR) * (1.f / C) + eps);
-      u32x4 q;
-      uint32_t* qq = (uint32_t*)&q;
+      ln_f32x2 zz[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         ln_f32x2 z = (v[p] * rstd) * g[p] + b[p];
         if (act == 1) z = ln_gelu2(z);
         if (drop.thr) z = z * ln_dropout_mask2(drop, rr[u], li * 4 + p, C / 2);
-        qq[p] = ln_pack2(z);
+        zz[p] = z;
       }
-      *(u32x4*)(y + rr[u] * C + li * 8) = q;
+      ln_store8<T>(y + rr[u] * C + li * 8, zz);
       if (mean_rstd && li == 0) {
         mean_rstd[rr[u] * 2] = mean;
         mean_rstd[rr[u] * 2 + 1] = rstd;
@@ -231,10 +255,10 @@ ln_act_fwd_vec_kernel(const uint16_t* __restrict__ x, int64_t n, const float* __
   }
 }
 
-template <int LPR, bool GELU>
-__device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+template <int LPR, bool GELU, typename T>
+__device__ __forceinline__ void ln_act_bwd_vec_body(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    const float* __restrict__ mean_rstd, uint16_t* __restrict__ dx,
+                                                    const float* __restrict__ mean_rstd, T* __restrict__ dx,
                                                     float* __restrict__ partials, const LnDropout& drop) {
   constexpr int C = LPR * 8, RPB = 256 / LPR;
   const int li = threadIdx.x % LPR, rloc = threadIdx.x / LPR;
@@ -251,12 +275,12 @@ __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__
     const int64_t r1 = r0 + stride;
     const bool two = r1 < n;
     const int64_t rr[2] = {r0, two ? r1 : r0};
-    u32x4 xin[2], din[2];
+    Ln8 xin[2], din[2];
     float mean[2], rstd[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      xin[u] = *(const u32x4*)(x + rr[u] * C + li * 8);
-      din[u] = *(const u32x4*)(dy + rr[u] * C + li * 8);
+      xin[u] = ln_load8<T>(x + rr[u] * C + li * 8);
+      din[u] = ln_load8<T>(dy + rr[u] * C + li * 8);
       mean[u] = mean_rstd[rr[u] * 2];
       rstd[u] = mean_rstd[rr[u] * 2 + 1];
     }
@@ -264,8 +288,8 @@ __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && !two) break;
       ln_f32x2 xv[4], dv[4], dzg[4];
-      ln_unpack8(xin[u], xv);
-      ln_unpack8(din[u], dv);
+      ln_unpack8t<T>(xin[u], xv);
+      ln_unpack8t<T>(din[u], dv);
       if (drop.thr) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) dv[p] = dv[p] * ln_dropout_mask2(drop, rr[u], li * 4 + p, C / 2);
@@ -274,7 +298,14 @@ __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__
       ln_bwd_piece8<GELU>(xv, dv, mean[u], rstd[u], g, b, dg, db, dzg, s1, s2);
       s1 = group_sum(s1, LPR) * (1.f / C);
       s2 = group_sum(s2, LPR) * (1.f / C);
-      *(u32x4*)(dx + rr[u] * C + li * 8) = ln_bwd_finish8(xv, dzg, rstd[u], s1, s2);
+      if (sizeof(T) == 2) {
+        *(u32x4*)(dx + rr[u] * C + li * 8) = ln_bwd_finish8(xv, dzg, rstd[u], s1, s2);
+      } else {
+        ln_f32x2 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = ((dzg[p] - s1) - xv[p] * s2) * rstd[u];
+        ln_store8<T>(dx + rr[u] * C + li * 8, o);
+      }
     }
   }
   extern __shared__ __attribute__((aligned(16))) float red[];  // [RPB][2*C]
@@ -292,14 +323,14 @@ __device__ __forceinline__ void ln_act_bwd_vec_body(const uint16_t* __restrict__
     slab[i] = s;
   }
 }
-template <int LPR>
+template <int LPR, typename T = uint16_t>
 __global__ void __launch_bounds__(256)
-ln_act_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t n,
+ln_act_bwd_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n,
                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                      const float* __restrict__ mean_rstd, int act, uint16_t* __restrict__ dx,
+                      const float* __restrict__ mean_rstd, int act, T* __restrict__ dx,
                       float* __restrict__ partials, LnDropout drop) {
-  if (act == 1) ln_act_bwd_vec_body<LPR, true>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
-  else ln_act_bwd_vec_body<LPR, false>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
+  if (act == 1) ln_act_bwd_vec_body<LPR, true, T>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
+  else ln_act_bwd_vec_body<LPR, false, T>(x, dy, n, gamma, beta, mean_rstd, dx, partials, drop);
 }
 
 // Wide rows (C = 512 * VEC, e.g. the 1024-wide layers of the occupancy decoder): one wave per row, VEC
@@ -490,9 +521,9 @@ inline int vec_blocks(int64_t n, int c, int cap) {
 template <typename T>
 int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* beta, float eps,
                int act, T* y, float* mean_rstd, hipStream_t stream, LnDropout drop = LnDropout{0u, 1.f, 0u, 0u}) {
-  if (sizeof(T) == 2 && vec_ok(c)) {
+  if (vec_ok(c) && (sizeof(T) == 2 || drop.thr == 0)) {
     const int grid = vec_blocks(n, c, 4096);
-#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_vec_kernel<L>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, n, gamma, beta, eps, act, (uint16_t*)y, mean_rstd, drop)
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_vec_kernel<L, T>), dim3(grid), dim3(256), 0, stream, x, n, gamma, beta, eps, act, y, mean_rstd, drop)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
@@ -524,7 +555,7 @@ int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* be
 
 // rows of the partials slab = blocks of the backward kernel (same choice as launch_bwd below)
 inline int bwd_partial_rows(int64_t n, int c, bool two_byte) {
-  if (two_byte && vec_ok(c)) return vec_blocks(n, c, kBwdMaxBlocks);
+  if (vec_ok(c)) return vec_blocks(n, c, kBwdMaxBlocks);
   if (two_byte && (c == 1024 || c == 1536 || c == 2048)) {
     int64_t gb = ococc_cdiv(n, 4);
     return (int)(gb > kBwdMaxBlocks ? kBwdMaxBlocks : (gb < 1 ? 1 : gb));
@@ -536,9 +567,9 @@ template <typename T>
 int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, const float* beta,
                const float* mean_rstd, int act, T* dx, float* dgamma, float* dbeta, float* partials,
                hipStream_t stream, LnDropout drop = LnDropout{0u, 1.f, 0u, 0u}) {
-  if (sizeof(T) == 2 && vec_ok(c)) {
-    const int grid = bwd_partial_rows(n, c, true);
-#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, (const uint16_t*)x, (const uint16_t*)dy, n, gamma, beta, mean_rstd, act, (uint16_t*)dx, partials, drop)
+  if (vec_ok(c) && (sizeof(T) == 2 || drop.thr == 0)) {
+    const int grid = bwd_partial_rows(n, c, sizeof(T) == 2);
+#define CALL(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_vec_kernel<L, T>), dim3(grid), dim3(256), (256 / L) * 2 * (L * 8) * 4, stream, x, dy, n, gamma, beta, mean_rstd, act, dx, partials, drop)
     OCOCC_LN_VEC_SWITCH(c / 8, CALL)
 #undef CALL
     OCOCC_CHECK_LAUNCH();
