@@ -208,3 +208,49 @@ def test_tall_linear_matches_nn_linear():
     assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
     small = torch.randn(100, 24, requires_grad=True)   # below the threshold: the stock path
     assert lin(small).grad_fn.name() != '_TallLinearBackward'
+
+
+def test_tall_addmm_and_qkv_projection_match_plain_torch():
+    """linear.tall_addmm (decoder first layer) and sst_modules._QkvProjection (q | k | v written into one buffer) are
+    pure torch compositions: same values and gradients as the straightforward expressions, on the CPU."""
+    import torch
+    from objectcentricocccompletion_amd import linear
+    from objectcentricocccompletion_amd.sst.sst_modules import _QkvProjection
+    torch.manual_seed(1)
+    n = linear.TALL_ROWS + 999
+    base = torch.randn(n, 48, requires_grad=True)
+    x = torch.randn(n, 12)
+    w = torch.randn(48, 12, requires_grad=True)
+    g = torch.randn(n, 48)
+    linear.tall_addmm(base, x, w).backward(g)
+    got = (base.grad.clone(), w.grad.clone())
+    base.grad = w.grad = None
+    torch.addmm(base, x, w.t()).backward(g)
+    assert torch.equal(got[0], base.grad) and torch.allclose(got[1], w.grad, rtol=1e-4, atol=1e-3)
+    E, V = 16, 1000
+    xx = torch.randn(V, E, requires_grad=True)
+    pos = torch.randn(V, E)
+    w3 = torch.randn(3 * E, E, requires_grad=True)
+    b3 = torch.randn(3 * E, requires_grad=True)
+    gg = torch.randn(V, 3 * E)
+    _QkvProjection.apply(xx, pos, w3, b3).backward(gg)
+    got = [t.grad.clone() for t in (xx, w3, b3)]
+    for t in (xx, w3, b3):
+        t.grad = None
+    ref = torch.cat([torch.nn.functional.linear(xx + pos, w3[:2 * E], b3[:2 * E]), torch.nn.functional.linear(xx, w3[2 * E:], b3[2 * E:])], 1)
+    assert torch.allclose(_QkvProjection.apply(xx, pos, w3, b3), ref, rtol=1e-5, atol=1e-5)
+    ref.backward(gg)
+    for a, t in zip(got, (xx, w3, b3)):
+        assert torch.allclose(a, t.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_build_mlp_folds_dropout_into_the_layernorm():
+    """Sequential(Linear, norm, act, Dropout) of sst_ops.build_mlp: child indices and state-dict keys stay the
+    reference's; the Dropout's probability moves into the LayerNorm (applied by its kernel in training mode)."""
+    from objectcentricocccompletion_amd.norm import FoldedDropout, LayerNorm
+    from objectcentricocccompletion_amd.sst.sst_ops import build_mlp
+    mlp = build_mlp(60, [32, 16], dict(type='LN', eps=1e-3), act='gelu', dropout=0.1)
+    assert isinstance(mlp[0][1], LayerNorm) and mlp[0][1].fused_dropout == 0.1 and isinstance(mlp[0][3], FoldedDropout)
+    assert list(mlp.state_dict()) == ['0.0.weight', '0.1.weight', '0.1.bias', '1.0.weight', '1.1.weight', '1.1.bias']
+    plain = build_mlp(60, [32], dict(type='LN', eps=1e-3), act='gelu', dropout=0)
+    assert len(plain[0]) == 3 and plain[0][1].fused_dropout == 0.0
