@@ -436,7 +436,7 @@ def main():
     from objectcentricocccompletion_amd.spconv import ops as sp_ops
 
     torch.manual_seed(0)  # identical initial weights on every rank
-    model = SubMOccEncoder().to(dev)
+    model = SubMOccEncoder(grouped_points=True).to(dev)
     params = [p for p in model.parameters()]
     use_graph = not args.no_graph
     from objectcentricocccompletion_amd.optim import AdamW

@@ -31,6 +31,27 @@ ENABLED = os.environ.get('OCOCC_DEFER_PARAM_REDUCE', '1') != '0'  # 0: always th
 # queue therefore stays off until the code that owns the gradient exchange says it reads gradients only AFTER
 # backward() has returned -- dist.GradBuckets does (pack() / all_reduce() run behind the pass).
 GRADS_READ_AFTER_BACKWARD = False
+_readers = {}    # id(gradient exchange object) -> it reads .grad only after backward() has returned
+
+
+def note_gradient_reader(owner, after_backward):
+    """A gradient exchange (dist.GradBuckets) states how it reads gradients.  The queue is on at world size > 1 only
+    while EVERY live exchange reads after the pass (one hook-driven exchange turns it off for all)."""
+    global GRADS_READ_AFTER_BACKWARD
+    import weakref
+    key = id(owner)
+    _readers[key] = bool(after_backward)
+    weakref.finalize(owner, _forget_reader, key)
+    GRADS_READ_AFTER_BACKWARD = all(_readers.values())
+
+
+def _forget_reader(key):
+    global GRADS_READ_AFTER_BACKWARD
+    _readers.pop(key, None)
+    GRADS_READ_AFTER_BACKWARD = bool(_readers) and all(_readers.values())
+
+
+_pass_id = None  # graph-task id of the pass the queues belong to
 _flushers = {}   # kind -> fn(list of jobs)
 _jobs = {}       # kind -> [job, ...] of the running pass
 _grads = []      # (param, finished-at-flush buffer)
@@ -86,6 +107,12 @@ def defer(kind, job, grads):
         torch.autograd.Variable._execution_engine.queue_callback(_flush)
     except RuntimeError:  # "Final callbacks can only be installed during backward pass"
         return False
+    global _pass_id
+    task = torch._C._current_graph_task_id()
+    if task != _pass_id:   # a new pass: whatever an interrupted pass (OOM, a raising hook) left queued is void
+        if not _held and (_jobs or _grads):
+            discard()
+        _pass_id = task
     _jobs.setdefault(kind, []).append(job)
     for p, v in grads:
         _grads.append((p, v.detach()))
@@ -119,6 +146,8 @@ class hold(object):
     def __exit__(self, *exc):
         global _held
         _held = self._prev
+        if exc and exc[0] is not None:   # the pass raised under hold(): its queued sums belong to nothing
+            discard()
         return False
 
 

@@ -67,10 +67,7 @@ class GradBuckets(object):
         self.wire_dtype = wire_dtype
         self.overlap = bool(overlap)
         from . import _deferred
-        # after-the-pass mode reads gradients once backward() has returned: the end-of-backward parameter-gradient
-        # reductions (_deferred.py) are safe next to it.  The hooks of overlap mode watch the engine's hand-over, so
-        # every hooked parameter takes the immediate per-layer reduction by itself (_deferred.deferrable).
-        _deferred.GRADS_READ_AFTER_BACKWARD = not self.overlap
+        self._hooked = False
         self.buckets = []  # (flat buffer, [(param, offset, numel)])
         cur, cur_n = [], 0
         elem = 2 if wire_dtype in (torch.bfloat16, torch.float16) else 4
@@ -85,12 +82,16 @@ class GradBuckets(object):
             self._close(cur, cur_n)
         self._works = []
         if self.overlap:
-            self._pending = [len(items) for _, items in self.buckets]
             self._where = {}
-            for bi, (_, items) in enumerate(self.buckets):
-                for p, off, n in items:
-                    self._where[id(p)] = (bi, off, n)
-                    p.register_post_accumulate_grad_hook(self._on_grad)
+            self._reset_pass()
+            # world size 1 has nothing to exchange: no hooks, so the end-of-backward reductions stay on
+            if self._active() or os.environ.get('WORLD_SIZE', '1') != '1':
+                for bi, (_, items) in enumerate(self.buckets):
+                    for p, off, n in items:
+                        self._where[id(p)] = (bi, off, n)
+                        p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooked = True
+        _deferred.note_gradient_reader(self, after_backward=not (self.overlap and self._hooked))
 
     def _close(self, items, n):
         p0 = items[0][0]
@@ -101,36 +102,60 @@ class GradBuckets(object):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     # ---- overlap mode -------------------------------------------------------------------------------------
+    def _reset_pass(self):
+        self._pending = [len(items) for _, items in self.buckets]
+        self._got = [set() for _ in self.buckets]
+        self._next = 0          # buckets [0, _next) have been handed to the collective library
+        self._works = []
+        self._pass_id = None    # autograd graph-task id of the pass whose gradients the buckets hold
+
+    def _launch_ready(self):
+        """Collectives go out strictly in bucket order on every rank -- bucket i only once 0..i-1 are out -- whatever
+        order the gradients arrived in locally (a rank whose batch skipped a sub-module would otherwise issue its
+        all-reduces in another order than its peers: a hang, or sums of mismatched buckets)."""
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._works.append(dist.all_reduce(self.buckets[self._next][0], async_op=True))
+            self._next += 1
+
     def _on_grad(self, p):
         if not self._active():
             return
+        task = torch._C._current_graph_task_id()
+        if task != self._pass_id:   # first gradient of a pass: forget whatever an interrupted pass left behind
+            self._reset_pass()
+            self._pass_id = task
         bi, off, n = self._where[id(p)]
+        if bi < self._next or id(p) in self._got[bi]:
+            return              # second accumulation into the same leaf: finish() re-packs nothing already sent
         flat = self.buckets[bi][0]
         flat[off:off + n].view_as(p).copy_(p.grad)
+        self._got[bi].add(id(p))
         self._pending[bi] -= 1
-        if self._pending[bi] == 0:
-            self._works.append((bi, dist.all_reduce(flat, async_op=True)))
+        self._launch_ready()
 
     def finish(self):
-        """Overlap mode, after backward(): launch the buckets that are still waiting for a gradient (parameters that
-        took no part in the pass count as zero), wait for all collectives, write the averages into ``.grad``."""
+        """Overlap mode, after backward(): pack the buckets that still wait for a gradient (parameters that took no
+        part in the pass count as zero) and launch them in bucket order, wait for all collectives, write the averages
+        into ``.grad``."""
         if not self._active():
             return
-        launched = {bi for bi, _ in self._works}
-        for bi, (flat, items) in enumerate(self.buckets):
-            if bi in launched:
-                continue
-            for p, off, n in items:  # a bucket that did not complete is packed whole here
-                if p.grad is None:
-                    flat[off:off + n].zero_()
-                else:
-                    flat[off:off + n].view_as(p).copy_(p.grad)
-            self._works.append((bi, dist.all_reduce(flat, async_op=True)))
-        for _, w in self._works:
-            w.wait()
-        self._works = []
-        self._pending = [len(items) for _, items in self.buckets]
-        self.unpack()
+        try:
+            for bi in range(self._next, len(self.buckets)):
+                flat, items = self.buckets[bi]
+                for p, off, n in items:
+                    if id(p) in self._got[bi]:
+                        continue
+                    if p.grad is None:
+                        flat[off:off + n].zero_()
+                    else:
+                        flat[off:off + n].view_as(p).copy_(p.grad)
+                self._pending[bi] = 0
+            self._launch_ready()
+            for w in self._works:
+                w.wait()
+            self.unpack()
+        finally:
+            self._reset_pass()
 
     # ---- after-the-pass mode ------------------------------------------------------------------------------
     def pack(self):

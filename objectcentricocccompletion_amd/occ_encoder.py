@@ -21,11 +21,13 @@ class SubMOccEncoder(nn.Module):
 
     def __init__(self, in_channels=16, channels=(32, 64, 128), voxel_size=(0.2, 0.2, 0.2),
                  point_cloud_range=(-4, -4, -4, 4, 4, 4), norm_cfg=dict(type='LN', eps=1e-3),
-                 act_type='gelu', feature_dtype=torch.bfloat16, fused_front_end=True, grouped_points=True):
-        """``grouped_points``: the points of one object grid are contiguous in the input (batch_idx non-decreasing), as
-        the per-object pipelines deliver them; the fixed-capacity geometry then runs through the per-grid LDS kernels
-        (voxel.object_grid_geometry).  A batch that breaks the promise is reported through the status word of the
-        returned meta tensor and its stray points are dropped."""
+                 act_type='gelu', feature_dtype=torch.bfloat16, fused_front_end=True, grouped_points=False):
+        """``grouped_points=True`` is the caller's promise that the points of one object grid are contiguous in the
+        input (batch_idx non-decreasing), as the per-object pipelines and synthetic_object_grids deliver them; the
+        fixed-capacity geometry then runs through the per-grid LDS kernels (voxel.object_grid_geometry).  The
+        reference's voxelisation has no such requirement, so the default is the general path.  With the promise
+        given, a batch that breaks it is reported through the status word of the returned meta tensor (its stray
+        points are dropped); ``check_geometry`` reads that word back and raises -- call it outside graph capture."""
         super().__init__()
         self.grouped_points = bool(grouped_points)
         self.fused_front_end = bool(fused_front_end) and feature_dtype in (torch.bfloat16, torch.float32)
@@ -74,6 +76,16 @@ class SubMOccEncoder(nn.Module):
                                                      conv.stride, conv.padding, conv.dilation, conv.output_padding,
                                                      True, False, grid=x.grid)
         x.indice_dict[key] = (outids, x.indices, pairs, num, self.sparse_shape)
+        return x
+
+    @staticmethod
+    def check_geometry(x):
+        """Read back the status word of a grouped-points geometry (one device sync; not inside a graph capture) and
+        raise if the batch broke the ordering promise or overflowed its fixed capacity."""
+        meta = getattr(x, 'meta', None)
+        if meta is not None and int(meta[1]) != 0:
+            raise ValueError('object_grid_geometry: batch_idx is not non-decreasing (or a grid overflowed its capacity); '
+                             'stray points were dropped -- build the encoder with grouped_points=False for such batches')
         return x
 
     def prepare_weights(self, grad=None):

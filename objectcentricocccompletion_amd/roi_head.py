@@ -96,7 +96,8 @@ class TrackletRoIHeadOCC(nn.Module):
             over = trk.boxes.new_zeros(len(trk))
             if hi > lo:
                 over = ious[lo:hi] if own == list(range(len(trk))) else over.index_copy(0, host_index(own, dev), ious[lo:hi])
-            trk._self_iou_cache = {id(cands[c]): over}
+            # valid for this candidate object and for the box tensors as they are now (in-place transforms bump _version)
+            trk._self_iou_cache = (cands[c], trk.boxes, over, trk.boxes._version, cands[c].boxes._version)
         return out_trks, out_occs, out_scores
 
     def _assign_and_sample(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list, pts_batch_idx,

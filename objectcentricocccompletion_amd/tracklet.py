@@ -95,9 +95,13 @@ class Tracklet(object):
     def self_ious(self, trk):
         """Per own box: IoU with the other tracklet's box of the same timestamp, 0 if none (:278-288).  The RoI head
         computes these for a whole batch in one launch and leaves them in ``_self_iou_cache`` (roi_head.py)."""
-        hit = getattr(self, '_self_iou_cache', {}).get(id(trk))
+        hit = getattr(self, '_self_iou_cache', None)
         if hit is not None:
-            return hit
+            cand, boxes, over = hit[:3]
+            # the very candidate object, and neither side transformed since (the in-place transforms bump _version)
+            if cand is trk and boxes is self.boxes and hit[3:] == (self.boxes._version, trk.boxes._version):
+                return over
+            self._self_iou_cache = None
         out = self.boxes.new_zeros(len(self))
         i1, _ = self.common_frames(trk)
         if len(i1) == 0:

@@ -43,7 +43,8 @@ def _worker(rank, world, port, q):
     twin = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 3))
     twin.load_state_dict(model.state_dict())
     unused = torch.nn.Parameter(torch.ones(5))
-    ob = od.GradBuckets(list(twin.parameters()) + [unused], bucket_bytes=256, overlap=True)
+    # (buckets go out strictly in index order = reverse registration order: registered first, `unused` sits in the last)
+    ob = od.GradBuckets([unused] + list(twin.parameters()), bucket_bytes=256, overlap=True)
     (((twin(x_all[lo:hi]) - y_all[lo:hi]) ** 2).sum() / 8 * world).backward()
     launched_in_pass = len(ob._works)
     ob.finish()
@@ -115,6 +116,98 @@ def test_world_size_2_bucketed_allreduce_matches_single_process():
     (((model(x_all) - y_all) ** 2).sum() / 8).backward()
     for p, g in zip(model.parameters(), g0):
         assert torch.allclose(p.grad, g, atol=1e-6)
+
+
+def _worker_uneven(rank, world, port, q):
+    """Rank 1 skips a sub-module in its pass (heads.py skips roi_encode for an empty batch): its buckets complete only in
+    finish(), yet both ranks must hand the SAME bucket sequence to the collective library."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from objectcentricocccompletion_amd import dist as od
+    od.init_dist('gloo')
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    ob = od.GradBuckets(params, bucket_bytes=16 * 4, overlap=True)      # 20 elements per layer -> ~2 buckets each
+    order = []
+    real = dist.all_reduce
+
+    def spy(t, *args, **kw):
+        order.append([i for i, (flat, _) in enumerate(ob.buckets) if flat.data_ptr() == t.data_ptr()][0])
+        return real(t, *args, **kw)
+    od.dist.all_reduce = spy
+    results = []
+    for step in range(2):   # second pass: state of the first one must be gone
+        for p in params:
+            p.grad = None
+        order.clear()
+        x = torch.ones(3, 4) * (rank + 1 + step)
+        h = a(x)
+        if rank == 0:
+            h = b(h)            # rank 1 never touches b
+        c(h).sum().backward()
+        in_pass = list(order)
+        ob.finish()
+        results.append((in_pass, list(order), [None if p.grad is None else p.grad.numpy().copy() for p in params]))
+    od.dist.all_reduce = real
+    # an interrupted pass (backward raised, finish() never ran) must not leak into the next one
+    for p in params:
+        p.grad = None
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+    try:
+        c(Boom.apply(a(torch.ones(3, 4)))).sum().backward()
+    except RuntimeError:
+        pass
+    for p in params:
+        p.grad = None
+    c(a(torch.ones(3, 4) * (rank + 1))).sum().backward()
+    ob.finish()
+    after_boom = [None if p.grad is None else p.grad.numpy().copy() for p in params]
+    q.put((rank, results, after_boom))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlap_buckets_go_out_in_index_order_when_one_rank_skips_a_module():
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, res0, boom0), (_, res1, boom1) = out
+    for (in0, all0, g0), (in1, all1, g1) in zip(res0, res1):
+        assert all0 == all1 == sorted(all0) and len(all0) == len(set(all0)) >= 3   # same sequence, strictly by index
+        assert len(in0) >= 1                                      # rank 0 did overlap part of the exchange
+        assert len(in1) < len(all1)                               # rank 1 had to wait for finish() for b's buckets
+        for x, y in zip(g0, g1):
+            assert np.allclose(x, y)                              # both ranks hold the same averages
+    # reference for step 0: mean over ranks of the local gradients
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+    c(b(a(torch.ones(3, 4)))).sum().backward()
+    g_rank0 = [p.grad.clone() for m in (a, b, c) for p in m.parameters()]
+    for m in (a, b, c):
+        m.zero_grad()
+    c(a(torch.ones(3, 4) * 2)).sum().backward()
+    g_rank1 = [torch.zeros_like(p) if p.grad is None else p.grad for m in (a, b, c) for p in m.parameters()]
+    for got, x, y in zip(res0[0][2], g_rank0, g_rank1):
+        assert np.allclose(got, ((x + y) / 2).numpy(), atol=1e-6)
+    for x, y in zip(boom0, boom1):
+        assert np.allclose(x, y)
 
 
 def test_shard_range_covers_everything():

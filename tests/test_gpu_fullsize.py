@@ -116,7 +116,7 @@ def test_graph_replay_matches_eager_full_size(dev, scene):
     from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder
     xyz, feats, bidx, _ = scene
     torch.manual_seed(0)
-    model = SubMOccEncoder().to(dev)
+    model = SubMOccEncoder(grouped_points=True).to(dev)
     with torch.no_grad():
         n = model(xyz, feats, bidx, B).features.shape[0]
     d = torch.zeros(xyz.shape[0], 128, dtype=torch.bfloat16, device=dev)

@@ -98,7 +98,7 @@ def test_encoder_uses_the_fused_geometry_and_matches(dev):
     torch.manual_seed(0)
     B, P = 6, 700
     xyz, feats, bidx = synthetic_object_grids(B, P, seed=5, device=dev)
-    model = SubMOccEncoder().to(dev)
+    model = SubMOccEncoder(grouped_points=True).to(dev)
     outs = []
     for grouped in (True, False):
         model.grouped_points = grouped

@@ -6,7 +6,7 @@ from objectcentricocccompletion_amd.graph import GraphedStep
 from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-model = SubMOccEncoder().to(dev)
+model = SubMOccEncoder(grouped_points=True).to(dev)
 B = 4
 xyz, feats, bidx = synthetic_object_grids(B, 500, seed=3, device=dev)
 d = torch.zeros(xyz.shape[0], 128, dtype=torch.bfloat16, device=dev)

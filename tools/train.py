@@ -89,7 +89,11 @@ def main():
             opt.load_state_dict(ck['optimizer'])
     broadcast_parameters(model)
     opt.init_state()
-    max_iters = args.max_iters or (start + args.iters)
+    saved_max = ck.get('meta', {}).get('max_iters') if args.resume_from else None
+    max_iters = args.max_iters or saved_max or (start + args.iters)   # a resumed run stays on the ONE cycle it began
+    if args.max_iters and saved_max and args.max_iters != saved_max and rank == 0:
+        print(f'warning: --max-iters {args.max_iters} differs from the checkpoint\'s {saved_max}: the cyclic LR '
+              f'schedule changes shape mid-run', flush=True)
     buckets = GradBuckets(model.parameters(), overlap=True)
     samples = cfg.get('data', {}).get('samples_per_gpu', 4)
     ds = None
