@@ -518,6 +518,78 @@ int ococc_window_attn_bwd_gather_bf16(const uint16_t* q, const uint16_t* k, cons
                                       uint16_t* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
                                       ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * B7, fused  one SST encoder layer as two tile kernels per direction
+ * replaces EncoderLayer.forward (post-norm, mmdet3d/models/sst/sst_basic_block_v2.py:105-127):
+ *   window_attn_block:  y1 = norm1(x + self_attn(q = k = x + pos, v = x))   (WindowAttention.forward :41-75 around
+ *                        nn.MultiheadAttention on flat2window_v2 / window2flat_v2 copies, sst_ops.py:66-148)
+ *   token_ffn_block:    y2 = norm2(y1 + linear2(act(linear1(y1))))
+ * d_model 128, 8 heads of 16, feed-forward 256; tokens bf16 [num_tokens, 128] in the model's flat order; all sums f32.
+ *
+ * Weights arrive as MFMA A-operand fragments: ococc_linear_fragments_bf16 turns f32 matrices S (rows x cols, any
+ * element strides -- a transposed view is just swapped strides) into bf16 [rows/16][cols/32][64 lanes][8]:
+ * lane 16 g + r of block (rb, cs) holds S[16 rb + r][32 cs + 8 g .. + 7].  For y = x W^T pass W ([out, in] as
+ * nn.Linear stores it); for the input gradient dx = dy W pass W^T (rows = in, cols = out).
+ *
+ * Windows -> tiles: ococc_window_tile_plan packs whole windows (win_len[w] <= 64 tokens, their flat rows at
+ * tok[win_off[w] .. + win_len[w])) greedily, in the given order, into tiles of 64 token slots: tile_rows [tiles*64]
+ * = flat row of the slot or -1, tile_span [tiles*64] = lo | hi << 8, the slots of the slot's window (0: empty).
+ * cap_tiles >= num_windows rows of both arrays are initialised; *num_tiles (device) receives the tiles in use.
+ * A slot attends exactly the slots of its span: the key_padding_mask of the reference is the span.
+ *
+ * Backward kernels recompute their block from its input (nothing else is saved by the forward) and also write the
+ * operands of the weight gradients -- attention block: dqkv [*,384] (gradients of q | k | v), attn_out [*,128] (input
+ * of out_proj), dz [*,128] (gradient at norm1's input = gradient of out_proj's output); FFN block: act_out [*,256]
+ * (input of linear2), dh [*,256] (gradient of linear1's output), dz [*,128] (gradient of linear2's output) -- and one
+ * row [dgamma(128) | dbeta(128)] f32 of LayerNorm parameter-gradient partial sums per tile (ln_partial).
+ * dx includes the residual path.  No atomics: bit-reproducible.
+ * ------------------------------------------------------------------------ */
+int ococc_linear_fragments_bf16(int32_t count, const void* const* src, const int64_t* rows, const int64_t* cols,
+                                const int64_t* row_stride, const int64_t* col_stride, void* const* dst,
+                                ococc_stream_t stream);
+int64_t ococc_window_tile_plan_workspace_bytes(int64_t num_windows);
+int ococc_window_tile_plan(const int32_t* win_len, const int64_t* win_off, const int32_t* tok, int64_t num_windows,
+                           int32_t tile_slots, int64_t cap_tiles, int32_t* tile_rows, int32_t* tile_span,
+                           int32_t* num_tiles, void* workspace, int64_t workspace_bytes, ococc_stream_t stream);
+int ococc_window_attn_block_fwd_bf16(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows,
+                                     const int32_t* tile_span, int64_t num_tiles, int32_t d_model, int32_t num_heads,
+                                     const uint16_t* wqkv_frag, const float* bqkv, const uint16_t* wo_frag,
+                                     const float* bo, const float* ln_weight, const float* ln_bias, float eps,
+                                     uint16_t* y, ococc_stream_t stream);
+int ococc_window_attn_block_bwd_bf16(const uint16_t* x, const uint16_t* pos, const uint16_t* dy,
+                                     const int32_t* tile_rows, const int32_t* tile_span, int64_t num_tiles,
+                                     int32_t d_model, int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
+                                     const uint16_t* wo_frag, const float* bo, const float* ln_weight, float eps,
+                                     const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag, uint16_t* dx,
+                                     uint16_t* dqkv, uint16_t* dz, uint16_t* attn_out, float* ln_partial,
+                                     ococc_stream_t stream);
+int ococc_token_ffn_block_fwd_bf16(const uint16_t* x, int64_t num_tokens, int32_t d_model, int32_t d_ffn,
+                                   const uint16_t* w1_frag, const float* b1, const uint16_t* w2_frag, const float* b2,
+                                   const float* ln_weight, const float* ln_bias, float eps, int32_t act, uint16_t* y,
+                                   ococc_stream_t stream);
+int ococc_token_ffn_block_bwd_bf16(const uint16_t* x, const uint16_t* dy, int64_t num_tokens, int32_t d_model,
+                                   int32_t d_ffn, const uint16_t* w1_frag, const float* b1, const uint16_t* w2_frag,
+                                   const float* b2, const float* ln_weight, float eps, int32_t act,
+                                   const uint16_t* w2_t_frag, const uint16_t* w1_t_frag, uint16_t* dx,
+                                   uint16_t* act_out, uint16_t* dh, uint16_t* dz, float* ln_partial,
+                                   ococc_stream_t stream);
+
+/* Weight gradients of token-wise linears (replaces the dW / db that autograd derives for nn.Linear /
+ * nn.MultiheadAttention's in_proj in the reference, sst_basic_block_v2.py:41-127): for each of `count` pairs
+ *   dW_i[n][k] = sum_t G_i[t][n] X_i[t][k],  db_i[n] = sum_t G_i[t][n]
+ * G_i: bf16 [num_tokens, ldg_i] (n_i columns used, n_i a multiple of 64), X_i: bf16 [num_tokens, k_i], k_i 128 or 256;
+ * xadd_i (optional): a second bf16 [num_tokens, k_i] operand, rows n < add_rows_i of dW use bf16(X + xadd) (the q | k
+ * rows of in_proj see x + pos, the v rows x).  The token range is cut into `slabs` (ococc_token_wgrad_slabs) and every
+ * slab leaves f32 partials dw_partial_i [slabs, n_i, k_i], db_partial_i [slabs, n_i];
+ * ococc_partial_rows_sum_f32 (dst[c] = sum_r src[r][c], fixed order) finishes them.  No atomics. */
+int64_t ococc_token_wgrad_slabs(int64_t num_tokens);
+int ococc_token_wgrad_bf16(int32_t count, const void* const* g, const int64_t* ldg, const int64_t* n,
+                           const void* const* x, const void* const* xadd, const int64_t* add_rows, const int64_t* k,
+                           int64_t num_tokens, int64_t slabs, void* const* dw_partial, void* const* db_partial,
+                           ococc_stream_t stream);
+int ococc_partial_rows_sum_f32(int32_t count, const void* const* src, const int64_t* rows, const int64_t* cols,
+                               void* const* dst, ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

@@ -103,6 +103,21 @@ SIGNATURES = {
     'ococc_window_attn_bwd_gather_bf16': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
                                                   c_vp, c_i64, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64,
                                                   c_i64, c_vp]),
+    'ococc_linear_fragments_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
+                                            ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
+    'ococc_window_tile_plan_workspace_bytes': (c_i64, [c_i64]),
+    'ococc_window_tile_plan': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_window_attn_block_fwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_f32, c_vp, c_vp]),
+    'ococc_window_attn_block_bwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_token_ffn_block_fwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
+                                               c_i32, c_vp, c_vp]),
+    'ococc_token_ffn_block_bwd_bf16': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
+                                               c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_token_wgrad_slabs': (c_i64, [c_i64]),
+    'ococc_token_wgrad_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i64, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp]),
+    'ococc_partial_rows_sum_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_adamw_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),

@@ -379,6 +379,38 @@ def _window_maps(ind_dict, key_padding_dict):
     return maps
 
 
+FUSED_ENCODER_LAYER = True   # False: the per-operator flat path (GEMMs through torch + the per-window attention kernels)
+
+
+def _fused_maps(ind_dict, pos_dict, key_padding_dict, num_tokens, dtype):
+    """(TilePlan of the drop levels whose windows fit a 64-slot tile, (rows, maps) of the larger ones or None,
+    positional embedding in flat token order), cached on the index dict of the shift."""
+    hit = ind_dict.get('_ococc_fused')
+    if hit is None:
+        from .fused_block import TILE, TilePlan
+        maps = _window_maps(ind_dict, key_padding_dict)
+        pos_flat = ind_dict.get('_ococc_pos_flat')
+        if pos_flat is None:
+            pos_flat = window2flat_v2(pos_dict, ind_dict).to(dtype).contiguous()
+            ind_dict['_ococc_pos_flat'] = pos_flat
+        small = [(tok, key_len, nW, T) for (slot, pos, nW, T, key_len, tok) in maps.values() if T <= TILE]
+        large = {dl: m for dl, m in maps.items() if m[3] > TILE}
+        device = pos_flat.device
+        plan = TilePlan(small, device)
+        big = None
+        if large:
+            rows = torch.cat([m[1] for m in large.values()])            # flat rows of the large windows' tokens
+            inv = torch.full((num_tokens,), -1, dtype=torch.int32, device=device)
+            inv[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=device)
+            remapped = {}
+            for dl, (slot, pos, nW, T, key_len, tok) in large.items():
+                t2 = torch.where(tok >= 0, inv[tok.clamp(min=0).long()], tok)
+                remapped[dl] = (slot, inv[pos].long(), nW, T, key_len, t2)
+            big = (rows, remapped)
+        hit = ind_dict['_ococc_fused'] = (plan, big, pos_flat)
+    return hit
+
+
 class WindowMultiheadAttention(nn.Module):
     """Parameter layout of nn.MultiheadAttention (in_proj_weight [3E,E], in_proj_bias,
     out_proj.{weight,bias}); batch-first padded windows [nW, T, E]; attention core on the HIP kernel."""
@@ -509,6 +541,7 @@ class EncoderLayer(nn.Module):
             self.norm1, self.norm2 = nn.LayerNorm(d_model), nn.LayerNorm(d_model)
         self.dropout1, self.dropout2 = nn.Dropout(mlp_dropout), nn.Dropout(mlp_dropout)
         self.activation = _activation(activation)
+        self._act_name = activation
         self.post_norm = layer_cfg.get('post_norm', True)
         self.compute_dtype = layer_cfg.get('compute_dtype', None)
 
@@ -525,6 +558,36 @@ class EncoderLayer(nn.Module):
         h = self.activation(lin(x.to(dt), self.linear1.weight.to(dt), self.linear1.bias.to(dt)))
         return lin(self.dropout(h), self.linear2.weight.to(dt), self.linear2.bias.to(dt))
 
+    def _fusable(self):
+        """The tile kernels of csrc/window_block.hip cover the reference SST configuration (d_model 128, 8 heads, ffn
+        256, LayerNorm, post-norm, no dropout, softmax attention): anything else keeps the per-operator path."""
+        mha = self.win_attn.self_attn
+        drop = self.training and (self.dropout.p > 0 or self.dropout1.p > 0 or self.dropout2.p > 0)
+        return (FUSED_ENCODER_LAYER and self.compute_dtype == torch.bfloat16 and self.post_norm and not self.use_bn
+                and mha.tau is None and mha.embed_dim == 128 and mha.num_heads == 8 and self.linear1.out_features == 256
+                and self._act_name in ('gelu', 'relu') and not drop)
+
+    def _forward_fused(self, src, pos_dict, ind_dict, key_padding_mask_dict):
+        from . import fused_block as fb
+        mha = self.win_attn.self_attn
+        dt = self.compute_dtype
+        x = src.to(dt).contiguous()
+        plan, big, pos_flat = _fused_maps(ind_dict, pos_dict, key_padding_mask_dict, x.shape[0], dt)
+        covered = plan.tokens == x.shape[0]
+        y1 = fb.AttnBlock.apply(x, pos_flat, plan, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                                mha.out_proj.bias, self.norm1.weight, self.norm1.bias, self.norm1.eps, mha.num_heads,
+                                covered)
+        if big is not None:   # windows of more than 64 tokens: per-window kernels on the rows they own
+            rows, maps = big
+            xb = x.index_select(0, rows)
+            ob = mha.forward_flat(xb, pos_flat.index_select(0, rows), maps, dt)
+            y1 = y1.index_copy(0, rows, self._ln(self.norm1, xb + ob))
+        return fb.FfnBlock.apply(y1, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                                 self.norm2.weight, self.norm2.bias, self.norm2.eps, self._act_name)
+
+    def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
+        if self.compute_dtype is not None and self._fusable():
+            return self._forward_fused(src, pos_dict, ind_dict, key_padding_mask_dict)
     def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
         if self.compute_dtype is not None:
             src = src.to(self.compute_dtype)  # bf16 residual stream; LN statistics and GEMM accumulation stay f32
