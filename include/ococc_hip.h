@@ -541,13 +541,16 @@ int ococc_window_attn_bwd_gather_bf16(const uint16_t* q, const uint16_t* k, cons
  * operands of the weight gradients -- attention block: dqkv [*,384] (gradients of q | k | v), attn_out [*,128] (input
  * of out_proj), dz [*,128] (gradient at norm1's input = gradient of out_proj's output); FFN block: act_out [*,256]
  * (input of linear2), dh [*,256] (gradient of linear1's output), dz [*,128] (gradient of linear2's output) -- and one
- * row [dgamma(128) | dbeta(128)] f32 of LayerNorm parameter-gradient partial sums per tile (ln_partial).
+ * row [dgamma(128) | dbeta(128)] f32 of LayerNorm parameter-gradient partial sums per persistent workgroup
+ * (ln_partial: ococc_window_block_partial_rows(tiles) rows; an FFN block has ceil(num_tokens / 64) tiles).
  * dx includes the residual path.  No atomics: bit-reproducible.
+ * All four kernels run as persistent workgroups that keep the block's weight fragments in registers.
  * ------------------------------------------------------------------------ */
 int ococc_linear_fragments_bf16(int32_t count, const void* const* src, const int64_t* rows, const int64_t* cols,
                                 const int64_t* row_stride, const int64_t* col_stride, void* const* dst,
                                 ococc_stream_t stream);
 int64_t ococc_window_tile_plan_workspace_bytes(int64_t num_windows);
+int64_t ococc_window_block_partial_rows(int64_t num_tiles);
 int ococc_window_tile_plan(const int32_t* win_len, const int64_t* win_off, const int32_t* tok, int64_t num_windows,
                            int32_t tile_slots, int64_t cap_tiles, int32_t* tile_rows, int32_t* tile_span,
                            int32_t* num_tiles, void* workspace, int64_t workspace_bytes, ococc_stream_t stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     'ococc_linear_fragments_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
     'ococc_window_tile_plan_workspace_bytes': (c_i64, [c_i64]),
+    'ococc_window_block_partial_rows': (c_i64, [c_i64]),
     'ococc_window_tile_plan': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_window_attn_block_fwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
                                                  c_vp, c_vp, c_f32, c_vp, c_vp]),

@@ -62,21 +62,26 @@ __device__ __forceinline__ f32x4 unpack4(const u32x2 v) {
 }
 __device__ __forceinline__ s16x4 ld4(const uint16_t* p) { return *(const s16x4*)p; }
 
+
 // ---------------------------------------------------------------------------------------------------------------
-// out^T[n][m] += sum_k W[n][k] X[m][k] for the wave's NB blocks of 16 output channels starting at block nb0 and the
-// 4 token blocks of the tile.  wf: fragment-major weights [n block][k step][lane][8]; xs: LDS tile [64][ldb] bf16.
-// All fragments of the wave's slice are requested before the first MFMA (NB*KS <= 24 loads of 16 B per lane in
-// flight): the L2 latency of the weight stream is paid once per GEMM, not once per k step.
-template <int NB, int KS>
-__device__ __forceinline__ void tile_gemm(const uint16_t* __restrict__ wf, int nb0, const uint16_t* xs, int ldb,
-                                          f32x4 (&acc)[NB][4]) {
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const bf16x8* wp = (const bf16x8*)wf + (size_t)nb0 * KS * 64 + lane;
-  bf16x8 a[NB][KS];
+// GEMM pieces.  out^T[n][m] += sum_k W[n][k] X[m][k] for NB blocks of 16 output channels and the 4 token blocks of the
+// tile.  The weight fragments of a wave's channel slice go L2 -> registers (load_frags), requested one GEMM ahead of
+// their use; xs: LDS tile [64][ldb] bf16.
+template <int NB, int KS, bool STREAM = true>
+__device__ __forceinline__ void load_frags(const int tid_, const uint16_t* __restrict__ wf, int nb0, bf16x8 (&a)[NB][KS]) {
+  // STREAM: the pointer passes through an empty asm -- the loads are loop invariant, and hoisted out of the persistent
+  // tile loop all fragments of a kernel would have to live in registers at once (which is what the backward kernels,
+  // one workgroup per CU with 512 registers per lane, do on purpose with STREAM = false)
+  if (STREAM) asm volatile("" : "+s"(wf));
+  const bf16x8* wp = (const bf16x8*)wf + (size_t)nb0 * KS * 64 + (tid_ & 63);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[nb][ks] = wp[(nb * KS + ks) * 64];
+}
+template <int NB, int KS>
+__device__ __forceinline__ void tile_gemm(const int tid_, const bf16x8 (&a)[NB][KS], const uint16_t* xs, int ldb, f32x4 (&acc)[NB][4]) {
+  const int lane = tid_ & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     bf16x8 b[4];
@@ -99,9 +104,10 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[NB][4]) {
 }
 
 // Sum over the 128 channels of each of the lane's 4 tokens (token mb*16 + c): the lane's own values, its three
-// partner lanes (same c, other g) and the other three waves through `red` ([4 waves][64 tokens] floats).  One barrier.
-__device__ __forceinline__ void token_sums(float (&part)[4], float* red) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+// partner lanes (same c, other g) and the other waves through `red` ([NW waves][64 tokens] floats).  One barrier.
+template <int NW>
+__device__ __forceinline__ void token_sums(const int tid_, float (&part)[4], float* red) {
+  const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     float p = part[mb];
@@ -113,42 +119,46 @@ __device__ __forceinline__ void token_sums(float (&part)[4], float* red) {
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int t = mb * 16 + c;
-    part[mb] = (red[t] + red[TM + t]) + (red[2 * TM + t] + red[3 * TM + t]);
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w * TM + t];
+    part[mb] = s;
   }
 }
 
-// LayerNorm statistics of z (the wave's 2 channel blocks x 4 token blocks; a token's 128 channels are spread over the
-// 4 waves): two passes (mean, then centred squares).  z <- xhat = (z - mean) * rstd; rstd returned per token block.
-__device__ __forceinline__ void tile_layernorm(f32x4 (&z)[2][4], float eps, float* red0, float* red1, float (&rstd)[4]) {
+// LayerNorm statistics of z (the wave's NB channel blocks x 4 token blocks; a token's 128 channels are spread over the
+// waves): two passes (mean, then centred squares).  z <- xhat = (z - mean) * rstd; rstd returned per token block.
+template <int NW, int NB>
+__device__ __forceinline__ void tile_layernorm(const int tid_, f32x4 (&z)[NB][4], float eps, float* red0, float* red1, float (&rstd)[4]) {
   float s[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     s[mb] = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[mb] += z[nb][mb][r];
   }
-  token_sums(s, red0);
+  token_sums<NW>(tid_, s, red0);
   float q[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const float mean = s[mb] * (1.f / E);
     q[mb] = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         z[nb][mb][r] -= mean;
         q[mb] += z[nb][mb][r] * z[nb][mb][r];
       }
   }
-  token_sums(q, red1);
+  token_sums<NW>(tid_, q, red1);
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     rstd[mb] = rsqrtf(q[mb] * (1.f / E) + eps);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) z[nb][mb][r] *= rstd[mb];
   }
@@ -156,15 +166,16 @@ __device__ __forceinline__ void tile_layernorm(f32x4 (&z)[2][4], float eps, floa
 
 // LayerNorm backward on the wave's slice: xh = xhat, dy = gradient of the LN output -> dy <- gradient of the LN
 // input; adds the tile's terms to dgam / dbet (per lane: channels 16(nb0+nb)+4g+r, summed over the lane's tokens).
-__device__ __forceinline__ void tile_layernorm_bwd(const f32x4 (&xh)[2][4], f32x4 (&dy)[2][4], const f32x4 (&gam)[2],
-                                                   const float (&rstd)[4], float* red0, float* red1, f32x4 (&dgam)[2],
-                                                   f32x4 (&dbet)[2]) {
+template <int NW, int NB>
+__device__ __forceinline__ void tile_layernorm_bwd(const int tid_, const f32x4 (&xh)[NB][4], f32x4 (&dy)[NB][4], const f32x4 (&gam)[NB],
+                                                   const float (&rstd)[4], float* red0, float* red1,
+                                                   f32x4 (&dgam)[NB], f32x4 (&dbet)[NB]) {
   float s1[4], s2[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     s1[mb] = s2[mb] = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float d = dy[nb][mb][r];
@@ -176,24 +187,26 @@ __device__ __forceinline__ void tile_layernorm_bwd(const f32x4 (&xh)[2][4], f32x
         s2[mb] += dg * xh[nb][mb][r];
       }
   }
-  token_sums(s1, red0);
-  token_sums(s2, red1);
+  token_sums<NW>(tid_, s1, red0);
+  token_sums<NW>(tid_, s2, red1);
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const float m1 = s1[mb] * (1.f / E), m2 = s2[mb] * (1.f / E);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dy[nb][mb][r] = ((dy[nb][mb][r] - m1) - xh[nb][mb][r] * m2) * rstd[mb];
   }
 }
 
-// per-channel sums of the wave's slice over the tile's tokens -> one row of partial sums per tile ([2][128] floats)
-__device__ __forceinline__ void store_param_partials(const f32x4 (&dgam)[2], const f32x4 (&dbet)[2], int nb0,
+// per-channel sums of the wave's slice over all the tokens the workgroup has seen -> its row of partial sums
+// ([dgamma(128) | dbeta(128)] floats)
+template <int NB>
+__device__ __forceinline__ void store_param_partials(const int tid_, const f32x4 (&dgam)[NB], const f32x4 (&dbet)[NB], int nb0,
                                                      float* __restrict__ dst) {
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int lane = tid_ & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float a = dgam[nb][r], b = dbet[nb][r];
@@ -209,28 +222,47 @@ __device__ __forceinline__ void store_param_partials(const f32x4 (&dgam)[2], con
     }
 }
 
-// rows of a [64][ld] bf16 LDS tile <-> rows of a global [*, width] bf16 tensor, 16 B per lane, whole rows coalesced
-template <int WIDTH>
+// rows of a [64][ld] bf16 LDS tile -> rows of a global [*, WIDTH] bf16 tensor, 16 B per lane, whole rows coalesced
+template <int NW, int WIDTH>
 __device__ __forceinline__ void tile_store_rows(const uint16_t* ts, int ld, uint16_t* __restrict__ dst, const int* rows_s,
                                                 int64_t row0, int64_t nrows) {
   constexpr int PP = WIDTH / 8;
-  for (int i = threadIdx.x; i < TM * PP; i += kThreads) {
-    const int s = i / PP, p = i % PP;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // (keeps the per-piece address arithmetic out of the registers between calls)
+#pragma unroll
+  for (int i0 = 0; i0 < TM * PP; i0 += NW * 64) {
+    const int i = i0 + tid, s = i / PP, p = i % PP;
     const int64_t r = rows_s ? (int64_t)rows_s[s] : (row0 + s < nrows ? row0 + s : -1);
     if (r >= 0) *(u32x4*)(dst + r * WIDTH + p * 8) = *(const u32x4*)(ts + s * ld + p * 8);
   }
 }
-__device__ __forceinline__ void tile_load_rows(uint16_t* ts, int ld, const uint16_t* __restrict__ src, const int* rows_s,
-                                               int64_t row0, int64_t nrows) {
-  constexpr int PP = E / 8;
-  for (int i = threadIdx.x; i < TM * PP; i += kThreads) {
-    const int s = i / PP, p = i % PP;
-    const int64_t r = rows_s ? (int64_t)rows_s[s] : (row0 + s < nrows ? row0 + s : -1);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r >= 0) v = *(const u32x4*)(src + r * E + p * 8);
-    *(u32x4*)(ts + s * ld + p * 8) = v;
+
+// the thread's 16-byte pieces of a [64][128] bf16 tile: registers <- global rows (zeros for missing rows), -> LDS
+template <int NW>
+struct TilePieces {
+  static constexpr int P = TM * (E / 8) / (NW * 64);   // 4 (256 threads) or 2 (512)
+  u32x4 v[P];
+  __device__ __forceinline__ void fetch(const uint16_t* __restrict__ src, const int* rows_s, int64_t row0, int64_t nrows) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int i = tid + j * NW * 64, s = i >> 4, p = i & 15;
+      const int64_t r = rows_s ? (int64_t)rows_s[s] : (row0 + s < nrows ? row0 + s : -1);
+      v[j] = u32x4{0u, 0u, 0u, 0u};
+      if (r >= 0 && src) v[j] = *(const u32x4*)(src + r * E + p * 8);
+    }
   }
-}
+  __device__ __forceinline__ void stash(uint16_t* ts, int ld) const {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int i = tid + j * NW * 64, s = i >> 4, p = i & 15;
+      *(u32x4*)(ts + s * ld + p * 8) = v[j];
+    }
+  }
+};
 
 __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
@@ -239,72 +271,87 @@ __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
 }
 
 template <int ACT>  // 0 gelu (erf), 1 relu
-__device__ __forceinline__ float act_fwd(float h) {
-  return ACT == 0 ? ln_gelu1(h) : fmaxf(h, 0.f);
+__device__ __forceinline__ f32x4 act_fwd4(const f32x4 h) {
+  if (ACT == 0) {
+    const ln_f32x2 a = ln_gelu2(ln_f32x2{h[0], h[1]}), b = ln_gelu2(ln_f32x2{h[2], h[3]});
+    return f32x4{a.x, a.y, b.x, b.y};
+  }
+  return f32x4{fmaxf(h[0], 0.f), fmaxf(h[1], 0.f), fmaxf(h[2], 0.f), fmaxf(h[3], 0.f)};
 }
 template <int ACT>
-__device__ __forceinline__ float act_grad(float h) {
-  return ACT == 0 ? ln_gelu_grad2(ln_f32x2{h, h}).x : (h > 0.f ? 1.f : 0.f);
+__device__ __forceinline__ f32x4 act_grad4(const f32x4 h) {
+  if (ACT == 0) {
+    const ln_f32x2 a = ln_gelu_grad2(ln_f32x2{h[0], h[1]}), b = ln_gelu_grad2(ln_f32x2{h[2], h[3]});
+    return f32x4{a.x, a.y, b.x, b.y};
+  }
+  return f32x4{h[0] > 0.f ? 1.f : 0.f, h[1] > 0.f ? 1.f : 0.f, h[2] > 0.f ? 1.f : 0.f, h[3] > 0.f ? 1.f : 0.f};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shared front of the attention block (forward and the recompute of the backward):
-//   xs <- x rows of the tile;  V = Wv x + bv;  xs += pos;  Q | K = Wqk (x + pos) + bqk   -> qs [64][Q | K | V]
 struct TileMeta {
   int rows[TM];   // flat token row of each slot, -1 = empty
   int span[TM];   // lo | hi << 8: the slots of the slot's window; 0 for an empty slot
 };
-
-__device__ __forceinline__ void attn_front(const uint16_t* __restrict__ x, const uint16_t* __restrict__ pos,
-                                           const uint16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                           const TileMeta* tm, uint16_t* xs, uint16_t* qs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  // x -> xs, the matching pieces of pos kept in registers until V has been computed
-  u32x4 pv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = threadIdx.x + j * kThreads, s = i >> 4, p = i & 15;
-    const int r = tm->rows[s];
-    u32x4 v = {0u, 0u, 0u, 0u};
-    pv[j] = u32x4{0u, 0u, 0u, 0u};
-    if (r >= 0) {
-      v = *(const u32x4*)(x + (int64_t)r * E + p * 8);
-      if (pos) pv[j] = *(const u32x4*)(pos + (int64_t)r * E + p * 8);
-    }
-    *(u32x4*)(xs + s * LDX + p * 8) = v;
+__device__ __forceinline__ void load_meta(const int tid_, TileMeta* tm, const int32_t* tile_rows, const int32_t* tile_span, int64_t tile) {
+  if (tid_ < TM) {
+    tm->rows[tid_] = tile_rows[tile * TM + tid_];
+    tm->span[tid_] = tile_span[tile * TM + tid_];
   }
+}
+
+// Front of the attention block (forward, and the recompute of the backward), given the x / pos pieces of the tile in
+// registers and the V fragments of the in-projection already requested (fv):
+//   xs <- x;  V = Wv x + bv;  xs <- bf16(x + pos);  Q | K = Wqk (x + pos) + bqk   -> qs [64][Q | K | V].
+// Weight fragments are always requested one phase ahead of the GEMM that uses them, so that their L2 latency runs
+// under the previous phase: Wqk during the V GEMM, and the caller's `after_qk` (the out-projection's) during Q | K.
+// `first` runs behind the first barrier (the caller loads the next tile's meta there), `between` after the pos pieces
+// have been consumed (the caller fetches the next tile's rows there: its meta is visible by then).
+template <int NW, bool RES, typename F0, typename F, typename F2>
+__device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __restrict__ wqkv, const bf16x8 (&fv)[8 / NW][4],
+                                           const bf16x8 (&fqk_res)[16 / NW][4], const float* __restrict__ bqkv,
+                                           TilePieces<NW>& xv, TilePieces<NW>& pv, bool has_pos, uint16_t* xs,
+                                           uint16_t* qs, F0 first, F between, F2 after_qk) {
+  const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  constexpr int NQK = 16 / NW, NV = 8 / NW;
+  xv.stash(xs, LDX);
   __syncthreads();
+  first();   // every thread has left the previous tile behind
+  bf16x8 fqk[NQK][4];
   {
-    f32x4 acc[2][4];
+    f32x4 acc[NV][4];
     zero_acc(acc);
-    tile_gemm<2, 4>(wqkv, 16 + 2 * wave, xs, LDX, acc);   // V: channel blocks 16..23 of the in-projection
+    tile_gemm<NV, 4>(tid_, fv, xs, LDX, acc);
+    if (!RES) load_frags<NQK, 4>(tid_, wqkv, NQK * wave, fqk);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int n = 16 * (16 + 2 * wave + nb) + 4 * g;
+    for (int nb = 0; nb < NV; ++nb) {
+      const int n = 16 * (16 + NV * wave + nb) + 4 * g;
       const f32x4 b = *(const f32x4*)(bqkv + n);
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(acc[nb][mb] + b);
     }
   }
   __syncthreads();
+  if (has_pos) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {   // xs <- bf16(x + pos), in place, every thread its own pieces
-    const int i = threadIdx.x + j * kThreads, s = i >> 4, p = i & 15;
-    u32x4 v = *(const u32x4*)(xs + s * LDX + p * 8);
-    v.x = add_bf16x2(v.x, pv[j].x);
-    v.y = add_bf16x2(v.y, pv[j].y);
-    v.z = add_bf16x2(v.z, pv[j].z);
-    v.w = add_bf16x2(v.w, pv[j].w);
-    if (pos) *(u32x4*)(xs + s * LDX + p * 8) = v;
+    for (int j = 0; j < TilePieces<NW>::P; ++j) {   // xs <- bf16(x + pos), every thread its own pieces
+      xv.v[j].x = add_bf16x2(xv.v[j].x, pv.v[j].x);
+      xv.v[j].y = add_bf16x2(xv.v[j].y, pv.v[j].y);
+      xv.v[j].z = add_bf16x2(xv.v[j].z, pv.v[j].z);
+      xv.v[j].w = add_bf16x2(xv.v[j].w, pv.v[j].w);
+    }
+    xv.stash(xs, LDX);
   }
+  between();
   __syncthreads();
   {
-    f32x4 acc[4][4];
+    f32x4 acc[NQK][4];
     zero_acc(acc);
-    tile_gemm<4, 4>(wqkv, 4 * wave, xs, LDX, acc);        // Q | K: channel blocks 0..15
+    if (RES) tile_gemm<NQK, 4>(tid_, fqk_res, xs, LDX, acc);
+    else tile_gemm<NQK, 4>(tid_, fqk, xs, LDX, acc);
+    after_qk();
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int n = 16 * (4 * wave + nb) + 4 * g;
+    for (int nb = 0; nb < NQK; ++nb) {
+      const int n = 16 * (NQK * wave + nb) + 4 * g;
       const f32x4 b = *(const f32x4*)(bqkv + n);
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(acc[nb][mb] + b);
@@ -314,8 +361,8 @@ __device__ __forceinline__ void attn_front(const uint16_t* __restrict__ x, const
 }
 
 // key-tile range [lo, hi] that the 16 queries of query tile qt can see (union of their windows); hi < lo: none
-__device__ __forceinline__ void tile_range(const TileMeta* tm, int qt, int& klo, int& khi) {
-  const int c = threadIdx.x & 15;
+__device__ __forceinline__ void tile_range(const int tid_, const TileMeta* tm, int qt, int& klo, int& khi) {
+  const int c = tid_ & 15;
   const int sp = tm->span[qt * 16 + c];
   int lo = sp & 255, hi = sp >> 8;
   int a = hi > lo ? (lo >> 4) : 99, b = hi > lo ? ((hi - 1) >> 4) : -1;
@@ -324,16 +371,16 @@ __device__ __forceinline__ void tile_range(const TileMeta* tm, int qt, int& klo,
     a = min(a, __shfl_xor(a, m, 64));
     b = max(b, __shfl_xor(b, m, 64));
   }
-  klo = a;
-  khi = b;
+  klo = __builtin_amdgcn_readfirstlane(a);   // (every lane holds the same pair: scalar branches on the tile range)
+  khi = __builtin_amdgcn_readfirstlane(b);
 }
 
 // Attention of head h for the 16 queries of tile qt (lane: query c): S^T = K Q^T (16x16x16 MFMA, keys on the rows),
 // softmax over the keys of the query's window in registers, O^T = V^T P^T (16x16x32 MFMA, V^T by transposing reads).
 // Returns o (d = 4g + r of query c) and the log-sum-exp of the query.
-__device__ __forceinline__ f32x4 attn_head_fwd(const uint16_t* qs, int h, int qt, int klo, int khi, int span_q,
+__device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* qs, int h, int qt, int klo, int khi, int span_q,
                                                float& lse) {
-  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int lane = tid_ & 63, c = lane & 15, g = lane >> 4;
   const int q_ = c >> 2, p_ = c & 3;
   const uint16_t* qh = qs + h * HD;
   const uint16_t* kh = qs + E + h * HD;
@@ -362,13 +409,18 @@ __device__ __forceinline__ f32x4 attn_head_fwd(const uint16_t* qs, int h, int qt
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < 4; ++kt) {
+    if (kt >= klo && kt <= khi) {   // (a window of ~10 tokens touches one or two of the four key tiles)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = m > -INFINITY ? __expf(s[kt][r] - m) : 0.f;
-      s[kt][r] = e;
-      sum += e;
+      for (int r = 0; r < 4; ++r) {
+        const float e = m > -INFINITY ? __expf(s[kt][r] - m) : 0.f;
+        s[kt][r] = e;
+        sum += e;
+      }
+    } else {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
@@ -385,80 +437,128 @@ __device__ __forceinline__ f32x4 attn_head_fwd(const uint16_t* qs, int h, int qt
   return o;
 }
 
-constexpr int kAttnLds = (TM * LDX + TM * LDQ) * 2 + 2 * 4 * TM * 4 + (int)sizeof(TileMeta) + NH * TM * 4;
+// all heads of the tile: wave w runs heads [w * 8 / NW, (w + 1) * 8 / NW); o -> os (row stride LDX), lse -> lse_s or null
+template <int NW>
+__device__ __forceinline__ void attn_tile_fwd(const int tid_, const TileMeta* tm, const uint16_t* qs, uint16_t* os, float* lse_s) {
+  const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  for (int qt = 0; qt < 4; ++qt) {
+    int klo, khi;
+    tile_range(tid_, tm, qt, klo, khi);
+    const int sp = tm->span[qt * 16 + c];
+#pragma unroll
+    for (int hh = 0; hh < NH / NW; ++hh) {
+      const int h = (NH / NW) * wave + hh;
+      float lse;
+      const f32x4 o = attn_head_fwd(tid_, qs, h, qt, klo, khi, sp, lse);
+      *(u32x2*)(os + (qt * 16 + c) * LDX + h * HD + 4 * g) = pack4(o);
+      if (lse_s && g == 0) lse_s[h * TM + qt * 16 + c] = lse;
+    }
+  }
+}
+
+template <int NW_>
+constexpr int attn_lds() {
+  return (TM * LDX + TM * LDQ) * 2 + 2 * NW_ * TM * 4 + 2 * (int)sizeof(TileMeta) + NH * TM * 4;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kThreads, 2)
+// All four block kernels: persistent workgroups of 4 waves, two per CU, looping over tiles.  The x (/ pos) rows of the
+// next tile are fetched into registers while this one computes; weight fragments are requested one GEMM ahead.
+constexpr int NW = 4;
+
+// Forward of the attention block.
+__global__ void __launch_bounds__(256, 2)
 window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ pos,
                              const int32_t* __restrict__ tile_rows, const int32_t* __restrict__ tile_span,
-                             const uint16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
+                             int64_t num_tiles, const uint16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
                              const uint16_t* __restrict__ wo, const float* __restrict__ bo,
                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                              uint16_t* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint16_t* xs = (uint16_t*)smem;                 // x | x + pos | attention output | y staging
-  uint16_t* qs = xs + TM * LDX;                   // Q | K | V
+  uint16_t* xs = (uint16_t*)smem;                 // x | x + pos | attention output
+  uint16_t* qs = xs + TM * LDX;                   // Q | K | V, then y staging
   float* red0 = (float*)(qs + TM * LDQ);
-  float* red1 = red0 + 4 * TM;
-  TileMeta* tm = (TileMeta*)(red1 + 4 * TM);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int64_t tile = blockIdx.x;
-  if (threadIdx.x < TM) {
-    tm->rows[threadIdx.x] = tile_rows[tile * TM + threadIdx.x];
-    tm->span[threadIdx.x] = tile_span[tile * TM + threadIdx.x];
-  }
+  float* red1 = red0 + NW * TM;
+  TileMeta* tms = (TileMeta*)(red1 + NW * TM);    // [2]: this tile's and the next one's
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  bf16x8 fv[2][4], fo[2][4], fqk_none[4][4] = {};   // (fqk_none: unused, the forward streams Wqk inside attn_front)
+  load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);
+  int64_t tile = blockIdx.x;
+  load_meta(tid_, &tms[0], tile_rows, tile_span, tile);
   __syncthreads();
-  attn_front(x, pos, wqkv, bqkv, tm, xs, qs);
-  // attention: wave w runs heads 2w, 2w + 1; the output goes where x + pos was (its last reader was the Q | K GEMM)
-  for (int qt = 0; qt < 4; ++qt) {
-    int klo, khi;
-    tile_range(tm, qt, klo, khi);
-    const int sp = tm->span[qt * 16 + c];
+  TilePieces<NW> xv, pv;
+  xv.fetch(x, tms[0].rows, 0, 0);
+  pv.fetch(pos, tms[0].rows, 0, 0);
+#pragma unroll 1
+  for (int it = 0; tile < num_tiles; tile += gridDim.x, ++it) {
+    // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
+    // arithmetic that hangs on them would sit in ~100 registers for the whole kernel)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+    const TileMeta* tm = &tms[it & 1];
+    const int64_t next = tile + gridDim.x;
+    // the residual (x at the lanes' output positions) is asked for now and used after the attention
+    u32x2 res[2][4];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      float lse;
-      const f32x4 o = attn_head_fwd(qs, h, qt, klo, khi, sp, lse);
-      *(u32x2*)(xs + (qt * 16 + c) * LDX + h * HD + 4 * g) = pack4(o);
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int r = tm->rows[mb * 16 + c];
+        res[nb][mb] = u32x2{0u, 0u};
+        if (r >= 0) res[nb][mb] = *(const u32x2*)(x + (int64_t)r * E + 16 * (2 * wave + nb) + 4 * g);
+      }
+    attn_front<NW, false>(tid_, 
+        wqkv, fv, fqk_none, bqkv, xv, pv, pos != nullptr, xs, qs,
+        [&]() {
+          if (next < num_tiles) load_meta(tid_, &tms[(it & 1) ^ 1], tile_rows, tile_span, next);
+        },
+        [&]() {
+          if (next < num_tiles) {   // (the next tile's meta: written behind the first barrier, read behind the second)
+            xv.fetch(x, tms[(it & 1) ^ 1].rows, 0, 0);
+            pv.fetch(pos, tms[(it & 1) ^ 1].rows, 0, 0);
+          }
+        },
+        [&]() { load_frags<2, 4>(tid_, wo, 2 * wave, fo); });
+    attn_tile_fwd<NW>(tid_, tm, qs, xs, nullptr);   // o goes where x + pos was (its last reader was the Q | K GEMM)
+    __syncthreads();
+    f32x4 z[2][4];
+    zero_acc(z);
+    tile_gemm<2, 4>(tid_, fo, xs, LDX, z);
+    load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);    // the next tile's first GEMM
+    f32x4 gam[2], bet[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = 16 * (2 * wave + nb) + 4 * g;
+      const f32x4 b = *(const f32x4*)(bo + n);
+      gam[nb] = *(const f32x4*)(ln_w + n);
+      bet[nb] = *(const f32x4*)(ln_b + n);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) z[nb][mb] = z[nb][mb] + b + unpack4(res[nb][mb]);
     }
-  }
-  __syncthreads();
-  // out-projection + residual + LayerNorm
-  f32x4 z[2][4];
-  zero_acc(z);
-  tile_gemm<2, 4>(wo, 2 * wave, xs, LDX, z);
-  f32x4 gam[2], bet[2];
+    float rstd[4];
+    tile_layernorm<NW, 2>(tid_, z, eps, red0, red1, rstd);
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-    const f32x4 b = *(const f32x4*)(bo + n);
-    gam[nb] = *(const f32x4*)(ln_w + n);
-    bet[nb] = *(const f32x4*)(ln_b + n);
+    for (int nb = 0; nb < 2; ++nb) {   // y staged over Q | K | V (last read by the attention, two barriers ago)
+      const int n = 16 * (2 * wave + nb) + 4 * g;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int r = tm->rows[mb * 16 + c];
-      f32x4 res = {0.f, 0.f, 0.f, 0.f};
-      if (r >= 0) res = unpack4(*(const u32x2*)(x + (int64_t)r * E + n));
-      z[nb][mb] = z[nb][mb] + b + res;
+      for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
     }
+    __syncthreads();
+    tile_store_rows<NW, E>(qs, LDQ, y, tm->rows, 0, 0);
+    // (the next iteration writes xs before its first barrier: xs was last read by the out-projection GEMM, before the
+    // LayerNorm barriers; it writes qs and this tile's meta slot only behind that barrier)
   }
-  float rstd[4];
-  tile_layernorm(z, eps, red0, red1, rstd);   // (its first barrier also ends every wave's reads of xs)
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
-  }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, y, tm->rows, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kFfnLds = (TM * LDX + TM * LDH) * 2 + 2 * 4 * TM * 4;
+template <int NW_>
+constexpr int ffn_lds() {
+  return (TM * LDX + TM * LDH) * 2 + 2 * NW_ * TM * 4;
+}
 
 template <int ACT>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(256, 2)
 token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, const uint16_t* __restrict__ w1,
                            const float* __restrict__ b1, const uint16_t* __restrict__ w2, const float* __restrict__ b2,
                            const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
@@ -467,62 +567,79 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
   uint16_t* xs = (uint16_t*)smem;
   uint16_t* hs = xs + TM * LDX;
   float* red0 = (float*)(hs + TM * LDH);
-  float* red1 = red0 + 4 * TM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TM;
-  tile_load_rows(xs, LDX, x, nullptr, row0, num_tokens);
-  __syncthreads();
-  {
-    f32x4 acc[4][4];
-    zero_acc(acc);
-    tile_gemm<4, 4>(w1, 4 * wave, xs, LDX, acc);
+  float* red1 = red0 + NW * TM;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  bf16x8 f1[4][4], f2[2][8];
+  load_frags<4, 4>(tid_, w1, 4 * wave, f1);
+  const int64_t tiles = (num_tokens + TM - 1) / TM;
+  int64_t tile = blockIdx.x;
+  TilePieces<NW> xv;
+  xv.fetch(x, nullptr, tile * TM, num_tokens);
+#pragma unroll 1
+  for (; tile < tiles; tile += gridDim.x) {
+    // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
+    // arithmetic that hangs on them would sit in ~100 registers for the whole kernel)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+    const int64_t row0 = tile * TM;
+    xv.stash(xs, LDX);
+    if (tile + gridDim.x < tiles) xv.fetch(x, nullptr, (tile + gridDim.x) * TM, num_tokens);
+    __syncthreads();
+    {
+      f32x4 acc[4][4];
+      zero_acc(acc);
+      tile_gemm<4, 4>(tid_, f1, xs, LDX, acc);
+      load_frags<2, 8>(tid_, w2, 2 * wave, f2);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int n = 16 * (4 * wave + nb) + 4 * g;
-      const f32x4 b = *(const f32x4*)(b1 + n);
+      for (int nb = 0; nb < 4; ++nb) {
+        const int n = 16 * (4 * wave + nb) + 4 * g;
+        const f32x4 b = *(const f32x4*)(b1 + n);
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        f32x4 h = acc[nb][mb] + b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = act_fwd<ACT>(h[r]);
-        *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(h);
+        for (int mb = 0; mb < 4; ++mb) *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(act_fwd4<ACT>(acc[nb][mb] + b));
       }
     }
+    __syncthreads();
+    f32x4 z[2][4];
+    zero_acc(z);
+    tile_gemm<2, 8>(tid_, f2, hs, LDH, z);
+    load_frags<4, 4>(tid_, w1, 4 * wave, f1);           // the next tile's first GEMM
+    f32x4 gam[2], bet[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = 16 * (2 * wave + nb) + 4 * g;
+      const f32x4 b = *(const f32x4*)(b2 + n);
+      gam[nb] = *(const f32x4*)(ln_w + n);
+      bet[nb] = *(const f32x4*)(ln_b + n);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        z[nb][mb] = z[nb][mb] + b + unpack4(*(const u32x2*)(xs + (mb * 16 + c) * LDX + n));
+    }
+    float rstd[4];
+    tile_layernorm<NW, 2>(tid_, z, eps, red0, red1, rstd);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = 16 * (2 * wave + nb) + 4 * g;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
+    }
+    __syncthreads();
+    tile_store_rows<NW, E>(hs, LDH, y, nullptr, row0, num_tokens);
   }
-  __syncthreads();
-  f32x4 z[2][4];
-  zero_acc(z);
-  tile_gemm<2, 8>(w2, 2 * wave, hs, LDH, z);
-  f32x4 gam[2], bet[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-    const f32x4 b = *(const f32x4*)(b2 + n);
-    gam[nb] = *(const f32x4*)(ln_w + n);
-    bet[nb] = *(const f32x4*)(ln_b + n);
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-      z[nb][mb] = z[nb][mb] + b + unpack4(*(const u32x2*)(xs + (mb * 16 + c) * LDX + n));
-  }
-  float rstd[4];
-  tile_layernorm(z, eps, red0, red1, rstd);
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
-  }
-  __syncthreads();
-  tile_store_rows<E>(hs, LDH, y, nullptr, row0, num_tokens);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The two backward kernels carry more live values per lane than the forward ones (act'(h), the LayerNorm gradient, the
+// three gradients of a head): with 4 waves per tile they spilled ~200 registers.  They run 8 waves per tile, one
+// workgroup per CU -- every wave owns half as many channel blocks (and one head) -- and request a GEMM's fragments
+// when it starts rather than one GEMM ahead.
+//
 // Backward of the FFN block.  In: x (= y1), dy (gradient of y2).  Out: dx (gradient of y1, residual path included),
-// and the weight-gradient operands a = act(h) [*,256], dh [*,256], dz [*,128] (gradient at the LN input), plus one row
-// of LN parameter-gradient partial sums per tile.  act'(h) stays (as bf16) in the registers of the lanes that computed h: the
-// gradient of act(h) arrives in the same lanes, because the two GEMMs have the same shape.
+// and the weight-gradient operands a = act(h) [*,256], dh [*,256], dz [*,128] (gradient at the LN input), plus one
+// row of LN parameter-gradient partial sums per workgroup.  act'(h) stays (as bf16) in the registers of the lanes
+// that computed h: the gradient of act(h) arrives in the same lanes, because the two GEMMs have the same shape.
 template <int ACT>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(512, 2)
 token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int64_t num_tokens,
                            const uint16_t* __restrict__ w1, const float* __restrict__ b1,
                            const uint16_t* __restrict__ w2, const float* __restrict__ b2,
@@ -530,328 +647,351 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
                            const uint16_t* __restrict__ w1t, uint16_t* __restrict__ dx, uint16_t* __restrict__ a_out,
                            uint16_t* __restrict__ dh_out, uint16_t* __restrict__ dz_out,
                            float* __restrict__ ln_partial) {
+  constexpr int NW = 8;                // (shadows the file-wide 4: see the comment on the backward kernels above)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* xs = (uint16_t*)smem;      // y1 | dz2 | dx staging
   uint16_t* hs = xs + TM * LDX;        // act(h) | dh
   float* red0 = (float*)(hs + TM * LDH);
-  float* red1 = red0 + 4 * TM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TM;
-  tile_load_rows(xs, LDX, x, nullptr, row0, num_tokens);
-  __syncthreads();
-  u32x2 gact[4][4];   // act'(h) of the lane's 64 pre-activations, packed bf16 (the d act GEMM below has the same shape)
-  {
-    f32x4 hpre[4][4];
-    zero_acc(hpre);
-    tile_gemm<4, 4>(w1, 4 * wave, xs, LDX, hpre);
+  float* red1 = red0 + NW * TM;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  // (fragments are requested when a GEMM starts, not one GEMM ahead: see above)
+  const f32x4 gam[1] = {*(const f32x4*)(ln_w + 16 * wave + 4 * g)};
+  f32x4 dgam[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dbet[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int64_t tiles = (num_tokens + TM - 1) / TM;
+  int64_t tile = blockIdx.x;
+  TilePieces<NW> xv;
+  xv.fetch(x, nullptr, tile * TM, num_tokens);
+#pragma unroll 1
+  for (; tile < tiles; tile += gridDim.x) {
+    // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
+    // arithmetic that hangs on them would sit in ~100 registers for the whole kernel)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+    const int64_t row0 = tile * TM;
+    xv.stash(xs, LDX);
+    if (tile + gridDim.x < tiles) xv.fetch(x, nullptr, (tile + gridDim.x) * TM, num_tokens);
+    __syncthreads();
+    const int n1 = 16 * wave + 4 * g;   // the lane's 4 channels of the 128-wide tensors
+    u32x2 gact[2][4];
+    {
+      bf16x8 f[2][4];
+      load_frags<2, 4>(tid_, w1, 2 * wave, f);
+      f32x4 hpre[2][4];
+      zero_acc(hpre);
+      tile_gemm<2, 4>(tid_, f, xs, LDX, hpre);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int n = 16 * (4 * wave + nb) + 4 * g;
-      const f32x4 b = *(const f32x4*)(b1 + n);
+      for (int nb = 0; nb < 2; ++nb) {
+        const int n = 16 * (2 * wave + nb) + 4 * g;
+        const f32x4 b = *(const f32x4*)(b1 + n);
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const f32x4 hp = hpre[nb][mb] + b;
-        f32x4 h, dh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = act_fwd<ACT>(hp[r]);
-          dh[r] = act_grad<ACT>(hp[r]);
+        for (int mb = 0; mb < 4; ++mb) {
+          const f32x4 hp = hpre[nb][mb] + b;
+          gact[nb][mb] = pack4(act_grad4<ACT>(hp));
+          *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(act_fwd4<ACT>(hp));
         }
-        gact[nb][mb] = pack4(dh);
-        *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(h);
       }
     }
-  }
-  __syncthreads();
-  tile_store_rows<FF>(hs, LDH, a_out, nullptr, row0, num_tokens);
-  f32x4 z[2][4];
-  zero_acc(z);
-  tile_gemm<2, 8>(w2, 2 * wave, hs, LDH, z);
-  f32x4 gam[2], dgam[2], dbet[2];
-  f32x4 dz[2][4];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-    const f32x4 b = *(const f32x4*)(b2 + n);
-    gam[nb] = *(const f32x4*)(ln_w + n);
-    dgam[nb] = dbet[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      z[nb][mb] = z[nb][mb] + b + unpack4(*(const u32x2*)(xs + (mb * 16 + c) * LDX + n));
-      const int64_t r = row0 + mb * 16 + c;
-      dz[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (r < num_tokens) dz[nb][mb] = unpack4(*(const u32x2*)(dy + r * E + n));
+    __syncthreads();
+    tile_store_rows<NW, FF>(hs, LDH, a_out, nullptr, row0, num_tokens);
+    f32x4 z[1][4], dz[1][4];
+    zero_acc(z);
+    {
+      bf16x8 f[1][8];
+      load_frags<1, 8>(tid_, w2, wave, f);
+      tile_gemm<1, 8>(tid_, f, hs, LDH, z);
     }
-  }
-  float rstd[4];
-  tile_layernorm(z, eps, red0, red1, rstd);                       // z = xhat2
-  tile_layernorm_bwd(z, dz, gam, rstd, red0, red1, dgam, dbet);   // dz = gradient at the LN input (f32)
-  store_param_partials(dgam, dbet, 2 * wave, ln_partial + (int64_t)blockIdx.x * 2 * E);
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {   // (every wave is past its reads of y1: the barriers of the LN sums)
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(dz[nb][mb]);
-  }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, dz_out, nullptr, row0, num_tokens);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {   // two channel-block pairs at a time: h, d act and the fragments share 256 registers
-    f32x4 da[2][4];
-    zero_acc(da);
-    tile_gemm<2, 4>(w2t, 4 * wave + 2 * half, xs, LDX, da);   // d act(h) = W2^T dz
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int n = 16 * (4 * wave + 2 * half + nb) + 4 * g;
+    {
+      const f32x4 b = *(const f32x4*)(b2 + n1);
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        const f32x4 d = da[nb][mb] * unpack4(gact[2 * half + nb][mb]);
-        *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(d);   // over act(h): its last reader was the W2 GEMM
+        z[0][mb] = z[0][mb] + b + unpack4(*(const u32x2*)(xs + (mb * 16 + c) * LDX + n1));
+        const int64_t r = row0 + mb * 16 + c;
+        dz[0][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < num_tokens) dz[0][mb] = unpack4(*(const u32x2*)(dy + r * E + n1));
       }
     }
-  }
-  __syncthreads();
-  tile_store_rows<FF>(hs, LDH, dh_out, nullptr, row0, num_tokens);
-  f32x4 gx[2][4];
-  zero_acc(gx);
-  tile_gemm<2, 8>(w1t, 2 * wave, hs, LDH, gx);     // W1^T dh
-  // (the dz tile in xs -- B operand of the d act GEMM, source of dz_out -- was last read before the barrier above)
+    float rstd[4];
+    tile_layernorm<NW, 1>(tid_, z, eps, red0, red1, rstd);                       // z = xhat2
+    tile_layernorm_bwd<NW, 1>(tid_, z, dz, gam, rstd, red0, red1, dgam, dbet);   // dz = gradient at the LN input (f32)
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
+    for (int mb = 0; mb < 4; ++mb)   // (every wave is past its reads of y1: the barriers of the LN sums)
+      *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(dz[0][mb]);
+    __syncthreads();
+    tile_store_rows<NW, E>(xs, LDX, dz_out, nullptr, row0, num_tokens);
+    {
+      bf16x8 f[2][4];
+      load_frags<2, 4>(tid_, w2t, 2 * wave, f);
+      f32x4 da[2][4];
+      zero_acc(da);
+      tile_gemm<2, 4>(tid_, f, xs, LDX, da);           // d act(h) = W2^T dz
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(gx[nb][mb] + dz[nb][mb]);
+      for (int nb = 0; nb < 2; ++nb) {
+        const int n = 16 * (2 * wave + nb) + 4 * g;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)           // over act(h): its last reader was the W2 GEMM
+          *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(da[nb][mb] * unpack4(gact[nb][mb]));
+      }
+    }
+    __syncthreads();
+    tile_store_rows<NW, FF>(hs, LDH, dh_out, nullptr, row0, num_tokens);
+    f32x4 gx[1][4];
+    zero_acc(gx);
+    {
+      bf16x8 f[1][8];
+      load_frags<1, 8>(tid_, w1t, wave, f);
+      tile_gemm<1, 8>(tid_, f, hs, LDH, gx);           // W1^T dh
+    }
+    // (the dz tile in xs -- B operand of the d act GEMM, source of dz_out -- was last read before the barrier above)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(gx[0][mb] + dz[0][mb]);
+    __syncthreads();
+    tile_store_rows<NW, E>(xs, LDX, dx, nullptr, row0, num_tokens);
+    __syncthreads();   // the next tile's y1 goes into xs
   }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, dx, nullptr, row0, num_tokens);
+  store_param_partials<1>(tid_, dgam, dbet, wave, ln_partial + (int64_t)blockIdx.x * 2 * E);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of the attention block.  In: x, pos, dy (gradient of y1).  Out: dx, and for the weight gradients dqkv
-// [*,384], o (attention output) [*,128], dz (gradient at the LN input) [*,128]; LN partial sums per tile.
-__global__ void __launch_bounds__(kThreads, 2)
+// [*,384], o (attention output) [*,128], dz (gradient at the LN input) [*,128]; LN partial sums per workgroup.
+__global__ void __launch_bounds__(512, 2)
 window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ pos,
                              const uint16_t* __restrict__ dy, const int32_t* __restrict__ tile_rows,
-                             const int32_t* __restrict__ tile_span, const uint16_t* __restrict__ wqkv,
-                             const float* __restrict__ bqkv, const uint16_t* __restrict__ wo,
-                             const float* __restrict__ bo, const float* __restrict__ ln_w, float eps,
-                             const uint16_t* __restrict__ wot, const uint16_t* __restrict__ wqkvt,
-                             uint16_t* __restrict__ dx, uint16_t* __restrict__ dqkv_out,
-                             uint16_t* __restrict__ dz_out, uint16_t* __restrict__ o_out,
-                             float* __restrict__ ln_partial) {
+                             const int32_t* __restrict__ tile_span, int64_t num_tiles,
+                             const uint16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
+                             const uint16_t* __restrict__ wo, const float* __restrict__ bo,
+                             const float* __restrict__ ln_w, float eps, const uint16_t* __restrict__ wot,
+                             const uint16_t* __restrict__ wqkvt, uint16_t* __restrict__ dx,
+                             uint16_t* __restrict__ dqkv_out, uint16_t* __restrict__ dz_out,
+                             uint16_t* __restrict__ o_out, float* __restrict__ ln_partial) {
+  constexpr int NW = 8;                           // one head per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* xs = (uint16_t*)smem;                 // x | x + pos | o | dz1 | dO | dx staging
   uint16_t* qs = xs + TM * LDX;                   // Q | K | V, then dQ | dK | dV in place
   float* red0 = (float*)(qs + TM * LDQ);
-  float* red1 = red0 + 4 * TM;
-  TileMeta* tm = (TileMeta*)(red1 + 4 * TM);
-  float* lse_s = (float*)(tm + 1);                // [8 heads][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int q_ = c >> 2, p_ = c & 3;
-  const int64_t tile = blockIdx.x;
-  if (threadIdx.x < TM) {
-    tm->rows[threadIdx.x] = tile_rows[tile * TM + threadIdx.x];
-    tm->span[threadIdx.x] = tile_span[tile * TM + threadIdx.x];
-  }
+  float* red1 = red0 + NW * TM;
+  TileMeta* tms = (TileMeta*)(red1 + NW * TM);
+  float* lse_s = (float*)(tms + 2);               // [8 heads][64]
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  bf16x8 fv[1][4], fqk_none[2][4] = {};
+  load_frags<1, 4>(tid_, wqkv, 16 + wave, fv);
+  const f32x4 gam[1] = {*(const f32x4*)(ln_w + 16 * wave + 4 * g)};
+  f32x4 dgam[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dbet[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+  int64_t tile = blockIdx.x;
+  load_meta(tid_, &tms[0], tile_rows, tile_span, tile);
   __syncthreads();
-  attn_front(x, pos, wqkv, bqkv, tm, xs, qs);
-  for (int qt = 0; qt < 4; ++qt) {
-    int klo, khi;
-    tile_range(tm, qt, klo, khi);
-    const int sp = tm->span[qt * 16 + c];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int h = 2 * wave + hh;
-      float lse;
-      const f32x4 o = attn_head_fwd(qs, h, qt, klo, khi, sp, lse);
-      *(u32x2*)(xs + (qt * 16 + c) * LDX + h * HD + 4 * g) = pack4(o);
-      if (g == 0) lse_s[h * TM + qt * 16 + c] = lse;
-    }
-  }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, o_out, tm->rows, 0, 0);
-  f32x4 z[2][4];
-  zero_acc(z);
-  tile_gemm<2, 4>(wo, 2 * wave, xs, LDX, z);
-  f32x4 gam[2], dgam[2], dbet[2];
-  f32x4 dz[2][4];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-    const f32x4 b = *(const f32x4*)(bo + n);
-    gam[nb] = *(const f32x4*)(ln_w + n);
-    dgam[nb] = dbet[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  TilePieces<NW> xv, pv;
+  xv.fetch(x, tms[0].rows, 0, 0);
+  pv.fetch(pos, tms[0].rows, 0, 0);
+#pragma unroll 1
+  for (int it = 0; tile < num_tiles; tile += gridDim.x, ++it) {
+    // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
+    // arithmetic that hangs on them would sit in ~100 registers for the whole kernel)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+    const int q_ = c >> 2, p_ = c & 3;
+    const TileMeta* tm = &tms[it & 1];
+    const int64_t next = tile + gridDim.x;
+    attn_front<NW, false>(tid_, 
+        wqkv, fv, fqk_none, bqkv, xv, pv, pos != nullptr, xs, qs,
+        [&]() {
+          if (next < num_tiles) load_meta(tid_, &tms[(it & 1) ^ 1], tile_rows, tile_span, next);
+        },
+        [&]() {
+          if (next < num_tiles) {
+            xv.fetch(x, tms[(it & 1) ^ 1].rows, 0, 0);
+            pv.fetch(pos, tms[(it & 1) ^ 1].rows, 0, 0);
+          }
+        },
+        [&]() {});
+    // the residual and dy at the lanes' output positions: asked for now, used after the attention
+    const int n1 = 16 * wave + 4 * g;   // the lane's 4 channels of the 128-wide tensors
+    u32x2 res[4];
+    f32x4 dz[1][4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
       const int r = tm->rows[mb * 16 + c];
-      f32x4 res = {0.f, 0.f, 0.f, 0.f};
-      dz[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      res[mb] = u32x2{0u, 0u};
+      dz[0][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (r >= 0) {
-        res = unpack4(*(const u32x2*)(x + (int64_t)r * E + n));
-        dz[nb][mb] = unpack4(*(const u32x2*)(dy + (int64_t)r * E + n));
+        res[mb] = *(const u32x2*)(x + (int64_t)r * E + n1);
+        dz[0][mb] = unpack4(*(const u32x2*)(dy + (int64_t)r * E + n1));
       }
-      z[nb][mb] = z[nb][mb] + b + res;
     }
-  }
-  float rstd[4];
-  tile_layernorm(z, eps, red0, red1, rstd);
-  tile_layernorm_bwd(z, dz, gam, rstd, red0, red1, dgam, dbet);   // dz = dz1, kept in registers for the residual
-  store_param_partials(dgam, dbet, 2 * wave, ln_partial + tile * 2 * E);
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {   // over o: every wave is past the out-projection GEMM and the o_out copy
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(dz[nb][mb]);
-  }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, dz_out, tm->rows, 0, 0);
-  {
-    f32x4 go[2][4];
-    zero_acc(go);
-    tile_gemm<2, 4>(wot, 2 * wave, xs, LDX, go);   // dO = Wo^T dz1
-    __syncthreads();                                // dz1 tile: read by every wave's GEMM and by the copy above
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(go[nb][mb]);
+    attn_tile_fwd<NW>(tid_, tm, qs, xs, lse_s);
+    __syncthreads();
+    tile_store_rows<NW, E>(xs, LDX, o_out, tm->rows, 0, 0);
+    f32x4 z[1][4];
+    zero_acc(z);
+    {
+      bf16x8 f[1][4];
+      load_frags<1, 4>(tid_, wo, wave, f);
+      tile_gemm<1, 4>(tid_, f, xs, LDX, z);
     }
-  }
-  __syncthreads();
-  // attention backward, wave w: heads 2w, 2w + 1.  Pass 1 (lanes own queries): dQ and delta; pass 2 (lanes own
-  // keys): dK, dV.  Both recompute the probabilities with 16x16x16 MFMAs; the gradients of a head replace its Q, K, V
-  // in place once both passes have read them (only this wave touches the head's columns).
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    const int h = 2 * wave + hh;
-    const uint16_t* qh = qs + h * HD;
-    const uint16_t* kh = qs + E + h * HD;
-    const uint16_t* vh = qs + 2 * E + h * HD;
-    const uint16_t* dh_ = xs + h * HD;              // dO of the head, row stride LDX
-    float* lq = lse_s + h * TM;
-    float* dl = red0;                               // delta of the head's queries: [wave][64] (red0 is free here)
-    f32x4 gq[4], gk[4], gv[4];
+    {
+      const f32x4 b = *(const f32x4*)(bo + n1);
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      int klo, khi;
-      tile_range(tm, qt, klo, khi);
-      const int qi = qt * 16 + c;
-      const int sp = tm->span[qi];
-      const int lo = sp & 255, hi = sp >> 8;
-      const s16x4 bq = ld4(qh + qi * LDQ + 4 * g);
-      const s16x4 bdo = ld4(dh_ + qi * LDX + 4 * g);
-      const float lse_q = lq[qi];
-      f32x4 pT[4], dpT[4];
-      float delta = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        pT[kt] = dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kt >= klo && kt <= khi) {
-          const s16x4 ak = ld4(kh + (kt * 16 + c) * LDQ + 4 * g);
-          const s16x4 av = ld4(vh + (kt * 16 + c) * LDQ + 4 * g);
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bq, zero, 0, 0, 0);    // S^T[key][query]
-          const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bdo, zero, 0, 0, 0);   // dP^T[key][query]
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kt * 16 + 4 * g + r;
-            const float p = (key >= lo && key < hi) ? __expf(sc[r] * 0.25f - lse_q) : 0.f;
-            pT[kt][r] = p;
-            dpT[kt][r] = dp[r];
-            delta += p * dp[r];
-          }
-        }
-      }
-      delta += __shfl_xor(delta, 16, 64);
-      delta += __shfl_xor(delta, 32, 64);
-      if (g == 0) dl[wave * TM + qi] = delta;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (2 * u + 1 >= klo && 2 * u <= khi) {
-          f32x4 d0, d1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            d0[r] = pT[2 * u][r] * (dpT[2 * u][r] - delta) * 0.25f;
-            d1[r] = pT[2 * u + 1][r] * (dpT[2 * u + 1][r] - delta) * 0.25f;
-          }
-          const uint16_t* a0 = kh + (32 * u + 4 * g + q_) * LDQ + 4 * p_;
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(a0, a0 + 16 * LDQ), pack_tiles(d0, d1), acc, 0, 0, 0);
-        }
-      }
-      gq[qt] = acc;   // dQ^T: d = 4g + r of query c
+      for (int mb = 0; mb < 4; ++mb) z[0][mb] = z[0][mb] + b + unpack4(res[mb]);
     }
-    // (delta written by this wave's g == 0 lanes, read below by all its lanes: LDS ops of a wave complete in order)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    float rstd[4];
+    tile_layernorm<NW, 1>(tid_, z, eps, red0, red1, rstd);
+    tile_layernorm_bwd<NW, 1>(tid_, z, dz, gam, rstd, red0, red1, dgam, dbet);   // dz = dz1, kept for the residual
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      int qlo, qhi;
-      tile_range(tm, kt, qlo, qhi);   // the windows are equivalence classes: the same range read as query tiles
-      const int kj = kt * 16 + c;
-      const int spk = tm->span[kj];
-      const int klo_ = spk & 255, khi_ = spk >> 8;
-      const s16x4 bk = ld4(kh + kj * LDQ + 4 * g);
-      const s16x4 bv = ld4(vh + kj * LDQ + 4 * g);
-      f32x4 dsv[4], pv[4];
+    for (int mb = 0; mb < 4; ++mb)   // over o: every wave is past the out-projection GEMM and the o_out copy
+      *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(dz[0][mb]);
+    __syncthreads();
+    tile_store_rows<NW, E>(xs, LDX, dz_out, tm->rows, 0, 0);
+    {
+      f32x4 go[1][4];
+      zero_acc(go);
+      bf16x8 f[1][4];
+      load_frags<1, 4>(tid_, wot, wave, f);
+      tile_gemm<1, 4>(tid_, f, xs, LDX, go);    // dO = Wo^T dz1
+      __syncthreads();                     // dz1 tile: read by every wave's GEMM and by the copy above
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(go[0][mb]);
+    }
+    __syncthreads();
+    // attention backward, one head per wave.  Pass 1 (lanes own queries): dQ and delta; pass 2 (lanes own
+    // keys): dK, dV.  Both recompute the probabilities with 16x16x16 MFMAs; the gradients of a head replace its Q, K, V
+    // in place once both passes have read them (only this wave touches the head's columns).
+    {
+      const int h = wave;
+      const uint16_t* qh = qs + h * HD;
+      const uint16_t* kh = qs + E + h * HD;
+      const uint16_t* vh = qs + 2 * E + h * HD;
+      const uint16_t* dh_ = xs + h * HD;            // dO of the head, row stride LDX
+      float* lq = lse_s + h * TM;
+      float* dl = red0 + wave * TM;                 // delta of the head's queries (red0 is free here)
+      f32x4 gq[4], gk[4], gv[4];
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
-        dsv[qt] = pv[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (qt >= qlo && qt <= qhi) {
-          const s16x4 aq = ld4(qh + (qt * 16 + c) * LDQ + 4 * g);
-          const s16x4 ado = ld4(dh_ + (qt * 16 + c) * LDX + 4 * g);
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bk, zero, 0, 0, 0);    // S[query][key]
-          const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ado, bv, zero, 0, 0, 0);   // dP[query][key]
-          const f32x4 l4 = *(const f32x4*)(lq + qt * 16 + 4 * g);
-          const f32x4 d4 = *(const f32x4*)(dl + wave * TM + qt * 16 + 4 * g);
+        int klo, khi;
+        tile_range(tid_, tm, qt, klo, khi);
+        const int qi = qt * 16 + c;
+        const int sp = tm->span[qi];
+        const int lo = sp & 255, hi = sp >> 8;
+        const s16x4 bq = ld4(qh + qi * LDQ + 4 * g);
+        const s16x4 bdo = ld4(dh_ + qi * LDX + 4 * g);
+        const float lse_q = lq[qi];
+        f32x4 pT[4], dpT[4];
+        float delta = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qi = qt * 16 + 4 * g + r;   // a query sees this key iff both sit in the same (non-empty) window
-            const float p = (qi >= klo_ && qi < khi_) ? __expf(sc[r] * 0.25f - l4[r]) : 0.f;
-            pv[qt][r] = p;
-            dsv[qt][r] = p * (dp[r] - d4[r]) * 0.25f;
+        for (int kt = 0; kt < 4; ++kt) {
+          pT[kt] = dpT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kt >= klo && kt <= khi) {
+            const s16x4 ak = ld4(kh + (kt * 16 + c) * LDQ + 4 * g);
+            const s16x4 av = ld4(vh + (kt * 16 + c) * LDQ + 4 * g);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bq, zero, 0, 0, 0);    // S^T[key][query]
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bdo, zero, 0, 0, 0);   // dP^T[key][query]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + 4 * g + r;
+              const float p = (key >= lo && key < hi) ? __expf(sc[r] * 0.25f - lse_q) : 0.f;
+              pT[kt][r] = p;
+              dpT[kt][r] = dp[r];
+              delta += p * dp[r];
+            }
           }
         }
-      }
-      f32x4 acck = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        if (g == 0) dl[qi] = delta;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (2 * u + 1 >= qlo && 2 * u <= qhi) {
-          const uint16_t* aq0 = qh + (32 * u + 4 * g + q_) * LDQ + 4 * p_;
-          const uint16_t* ad0 = dh_ + (32 * u + 4 * g + q_) * LDX + 4 * p_;
-          acck = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(aq0, aq0 + 16 * LDQ),
-                                                         pack_tiles(dsv[2 * u], dsv[2 * u + 1]), acck, 0, 0, 0);
-          accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(ad0, ad0 + 16 * LDX),
-                                                         pack_tiles(pv[2 * u], pv[2 * u + 1]), accv, 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+          if (2 * u + 1 >= klo && 2 * u <= khi) {
+            f32x4 d0, d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              d0[r] = pT[2 * u][r] * (dpT[2 * u][r] - delta) * 0.25f;
+              d1[r] = pT[2 * u + 1][r] * (dpT[2 * u + 1][r] - delta) * 0.25f;
+            }
+            const uint16_t* a0 = kh + (32 * u + 4 * g + q_) * LDQ + 4 * p_;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(a0, a0 + 16 * LDQ), pack_tiles(d0, d1), acc, 0, 0, 0);
+          }
         }
+        gq[qt] = acc;   // dQ^T: d = 4g + r of query c
       }
-      gk[kt] = acck;
-      gv[kt] = accv;
+      // (delta written by this wave's g == 0 lanes, read below by all its lanes: LDS ops of a wave complete in order)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        int qlo, qhi;
+        tile_range(tid_, tm, kt, qlo, qhi);   // the windows are equivalence classes: the same range read as query tiles
+        const int kj = kt * 16 + c;
+        const int spk = tm->span[kj];
+        const int klo_ = spk & 255, khi_ = spk >> 8;
+        const s16x4 bk = ld4(kh + kj * LDQ + 4 * g);
+        const s16x4 bv = ld4(vh + kj * LDQ + 4 * g);
+        f32x4 dsv[4], pvv[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          dsv[qt] = pvv[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (qt >= qlo && qt <= qhi) {
+            const s16x4 aq = ld4(qh + (qt * 16 + c) * LDQ + 4 * g);
+            const s16x4 ado = ld4(dh_ + (qt * 16 + c) * LDX + 4 * g);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bk, zero, 0, 0, 0);    // S[query][key]
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ado, bv, zero, 0, 0, 0);   // dP[query][key]
+            const f32x4 l4 = *(const f32x4*)(lq + qt * 16 + 4 * g);
+            const f32x4 d4 = *(const f32x4*)(dl + qt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qi = qt * 16 + 4 * g + r;   // a query sees this key iff both sit in the same (non-empty) window
+              const float p = (qi >= klo_ && qi < khi_) ? __expf(sc[r] * 0.25f - l4[r]) : 0.f;
+              pvv[qt][r] = p;
+              dsv[qt][r] = p * (dp[r] - d4[r]) * 0.25f;
+            }
+          }
+        }
+        f32x4 acck = {0.f, 0.f, 0.f, 0.f}, accv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (2 * u + 1 >= qlo && 2 * u <= qhi) {
+            const uint16_t* aq0 = qh + (32 * u + 4 * g + q_) * LDQ + 4 * p_;
+            const uint16_t* ad0 = dh_ + (32 * u + 4 * g + q_) * LDX + 4 * p_;
+            acck = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(aq0, aq0 + 16 * LDQ),
+                                                           pack_tiles(dsv[2 * u], dsv[2 * u + 1]), acck, 0, 0, 0);
+            accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_pair(ad0, ad0 + 16 * LDX),
+                                                           pack_tiles(pvv[2 * u], pvv[2 * u + 1]), accv, 0, 0, 0);
+          }
+        }
+        gk[kt] = acck;
+        gv[kt] = accv;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint16_t* row = qs + (t * 16 + c) * LDQ + h * HD + 4 * g;
+        *(u32x2*)(row) = pack4(gq[t]);
+        *(u32x2*)(row + E) = pack4(gk[t]);
+        *(u32x2*)(row + 2 * E) = pack4(gv[t]);
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      uint16_t* row = qs + (t * 16 + c) * LDQ + h * HD + 4 * g;
-      *(u32x2*)(row) = pack4(gq[t]);
-      *(u32x2*)(row + E) = pack4(gk[t]);
-      *(u32x2*)(row + 2 * E) = pack4(gv[t]);
+    __syncthreads();
+    tile_store_rows<NW, 3 * E>(qs, LDQ, dqkv_out, tm->rows, 0, 0);
+    f32x4 gx[1][4];
+    zero_acc(gx);
+    {
+      bf16x8 f[1][12];
+      load_frags<1, 12>(tid_, wqkvt, wave, f);
+      tile_gemm<1, 12>(tid_, f, qs, LDQ, gx);   // dx = Wqkv^T dqkv (+ dz1: the residual)
     }
-  }
-  __syncthreads();
-  tile_store_rows<3 * E>(qs, LDQ, dqkv_out, tm->rows, 0, 0);
-  f32x4 gx[2][4];
-  zero_acc(gx);
-  tile_gemm<2, 12>(wqkvt, 2 * wave, qs, LDQ, gx);   // dx = Wqkv^T dqkv (+ dz1: the residual)
+    load_frags<1, 4>(tid_, wqkv, 16 + wave, fv);   // the next tile's first GEMM
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {   // over dO: its last readers were the attention passes, before the barrier above
-    const int n = 16 * (2 * wave + nb) + 4 * g;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n) = pack4(gx[nb][mb] + dz[nb][mb]);
+    for (int mb = 0; mb < 4; ++mb)   // over dO: its last readers were the attention passes, before the barrier above
+      *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(gx[0][mb] + dz[0][mb]);
+    __syncthreads();
+    tile_store_rows<NW, E>(xs, LDX, dx, tm->rows, 0, 0);
+    __syncthreads();   // the next tile's x goes into xs, its Q | K | V into qs, its meta into this tile's slot
   }
-  __syncthreads();
-  tile_store_rows<E>(xs, LDX, dx, tm->rows, 0, 0);
+  store_param_partials<1>(tid_, dgam, dbet, wave, ln_partial + (int64_t)blockIdx.x * 2 * E);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1122,6 +1262,18 @@ __global__ void __launch_bounds__(256) partial_rows_sum_kernel(RowSumPack pk) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// persistent grids: `per_cu` workgroups on every CU, never more workgroups than tiles
+inline int block_grid(int64_t tiles, int per_cu) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  const int64_t cap = (int64_t)cus * per_cu;
+  return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
+}
+
 }  // namespace
 
 extern "C" int ococc_linear_fragments_bf16(int32_t count, const void* const* src, const int64_t* rows,
@@ -1201,10 +1353,10 @@ extern "C" int ococc_window_attn_block_fwd_bf16(const uint16_t* x, const uint16_
                     aligned16(bqkv) && aligned16(bo) && aligned16(ln_weight) && aligned16(ln_bias),
                 "buffers must be 16-byte aligned");
   OCOCC_HIP(hipFuncSetAttribute((const void*)window_attn_block_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kAttnLds));
-  hipLaunchKernelGGL(window_attn_block_fwd_kernel, dim3((unsigned)num_tiles), dim3(kThreads), kAttnLds,
-                     (hipStream_t)stream, x, pos, tile_rows, tile_span, wqkv_frag, bqkv, wo_frag, bo, ln_weight,
-                     ln_bias, eps, y);
+                                attn_lds<4>()));
+  hipLaunchKernelGGL(window_attn_block_fwd_kernel, dim3((unsigned)block_grid(num_tiles, 2)), dim3(256), attn_lds<4>(),
+                     (hipStream_t)stream, x, pos, tile_rows, tile_span, num_tiles, wqkv_frag, bqkv, wo_frag, bo,
+                     ln_weight, ln_bias, eps, y);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
@@ -1228,10 +1380,10 @@ extern "C" int ococc_window_attn_block_bwd_bf16(const uint16_t* x, const uint16_
                     aligned16(wqkv_t_frag) && aligned16(bqkv) && aligned16(bo) && aligned16(ln_weight),
                 "buffers must be 16-byte aligned");
   OCOCC_HIP(hipFuncSetAttribute((const void*)window_attn_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kAttnLds));
-  hipLaunchKernelGGL(window_attn_block_bwd_kernel, dim3((unsigned)num_tiles), dim3(kThreads), kAttnLds,
-                     (hipStream_t)stream, x, pos, dy, tile_rows, tile_span, wqkv_frag, bqkv, wo_frag, bo, ln_weight, eps,
-                     wo_t_frag, wqkv_t_frag, dx, dqkv, dz, attn_out, ln_partial);
+                                attn_lds<8>()));
+  hipLaunchKernelGGL(window_attn_block_bwd_kernel, dim3((unsigned)block_grid(num_tiles, 1)), dim3(512), attn_lds<8>(),
+                     (hipStream_t)stream, x, pos, dy, tile_rows, tile_span, num_tiles, wqkv_frag, bqkv, wo_frag, bo,
+                     ln_weight, eps, wo_t_frag, wqkv_t_frag, dx, dqkv, dz, attn_out, ln_partial);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
@@ -1247,12 +1399,12 @@ extern "C" int ococc_token_ffn_block_fwd_bf16(const uint16_t* x, int64_t num_tok
   OCOCC_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w1_frag) && aligned16(w2_frag) && aligned16(b1) &&
                     aligned16(b2) && aligned16(ln_weight) && aligned16(ln_bias),
                 "buffers must be 16-byte aligned");
-  const unsigned grid = (unsigned)ococc_cdiv(num_tokens, TM);
+  const unsigned grid = (unsigned)block_grid(ococc_cdiv(num_tokens, TM), 2);
 #define OCOCC_FFN_FWD(A)                                                                                          \
   do {                                                                                                            \
     OCOCC_HIP(hipFuncSetAttribute((const void*)token_ffn_block_fwd_kernel<A>,                                     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));                          \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(token_ffn_block_fwd_kernel<A>), dim3(grid), dim3(kThreads), kFfnLds,       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ffn_lds<4>()));                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(token_ffn_block_fwd_kernel<A>), dim3(grid), dim3(256), ffn_lds<4>(),       \
                        (hipStream_t)stream, x, num_tokens, w1_frag, b1, w2_frag, b2, ln_weight, ln_bias, eps, y); \
   } while (0)
   if (act == 0) OCOCC_FFN_FWD(0);
@@ -1278,12 +1430,12 @@ extern "C" int ococc_token_ffn_block_bwd_bf16(const uint16_t* x, const uint16_t*
                     aligned16(w1_frag) && aligned16(w2_frag) && aligned16(w2_t_frag) && aligned16(w1_t_frag) &&
                     aligned16(b1) && aligned16(b2) && aligned16(ln_weight),
                 "buffers must be 16-byte aligned");
-  const unsigned grid = (unsigned)ococc_cdiv(num_tokens, TM);
+  const unsigned grid = (unsigned)block_grid(ococc_cdiv(num_tokens, TM), 1);
 #define OCOCC_FFN_BWD(A)                                                                                           \
   do {                                                                                                             \
     OCOCC_HIP(hipFuncSetAttribute((const void*)token_ffn_block_bwd_kernel<A>,                                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds));                           \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(token_ffn_block_bwd_kernel<A>), dim3(grid), dim3(kThreads), kFfnLds,        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ffn_lds<8>()));                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(token_ffn_block_bwd_kernel<A>), dim3(grid), dim3(512), ffn_lds<8>(),        \
                        (hipStream_t)stream, x, dy, num_tokens, w1_frag, b1, w2_frag, b2, ln_weight, eps, w2_t_frag, \
                        w1_t_frag, dx, act_out, dh, dz, ln_partial);                                                \
   } while (0)
@@ -1292,6 +1444,11 @@ extern "C" int ococc_token_ffn_block_bwd_bf16(const uint16_t* x, const uint16_t*
 #undef OCOCC_FFN_BWD
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
+}
+
+extern "C" int64_t ococc_window_block_partial_rows(int64_t num_tiles) {
+  // rows of ln_partial a backward block kernel writes for this many tiles (one per persistent workgroup)
+  return num_tiles < 0 ? -1 : (num_tiles == 0 ? 0 : block_grid(num_tiles, 1));
 }
 
 extern "C" int64_t ococc_token_wgrad_slabs(int64_t num_tokens) {

@@ -139,14 +139,15 @@ class AttnBlock(torch.autograd.Function):
         dqkv = new((V, 3 * E), dtype=torch.bfloat16, device=x.device)
         dz = new((V, E), dtype=torch.bfloat16, device=x.device)
         o = new((V, E), dtype=torch.bfloat16, device=x.device)
-        lnp = torch.empty((plan.num_tiles, 2, E), dtype=torch.float32, device=x.device)
+        prow = int(L.lib.ococc_window_block_partial_rows(plan.num_tiles))
+        lnp = torch.empty((prow, 2, E), dtype=torch.float32, device=x.device)
         L.check(L.lib.ococc_window_attn_block_bwd_bf16(
             L.ptr(x), L.ptr(pos), L.ptr(dy), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, H, L.ptr(wqkv),
             L.ptr(bq), L.ptr(wo), L.ptr(bo), L.ptr(g1), eps, L.ptr(wot), L.ptr(wqkvt), L.ptr(dx), L.ptr(dqkv), L.ptr(dz),
             L.ptr(o), L.ptr(lnp), L.stream()), 'window_attn_block_bwd')
         # rows outside the plan hold zeros in dqkv / dz: they add nothing to the sums below
         (dwqkv, dbqkv), (dwo, dbo) = _wgrad([(dqkv, 3 * E, x, pos, 2 * E), (dz, E, o, None, 0)], V, x.device)
-        dg, db = _ln_param_sums(lnp, plan.num_tiles)
+        dg, db = _ln_param_sums(lnp, prow)
         return (dx, None, None, dwqkv.to(in_w.dtype), dbqkv.to(in_b.dtype), dwo.to(out_w.dtype), dbo.to(out_b.dtype),
                 dg.to(ln_w.dtype), db.to(ln_w.dtype), None, None, None)
 
@@ -183,12 +184,12 @@ class FfnBlock(torch.autograd.Function):
         a = torch.empty((V, F), dtype=torch.bfloat16, device=dev)
         dh = torch.empty((V, F), dtype=torch.bfloat16, device=dev)
         dz = torch.empty((V, E), dtype=torch.bfloat16, device=dev)
-        tiles = (V + TILE - 1) // TILE
-        lnp = torch.empty((tiles, 2, E), dtype=torch.float32, device=dev)
+        prow = int(L.lib.ococc_window_block_partial_rows((V + TILE - 1) // TILE))
+        lnp = torch.empty((prow, 2, E), dtype=torch.float32, device=dev)
         L.check(L.lib.ococc_token_ffn_block_bwd_bf16(
             L.ptr(x), L.ptr(dy), V, E, F, L.ptr(f1), L.ptr(c1), L.ptr(f2), L.ptr(c2), L.ptr(g), eps, ACT[act], L.ptr(f2t),
             L.ptr(f1t), L.ptr(dx), L.ptr(a), L.ptr(dh), L.ptr(dz), L.ptr(lnp), L.stream()), 'token_ffn_block_bwd')
         (dw1, db1), (dw2, db2) = _wgrad([(dh, F, x, None, 0), (dz, E, a, None, 0)], V, dev)
-        dg, db = _ln_param_sums(lnp, tiles)
+        dg, db = _ln_param_sums(lnp, prow)
         return (dx, dw1.to(w1.dtype), db1.to(b1.dtype), dw2.to(w2.dtype), db2.to(b2.dtype), dg.to(ln_w.dtype),
                 db.to(ln_w.dtype), None, None)

@@ -394,7 +394,7 @@ def _fused_maps(ind_dict, pos_dict, key_padding_dict, num_tokens, dtype):
             pos_flat = window2flat_v2(pos_dict, ind_dict).to(dtype).contiguous()
             ind_dict['_ococc_pos_flat'] = pos_flat
         small = [(tok, key_len, nW, T) for (slot, pos, nW, T, key_len, tok) in maps.values() if T <= TILE]
-        large = {dl: m for dl, m in maps.items() if m[3] > TILE}
+        large = {dl: m for dl, m in maps.items() if m[3] > TILE and m[2] > 0 and m[1].numel() > 0}
         device = pos_flat.device
         plan = TilePlan(small, device)
         big = None
@@ -588,7 +588,6 @@ class EncoderLayer(nn.Module):
     def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
         if self.compute_dtype is not None and self._fusable():
             return self._forward_fused(src, pos_dict, ind_dict, key_padding_mask_dict)
-    def forward(self, src, pos_dict, ind_dict, key_padding_mask_dict):
         if self.compute_dtype is not None:
             src = src.to(self.compute_dtype)  # bf16 residual stream; LN statistics and GEMM accumulation stay f32
             assert self.post_norm
