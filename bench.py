@@ -255,9 +255,9 @@ def bench_sst(args, world, rank, dev):
     """configs[4], one GPU's share: 32 object grids of 80x80x64 cells at 0.1 m (the reference's window
     partition asserts z < x, sst_ops.py:283, so the cube is cut to 6.4 m in z; ~8 000 active voxels each),
     voxelise -> scatter-mean -> Linear(16->128) -> SSTInputLayerV2 (3-D windows 8x8x8, drop levels
-    30/60/100 tokens) -> 2 BasicShiftBlockV2 (d_model 128, 8 heads, ffn 256), bf16 attention core,
-    fwd + bwd + AdamW.  The roofline line is the window-attention forward kernel against the dense
-    bf16 MFMA peak (flops = 4 T^2 d per window and head over the padded T the kernel runs)."""
+    30/60/100 tokens) -> 2 BasicShiftBlockV2 (d_model 128, 8 heads, ffn 256) on the fused encoder-layer kernels,
+    fwd + bwd + AdamW.  The roofline line is the forward of the encoder layers (attention block + FFN block kernels)
+    against the dense bf16 MFMA peak, flops counted on the real tokens and windows."""
     from objectcentricocccompletion_amd.dist import GradBuckets, broadcast_parameters
     from objectcentricocccompletion_amd.occ_encoder import synthetic_object_grids
     from objectcentricocccompletion_amd.optim import AdamW
@@ -282,16 +282,18 @@ def bench_sst(args, world, rank, dev):
     xyz, feats, bidx = synthetic_object_grids(G, P, seed=rank, device=dev)
     xyz[:, 2] *= 0.8
 
-    class AttnProbe(object):
+    class BlockProbe(object):
+        """HIP events around the fused forward kernels (recorded on the launch stream)."""
+
         def __init__(self):
             self.items = []
 
-        def wrap(self, nW, T, H, D, launch):
+        def wrap(self, name, flops, launch):
             a, b = L_.Timer(), L_.Timer()
             a.record()
             launch()
             b.record()
-            self.items.append((a, b, 4.0 * nW * H * T * T * D))
+            self.items.append((name, a, b, flops))
 
     from objectcentricocccompletion_amd import _lib as L_
 
@@ -315,8 +317,9 @@ def bench_sst(args, world, rank, dev):
     d_out = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
     for _ in range(args.warmup):
         step()
-    probe = AttnProbe()
-    sm.set_attn_probe(probe)
+    from objectcentricocccompletion_amd.sst import fused_block as fb
+    probe = BlockProbe()
+    fb.set_probe(probe)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -327,15 +330,23 @@ def bench_sst(args, world, rank, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    sm.set_attn_probe(None)
+    fb.set_probe(None)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if rank == 0:
-        ms = sum(a.elapsed_ms(b) for a, b, _ in probe.items)
-        fl = sum(f for _, _, f in probe.items)
+        per = {}
+        for name, a, b, f in probe.items:
+            t = per.setdefault(name, [0.0, 0.0, 0])
+            t[0] += a.elapsed_ms(b)
+            t[1] += f
+            t[2] += 1
+        ms = sum(t[0] for t in per.values())
+        fl = sum(t[1] for t in per.values())
         tflops = fl / (ms * 1e-3) / 1e12 if ms else None
+        detail = {k: {'launches': t[2], 'avg_us': round(t[0] / t[2] * 1e3, 1), 'tflops': round(t[1] / (t[0] * 1e-3) / 1e12, 1)}
+                  for k, t in per.items() if t[0] > 0}
         print(json.dumps({
             'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * G * args.steps / dt, 1),
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -345,10 +356,12 @@ def bench_sst(args, world, rank, dev):
                                    'SST path (windows 8x8x8, drop levels 30/60/100, d_model 128, 8 heads, ffn 256, '
                                    '2 BasicShiftBlockV2), fwd+bwd+AdamW', 'grids_per_gpu': G, 'active_voxels': int(n_act),
                        'parallelism': f'dp{world}', 'launch': 'eager launches'},
-            'roofline': {'kernel': 'window_attn_fwd_kernel (all drop levels, both shifts)', 'bound': 'mfma',
-                         'achieved': round(tflops, 2) if tflops else None, 'peak': 2500.0, 'unit': 'TFLOP/s',
-                         'frac': round(tflops / 2500.0, 5) if tflops else None, 'traffic': None,
-                         'launches_timed': len(probe.items)},
+            # forward of an encoder layer = window_attn_block_fwd_kernel + token_ffn_block_fwd_kernel: algorithmic flops of
+            # the projections, the attention of every real window and the FFN on the real tokens, over the two kernels' time
+            'roofline': {'kernel': 'encoder-layer forward: window_attn_block_fwd_kernel + token_ffn_block_fwd_kernel',
+                         'bound': 'mfma', 'achieved': round(tflops, 2) if tflops else None, 'peak': 2500.0,
+                         'unit': 'TFLOP/s', 'frac': round(tflops / 2500.0, 5) if tflops else None, 'traffic': None,
+                         'launches_timed': len(probe.items), 'per_kernel': detail},
             'cpu_baseline': None}), flush=True)
 
 

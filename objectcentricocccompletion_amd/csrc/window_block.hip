@@ -480,7 +480,8 @@ window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
   float* red0 = (float*)(qs + TM * LDQ);
   float* red1 = red0 + NW * TM;
   TileMeta* tms = (TileMeta*)(red1 + NW * TM);    // [2]: this tile's and the next one's
-  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, g = lane >> 4;
+  (void)g;
   bf16x8 fv[2][4], fo[2][4], fqk_none[4][4] = {};   // (fqk_none: unused, the forward streams Wqk inside attn_front)
   load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);
   int64_t tile = blockIdx.x;
@@ -568,7 +569,8 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
   uint16_t* hs = xs + TM * LDX;
   float* red0 = (float*)(hs + TM * LDH);
   float* red1 = red0 + NW * TM;
-  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, g = lane >> 4;
+  (void)g;
   bf16x8 f1[4][4], f2[2][8];
   load_frags<4, 4>(tid_, w1, 4 * wave, f1);
   const int64_t tiles = (num_tokens + TM - 1) / TM;
@@ -653,7 +655,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
   uint16_t* hs = xs + TM * LDX;        // act(h) | dh
   float* red0 = (float*)(hs + TM * LDH);
   float* red1 = red0 + NW * TM;
-  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, g = lane >> 4;
   // (fragments are requested when a GEMM starts, not one GEMM ahead: see above)
   const f32x4 gam[1] = {*(const f32x4*)(ln_w + 16 * wave + 4 * g)};
   f32x4 dgam[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dbet[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -773,7 +775,8 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
   float* red1 = red0 + NW * TM;
   TileMeta* tms = (TileMeta*)(red1 + NW * TM);
   float* lse_s = (float*)(tms + 2);               // [8 heads][64]
-  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, g = lane >> 4;
+  (void)g;
   bf16x8 fv[1][4], fqk_none[2][4] = {};
   load_frags<1, 4>(tid_, wqkv, 16 + wave, fv);
   const f32x4 gam[1] = {*(const f32x4*)(ln_w + 16 * wave + 4 * g)};
@@ -1023,15 +1026,27 @@ __global__ void __launch_bounds__(256) linear_fragments_kernel(FragPack pk) {
 // fit over the windows in their given order, run by one workgroup: each thread packs a chunk of >= 128 consecutive
 // windows on its own (a tile never spans two chunks: ~1 half-empty tile per chunk), a block scan numbers the tiles.
 constexpr int kPlanThreads = 1024;
+constexpr int kPlanLdsWindows = 96 * 1024;   // window populations staged in LDS as bytes (a window has <= 64 tokens)
 __global__ void __launch_bounds__(kPlanThreads)
 window_tile_plan_kernel(const int32_t* __restrict__ win_len, int64_t num_windows, int32_t* __restrict__ win_tile,
                         int32_t* __restrict__ win_base, int32_t* __restrict__ num_tiles) {
   __shared__ int cnt[kPlanThreads];
+  extern __shared__ uint8_t lens[];
+  // one coalesced pass brings the populations on chip: the greedy loops below are chains of dependent reads
+  const bool staged = num_windows <= kPlanLdsWindows;
+  if (staged) {
+    for (int64_t i = threadIdx.x; i < num_windows; i += kPlanThreads) {
+      const int n = win_len[i];
+      lens[i] = (uint8_t)(n < 0 ? 0 : (n > 255 ? 255 : n));
+    }
+    __syncthreads();
+  }
+  auto len_of = [&](int64_t w) -> int { return staged ? (int)lens[w] : win_len[w]; };
   const int64_t chunk = max((int64_t)128, (num_windows + kPlanThreads - 1) / kPlanThreads);
   const int64_t w0 = (int64_t)threadIdx.x * chunk, w1 = min(num_windows, w0 + chunk);
   int tiles = 0, fill = 0;
   for (int64_t w = w0; w < w1; ++w) {
-    const int n = win_len[w];
+    const int n = len_of(w);
     if (n <= 0) continue;
     if (fill + n > TM) {
       ++tiles;
@@ -1051,9 +1066,8 @@ window_tile_plan_kernel(const int32_t* __restrict__ win_len, int64_t num_windows
   int tile = cnt[threadIdx.x] - tiles;
   if (threadIdx.x == kPlanThreads - 1) *num_tiles = cnt[threadIdx.x];
   fill = 0;
-  bool open = false;
   for (int64_t w = w0; w < w1; ++w) {
-    const int n = win_len[w];
+    const int n = len_of(w);
     if (n <= 0) {
       win_tile[w] = -1;
       win_base[w] = 0;
@@ -1063,12 +1077,10 @@ window_tile_plan_kernel(const int32_t* __restrict__ win_len, int64_t num_windows
       ++tile;
       fill = 0;
     }
-    open = true;
     win_tile[w] = tile;
     win_base[w] = fill;
     fill += n;
   }
-  (void)open;
 }
 
 __global__ void __launch_bounds__(256)
@@ -1327,8 +1339,10 @@ extern "C" int ococc_window_tile_plan(const int32_t* win_len, const int64_t* win
   int32_t* win_base = (int32_t*)((char*)workspace + ococc_align_up(num_windows * 4, 256));
   OCOCC_HIP(hipMemsetAsync(tile_rows, 0xff, (size_t)cap_tiles * TM * 4, stream));
   OCOCC_HIP(hipMemsetAsync(tile_span, 0, (size_t)cap_tiles * TM * 4, stream));
-  hipLaunchKernelGGL(window_tile_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, win_len, num_windows, win_tile,
-                     win_base, num_tiles);
+  const int plan_lds = num_windows <= kPlanLdsWindows ? (int)ococc_align_up(num_windows, 16) : 0;
+  OCOCC_HIP(hipFuncSetAttribute((const void*)window_tile_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, plan_lds));
+  hipLaunchKernelGGL(window_tile_plan_kernel, dim3(1), dim3(kPlanThreads), plan_lds, stream, win_len, num_windows,
+                     win_tile, win_base, num_tiles);
   hipLaunchKernelGGL(window_tile_fill_kernel, dim3((unsigned)ococc_cdiv(num_windows * 64, 256)), dim3(256), 0, stream,
                      win_len, win_off, tok, num_windows, win_tile, win_base, tile_rows, tile_span);
   OCOCC_CHECK_LAUNCH();

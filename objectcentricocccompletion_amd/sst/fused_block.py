@@ -17,6 +17,19 @@ from .. import _lib as L
 
 TILE = 64
 ACT = {'gelu': 0, 'relu': 1}
+_probe = None   # measurement hook (bench.py --workload sst): .wrap(name, flops, launch) brackets a forward kernel with events
+
+
+def set_probe(probe):
+    global _probe
+    _probe = probe
+
+
+def _run(name, flops, launch):
+    if _probe is not None:
+        _probe.wrap(name, flops, launch)
+    else:
+        launch()
 
 
 def _vp(ptrs):
@@ -58,7 +71,7 @@ class TilePlan(object):
             toks.append(tok)
             base += nW * T
         n = sum(int(l.numel()) for l in lens)
-        self.num_tiles, self.tokens = 0, 0
+        self.num_tiles, self.tokens, self.sum_sq = 0, 0, 0.0
         self.rows = self.span = None
         if n == 0:
             return
@@ -72,7 +85,8 @@ class TilePlan(object):
                                              L.ptr(self.span), L.ptr(count), L.ptr(ws), nbytes, L.stream()),
                 'window_tile_plan')
         self.num_tiles = int(count.item())      # one read-back per batch and shift (the input layer has several)
-        self.tokens = int(win_len.sum().item())
+        stats = torch.stack([win_len.sum(), (win_len.double() ** 2).sum().long()]).tolist()   # (one read-back)
+        self.tokens, self.sum_sq = int(stats[0]), float(stats[1])   # sum_sq: sum of squared populations (attention flops)
         self.rows, self.span = self.rows[:self.num_tiles * TILE], self.span[:self.num_tiles * TILE]
 
 
@@ -119,10 +133,12 @@ class AttnBlock(torch.autograd.Function):
         bq, bo = in_b.detach().float().contiguous(), out_b.detach().float().contiguous()
         g1, b1 = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
         y = torch.empty_like(x) if covered else torch.zeros_like(x)
-        L.check(L.lib.ococc_window_attn_block_fwd_bf16(L.ptr(x), L.ptr(pos), L.ptr(plan.rows), L.ptr(plan.span),
-                                                       plan.num_tiles, E, num_heads, L.ptr(wqkv), L.ptr(bq), L.ptr(wo),
-                                                       L.ptr(bo), L.ptr(g1), L.ptr(b1), float(eps), L.ptr(y), L.stream()),
-                'window_attn_block_fwd')
+        # algorithmic flops on the real tokens: in-projection 2*3E*E, out-projection 2*E*E per token, attention 4*n*E per
+        # token of an n-token window (what the reference's nn.MultiheadAttention computes without its padding)
+        flops = plan.tokens * 8.0 * E * E + 4.0 * E * plan.sum_sq
+        _run('window_attn_block_fwd', flops, lambda: L.check(L.lib.ococc_window_attn_block_fwd_bf16(
+            L.ptr(x), L.ptr(pos), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, num_heads, L.ptr(wqkv), L.ptr(bq),
+            L.ptr(wo), L.ptr(bo), L.ptr(g1), L.ptr(b1), float(eps), L.ptr(y), L.stream()), 'window_attn_block_fwd'))
         ctx.save_for_backward(x, pos, in_w, in_b, out_w, out_b, ln_w)
         ctx.misc = (plan, float(eps), int(num_heads), bool(covered), wqkv, wo, bq, bo, g1)
         return y
@@ -164,9 +180,9 @@ class FfnBlock(torch.autograd.Function):
         c1, c2 = b1.detach().float().contiguous(), b2.detach().float().contiguous()
         g, b = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
         y = torch.empty_like(x)
-        L.check(L.lib.ococc_token_ffn_block_fwd_bf16(L.ptr(x), V, E, F, L.ptr(f1), L.ptr(c1), L.ptr(f2), L.ptr(c2), L.ptr(g),
-                                                     L.ptr(b), float(eps), ACT[act], L.ptr(y), L.stream()),
-                'token_ffn_block_fwd')
+        _run('token_ffn_block_fwd', 4.0 * V * E * F, lambda: L.check(L.lib.ococc_token_ffn_block_fwd_bf16(
+            L.ptr(x), V, E, F, L.ptr(f1), L.ptr(c1), L.ptr(f2), L.ptr(c2), L.ptr(g), L.ptr(b), float(eps), ACT[act],
+            L.ptr(y), L.stream()), 'token_ffn_block_fwd'))
         ctx.save_for_backward(x, w1, b1, w2, b2, ln_w)
         ctx.misc = (float(eps), act, f1, f2, c1, c2, g)
         return y

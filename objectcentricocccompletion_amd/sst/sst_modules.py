@@ -12,7 +12,7 @@ from torch import nn
 from .. import _lib as L
 from ..norm import layer_norm_act
 from ..registry import BACKBONES, MIDDLE_ENCODERS, build_conv_layer, build_norm_layer
-from .sst_ops import (flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
+from .sst_ops import (LazyWindowDict, flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
                       window2flat_v2)
 
 
@@ -117,14 +117,17 @@ class SSTInputLayerV2(nn.Module):
         gap = feat_dim - pos.size(1)
         if gap > 0:
             pos = torch.cat([pos, torch.zeros((pos.size(0), gap), dtype=dtype, device=pos.device)], dim=1)
-        return flat2window_v2(pos, inds_dict)
+        inds_dict['_ococc_pos_flat_f32'] = pos   # flat token order: what the fused encoder layers read
+        return LazyWindowDict(lambda: flat2window_v2(pos, inds_dict))
 
     @torch.no_grad()
     def get_key_padding_mask(self, ind_dict):
-        n = len(ind_dict['voxel_drop_level'])
-        ones = torch.ones((n, 1), device=ind_dict['voxel_drop_level'].device).bool()
-        d = flat2window_v2(ones, ind_dict)
-        return {k: v.logical_not().squeeze(2) for k, v in d.items()}
+        def build():
+            n = len(ind_dict['voxel_drop_level'])
+            ones = torch.ones((n, 1), device=ind_dict['voxel_drop_level'].device).bool()
+            d = flat2window_v2(ones, ind_dict)
+            return {k: v.logical_not().squeeze(2) for k, v in d.items()}
+        return LazyWindowDict(build)
 
 
 _attn_probe = None  # measurement hook (bench.py --workload sst): .wrap(T, launch) times the forward kernel
@@ -366,15 +369,21 @@ def _window_maps(ind_dict, key_padding_dict):
     if maps is None:
         maps = {}
         info = ind_dict['batching_info']
+        pop = ind_dict.get('_ococc_populations')
         for dl in info:
             if dl not in ind_dict:
                 continue
             slot, flat_pos = ind_dict[dl]
-            mask = key_padding_dict[dl]
-            nW, T = mask.shape
+            if pop is not None and dl in pop:   # window populations straight from the group-rank kernel
+                key_len, T = pop[dl], info[dl]['max_tokens']
+                nW = int(key_len.numel())
+            else:
+                mask = key_padding_dict[dl]
+                nW, T = mask.shape
+                key_len = (~mask).sum(1).to(torch.int32)
             tok = torch.full((nW * T,), -1, dtype=torch.int32, device=slot.device)
             tok[slot] = flat_pos[0].to(torch.int32)
-            maps[dl] = (slot, flat_pos[0], nW, T, (~mask).sum(1).to(torch.int32), tok)
+            maps[dl] = (slot, flat_pos[0], nW, T, key_len, tok)
         ind_dict['_ococc_maps'] = maps
     return maps
 
@@ -391,7 +400,8 @@ def _fused_maps(ind_dict, pos_dict, key_padding_dict, num_tokens, dtype):
         maps = _window_maps(ind_dict, key_padding_dict)
         pos_flat = ind_dict.get('_ococc_pos_flat')
         if pos_flat is None:
-            pos_flat = window2flat_v2(pos_dict, ind_dict).to(dtype).contiguous()
+            flat32 = ind_dict.get('_ococc_pos_flat_f32')
+            pos_flat = (flat32 if flat32 is not None else window2flat_v2(pos_dict, ind_dict)).to(dtype).contiguous()
             ind_dict['_ococc_pos_flat'] = pos_flat
         small = [(tok, key_len, nW, T) for (slot, pos, nW, T, key_len, tok) in maps.values() if T <= TILE]
         large = {dl: m for dl, m in maps.items() if m[3] > TILE and m[2] > 0 and m[1].numel() > 0}
@@ -657,7 +667,6 @@ class SSTv2(nn.Module):
     def forward(self, voxel_info):
         num_shifts = 2
         assert voxel_info['voxel_coors'].dtype == torch.int64, 'data type of coors should be torch.int64!'
-        batch_size = int(voxel_info['voxel_coors'][:, 0].max().item()) + 1
         ind_dicts = [voxel_info[f'flat2win_inds_shift{i}'] for i in range(num_shifts)]
         masks = [voxel_info[f'key_mask_shift{i}'] for i in range(num_shifts)]
         poss = [voxel_info[f'pos_dict_shift{i}'] for i in range(num_shifts)]
@@ -667,6 +676,7 @@ class SSTv2(nn.Module):
         for block in self.block_list:
             out = block(out, poss, ind_dicts, masks)
         if self.to_bev:
+            batch_size = int(voxel_info['voxel_coors'][:, 0].max().item()) + 1   # (a read-back: only where the canvas needs it)
             out = self.recover_bev(out, voxel_info['voxel_coors'], batch_size)
         if self.num_attached_conv > 0:
             assert self.to_bev

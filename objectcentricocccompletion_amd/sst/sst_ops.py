@@ -195,27 +195,80 @@ def get_window_coors(coors, sparse_shape, window_shape, do_shift):
 
 
 @torch.no_grad()
-def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
+def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, populations=None):
     """Per drop level: slot of every voxel in the padded [num_windows * max_tokens] layout and the
-    voxel positions of that level (sst_ops.py:26-63)."""
+    voxel positions of that level (sst_ops.py:26-63).  ``populations`` (a dict) receives per level the tokens of every
+    window, which the group-rank kernel counts anyway: the key padding mask as a length."""
     out = {}
     for dl in drop_info:
         dl_mask = voxel_drop_lvl == dl
         if not dl_mask.any():
             continue
-        conti, inner, _ = group_rank(batch_win_inds[dl_mask])
+        conti, inner, counts = group_rank(batch_win_inds[dl_mask])
         max_tokens = drop_info[dl]['max_tokens']
         if debug:
             assert int(inner.max()) < max_tokens, f'Max inner inds({int(inner.max())}) larger(equal) than {max_tokens}'
         out[dl] = ((conti.long() * max_tokens + inner.long()), torch.where(dl_mask))
+        if populations is not None:
+            populations[dl] = counts.to(torch.int32)
     return out
 
 
 def get_flat2win_inds_v2(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
-    d = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug)
+    pop = {}
+    d = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug, populations=pop)
     d['voxel_drop_level'] = voxel_drop_lvl
     d['batching_info'] = drop_info
+    d['_ococc_populations'] = pop
     return d
+
+
+class LazyWindowDict(dict):
+    """A per-drop-level dict of padded window tensors that is only built when somebody reads it.  The reference's input
+    layer materialises the padded positional embedding and key padding masks up front (sst_input_layer_v2.py:122-126);
+    the fused encoder layers read neither -- they take the embedding in flat token order and the window populations --
+    so here the flat2window copies happen on first access."""
+
+    def __init__(self, build):
+        super().__init__()
+        self._build = build
+
+    def _fill(self):
+        if self._build is not None:
+            build, self._build = self._build, None
+            super().update(build())
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
 
 
 def flat2window(feat, voxel_drop_lvl, flat2win_inds_dict, drop_info, padding=0):
