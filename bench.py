@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--grids', type=int, default=GRIDS_PER_GPU)
     ap.add_argument('--points', type=int, default=POINTS_PER_GRID)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true',
+                    help='skip the short runs of the other workloads (ococcnet at 4 and 64 tracklets, sst) whose JSON lines '
+                         'the default run attaches under "also"')
     ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet', 'sst', 'decode'],
                     help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]; sst = configs[4] per-GPU share')
     ap.add_argument('--tracklets', type=int, default=4)
@@ -417,6 +420,28 @@ def bench_decode(args, world, rank, dev):
             'cpu_baseline': None}), flush=True)
 
 
+def also_workloads():
+    """Short runs (5 timed steps) of the other workloads, each in a child process of its own, so that the one JSON line the
+    driver records also carries configs[2] (at the config's 4 tracklets per GPU and at 64) and configs[4]'s SST path.
+    Not part of the timed region above; a failure is recorded, it never fails the run."""
+    import subprocess
+    out = {}
+    here = os.path.abspath(__file__)
+    for key, extra in (('ococcnet_b4', ['--workload', 'ococcnet', '--tracklets', '4']),
+                       ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
+                       ('sst', ['--workload', 'sst'])):
+        cmd = [sys.executable, here, '--steps', '5', '--warmup', '3', '--no-cpu-baseline'] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            d = json.loads(line[-1]) if line else {'error': (r.stderr or 'no output')[-300:]}
+            out[key] = {k: d[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'error')
+                        if k in d}
+        except Exception as e:   # noqa: BLE001 (timeout, missing device, ...)
+            out[key] = {'error': repr(e)[:300]}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -679,6 +704,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier)
             res['cpu_baseline'] = cpu_baseline(16, P, model)
+        if world == 1 and not args.no_also:
+            res['also'] = also_workloads()
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

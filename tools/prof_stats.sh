@@ -3,7 +3,7 @@
 tag=$1; shift
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o $tag -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$tag -o $tag -- python3 $GRAFT_REPO_ROOT/bench.py --no-also --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/bench.json 2>/dev/null
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open('$GRAFT_REPO_ROOT/gpurun_out/prof_$tag/${tag}_kernel_stats.csv')))
