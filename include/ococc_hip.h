@@ -593,6 +593,44 @@ int ococc_token_wgrad_bf16(int32_t count, const void* const* g, const int64_t* l
 int ococc_partial_rows_sum_f32(int32_t count, const void* const* src, const int64_t* rows, const int64_t* cols,
                                void* const* dst, ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * A6, fused  one per-point layer of the SIR encoders:  y = act(LayerNorm(W x)),  x assembled per row as
+ *   x = [ a (*) mul (*) colscale | b * bscale | v[inv] ]      (parts with 0 columns are absent)
+ * optionally with the segment maximum of y (rows sorted by segment: inv non-decreasing) in the same launch.
+ * replaces, per layer: the torch.cat / element-wise products that build the input, DynamicVFELayerV2
+ * (Linear(bias=False) -> LN -> GELU, mmdet3d/models/voxel_encoders/utils.py:174-189), scatter_v2(mode='max')
+ * (mmdet3d/ops/sst/sst_ops.py:150-181) and voxel_feats[unq_inv] of SIRLayer.forward
+ * (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832), and the layers of rel_mlp (sst_ops.py:333-360).
+ * All f32 (the reference runs these layers under force_fp32).  a [rows, lda] (ka columns used), mul [rows, ldm] or
+ * null, colscale [ka] or null, b [rows, ldb] (kb columns), v [num_segments, kv], inv [rows] int32;
+ * 1 <= ka + kb + kv <= 256, 1 <= n <= 144.  w_frag: ococc_point_mlp_pack_f32 of the Linear's weight [n, k]
+ * (ococc_point_mlp_fragment_floats(n, k) floats); wt_frag: the same call on the transposed view (rows k, cols n).
+ * ln_weight / ln_bias null: no normalisation.  act: 0 none, 1 GELU (erf), 2 ReLU.
+ * fwd: y [rows, n]; seg_max [num_segments, n] or null (filled with -inf, then maxima; every segment must own a row).
+ * ococc_point_mlp_segment_argmax: seg_arg [num_segments, n] = smallest row attaining the maximum.
+ * bwd (recomputes the layer): dy [rows, n] or null, d_seg_max + seg_arg or null ->
+ *   dz [rows, n] (gradient at the Linear's output), x_cat [rows, k] or null (the assembled input: dW = dz^T x_cat),
+ *   da, dmul [rows, ka], db [rows, kb] (each or null), dv [num_segments, kv] (caller-zeroed, added to with float
+ *   atomics at segment-run ends), ln_partial [ococc_point_mlp_tiles(rows), 2, n] (dgamma | dbeta partial sums).
+ * ------------------------------------------------------------------------ */
+int64_t ococc_point_mlp_fragment_floats(int32_t n, int32_t k);
+int64_t ococc_point_mlp_tiles(int64_t rows);
+int ococc_point_mlp_pack_f32(const float* w, int32_t n, int32_t k, int64_t row_stride, int64_t col_stride, float* frag,
+                             ococc_stream_t stream);
+int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, const float* mul, int32_t ldm, const float* colscale,
+                            const float* b, int32_t kb, int32_t ldb, float bscale, const float* v, int32_t kv,
+                            const int32_t* inv, int64_t rows, const float* w_frag, int32_t n, const float* ln_weight,
+                            const float* ln_bias, float eps, int32_t act, float* y, float* seg_max, int64_t num_segments,
+                            ococc_stream_t stream);
+int ococc_point_mlp_segment_argmax(const float* y, const float* seg_max, const int32_t* inv, int64_t rows, int32_t n,
+                                   int64_t num_segments, int32_t* seg_arg, ococc_stream_t stream);
+int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float* mul, int32_t ldm, const float* colscale,
+                            const float* b, int32_t kb, int32_t ldb, float bscale, const float* v, int32_t kv,
+                            const int32_t* inv, int64_t rows, const float* w_frag, const float* wt_frag, int32_t n,
+                            const float* ln_weight, const float* ln_bias, float eps, int32_t act, const float* dy,
+                            const float* d_seg_max, const int32_t* seg_arg, float* dz, float* x_cat, float* da,
+                            float* dmul, float* db, float* dv, float* ln_partial, ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

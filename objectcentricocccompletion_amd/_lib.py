@@ -119,6 +119,15 @@ SIGNATURES = {
     'ococc_token_wgrad_slabs': (c_i64, [c_i64]),
     'ococc_token_wgrad_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i64, c_i64, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp]),
     'ococc_partial_rows_sum_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
+    'ococc_point_mlp_fragment_floats': (c_i64, [c_i32, c_i32]),
+    'ococc_point_mlp_tiles': (c_i64, [c_i64]),
+    'ococc_point_mlp_pack_f32': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    'ococc_point_mlp_fwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
+                                        c_i64, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_point_mlp_segment_argmax': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),
+    'ococc_point_mlp_bwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
+                                        c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_adamw_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),

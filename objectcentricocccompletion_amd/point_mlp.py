@@ -1,0 +1,110 @@
+"""Fused per-point layers of the SIR encoders on csrc/point_mlp.hip:
+
+    y = act(LayerNorm(x W^T)),   x = [ a * mul * colscale | b * bscale | v[inv] ],   optionally seg_max(y)
+
+one launch where SIRLayer.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832) runs torch.cat / products,
+nn.Linear, LayerNorm, GELU, scatter_v2(max) and the gather-back one after the other.  f32 like the reference
+(force_fp32); the backward launch recomputes the layer from its inputs."""
+import torch
+
+from . import _lib as L
+from .linear import TALL_ROWS, sliced_wgrad
+
+ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
+
+
+def pack_weight(w):
+    """nn.Linear weight [n, k] (or a transposed view) -> f32 MFMA fragment tensor"""
+    n, k = w.shape
+    out = torch.empty(int(L.lib.ococc_point_mlp_fragment_floats(n, k)), dtype=torch.float32, device=w.device)
+    L.check(L.lib.ococc_point_mlp_pack_f32(L.ptr(w), n, k, w.stride(0), w.stride(1), L.ptr(out), L.stream()), 'point_mlp_pack')
+    return out
+
+
+def _f32(t):
+    return None if t is None else t.detach().float().contiguous()
+
+
+class _PointLayer(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, a, mul, b, v, weight, ln_w, ln_b, colscale, inv, bscale, eps, act, want_max, num_segments):
+        L.require_device(a, weight)
+        a_, mul_, b_, v_ = _f32(a), _f32(mul), _f32(b), _f32(v)
+        rows, ka = a_.shape
+        kb = 0 if b_ is None else b_.shape[1]
+        kv = 0 if v_ is None else v_.shape[1]
+        n = weight.shape[0]
+        assert weight.shape[1] == ka + kb + kv, (weight.shape, ka, kb, kv)
+        dev = a_.device
+        wf = pack_weight(weight.detach().float())
+        g, be = _f32(ln_w), _f32(ln_b)
+        y = torch.empty((rows, n), dtype=torch.float32, device=dev)
+        vmax = torch.empty((num_segments, n), dtype=torch.float32, device=dev) if want_max else None
+        L.check(L.lib.ococc_point_mlp_fwd_f32(
+            L.ptr(a_), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
+            0 if b_ is None else b_.stride(0), float(bscale), L.ptr(v_), kv, L.ptr(inv), rows, L.ptr(wf), n, L.ptr(g),
+            L.ptr(be), float(eps), ACT[act], L.ptr(y), L.ptr(vmax), int(num_segments), L.stream()), 'point_mlp_fwd')
+        ctx.save_for_backward(a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf)
+        ctx.misc = (float(bscale), float(eps), act, int(num_segments))
+        ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (a, mul, b, v))
+        return y, vmax
+
+    @staticmethod
+    def backward(ctx, dy, dvmax):
+        a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf = ctx.saved_tensors
+        bscale, eps, act, G = ctx.misc
+        rows, ka = a_.shape
+        kb = 0 if b_ is None else b_.shape[1]
+        kv = 0 if v_ is None else v_.shape[1]
+        n, k = weight.shape
+        dev = a_.device
+        need = ctx.needs_input_grad
+        dy = _f32(dy)
+        arg = None
+        if vmax is not None and dvmax is not None:
+            dvmax = _f32(dvmax)
+            arg = torch.empty((G, n), dtype=torch.int32, device=dev)
+            L.check(L.lib.ococc_point_mlp_segment_argmax(L.ptr(y), L.ptr(vmax), L.ptr(inv), rows, n, G, L.ptr(arg),
+                                                         L.stream()), 'segment_argmax')
+        else:
+            dvmax = None
+        wtf = pack_weight(weight.detach().float().t())
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dz = new(rows, n)
+        xcat = new(rows, k) if need[4] else None
+        da = new(rows, ka) if need[0] else None
+        dmul = new(rows, ka) if (mul_ is not None and need[1]) else None
+        db = new(rows, kb) if (b_ is not None and need[2]) else None
+        dv = torch.zeros((G, kv), dtype=torch.float32, device=dev) if (v_ is not None and need[3]) else None
+        tiles = int(L.lib.ococc_point_mlp_tiles(rows))
+        lnp = new(tiles, 2, n) if g is not None else None
+        L.check(L.lib.ococc_point_mlp_bwd_f32(
+            L.ptr(a_), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
+            0 if b_ is None else b_.stride(0), bscale, L.ptr(v_), kv, L.ptr(inv), rows, L.ptr(wf), L.ptr(wtf), n, L.ptr(g),
+            L.ptr(be), eps, ACT[act], L.ptr(dy), L.ptr(dvmax), L.ptr(arg), L.ptr(dz), L.ptr(xcat), L.ptr(da), L.ptr(dmul),
+            L.ptr(db), L.ptr(dv), L.ptr(lnp), L.stream()), 'point_mlp_bwd')
+        dw = None
+        if need[4]:
+            dw = (sliced_wgrad(dz, xcat) if rows >= TALL_ROWS else dz.t() @ xcat).to(weight.dtype)
+        dg = dbeta = None
+        if g is not None:
+            sums = lnp.sum(0)
+            dg, dbeta = sums[0], sums[1]
+        cast = lambda t, dt: None if t is None else t.to(dt)
+        dts = ctx.in_dtypes
+        return (cast(da, dts[0]), cast(dmul, dts[1]), cast(db, dts[2]), cast(dv, dts[3]), dw, dg, dbeta, None, None, None,
+                None, None, None, None)
+
+
+def point_layer(a, weight, ln_weight=None, ln_bias=None, eps=1e-5, act='gelu', mul=None, colscale=None, b=None, bscale=1.0,
+                v=None, inv=None, num_segments=0, seg_max=False):
+    """y [rows, n] (and the segment maxima [num_segments, n] when ``seg_max``).  ``inv``: int32 segment of every row,
+    non-decreasing; needed for ``v`` (rows of a per-segment tensor appended to the input) and for ``seg_max``."""
+    if (v is not None or seg_max) and inv is None:
+        raise ValueError('inv is needed to gather segment rows / reduce over segments')
+    if inv is not None and inv.dtype != torch.int32:
+        inv = inv.to(torch.int32)
+    y, vmax = _PointLayer.apply(a, mul, b, v, weight, ln_weight, ln_bias, colscale, inv, bscale, eps, act, bool(seg_max),
+                                int(num_segments))
+    return (y, vmax) if seg_max else y

@@ -3,18 +3,22 @@ voxel_encoder.py:686-832), DynamicVFELayerV2 (voxel_encoders/utils.py:147-189) a
 (mmdet3d/models/backbones/sir.py:16-88).  Same constructor arguments, parameter names
 (rel_mlp.<i>.0.weight, vfe_layers.<j>.{linear,norm}.*, block_list.<i>...) and outputs.
 
-Device work per layer: Linear -> cuBLAS-class GEMM (hipBLASLt through torch),
-LN(+GELU) -> ococc_layernorm_act_*, scatter max/mean -> ococc_segment_reduce_f32.
+Device work: every Linear -> LayerNorm -> activation of a layer, together with the products / concatenations /
+gather-backs that build its input and the segment maximum behind it, is one launch of ococc_point_mlp_*_f32
+(csrc/point_mlp.hip, f32 MFMA); options the kernel does not cover (batch norm, mean pooling, distance decoration)
+run the same chain from separate operators.
 """
 import torch
 from torch import nn
 
 from ._lib import const_tensor
-from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
-from .sst.sst_ops import (build_mlp, fuse_norm_act, get_activation_layer, scatter_v2,
-                          unique_with_inverse)
 from .linear import Linear
-from .voxel.scatter_points import gather_rows
+from .point_mlp import point_layer
+from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
+from .sst.sst_ops import build_mlp, fuse_norm_act, get_activation_layer, unique_with_inverse
+from .voxel.scatter_points import gather_rows, segment_reduce
+
+POINT_LAYER_KERNEL = True   # False: every Linear / LayerNorm / segment reduction of a SIRLayer as its own operator
 
 
 class DynamicVFELayerV2(nn.Module):
@@ -84,48 +88,104 @@ class SIRLayer(nn.Module):
         self.vfe_layers = nn.ModuleList(vfe_layers)
         self.num_vfe = len(vfe_layers)
 
+    # ---- forward ------------------------------------------------------------------------------------------------
+    # What the layer computes (voxel_encoder.py:764-832), per point p of group g = inv[p]:
+    #   c_p   = f_cluster_p / rel_dist_scaler          (given, or xyz_p - mean of the group's xyz)
+    #   x_p   = [ (xyz_p / xyz_normalizer, rest_p) * rel_mlp(c_p) | c_p / 10 if with_cluster_center | |xyz_p| if with_distance ]
+    #   y0_p  = vfe_0(x_p),  m0_g = max_{p in g} y0_p,   y1_p = vfe_1([y0_p | m0_g]),  m1_g = max y1_p, ...
+    # returned: the last y (+ the raw non-xyz input columns when the widths agree) and [m0 | m1 | ...].
+    # Two realisations: `_forward_fused` -- every Linear -> LN -> act (+ the max) of the chain is ONE launch of
+    # csrc/point_mlp.hip, the concatenations / products / gather-backs happen while the kernel assembles its input
+    # rows -- and `_forward_ops`, the same chain from separate operators for the options the kernel does not cover.
+    def _groups(self, coors, inv, group_coors):
+        if inv is None:
+            group_coors, inv = unique_with_inverse(coors)
+        return inv, group_coors
+
+    def _cluster_offsets(self, xyz, f_cluster, inv, num_groups):
+        if f_cluster is not None:
+            return f_cluster
+        centre = segment_reduce(xyz.float(), inv, num_groups, 'mean')
+        return xyz - gather_rows(centre, inv)
+
+    def _fusable(self):
+        from .norm import LayerNorm
+        if not POINT_LAYER_KERNEL or self.mode != 'max' or self._with_distance:
+            return False
+        blocks = [(v.linear, v.norm, v.act, v.dropout) for v in self.vfe_layers]
+        if self._with_rel_mlp:
+            blocks += [(b[0], b[1], b[2], b[3] if len(b) > 3 else None) for b in self.rel_mlp]
+        for lin, norm, act, drop in blocks:
+            if not (isinstance(norm, LayerNorm) and norm.fused_act in ('gelu', 'none') and isinstance(act, (nn.Identity, nn.ReLU))
+                    and lin.bias is None and lin.in_features <= 256 and lin.out_features <= 144):
+                return False
+            if drop is not None and self.training and getattr(drop, 'p', 0) > 0:
+                return False
+        return True
+
+    @staticmethod
+    def _act_of(norm, act):
+        return 'gelu' if norm.fused_act == 'gelu' else ('relu' if isinstance(act, nn.ReLU) else 'none')
+
+    def _forward_fused(self, features, f_cluster, inv, num_groups):
+        dev = features.device
+        raw = self.in_channels - 3 * (self._with_cluster_center + self._with_voxel_center)   # columns of `features`
+        scale = 1.0 / float(self.rel_dist_scaler)
+        gate = None
+        if self._with_rel_mlp:   # gate = rel_mlp(f_cluster / rel_dist_scaler), one launch per Linear -> LN -> act
+            gate = f_cluster
+            for i, blk in enumerate(self.rel_mlp):
+                lin, norm = blk[0], blk[1]
+                cs = const_tensor([scale] * lin.in_features, dev) if i == 0 else None
+                gate = point_layer(gate, lin.weight, norm.weight, norm.bias, norm.eps, self._act_of(norm, blk[2]), colscale=cs)
+        col = const_tensor([1.0 / v for v in self.xyz_normalizer] + [1.0] * (raw - 3), dev)
+        extra = f_cluster if self._with_cluster_center else None
+        maxima = []
+        y = None
+        for i, vfe in enumerate(self.vfe_layers):
+            act = self._act_of(vfe.norm, vfe.act)
+            if i == 0:
+                y, m = point_layer(features, vfe.linear.weight, vfe.norm.weight, vfe.norm.bias, vfe.norm.eps, act, mul=gate,
+                                   colscale=col, b=extra, bscale=scale / 10.0, inv=inv, num_segments=num_groups, seg_max=True)
+            else:
+                y, m = point_layer(y, vfe.linear.weight, vfe.norm.weight, vfe.norm.bias, vfe.norm.eps, act, v=maxima[-1],
+                                   inv=inv, num_segments=num_groups, seg_max=True)
+            maxima.append(m)
+        return y, torch.cat(maxima, dim=1)
+
+    def _forward_ops(self, features, f_cluster, inv, num_groups):
+        xyz = features[:, :3]
+        scaled = f_cluster / self.rel_dist_scaler
+        head = torch.cat([xyz / const_tensor(self.xyz_normalizer, features.device, features.dtype)[None, :],
+                          features[:, 3:]], dim=1)
+        if self._with_rel_mlp:
+            head = head * self.rel_mlp(scaled)
+        parts = [head]
+        if self._with_cluster_center:
+            parts.append(scaled / 10.0)
+        if self._with_distance:
+            parts.append(torch.norm(xyz, 2, 1, keepdim=True))
+        x = torch.cat(parts, dim=-1)
+        maxima = []
+        for i, vfe in enumerate(self.vfe_layers):
+            y = vfe(x)
+            maxima.append(segment_reduce(y.float(), inv, num_groups, 'mean' if self.mode == 'avg' else self.mode))
+            if i + 1 < len(self.vfe_layers):
+                x = torch.cat([y, gather_rows(maxima[-1], inv)], dim=1)
+        return y, torch.cat(maxima, dim=1)
+
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None,
                 return_inv=False, return_both=False, unq_inv_once=None, new_coors_once=None):
-        xyz_normalizer = const_tensor(self.xyz_normalizer, features.device, features.dtype)
-        features_ls = [torch.cat([features[:, :3] / xyz_normalizer[None, :], features[:, 3:]], dim=1)]
-        if self.with_shortcut:
-            shortcut = features[:, 3:]
-        if f_cluster is None:
-            voxel_mean, mean_coors, unq_inv = scatter_v2(features[:, :3], coors, mode='avg',
-                                                         unq_inv=unq_inv_once, new_coors=new_coors_once)
-            points_mean = gather_rows(voxel_mean, unq_inv)
-            f_cluster = (features[:, :3] - points_mean[:, :3]) / self.rel_dist_scaler
-        else:
-            f_cluster = f_cluster / self.rel_dist_scaler
-        if self._with_cluster_center:
-            features_ls.append(f_cluster / 10.0)
-        if self._with_rel_mlp:
-            features_ls[0] = features_ls[0] * self.rel_mlp(f_cluster)
-        if self._with_distance:
-            features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
-        features = torch.cat(features_ls, dim=-1)
-
-        voxel_feats_list = []
-        for i, vfe in enumerate(self.vfe_layers):
-            point_feats = vfe(features)
-            voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode,
-                                                           unq_inv=unq_inv_once, new_coors=new_coors_once)
-            voxel_feats_list.append(voxel_feats)
-            if i != len(self.vfe_layers) - 1:
-                features = torch.cat([point_feats, gather_rows(voxel_feats, unq_inv)], dim=1)
-        voxel_feats = torch.cat(voxel_feats_list, dim=1)
-
-        if return_both:
-            if self.with_shortcut and point_feats.shape == shortcut.shape:
-                point_feats = point_feats + shortcut
-            return point_feats, voxel_feats, voxel_coors
-        if self.return_point_feats:
-            if self.with_shortcut and point_feats.shape == shortcut.shape:
-                point_feats = point_feats + shortcut
-            return point_feats, voxel_feats
-        if return_inv:
-            return voxel_feats, voxel_coors, unq_inv
-        return voxel_feats, voxel_coors
+        inv, group_coors = self._groups(coors, unq_inv_once, new_coors_once)
+        num_groups = group_coors.size(0)
+        f_cluster = self._cluster_offsets(features[:, :3], f_cluster, inv, num_groups)
+        run = self._forward_fused if self._fusable() else self._forward_ops
+        point_feats, group_feats = run(features, f_cluster, inv, num_groups)
+        if return_both or self.return_point_feats:
+            if self.with_shortcut and point_feats.shape[1] == features.shape[1] - 3:
+                point_feats = point_feats + features[:, 3:]
+            return (point_feats, group_feats, group_coors) if return_both else (point_feats, group_feats)
+        return (group_feats, group_coors, inv) if return_inv else (group_feats, group_coors)
 
 
 @BACKBONES.register_module()
@@ -152,20 +212,14 @@ class SIR(nn.Module):
         self.block_list = nn.ModuleList(block_list)
 
     def forward(self, points, features, coors, f_cluster=None, dims=None):
-        if self.unique_once:
-            new_coors, unq_inv = unique_with_inverse(coors, dims)
-        else:
-            new_coors = unq_inv = None
-        out_feats = features
-        cluster_feat_list = []
+        """points [M, 3], features [M, C] -> (point features of the last block, [group maxima of all blocks], group coors);
+        the groups are found once when ``unique_once`` (backbones/sir.py:67-88)."""
+        group_coors, inv = unique_with_inverse(coors, dims) if self.unique_once else (None, None)
+        feats, per_block = features, []
+        last = len(self.block_list) - 1
         for i, block in enumerate(self.block_list):
-            in_feats = torch.cat([points, out_feats], 1)
-            if i < self.num_blocks - 1:
-                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv,
-                                                     new_coors_once=new_coors)
-            else:
-                out_feats, out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, return_both=True,
-                                                                unq_inv_once=unq_inv,
-                                                                new_coors_once=new_coors)
-            cluster_feat_list.append(out_cluster_feats)
-        return out_feats, torch.cat(cluster_feat_list, dim=1), out_coors
+            out = block(torch.cat([points, feats], 1), coors, f_cluster, return_both=(i == last), unq_inv_once=inv,
+                        new_coors_once=group_coors)
+            feats = out[0]
+            per_block.append(out[1])
+        return feats, torch.cat(per_block, dim=1), out[2]

@@ -1,0 +1,154 @@
+"""GPU parity of the fused per-point layer (csrc/point_mlp.hip, A6) against float64 torch math of the reference's chain
+Linear(bias=False) -> LayerNorm -> GELU -> scatter max with the gather-back / concatenation / product in front
+(voxel_encoder.py:764-832), forward and backward, at the channel widths the ococcnet config uses (odd ones included),
+and of the whole SIRLayer: fused realisation against the per-operator one."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_layer(a, w, g, be, eps, act, mul, cs, b, bs, v, inv, G, seg_max):
+    x = a
+    if mul is not None:
+        x = x * mul
+    if cs is not None:
+        x = x * cs
+    parts = [x]
+    if b is not None:
+        parts.append(b * bs)
+    if v is not None:
+        parts.append(v[inv.long()])
+    x = torch.cat(parts, 1)
+    z = x @ w.t()
+    if g is not None:
+        z = torch.nn.functional.layer_norm(z, (w.shape[0],), g, be, eps)
+    y = torch.nn.functional.gelu(z) if act == 'gelu' else (z.clamp(min=0) if act == 'relu' else z)
+    if not seg_max:
+        return y, None
+    m = torch.full((G, w.shape[0]), float('-inf'), dtype=y.dtype, device=y.device)
+    m = m.scatter_reduce(0, inv.long()[:, None].expand_as(y), y, 'amax')
+    return y, m
+
+
+@pytest.mark.parametrize('shape', [
+    # (rows, ka, mul?, colscale?, kb, kv, n, ln, act, seg_max)
+    (1000, 13, False, True, 0, 0, 16, True, 'gelu', False),     # rel_mlp layer 0 (RoI encoder)
+    (1000, 16, False, False, 0, 0, 32, True, 'gelu', False),
+    (777, 32, False, False, 0, 0, 24, True, 'gelu', False),     # odd output width
+    (1000, 32, False, False, 0, 0, 144, True, 'gelu', False),
+    (700, 3, False, True, 0, 0, 16, True, 'gelu', False),
+    (900, 32, False, False, 0, 0, 131, True, 'gelu', False),    # 131 outputs: padding inside the last block
+    (1000, 24, True, True, 0, 0, 128, True, 'gelu', True),      # vfe 0, RoI encoder block 0
+    (1000, 144, True, True, 0, 0, 128, True, 'gelu', True),
+    (1000, 15, True, True, 3, 0, 128, True, 'gelu', True),      # vfe 0, AE encoder (cluster centre appended)
+    (1000, 131, True, True, 3, 0, 128, True, 'gelu', True),
+    (1000, 128, False, False, 0, 128, 128, True, 'gelu', True), # vfe 1: gather-back
+    (130, 128, False, False, 0, 128, 128, True, 'relu', True),
+    (64, 20, False, False, 0, 0, 48, False, 'none', False),     # no norm
+    (5, 8, True, False, 2, 4, 16, True, 'gelu', True),          # fewer rows than a tile
+])
+def test_point_layer_vs_torch_f64(dev, shape):
+    from objectcentricocccompletion_amd.point_mlp import point_layer
+    rows, ka, has_mul, has_cs, kb, kv, n, ln, act, seg_max = shape
+    g = torch.Generator().manual_seed(sum(shape[:2]) + n)
+    G = max(1, rows // 37)
+    sizes = torch.randint(1, 74, (G,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(G), sizes)[:rows]
+    if inv.numel() < rows:
+        inv = torch.cat([inv, torch.full((rows - inv.numel(),), G - 1)])
+    G = int(inv.max()) + 1
+    R = lambda *s: torch.randn(*s, generator=g)
+    a, mul = R(rows, ka), (R(rows, ka) if has_mul else None)
+    cs = (torch.rand(ka, generator=g) + 0.5) if has_cs else None
+    b, v = (R(rows, kb) if kb else None), (R(G, kv) if kv else None)
+    w = R(n, ka + kb + kv) / (ka + kb + kv) ** 0.5
+    gam, bet = ((1 + 0.2 * R(n)), 0.1 * R(n)) if ln else (None, None)
+    dy, dm = R(rows, n), R(G, n)
+    bs = 0.37
+
+    def leaf(t, dt):
+        return None if t is None else t.to(dev, dt).requires_grad_(True)
+    outs = {}
+    for name, dt in (('hip', torch.float32), ('ref', torch.float64)):
+        A, M, B, V, W, Gm, Bt = (leaf(t, dt) for t in (a, mul, b, v, w, gam, bet))
+        csd = None if cs is None else cs.to(dev, dt)
+        invd = inv.to(dev, torch.int32)
+        if name == 'hip':
+            res = point_layer(A, W, Gm, Bt, 1e-3, act, mul=M, colscale=csd, b=B, bscale=bs, v=V, inv=invd if (kv or seg_max) else None,
+                              num_segments=G, seg_max=seg_max)
+            y, m = res if seg_max else (res, None)
+        else:
+            y, m = _ref_layer(A, W, Gm, Bt, 1e-3, act, M, csd, B, bs, V, invd, G, seg_max)
+        loss = (y * dy.to(dev, dt)).sum() + ((m * dm.to(dev, dt)).sum() if seg_max else 0)
+        loss.backward()
+        outs[name] = dict(y=y.detach(), m=None if m is None else m.detach(),
+                          grads=[None if t is None else t.grad for t in (A, M, B, V, W, Gm, Bt)])
+    rel = lambda x, r: float((x.double() - r).abs().max() / r.abs().max().clamp(min=1e-30))
+    assert rel(outs['hip']['y'], outs['ref']['y']) < 2e-5
+    if seg_max:
+        assert rel(outs['hip']['m'], outs['ref']['m']) < 2e-5
+    for gh, gr, nm in zip(outs['hip']['grads'], outs['ref']['grads'], ('a', 'mul', 'b', 'v', 'w', 'gamma', 'beta')):
+        if gr is None:
+            continue
+        assert gh is not None, nm
+        assert rel(gh, gr) < 2e-4, (nm, rel(gh, gr))
+
+
+def test_segment_max_ties_go_to_the_smallest_row(dev):
+    """Equal maxima inside a segment (duplicated points): the gradient of the maximum goes to the smallest row, the rule
+    of the reference's DynamicScatter (scatter_points_cuda.cu:136-160) that segment_reduce follows too."""
+    from objectcentricocccompletion_amd.point_mlp import point_layer
+    g = torch.Generator().manual_seed(3)
+    rows, k, n = 200, 8, 16
+    a = torch.randn(rows, k, generator=g)
+    a[50:60] = a[50]                    # ten identical rows inside segment 1, spread over one tile
+    a[130:140] = a[70]                  # and a copy of row 70 in the same segment but another tile
+    inv = torch.cat([torch.zeros(40), torch.ones(110), torch.full((50,), 2)]).int()
+    w = torch.randn(n, k, generator=g)
+    A = a.to(dev).requires_grad_(True)
+    y, m = point_layer(A, w.to(dev), None, None, 0.0, 'none', inv=inv.to(dev), num_segments=3, seg_max=True)
+    m.sum().backward()
+    yc = y.detach().cpu()
+    got = (A.grad.abs().sum(1) > 0).cpu()
+    for seg in range(3):
+        rows_of = torch.nonzero(inv == seg).flatten()
+        for ch in range(n):
+            col = yc[rows_of, ch]
+            first = int(rows_of[int(torch.nonzero(col == col.max()).flatten()[0])])
+            assert bool(got[first])
+    assert not bool(got[51:60].any()) and not bool(got[130:140].any())
+
+
+@pytest.mark.parametrize('cfg', [dict(in_channels=24, rel_in=13, cluster=False), dict(in_channels=15, rel_in=3, cluster=True)])
+def test_sir_layer_fused_equals_operator_path(dev, cfg):
+    from objectcentricocccompletion_amd import sir
+    g = torch.Generator().manual_seed(7)
+    layer = sir.SIRLayer(in_channels=cfg['in_channels'], feat_channels=[128, 128], with_cluster_center=cfg['cluster'],
+                         rel_mlp_hidden_dims=[16, 32], rel_mlp_in_channel=cfg['rel_in'], norm_cfg=dict(type='LN', eps=1e-3),
+                         mode='max', return_point_feats=True, rel_dist_scaler=10.0, xyz_normalizer=[20, 20, 4], act='gelu',
+                         dropout=0).to(dev)
+    assert layer._fusable()
+    M, G = 3000, 40
+    sizes = torch.randint(20, 130, (G,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(G), sizes)[:M]
+    M = inv.numel()
+    feats = torch.randn(M, cfg['in_channels'], generator=g).to(dev)
+    fc = torch.randn(M, 13, generator=g).to(dev) if not cfg['cluster'] else None
+    dp, dg = torch.randn(M, 128, generator=g).to(dev), torch.randn(int(inv.max()) + 1, 256, generator=g).to(dev)
+    runs = []
+    for fused in (True, False):
+        sir.POINT_LAYER_KERNEL = fused
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = feats.clone().requires_grad_(True)
+            pf, gf = layer(x, inv.to(dev).int(), fc)
+            ((pf * dp).sum() + (gf * dg).sum()).backward()
+            runs.append((pf.detach(), gf.detach(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()]))
+        finally:
+            sir.POINT_LAYER_KERNEL = True
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    a, b = runs
+    assert rel(a[0], b[0]) < 1e-4 and rel(a[1], b[1]) < 1e-4 and rel(a[2], b[2]) < 1e-3
+    for p, q in zip(a[3], b[3]):
+        assert rel(p, q) < 1e-3
