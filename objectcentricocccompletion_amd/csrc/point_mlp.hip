@@ -48,62 +48,154 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {   // dest
   else atomicMin((unsigned int*)addr, bits);
 }
 
-// x tile -> LDS (zero beyond the row count and in the padding columns up to kp)
+// Padded widths: the k range of a tile is padded with zeros to a multiple of 32 (eight MFMA k-steps: the fragment
+// prefetch below needs no bound checks), output channels to a multiple of 16.
+__host__ __device__ constexpr int pad_k(int k) { return (k + 31) & ~31; }
+__host__ __device__ constexpr int pad_n(int n) { return (n + 15) & ~15; }
+
+// x tile -> LDS.  Wave w builds rows 16 w .. 16 w + 15; the 64 lanes of a wave read consecutive columns of one row
+// (coalesced).  A lane's columns (lane, lane + 64, ...) keep their source for all rows, so the source pointers are
+// worked out once and the row loop is branch-free straight-line code: the loads of four rows are in flight together.
+// inv of the wave's rows sits in lanes 0..15 and is handed out by shuffles.
 __device__ __forceinline__ void assemble(const PointMlpIn& in, int64_t row0, int kp, int ld, float* xs, int* inv_s) {
-  const int k = in.ka + in.kb + in.kv;
-  if (in.inv && threadIdx.x < TR) inv_s[threadIdx.x] = row0 + threadIdx.x < in.rows ? in.inv[row0 + threadIdx.x] : -1;
-  for (int i = threadIdx.x; i < TR * kp; i += kT) {
-    const int r = i / kp, col = i - r * kp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = in.ka + in.kb + in.kv, kab = in.ka + in.kb;
+  int my_inv = 0;
+  if (in.inv && lane < 16) {
+    const int64_t row = row0 + 16 * wave + lane;
+    my_inv = row < in.rows ? in.inv[row] : -1;
+    inv_s[16 * wave + lane] = my_inv;
+  }
+  const float* src[4];     // element (row or segment) 0 of the lane's column in chunk j; a valid address even when unused
+  const float* gate[4];
+  int64_t stride[4], gstride[4];
+  float scale[4];
+  bool by_seg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = lane + 64 * j;
+    src[j] = gate[j] = in.a;
+    stride[j] = gstride[j] = 0;
+    scale[j] = 0.f;
+    by_seg[j] = false;
+    if (col < in.ka) {
+      src[j] = in.a + col;
+      stride[j] = in.lda;
+      scale[j] = in.colscale ? in.colscale[col] : 1.f;
+      if (in.mul) {
+        gate[j] = in.mul + col;
+        gstride[j] = in.ldm;
+      }
+    } else if (col < kab) {
+      src[j] = in.b + (col - in.ka);
+      stride[j] = in.ldb;
+      scale[j] = in.bscale;
+    } else if (col < k) {
+      src[j] = in.v + (col - kab);
+      stride[j] = in.kv;
+      scale[j] = 1.f;
+      by_seg[j] = true;
+    }
+  }
+  const bool gated = in.mul != nullptr;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = 16 * wave + rr;
     const int64_t row = row0 + r;
-    float val = 0.f;
-    if (row < in.rows && col < k) {
-      if (col < in.ka) {
-        val = in.a[row * in.lda + col];
-        if (in.mul) val *= in.mul[row * in.ldm + col];
-        if (in.colscale) val *= in.colscale[col];
-      } else if (col < in.ka + in.kb) {
-        val = in.b[row * in.ldb + (col - in.ka)] * in.bscale;
-      } else {
-        val = in.v[(int64_t)in.inv[row] * in.kv + (col - in.ka - in.kb)];
+    const bool ok = row < in.rows;
+    const int64_t rc = ok ? row : 0;
+    const int64_t seg = max(__shfl(my_inv, rr, 64), 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (64 * j < kp) {
+        float val = src[j][(by_seg[j] ? seg : rc) * stride[j]];
+        if (gated) val *= gstride[j] ? gate[j][rc * gstride[j]] : 1.f;
+        const int col = lane + 64 * j;
+        if (col < kp) xs[r * ld + col] = ok ? val * scale[j] : 0.f;
       }
     }
-    xs[r * ld + col] = val;
   }
 }
 
-// acc[nb][mb] += W[16 (nb0 + nb) .. +16][:] x[16 mb .. +16][:]^T ; wf: fragments [n block][k step][64 lanes]
+// rows of an LDS tile -> rows of a global [rows, width] tensor, a wave per 16 rows, lanes along the columns
+__device__ __forceinline__ void store_rows(const float* ts, int ld, float* __restrict__ dst, int width, int64_t row0,
+                                           int64_t rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = 16 * wave + rr;
+    if (row0 + r < rows)
+      for (int col = lane; col < width; col += 64) dst[(row0 + r) * width + col] = ts[r * ld + col];
+  }
+}
+
+// acc[nb][mb] += W[16 (nb0 + nb) .. +16][:] x[16 mb .. +16][:]^T ; wf: fragments [n block][k step][64 lanes], k steps
+// padded to a multiple of 8.  Blocks beyond the matrix's `nblocks` re-read its last block (their results are dropped).
+//
+// The weight fragments of a chunk of 8 k-steps are requested while the previous chunk's 8 * NBW * 4 MFMAs run.  The
+// compiler will not keep such a prefetch: it sinks plain loads of read-only memory to their uses (one L2 round trip in
+// front of every fourth MFMA, measured 3x slower), and volatile loads are serialised with vmcnt(0).  So the loads are
+// inline asm, invisible to the compiler, with hand-placed waits (the scheme of csrc/sparse_conv.hip's stream kernel):
+// two register sets take turns, no register with a load in flight is copied, `frag_wait<N>` + `frag_tie` stand in front
+// of every use (N = the loads of the OTHER set, issued later; older memory operations complete first), and a final
+// vmcnt(0) lets the last, unused prefetch land before the registers are reused.
+__device__ __forceinline__ void frag_load(float& dst, const float* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p));
+}
+template <int N>
+__device__ __forceinline__ void frag_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+__device__ __forceinline__ void frag_tie(float& v) { asm volatile("" : "+v"(v)); }
+
 template <int NBW>
-__device__ __forceinline__ void gemm_f32(const float* __restrict__ wf, int nb0, int nbn, int ksteps, const float* xs, int ld,
-                                         f32x4 (&acc)[NBW][4]) {
+__device__ __forceinline__ void gemm_f32(const float* __restrict__ wf, int nb0, int nblocks, int ksteps, const float* xs,
+                                         int ld, f32x4 (&acc)[NBW][4]) {
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const float* wp = wf + (size_t)nb0 * ksteps * 64 + lane;
-  float a[NBW][8], an[NBW][8];
-  auto fetch = [&](float (&dst)[NBW][8], int ks0) {
+  const float* wp[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) wp[nb] = wf + (size_t)min(nb0 + nb, nblocks - 1) * ksteps * 64 + lane;
+  float a0[NBW][8], a1[NBW][8];
+  const int last = ksteps - 8;
+  auto issue = [&](float (&dst)[NBW][8], int ks0) {
+    const int at = ks0 < last ? ks0 : last;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dst[nb][j] = (nb < nbn && ks0 + j < ksteps) ? wp[((size_t)nb * ksteps + ks0 + j) * 64] : 0.f;
+      for (int j = 0; j < 8; ++j) frag_load(dst[nb][j], wp[nb] + (size_t)(at + j) * 64);
   };
-  fetch(a, 0);
-  for (int ks0 = 0; ks0 < ksteps; ks0 += 8) {
-    fetch(an, ks0 + 8);   // eight k-steps ahead: their L2 latency runs under this chunk's 8 * NBW * 4 MFMAs
+  auto landed = [&](float (&dst)[NBW][8]) {
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) frag_tie(dst[nb][j]);
+  };
+  const float* xb = xs + c * ld + g;
+  auto compute = [&](const float (&a)[NBW][8], int ks0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (ks0 + j < ksteps) {
-        float b[4];
+      float b[4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) b[mb] = xs[(mb * 16 + c) * ld + 4 * (ks0 + j) + g];
+      for (int mb = 0; mb < 4; ++mb) b[mb] = xb[mb * 16 * ld + 4 * (ks0 + j)];
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
+      for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][j], b[mb], acc[nb][mb], 0, 0, 0);
-      }
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][j], b[mb], acc[nb][mb], 0, 0, 0);
     }
-#pragma unroll
-    for (int nb = 0; nb < NBW; ++nb)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a[nb][j] = an[nb][j];
+  };
+  issue(a0, 0);
+  for (int ks0 = 0; ks0 < ksteps; ks0 += 16) {
+    issue(a1, ks0 + 8);
+    frag_wait<8 * NBW>();
+    landed(a0);
+    compute(a0, ks0);
+    issue(a0, ks0 + 16);
+    frag_wait<8 * NBW>();
+    landed(a1);
+    if (ks0 + 8 < ksteps) compute(a1, ks0 + 8);
   }
+  frag_wait<0>();
+  landed(a0);
 }
 
 // sum over the channels of each of the lane's 4 rows (row mb*16 + c), across lanes and waves; one barrier
@@ -178,12 +270,21 @@ __device__ __forceinline__ void layernorm_rows(f32x4 (&z)[NBW][4], const Slice<N
   }
 }
 
-__device__ __forceinline__ float act_f(int act, float v) { return act == 1 ? ln_gelu1(v) : (act == 2 ? fmaxf(v, 0.f) : v); }
+template <int ACT>
+__device__ __forceinline__ f32x4 act_f4(const f32x4 v) {
+  if (ACT == 1) {
+    const ln_f32x2 a = ln_gelu2(ln_f32x2{v[0], v[1]}), b = ln_gelu2(ln_f32x2{v[2], v[3]});
+    return f32x4{a.x, a.y, b.x, b.y};
+  }
+  if (ACT == 2) return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  return v;
+}
 __device__ __forceinline__ float act_g(int act, float v) {
   return act == 1 ? ln_gelu_grad2(ln_f32x2{v, v}).x : (act == 2 ? (v > 0.f ? 1.f : 0.f) : 1.f);
 }
 
-constexpr int lds_floats(int kp, int np) { return TR * (kp + 2) + TR * (np + 2) + 2 * 4 * TR + TR; }
+// one LDS tile [64][max(kp, np) + 2] used in turn for x, y / dz and dx, + the LayerNorm exchange + inv
+__host__ __device__ constexpr int lds_floats(int kp, int np) { return TR * ((kp > np ? kp : np) + 2) + 2 * 4 * TR + TR; }
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int NBW>
@@ -191,10 +292,9 @@ __global__ void __launch_bounds__(kT, 2)
 point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const float* __restrict__ ln_w,
                      const float* __restrict__ ln_b, float eps, int act, float* __restrict__ y, float* __restrict__ vmax) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  const int k = in.ka + in.kb + in.kv, kp = (k + 3) & ~3, ld = kp + 2, np = (n + 15) & ~15, ldy = np + 2;
-  float* xs = smem_f;
-  float* ys = xs + TR * ld;
-  float* red0 = ys + TR * ldy;
+  const int k = in.ka + in.kb + in.kv, kp = pad_k(k), np = pad_k(n), ld = (kp > np ? kp : np) + 2;
+  float* xs = smem_f;                // x, then y
+  float* red0 = xs + TR * ld;
   float* red1 = red0 + 4 * TR;
   int* inv_s = (int*)(red1 + 4 * TR);
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -207,7 +307,8 @@ point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const f
   for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<NBW>(wf, sl.nb0, sl.nbn, kp >> 2, xs, ld, z);
+  gemm_f32<NBW>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
+  __syncthreads();   // x has been read by every wave: the tile now receives y
   if (ln_w) {
     float rstd[4];
     layernorm_rows<NBW>(z, sl, n, eps, red0, red1, rstd);
@@ -216,28 +317,32 @@ point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const f
   for (int nb = 0; nb < NBW; ++nb) {
     if (nb < sl.nbn) {
       const int ch = 16 * (sl.nb0 + nb) + 4 * g;
+      f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+      if (ln_w)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+        for (int r = 0; r < 4; ++r)
+          if (sl.live[nb][r]) {
+            gm[r] = ln_w[ch + r];
+            bt[r] = ln_b[ch + r];
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = z[nb][mb][r];
-          if (ln_w && sl.live[nb][r]) v = v * ln_w[ch + r] + ln_b[ch + r];
-          ys[(mb * 16 + c) * ldy + ch + r] = sl.live[nb][r] ? act_f(act, v) : 0.f;
-        }
+      for (int mb = 0; mb < 4; ++mb) {
+        const f32x4 pre = z[nb][mb] * gm + bt;
+        const f32x4 o = act == 1 ? act_f4<1>(pre) : (act == 2 ? act_f4<2>(pre) : pre);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[(mb * 16 + c) * ld + ch + r] = sl.live[nb][r] ? o[r] : 0.f;
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TR * n; i += kT) {   // rows of y, coalesced
-    const int r = i / n, col = i - r * n;
-    if (row0 + r < in.rows) y[(row0 + r) * n + col] = ys[r * ldy + col];
-  }
+  store_rows(xs, ld, y, n, row0, in.rows);
   if (vmax && threadIdx.x < n) {   // segment maxima: one thread per channel walks the tile's rows
     int cur = -1;
     float acc = 0.f;
+#pragma unroll 8
     for (int r = 0; r < TR; ++r) {
       const int seg = inv_s[r];
-      if (seg < 0) break;
-      const float v = ys[r * ldy + threadIdx.x];
+      const float v = xs[r * ld + threadIdx.x];
       if (seg != cur) {
         if (cur >= 0) atomic_max_f32(vmax + (int64_t)cur * n + threadIdx.x, acc);
         cur = seg;
@@ -263,36 +368,51 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
                      float* __restrict__ dz_out, float* __restrict__ xcat, float* __restrict__ da, float* __restrict__ dmul,
                      float* __restrict__ db, float* __restrict__ dv, float* __restrict__ ln_partial) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  const int k = in.ka + in.kb + in.kv, kp = (k + 3) & ~3, ld = kp + 2, np = (n + 15) & ~15, ldy = np + 2;
-  float* xs = smem_f;              // x, then dx
-  float* ys = xs + TR * ld;        // dz
-  float* red0 = ys + TR * ldy;
+  const int k = in.ka + in.kb + in.kv, kp = pad_k(k), np = pad_k(n), ld = (kp > np ? kp : np) + 2;
+  float* xs = smem_f;              // x, then dz, then dx
+  float* red0 = xs + TR * ld;
   float* red1 = red0 + 4 * TR;
   int* inv_s = (int*)(red1 + 4 * TR);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * TR;
   assemble(in, row0, kp, ld, xs, inv_s);
   __syncthreads();
-  if (xcat)
-    for (int i = threadIdx.x; i < TR * k; i += kT) {
-      const int r = i / k, col = i - r * k;
-      if (row0 + r < in.rows) xcat[(row0 + r) * k + col] = xs[r * ld + col];
-    }
+  if (xcat) store_rows(xs, ld, xcat, k, row0, in.rows);
   const Slice<NBW> sl(n);
   f32x4 z[NBW][4];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<NBW>(wf, sl.nb0, sl.nbn, kp >> 2, xs, ld, z);
+  gemm_f32<NBW>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
+  __syncthreads();   // x has been read (GEMM, xcat copy): the tile now receives dz
   float rstd[4] = {1.f, 1.f, 1.f, 1.f};
   if (ln_w) layernorm_rows<NBW>(z, sl, n, eps, red0, red1, rstd);   // z = xhat
   // d(pre-activation) = (dy + routed dvmax) * act'(pre), LayerNorm parameter sums, then the LayerNorm backward
   f32x4 d[NBW][4];
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  int segs[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) segs[mb] = inv_s[mb * 16 + c];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
     const int ch = 16 * (sl.nb0 + nb) + 4 * g;
+    // upstream gradients of the lane's 4 x 4 positions of this block, asked for together
+    f32x4 up[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int64_t row = row0 + mb * 16 + c;
+      up[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nb < sl.nbn && row < in.rows) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (sl.live[nb][r]) {
+            float u = dy ? dy[row * n + ch + r] : 0.f;
+            if (dvmax && arg[(int64_t)segs[mb] * n + ch + r] == (int32_t)row) u += dvmax[(int64_t)segs[mb] * n + ch + r];
+            up[mb][r] = u;
+          }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool live = sl.live[nb][r];
@@ -300,17 +420,8 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
       float dg = 0.f, dbt = 0.f;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        const int64_t row = row0 + mb * 16 + c;
-        float up = 0.f;
-        if (live && row < in.rows) {
-          if (dy) up = dy[row * n + ch + r];
-          if (dvmax) {
-            const int64_t seg = inv_s[mb * 16 + c];
-            if (arg[seg * n + ch + r] == (int32_t)row) up += dvmax[seg * n + ch + r];
-          }
-        }
         const float xh = z[nb][mb][r];
-        const float dpre = up * act_g(act, ln_w ? xh * gm + bt : xh);
+        const float dpre = up[mb][r] * act_g(act, ln_w ? xh * gm + bt : xh);
         dg += dpre * xh;
         dbt += dpre;
         const float v = dpre * gm;
@@ -343,10 +454,11 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
         for (int r = 0; r < 4; ++r)
           d[nb][mb][r] = sl.live[nb][r] ? ((d[nb][mb][r] - s1[mb] * inv_n) - z[nb][mb][r] * (s2[mb] * inv_n)) * rstd[mb] : 0.f;
   }
-  // dz -> LDS (zero in the padding channels, so that the contraction below may run over np)
-  for (int i = threadIdx.x; i < TR * (np - n); i += kT) {
-    const int r = i / (np - n), col = n + i % (np - n);
-    ys[r * ldy + col] = 0.f;
+  // dz -> LDS, zero up to pad_k(n) columns: the contraction of the second GEMM runs over that range
+  const int nk = pad_k(n);
+  for (int i = threadIdx.x; i < TR * (nk - n); i += kT) {
+    const int r = i / (nk - n), col = n + i % (nk - n);
+    xs[r * ld + col] = 0.f;
   }
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
@@ -356,23 +468,20 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (sl.live[nb][r]) ys[(mb * 16 + c) * ldy + ch + r] = d[nb][mb][r];
+          if (sl.live[nb][r]) xs[(mb * 16 + c) * ld + ch + r] = d[nb][mb][r];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TR * n; i += kT) {
-    const int r = i / n, col = i - r * n;
-    if (row0 + r < in.rows) dz_out[(row0 + r) * n + col] = ys[r * ldy + col];
-  }
+  store_rows(xs, ld, dz_out, n, row0, in.rows);
   // dx^T[kk][m] = sum_n W^T[kk][n] dz[m][n]: the wave's KBW blocks of 16 input channels
-  const int kblocks = (kp + 15) >> 4, kb0 = wave * KBW, kbn = max(0, min(KBW, kblocks - kb0));
+  const int kblocks = (k + 15) >> 4, kb0 = wave * KBW, kbn = max(0, min(KBW, kblocks - kb0));
   f32x4 gx[KBW][4];
 #pragma unroll
   for (int nb = 0; nb < KBW; ++nb)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) gx[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<KBW>(wtf, kb0, kbn, (n + 3) >> 2, ys, ldy, gx);   // (dz is zero in [n, np): the last k-step may run past n)
-  __syncthreads();   // every wave has left x (the forward GEMM's operand) and dz behind
+  gemm_f32<KBW>(wtf, kb0, kblocks, nk >> 2, xs, ld, gx);
+  __syncthreads();   // dz has been read (GEMM, dz_out copy): the tile now receives dx
 #pragma unroll
   for (int nb = 0; nb < KBW; ++nb) {
     if (nb < kbn) {
@@ -386,28 +495,32 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TR * (in.ka + in.kb); i += kT) {   // gradients of the direct parts
-    const int r = i / (in.ka + in.kb), col = i - r * (in.ka + in.kb);
-    const int64_t row = row0 + r;
-    if (row >= in.rows) continue;
-    const float gxv = xs[r * ld + col];
-    if (col < in.ka) {
-      const float cs = in.colscale ? in.colscale[col] : 1.f;
-      const float av = in.a[row * in.lda + col];
-      const float mv = in.mul ? in.mul[row * in.ldm + col] : 1.f;
-      if (da) da[row * in.ka + col] = gxv * mv * cs;
-      if (dmul) dmul[row * in.ka + col] = gxv * av * cs;
-    } else if (db) {
-      db[row * in.kb + (col - in.ka)] = gxv * in.bscale;
+  {   // gradients of the direct parts: a wave per 16 rows, lanes along the columns
+    const int kab = in.ka + in.kb;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int r = 16 * wave + rr;
+      const int64_t row = row0 + r;
+      if (row >= in.rows) continue;
+      for (int col = lane; col < kab; col += 64) {
+        const float gxv = xs[r * ld + col];
+        if (col < in.ka) {
+          const float cs = in.colscale ? in.colscale[col] : 1.f;
+          if (da) da[row * in.ka + col] = gxv * (in.mul ? in.mul[row * in.ldm + col] : 1.f) * cs;
+          if (dmul) dmul[row * in.ka + col] = gxv * in.a[row * in.lda + col] * cs;
+        } else if (db) {
+          db[row * in.kb + (col - in.ka)] = gxv * in.bscale;
+        }
+      }
     }
   }
   if (dv && in.kv > 0 && threadIdx.x < in.kv) {   // gradient of the gathered segment rows: run-length sums, float atomics
     const int col = in.ka + in.kb + threadIdx.x;
     int cur = -1;
     float acc = 0.f;
+#pragma unroll 8
     for (int r = 0; r < TR; ++r) {
       const int seg = inv_s[r];
-      if (seg < 0) break;
       const float v = xs[r * ld + col];
       if (seg != cur) {
         if (cur >= 0) atomicAdd(dv + (int64_t)cur * in.kv + threadIdx.x, acc);
@@ -421,11 +534,11 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
   }
 }
 
-// W [n][k] f32 (element strides) -> f32 MFMA A-operand fragments [ceil(n/16)][ceil(k/4)][64]: lane 16 g + r of block
+// W [n][k] f32 (element strides) -> f32 MFMA A-operand fragments [ceil(n/16)][pad_k(k)/4][64]: lane 16 g + r of block
 // (nb, ks) holds W[16 nb + r][4 ks + g]; zero where the matrix ends
 __global__ void __launch_bounds__(256)
 point_mlp_pack_kernel(const float* __restrict__ w, int n, int k, int64_t rs, int64_t cs, float* __restrict__ dst) {
-  const int ksteps = (k + 3) >> 2, nblocks = (n + 15) >> 4, total = nblocks * ksteps * 64;
+  const int ksteps = pad_k(k) >> 2, nblocks = (n + 15) >> 4, total = nblocks * ksteps * 64;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int lane = i & 63, blk = i >> 6, ks = blk % ksteps, nb = blk / ksteps;
     const int row = 16 * nb + (lane & 15), col = 4 * ks + (lane >> 4);
@@ -468,7 +581,7 @@ inline int nbw_of(int n) { return (((n + 15) >> 4) + 3) / 4; }
 }  // namespace
 
 extern "C" int64_t ococc_point_mlp_fragment_floats(int32_t n, int32_t k) {
-  return n <= 0 || k <= 0 ? -1 : (int64_t)((n + 15) >> 4) * ((k + 3) >> 2) * 64;
+  return n <= 0 || k <= 0 ? -1 : (int64_t)((n + 15) >> 4) * (pad_k(k) >> 2) * 64;
 }
 
 extern "C" int ococc_point_mlp_pack_f32(const float* w, int32_t n, int32_t k, int64_t row_stride, int64_t col_stride,
@@ -504,7 +617,7 @@ extern "C" int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, 
     hipLaunchKernelGGL(fill_kernel, dim3(ococc_grid_1d(num_segments * n, 256, 1024)), dim3(256), 0, stream, seg_max,
                        num_segments * n, -INFINITY);
   if (rows == 0) return OCOCC_OK;
-  const int k = ka + kb + kv, kp = (k + 3) & ~3, np = (n + 15) & ~15;
+  const int k = ka + kb + kv, kp = pad_k(k), np = pad_k(n);
   const int lds = lds_floats(kp, np) * 4;
   const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
 #define OCOCC_PM_FWD(NBW)                                                                                             \
@@ -538,10 +651,10 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
   OCOCC_REQUIRE((!d_seg_max) == (!seg_arg) && (!d_seg_max || inv), "the gradient of the segment maxima comes with seg_arg and inv");
   OCOCC_REQUIRE(!ln_weight || ln_partial, "LayerNorm partial rows missing");
   if (rows == 0) return OCOCC_OK;
-  const int k = ka + kb + kv, kp = (k + 3) & ~3, np = (n + 15) & ~15;
+  const int k = ka + kb + kv, kp = pad_k(k), np = pad_k(n);
   const int lds = lds_floats(kp, np) * 4;
   const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
-  const int kbw = (((kp + 15) >> 4) + 3) / 4;
+  const int kbw = (((k + 15) >> 4) + 3) / 4;
 #define OCOCC_PM_BWD(NBW, KBW)                                                                                            \
   do {                                                                                                                    \
     OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -8,6 +8,8 @@ gather-backs that build its input and the segment maximum behind it, is one laun
 (csrc/point_mlp.hip, f32 MFMA); options the kernel does not cover (batch norm, mean pooling, distance decoration)
 run the same chain from separate operators.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -19,6 +21,11 @@ from .sst.sst_ops import build_mlp, fuse_norm_act, get_activation_layer, unique_
 from .voxel.scatter_points import gather_rows, segment_reduce
 
 POINT_LAYER_KERNEL = True   # False: every Linear / LayerNorm / segment reduction of a SIRLayer as its own operator
+# The fused layer is one workgroup per 64 points with all phases in sequence: it removes ~15 launches per layer (the
+# config's own batch of 4 tracklets, ~8 k points, is launch bound) but at 1e5 points the separate library GEMM /
+# LayerNorm / segment kernels, each tuned for throughput, are faster (measured on MI355X, whole ococcnet step: 25.4 / 35.8 / 51.1 ms fused against
+# 33.5 / 41.9 / 53.6 ms at 4 / 16 / 32 tracklets = 8 k / 33 k / 65 k points, but 98 against 79 ms at 64 tracklets).  Above this many points the per-operator chain runs.
+POINT_LAYER_MAX_ROWS = int(os.environ.get('OCOCC_POINT_LAYER_MAX_ROWS', 80000))
 
 
 class DynamicVFELayerV2(nn.Module):
@@ -179,7 +186,8 @@ class SIRLayer(nn.Module):
         inv, group_coors = self._groups(coors, unq_inv_once, new_coors_once)
         num_groups = group_coors.size(0)
         f_cluster = self._cluster_offsets(features[:, :3], f_cluster, inv, num_groups)
-        run = self._forward_fused if self._fusable() else self._forward_ops
+        fused = self._fusable() and features.shape[0] <= POINT_LAYER_MAX_ROWS
+        run = self._forward_fused if fused else self._forward_ops
         point_feats, group_feats = run(features, f_cluster, inv, num_groups)
         if return_both or self.return_point_feats:
             if self.with_shortcut and point_feats.shape[1] == features.shape[1] - 3:
