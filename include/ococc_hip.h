@@ -631,6 +631,49 @@ int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float
                             const float* d_seg_max, const int32_t* seg_arg, float* dz, float* x_cat, float* da,
                             float* dmul, float* db, float* dv, float* ln_partial, ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * A11 / A10, fused  the occupancy decoder's per-query MLP, one launch per layer (or one for the whole MLP):
+ *   y = dropout(act(LayerNorm(x W^T + bias + add_rows[add_index]))),  optionally  head = y . head_weight + head_bias
+ * replaces OccDecoder.forward's conv_occ (mmdet3d/models/occ/occ_base.py:99-153): build_mlp's
+ * Sequential(Linear(bias=False), LN, GELU, Dropout) blocks 1596 -> 512 -> 1024 -> 1024 and the Linear(1024 -> 1) head
+ * (mmdet3d/ops/sst/sst_ops.py:333-360), and PosEncode.forward (occ_base.py:33-57).
+ * bf16 operands, f32 accumulation, f32 LayerNorm statistics over the f32 sums, bf16 activations.
+ * ococc_pos_encode_bf16: xyz f32 [rows, 3] -> out bf16 [rows, ld], columns [sin(pi 2^l x^) | cos(pi 2^l x^)] in the
+ *   reference's [2L][3] order, x^ = x normalised to [-1, 1] by bound = {lo xyz, hi xyz} (HOST pointer; null: x^ = x),
+ *   columns 6L .. ld - 1 zero.
+ * ococc_linear_fragments32_bf16: `count` (<= 16) f32 matrices S_i [rows_i, cols_i] (any strides; rows a multiple of
+ *   32) -> bf16 operand fragments of v_mfma_f32_32x32x16_bf16, columns zero-padded to padded_cols_i (multiple of 16):
+ *   dst_i[rb][cs][lane][j] = S_i[32 rb + (lane & 31)][16 cs + 8 (lane >> 5) + j].  The tables are HOST arrays.
+ * ococc_mlp_layer_fwd_bf16: x bf16 [rows, k], k a multiple of 64 up to 1024; w_frag the fragments of W [n, k],
+ *   n 512 or 1024; bias [n], add_rows f32 [*, n] with add_index int32 [rows], ln_weight / ln_bias [n], head_weight [n] with
+ *   head_bias [1] (device): each optional.  act: 0 none, 1 GELU (erf).  drop_threshold > 0: the counter-based keep mask of
+ *   ococc_layernorm_act_dropout_fwd_bf16 (same threshold and seed -> same mask).  y bf16 [rows, n] or null when only the head is wanted;
+ *   head_out f32 [rows] (the head reads the bf16-rounded activation, as the next Linear would).
+ * ococc_occ_mlp_fwd_bf16: the reference's decoder widths, 60 (padded to 64) -> 512 -> 1024 -> 1024 -> 1, in ONE launch;
+ *   a 64-row tile's activations stay in LDS between the layers.  pe bf16 [rows, 64] (ococc_pos_encode_bf16), add_rows
+ *   f32 [*, 512] with add_index [rows] (the per-RoI half of the first layer); w_frag / ln_weight / ln_bias: HOST tables
+ *   of 3 device pointers (fragments of [512, 64], [1024, 512], [1024, 1024]; f32 [n]); GELU after every LayerNorm;
+ *   head_weight f32 [1024], head_bias [1] or null; dropout_seeds: HOST array of 3 (read when drop_threshold > 0), the
+ *   masks of ococc_mlp_layer_fwd_bf16 called per layer with the same seeds.  out f32 [rows];  y0_out bf16 [rows, 512]
+ *   / y1_out bf16 [rows, 1024]: optional copies of the hidden activations (what a backward pass starts from).
+ *   Bit-identical to three ococc_mlp_layer_fwd_bf16 calls.
+ * ------------------------------------------------------------------------ */
+int ococc_pos_encode_bf16(const float* xyz, int64_t rows, const float* bound, int32_t num_freqs, uint16_t* out, int32_t ld,
+                          ococc_stream_t stream);
+int ococc_linear_fragments32_bf16(int32_t count, const void* const* src, const int64_t* rows, const int64_t* cols,
+                                  const int64_t* padded_cols, const int64_t* row_stride, const int64_t* col_stride,
+                                  void* const* dst, ococc_stream_t stream);
+int ococc_mlp_layer_fwd_bf16(const uint16_t* x, int64_t rows, int32_t k, const uint16_t* w_frag, int32_t n,
+                             const float* bias, const float* add_rows, const int32_t* add_index, const float* ln_weight,
+                             const float* ln_bias, float eps, int32_t act, uint32_t drop_threshold, uint64_t dropout_seed,
+                             uint16_t* y, const float* head_weight, const float* head_bias, float* head_out,
+                             ococc_stream_t stream);
+int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const float* add_rows, const int32_t* add_index,
+                           const void* const* w_frag, const void* const* ln_weight, const void* const* ln_bias, float eps,
+                           const float* head_weight, const float* head_bias, uint32_t drop_threshold,
+                           const uint64_t* dropout_seeds, uint16_t* y0_out, uint16_t* y1_out, float* out,
+                           ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

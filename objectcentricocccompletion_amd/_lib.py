@@ -128,6 +128,13 @@ SIGNATURES = {
     'ococc_point_mlp_bwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
                                         c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_pos_encode_bf16': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_f32), c_i32, c_vp, c_i32, c_vp]),
+    'ococc_linear_fragments32_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
+    'ococc_mlp_layer_fwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32,
+                                         ctypes.c_uint32, ctypes.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_occ_mlp_fwd_bf16': (c_i32, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                       c_f32, c_vp, c_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), c_vp, c_vp, c_vp,
+                                       c_vp]),
     'ococc_cast_f32_to_bf16': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_cast_bf16_to_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     'ococc_adamw_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),

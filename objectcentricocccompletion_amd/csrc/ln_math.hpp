@@ -59,6 +59,32 @@ __device__ __forceinline__ ln_f32x2 ln_gelu2(ln_f32x2 z) {
 }
 __device__ __forceinline__ float ln_gelu1(float z) { return ln_gelu2(ln_f32x2{z, z}).x; }
 
+// GELU with ONE transcendental per element, for epilogues that are VALU-bound next to the matrix pipe (mlp_layer.hip):
+//   GELU(z) = max(z, 0) - |z| u(|z|),   u(a) = (1 - erf(a / sqrt 2)) / 2 = 1 / (2 P(a)^16)
+// Abramowitz & Stegun 7.1.28, erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16, |error| <= 3e-7 (x >= 0); the coefficients
+// below are a_i / sqrt(2)^i.  No exponential, no sign select: 12 packed operations, 2 reciprocals and 4 single ones per
+// pair against 14 + 4 + 6 above.  |GELU error| <= 1.5e-7 |z|.
+__device__ __forceinline__ ln_f32x2 ln_gelu2_rcp(ln_f32x2 z) {
+  ln_f32x2 a, r, relu;
+  a.x = __builtin_fabsf(z.x);
+  a.y = __builtin_fabsf(z.y);
+  ln_f32x2 p = a * 5.38297500e-6f + 4.88906356e-5f;
+  p = p * a + 3.80035750e-5f;
+  p = p * a + 3.27762632e-3f;
+  p = p * a + 2.11410061e-2f;
+  p = p * a + 4.98673470e-2f;
+  p = p * a + 1.f;
+  r.x = __builtin_amdgcn_rcpf(p.x);
+  r.y = __builtin_amdgcn_rcpf(p.y);
+  r = r * r;
+  r = r * r;
+  r = r * r;
+  r = r * r;
+  relu.x = __builtin_fmaxf(z.x, 0.f);
+  relu.y = __builtin_fmaxf(z.y, 0.f);
+  return relu - (a * r) * 0.5f;
+}
+
 // Dropout behind the activation (build_mlp's Sequential(Linear, norm, act, Dropout), sst_ops.py:333-360), folded into
 // the LN kernels: the keep mask is a counter-based hash of (seed, element index) -- one 32-bit hash per channel pair,
 // 16 bits each against the threshold -- so the backward kernel regenerates it instead of reading a stored mask

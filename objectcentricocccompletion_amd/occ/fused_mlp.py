@@ -1,0 +1,143 @@
+"""The occupancy decoder's per-query MLP on csrc/mlp_layer.hip -- the MI355X form of OccDecoder.forward's conv_occ
+(mmdet3d/models/occ/occ_base.py:99-153; build_mlp, mmdet3d/ops/sst/sst_ops.py:333-360):
+
+    pe  = PosEncode(xyz)                                   ococc_pos_encode_bf16        bf16 [M, 64]
+    y0  = drop(GELU(LN(pe W_pe^T + roi_part[idx])))        ococc_mlp_layer_fwd_bf16     (roi_part: once per RoI, f32)
+    y1  = drop(GELU(LN(y0 W1^T)))                                  "
+    out = drop(GELU(LN(y1 W2^T))) . w_head + b_head                "                     (y2 never leaves the chip)
+
+One launch per layer, LayerNorm / GELU / dropout in the GEMM's epilogue; bf16 operands and activations, f32
+accumulation and statistics."""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+_probe = None   # measurement hook (bench.py --workload decode): .wrap(name, flops, launch)
+
+
+def set_probe(probe):
+    global _probe
+    _probe = probe
+
+
+def _run(name, flops, launch):
+    if _probe is not None:
+        _probe.wrap(name, flops, launch)
+    else:
+        launch()
+
+
+def _vp(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def _i64(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def pad16(k):
+    return (k + 15) // 16 * 16
+
+
+def pad64(k):
+    return (k + 63) // 64 * 64
+
+
+def linear_fragments32(mats, padded_cols=None):
+    """f32 matrices [n, k] (2-D views, any strides, n a multiple of 32) -> bf16 fragment tensors of
+    v_mfma_f32_32x32x16_bf16's A operand, columns zero-padded to ``padded_cols[i]``; one launch per 16."""
+    padded_cols = list(padded_cols) if padded_cols is not None else [pad16(m.shape[1]) for m in mats]
+    outs = []
+    for i in range(0, len(mats), 16):
+        part, pads = mats[i:i + 16], padded_cols[i:i + 16]
+        for m, p in zip(part, pads):
+            assert m.dim() == 2 and m.dtype == torch.float32 and m.shape[0] % 32 == 0 and p % 16 == 0 and p >= m.shape[1]
+        dst = [torch.empty(m.shape[0] * p, dtype=torch.bfloat16, device=m.device) for m, p in zip(part, pads)]
+        L.check(L.lib.ococc_linear_fragments32_bf16(
+            len(part), _vp([m.data_ptr() for m in part]), _i64([m.shape[0] for m in part]), _i64([m.shape[1] for m in part]),
+            _i64(pads), _i64([m.stride(0) for m in part]), _i64([m.stride(1) for m in part]),
+            _vp([d.data_ptr() for d in dst]), L.stream()), 'linear_fragments32')
+        outs += dst
+    return outs
+
+
+def pos_encode_bf16(xyz, num_freqs, bound=None, ld=None):
+    """xyz f32 [M, 3] -> bf16 [M, ld] (ld = 6 L rounded up to 64): PosEncode.forward (occ_base.py:33-57), zero padded."""
+    L.require_device(xyz)
+    xyz = xyz.detach().float().contiguous()
+    ld = pad64(6 * num_freqs) if ld is None else ld
+    out = torch.empty((xyz.size(0), ld), dtype=torch.bfloat16, device=xyz.device)
+    b = (ctypes.c_float * 6)(*[float(v) for v in bound]) if bound is not None else None
+    L.check(L.lib.ococc_pos_encode_bf16(L.ptr(xyz), xyz.size(0), b, int(num_freqs), L.ptr(out), ld, L.stream()), 'pos_encode')
+    return out
+
+
+def mlp_layer(x, w_frag, n, ln_weight=None, ln_bias=None, eps=1e-5, act='gelu', bias=None, add_rows=None, add_index=None,
+              drop_threshold=0, seed=0, head_weight=None, head_bias=None, want_y=True):
+    """(y bf16 [M, n] or None, head f32 [M] or None) of one fused layer; x bf16 [M, k] contiguous."""
+    L.require_device(x, w_frag)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    rows, k = x.shape
+    assert w_frag.numel() == n * k, (w_frag.numel(), n, k)
+    dev = x.device
+    y = torch.empty((rows, n), dtype=torch.bfloat16, device=dev) if want_y else None
+    head = torch.empty((rows,), dtype=torch.float32, device=dev) if head_weight is not None else None
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    bias, add_rows, ln_weight, ln_bias, head_weight, head_bias = map(
+        f32, (bias, add_rows, ln_weight, ln_bias, head_weight, head_bias))
+    if add_index is not None and add_index.dtype != torch.int32:
+        add_index = add_index.to(torch.int32)
+    code = {'none': 0, None: 0, 'gelu': 1}[act]
+    flops = 2.0 * rows * n * k
+    _run(f'mlp_layer_fwd_kernel k{k} n{n}', flops, lambda: L.check(L.lib.ococc_mlp_layer_fwd_bf16(
+        L.ptr(x), rows, k, L.ptr(w_frag), n, L.ptr(bias), L.ptr(add_rows), L.ptr(add_index), L.ptr(ln_weight),
+        L.ptr(ln_bias), float(eps), code, int(drop_threshold), int(seed), L.ptr(y), L.ptr(head_weight), L.ptr(head_bias),
+        L.ptr(head), L.stream()), 'mlp_layer_fwd'))
+    return y, head
+
+
+OCC_MLP_WIDTHS = (64, 512, 1024, 1024)   # the one-launch kernel's shape: the reference's decoder (ococcnet.py occ_mlp)
+
+
+def occ_mlp(pe, add_rows, add_index, w_frags, ln_weights, ln_biases, eps, head_weight, head_bias=None, drop_threshold=0,
+            seeds=None, want_hidden=False):
+    """All three layers + head in one launch (ococc_occ_mlp_fwd_bf16): logits f32 [M], and the hidden activations
+    (y0 bf16 [M, 512], y1 bf16 [M, 1024]) when ``want_hidden``."""
+    L.require_device(pe, add_rows)
+    assert pe.dtype == torch.bfloat16 and pe.is_contiguous() and pe.shape[1] == OCC_MLP_WIDTHS[0]
+    rows, dev = pe.size(0), pe.device
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    add_rows, head_weight, head_bias = f32(add_rows), f32(head_weight), f32(head_bias)
+    gs, bs = [f32(t) for t in ln_weights], [f32(t) for t in ln_biases]
+    assert add_rows.shape[1] == OCC_MLP_WIDTHS[1] and [g.numel() for g in gs] == list(OCC_MLP_WIDTHS[1:])
+    assert [w.numel() for w in w_frags] == [OCC_MLP_WIDTHS[i + 1] * OCC_MLP_WIDTHS[i] for i in range(3)]
+    if add_index.dtype != torch.int32:
+        add_index = add_index.to(torch.int32)
+    out = torch.empty((rows,), dtype=torch.float32, device=dev)
+    y0 = torch.empty((rows, OCC_MLP_WIDTHS[1]), dtype=torch.bfloat16, device=dev) if want_hidden else None
+    y1 = torch.empty((rows, OCC_MLP_WIDTHS[2]), dtype=torch.bfloat16, device=dev) if want_hidden else None
+    sd = (ctypes.c_uint64 * 3)(*[int(s) for s in seeds]) if drop_threshold else None
+    flops = 2.0 * rows * sum(OCC_MLP_WIDTHS[i + 1] * OCC_MLP_WIDTHS[i] for i in range(3))
+    _run('occ_mlp_fwd_kernel', flops, lambda: L.check(L.lib.ococc_occ_mlp_fwd_bf16(
+        L.ptr(pe), rows, L.ptr(add_rows), L.ptr(add_index), _vp([w.data_ptr() for w in w_frags]),
+        _vp([g.data_ptr() for g in gs]), _vp([b.data_ptr() for b in bs]), float(eps), L.ptr(head_weight), L.ptr(head_bias),
+        int(drop_threshold), sd, L.ptr(y0), L.ptr(y1), L.ptr(out), L.stream()), 'occ_mlp_fwd'))
+    return (out, y0, y1) if want_hidden else out
+
+
+class DecoderWeights(object):
+    """bf16 operand fragments of the decoder's Linear weights, rebuilt when a parameter changes (its version counter or
+    storage)."""
+
+    def __init__(self):
+        self._key = None
+        self.frags = None
+
+    def get(self, weights, pads):
+        key = tuple((w.data_ptr(), w._version, tuple(w.shape), tuple(w.stride())) for w in weights)
+        if key != self._key:
+            self.frags = linear_fragments32([w.detach() for w in weights], pads)
+            self._key = key
+        return self.frags

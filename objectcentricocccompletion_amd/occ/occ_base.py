@@ -22,6 +22,10 @@ from ..voxel.scatter_points import gather_rows
 from . import occ_ops
 
 
+FUSED_WHOLE_MLP = True   # ... and in ONE launch when the widths are the reference's 60 -> 512 -> 1024 -> 1024 -> 1
+FUSED_MLP = True   # bf16 inference of OccDecoder on the per-layer kernels of occ/fused_mlp.py (False: library GEMMs + LN kernels)
+
+
 class PosEncode(nn.Module):
     """x -> [sin(pi 2^l x^) , cos(pi 2^l x^)] for l = 0..L-1, x^ = x normalised to [-1,1] by
     `bound`; output layout [2L, 3] flattened (occ_base.py:33-57)."""
@@ -78,11 +82,67 @@ class OccDecoder(nn.Module):
     def _ln(self, x):
         return layer_norm_act(x, self.ln.weight, self.ln.bias, self.ln.eps, 'none') if self.use_ln else x
 
+    # ------------------------------------------------------------------ fused per-layer kernels (occ/fused_mlp.py)
+    def _fused_layers(self):
+        """[(Linear, LayerNorm)] of the hidden blocks + the head Linear when the MLP has the shape the fused kernels
+        take (Linear(bias optional) -> LN with folded GELU [-> folded dropout], widths 512 / 1024, one logit), else None."""
+        from ..norm import LayerNorm, FoldedDropout
+        if not (isinstance(self.conv_occ, nn.Sequential) and isinstance(self.pos_encode, PosEncode) and self.cls_dim == 1):
+            return None
+        blocks, head = list(self.conv_occ)[:-1], self.conv_occ[-1]
+        if not (isinstance(head, nn.Linear) and len(blocks) >= 2):
+            return None
+        out, k = [], None
+        for b in blocks:
+            if not (isinstance(b, nn.Sequential) and len(b) >= 2 and isinstance(b[0], nn.Linear) and isinstance(b[1], LayerNorm)
+                    and b[1].fused_act == 'gelu' and all(isinstance(m, (nn.Identity, FoldedDropout)) for m in list(b)[2:])):
+                return None
+            n = b[0].out_features
+            if n not in (512, 1024) or (k is not None and (b[0].in_features != k or k % 64 or k > 1024)):
+                return None
+            out.append((b[0], b[1]))
+            k = n
+        return out, head
+
+    def _forward_fused(self, layers, head, roi_features, smp_xyzs, pts_roi_inds):
+        """Inference form of forward() on the fused kernels: one launch per layer, the last one with the head folded in."""
+        from . import fused_mlp as fm
+        D = self.roi_feature_channels
+        lin0 = layers[0][0]
+        if not hasattr(self, '_fused_weights'):
+            self._fused_weights = fm.DecoderWeights()
+        pe_cols = lin0.in_features - D
+        mats = [lin0.weight[:, D:]] + [l.weight for l, _ in layers[1:]]
+        frags = self._fused_weights.get(mats, [fm.pad64(pe_cols)] + [l.in_features for l, _ in layers[1:]])
+        roi_part = torch.mm(self._ln(roi_features).float(), lin0.weight[:, :D].t())           # [K, H] f32, once per RoI
+        bound = self.pos_encode.norm_bound if self.pos_encode.use_norm else None
+        h = fm.pos_encode_bf16(smp_xyzs, self.pos_encode.L, bound)
+        idx = pts_roi_inds.to(torch.int32)
+        widths = (h.shape[1],) + tuple(l.out_features for l, _ in layers)
+        if (FUSED_WHOLE_MLP and widths == fm.OCC_MLP_WIDTHS and all(l.bias is None for l, _ in layers)
+                and len({ln.eps for _, ln in layers}) == 1):
+            out = fm.occ_mlp(h, roi_part, idx, frags, [ln.weight for _, ln in layers], [ln.bias for _, ln in layers],
+                             layers[0][1].eps, head.weight.view(-1), head.bias)
+            return out.view(-1, 1)
+        out = None
+        for i, ((lin, ln), wf) in enumerate(zip(layers, frags)):
+            last = i == len(layers) - 1
+            h, out = fm.mlp_layer(h, wf, lin.out_features, ln.weight, ln.bias, ln.eps, 'gelu', bias=lin.bias,
+                                  add_rows=roi_part if i == 0 else None, add_index=idx if i == 0 else None,
+                                  head_weight=head.weight.view(-1) if last else None,
+                                  head_bias=head.bias if last else None, want_y=not last)
+        return out.view(-1, 1)
+
     def forward(self, roi_features, smp_xyzs, pts_roi_inds):
         """roi_features [K,D], smp_xyzs [N,3], pts_roi_inds [N] in [0,K) -> logits [N, cls_dim]
         (occ_base.py:100-118), first layer factorised as described in the module docstring."""
         if not isinstance(self.conv_occ, nn.Sequential):
             return self.conv_occ(self._ln(roi_features)[pts_roi_inds.long()])
+        if self.compute_dtype == torch.bfloat16 and FUSED_MLP and smp_xyzs.is_cuda and not (
+                torch.is_grad_enabled() and (roi_features.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            fused = self._fused_layers()
+            if fused is not None and not (self.training and any(ln.fused_dropout for _, ln in fused[0])):
+                return self._forward_fused(fused[0], fused[1], roi_features, smp_xyzs, pts_roi_inds)
         first = self.conv_occ[0]
         lin = first[0] if isinstance(first, nn.Sequential) else first
         D = self.roi_feature_channels

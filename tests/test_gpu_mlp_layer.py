@@ -1,0 +1,215 @@
+"""GPU parity of the fused decoder-layer kernels (csrc/mlp_layer.hip, occ/fused_mlp.py) against oracle/decoder_ref.py
+with the kernels' bf16 rounding points, and of the fused OccDecoder path against the reference's golden logits."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as D
+from test_decoder_oracle_cpu import PREFIX, decoder_params
+
+pytestmark = pytest.mark.gpu
+BF16_ULP = 2.0 ** -7   # one step of a bf16 value v is at most 2^-7 |v| (8 significant bits)
+
+
+def bf16(t):
+    return t.to(torch.bfloat16)
+
+
+def test_pos_encode_bf16(dev):
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    g = torch.Generator().manual_seed(1)
+    for rows in (1, 7, 1000, 4099):
+        xyz = (torch.rand(rows, 3, generator=g) * 2 - 1) * torch.tensor([8., 8., 4.])
+        bound = [-8.0, -8.0, -4.0, 8.0, 8.0, 4.0]
+        out = fm.pos_encode_bf16(xyz.to(dev), 10, bound).cpu()
+        assert out.shape == (rows, 64) and bool((out[:, 60:] == 0).all())
+        ref = D.pos_encode(xyz, 10, bound)
+        # sin(pi 2^9 x): f32 arguments up to ~1600, device sinf vs libm differ by ~1e-4 there: at most one bf16 step
+        err = (out[:, :60].double() - ref.double()).abs()
+        assert float(err.max()) <= BF16_ULP, float(err.max())
+        assert float((out[:, :60] == bf16(ref)).float().mean()) > 0.98
+    raw = fm.pos_encode_bf16(xyz.to(dev), 4, None, ld=24).cpu()   # no normalisation, 24 columns exactly
+    assert float((raw.double() - D.pos_encode(xyz, 4, use_norm=False).double()).abs().max()) <= BF16_ULP
+
+
+def test_fragments32_layout(dev):
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(64, 60, generator=g)
+    wt = torch.randn(48, 96, generator=g).t()   # strided view, [96, 48]
+    f0, f1 = fm.linear_fragments32([w.to(dev), wt.to(dev)], [64, 48])
+    for src, frag, pad in ((w, f0, 64), (wt, f1, 48)):
+        n, k = src.shape
+        full = torch.zeros(n, pad)
+        full[:, :k] = src
+        lane = torch.arange(64)
+        exp = torch.empty(n // 32, pad // 16, 64, 8)
+        for rb in range(n // 32):
+            for cs in range(pad // 16):
+                rows = 32 * rb + (lane & 31)
+                cols = 16 * cs + 8 * (lane >> 5)
+                exp[rb, cs] = torch.stack([full[rows, cols + j] for j in range(8)], -1)
+        assert torch.equal(frag.cpu().view(n // 32, pad // 16, 64, 8), bf16(exp))
+
+
+CASES = [  # rows, k, n, add, bias, head
+    (1, 64, 512, True, False, False), (64, 64, 512, True, True, False), (1000, 64, 512, True, False, False),
+    (129, 512, 1024, False, False, False), (2500, 512, 1024, False, True, False),
+    (63, 1024, 1024, False, False, True), (3001, 1024, 1024, False, False, True),
+    (700, 1024, 512, False, False, True), (515, 256, 512, True, False, True), (300, 128, 1024, False, False, False),
+]
+
+
+@pytest.mark.parametrize('rows,k,n,add,bias,head', CASES)
+def test_mlp_layer_vs_oracle(dev, rows, k, n, add, bias, head):
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    g = torch.Generator().manual_seed(rows + k + n)
+    x = bf16(torch.randn(rows, k, generator=g))
+    W = torch.randn(n, k, generator=g) / k ** 0.5
+    gam, bet = 1 + 0.2 * torch.randn(n, generator=g), 0.2 * torch.randn(n, generator=g)
+    b = 0.3 * torch.randn(n, generator=g) if bias else None
+    G = 5
+    addrows = torch.randn(G, n, generator=g) if add else None
+    idx = torch.randint(0, G, (rows,), generator=g).int() if add else None
+    hw = torch.randn(n, generator=g) / n ** 0.5 if head else None
+    hb = torch.tensor([0.25]) if head else None
+    wf, = fm.linear_fragments32([W.to(dev)], [k])
+    to = lambda t: None if t is None else t.to(dev)
+    y, ho = fm.mlp_layer(x.to(dev), wf, n, to(gam), to(bet), 1e-3, 'gelu', bias=to(b), add_rows=to(addrows), add_index=to(idx),
+                         head_weight=to(hw), head_bias=to(hb), want_y=True)
+    ey, eh = D.mlp_layer(x, W, gam, bet, 1e-3, bias=b, add=addrows, idx=idx, head_w=hw, head_b=hb, rounding='bf16')
+    y = y.cpu().double()
+    # north_star: 1e-3 norm-wise.  Element-wise a value may land on the neighbouring bf16 (f32 vs f64 sums and the
+    # 1.5e-7 erf polynomial in front of the rounding): one bf16 step, relative to the LayerNorm output's scale (GELU
+    # shrinks negative values but not their absolute error)
+    assert float((y - ey).norm() / ey.norm()) < 1e-3
+    assert bool(((y - ey).abs() <= BF16_ULP * (ey.abs() + 0.05) + 1e-6).all()), float((y - ey).abs().max())
+    assert float(((y - ey) == 0).double().mean()) > 0.97
+    if head:
+        ho = ho.cpu().double()
+        assert float((ho - eh).norm() / eh.norm()) < 1e-3
+        only, ho2 = fm.mlp_layer(x.to(dev), wf, n, to(gam), to(bet), 1e-3, 'gelu', bias=to(b), add_rows=to(addrows),
+                                 add_index=to(idx), head_weight=to(hw), head_bias=to(hb), want_y=False)
+        assert only is None and torch.equal(ho2.cpu().double(), ho)   # same arithmetic with the activation left on chip
+
+
+def test_mlp_layer_without_norm_and_empty(dev):
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    g = torch.Generator().manual_seed(5)
+    x, W = bf16(torch.randn(200, 64, generator=g)), torch.randn(512, 64, generator=g) / 8
+    wf, = fm.linear_fragments32([W.to(dev)], [64])
+    y, _ = fm.mlp_layer(x.to(dev), wf, 512, act='none')
+    ey, _ = D.mlp_layer(x, W, None, None, 0.0, rounding='bf16', act='none')
+    assert float((y.cpu().double() - ey).norm() / ey.norm()) < 1e-3
+    y, h = fm.mlp_layer(x[:0].to(dev), wf, 512, act='none')
+    assert y.shape == (0, 512) and h is None
+
+
+def test_mlp_layer_dropout_mask_is_the_layernorm_kernels(dev):
+    """drop_threshold / seed select the same keep mask as ococc_layernorm_act_dropout_fwd_bf16 (norm.layer_norm_act's
+    folded dropout): a layer trained on either path sees the same units dropped."""
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    from objectcentricocccompletion_amd.norm import _LayerNormAct
+    g = torch.Generator().manual_seed(6)
+    rows, k, n = 777, 512, 1024
+    x, W = bf16(torch.randn(rows, k, generator=g)), torch.randn(n, k, generator=g) / k ** 0.5
+    gam, bet = torch.ones(n), torch.zeros(n)
+    wf, = fm.linear_fragments32([W.to(dev)], [k])
+    thr, seed = int(round(0.1 * 65536)), 123456789123
+    y, _ = fm.mlp_layer(x.to(dev), wf, n, gam.to(dev), bet.to(dev), 1e-3, 'gelu', drop_threshold=thr, seed=seed)
+    y0, _ = fm.mlp_layer(x.to(dev), wf, n, gam.to(dev), bet.to(dev), 1e-3, 'gelu')
+    z = (x.to(dev).float() @ bf16(W).to(dev).float().t()).to(torch.bfloat16)
+    ref = _LayerNormAct.apply(z, gam.to(dev), bet.to(dev), 1e-3, 1, thr, seed)
+    live = (y0 != 0) & (_LayerNormAct.apply(z, gam.to(dev), bet.to(dev), 1e-3, 1) != 0)
+    assert torch.equal((y == 0) & live, (ref == 0) & live)
+    frac = float(((y == 0) & live).float().sum() / live.float().sum())
+    assert 0.09 < frac < 0.11
+    kept = (y != 0) & live
+    scale = 65536.0 / (65536.0 - thr)
+    assert float(((y.float() - y0.float() * scale).abs()[kept] / (y0.float().abs()[kept] * scale + 1e-3)).max()) <= 2 * BF16_ULP
+
+
+def test_fused_decoder_vs_oracle_and_reference_golden(dev, golden_dir):
+    """OccDecoder on the fused kernels (bf16 inference) against (a) the oracle with the kernels' rounding points at
+    1e-3 and (b) the reference's own f32 logits (ococc_head.npz) at bf16 accuracy; decisions agree."""
+    from objectcentricocccompletion_amd.occ import occ_base
+    from objectcentricocccompletion_amd.occ.occ_base import OccDecoder
+    gold = np.load(os.path.join(golden_dir, 'ococc_head.npz'))
+    P = decoder_params()
+    dec = OccDecoder(1536, [512, 1024, 1024], pos_encode_L=10, norm_cfg=dict(type='LN', eps=1e-3), act='gelu',
+                     occ_dropout=0.1, use_ln=True)
+    dec.load_state_dict({k[len(PREFIX):]: v for k, v in P.items()})
+    dec = dec.to(dev).eval()
+    dec.compute_dtype = torch.bfloat16
+    feats = torch.from_numpy(gold['out_fused_roi_feats'])
+    xyz = torch.from_numpy(gold['dec_xyz'])
+    R, K, _ = xyz.shape
+    idx = torch.arange(R).repeat_interleave(K)
+    assert dec._fused_layers() is not None
+    calls = []
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+
+    class Probe:
+        def wrap(self, name, flops, launch):
+            calls.append(name)
+            launch()
+    fm.set_probe(Probe())
+    try:
+        with torch.no_grad():
+            out = dec(feats.to(dev), xyz.reshape(-1, 3).to(dev), idx.to(dev)).cpu().double().view(-1)
+    finally:
+        fm.set_probe(None)
+    assert calls == ['occ_mlp_fwd_kernel']   # the one-launch kernel ran
+    exp = D.decoder(P, PREFIX, feats, xyz.reshape(-1, 3), idx, rounding='bf16')
+    assert float((out - exp).norm() / exp.norm()) < 1e-3
+    ref = torch.from_numpy(gold['dec_logits']).double().view(-1)
+    assert float((out - ref).abs().max()) < 3e-2 * max(1.0, float(ref.abs().max()))
+    assert float(((out > 0) == (ref > 0)).float().mean()) > 0.995
+    # one launch per layer: the same bits
+    occ_base.FUSED_WHOLE_MLP = False
+    try:
+        with torch.no_grad():
+            per_layer = dec(feats.to(dev), xyz.reshape(-1, 3).to(dev), idx.to(dev)).cpu().double().view(-1)
+    finally:
+        occ_base.FUSED_WHOLE_MLP = True
+    assert torch.equal(per_layer, out)
+    # the library path of the same module (FUSED_MLP off) is the neighbour it replaces
+    occ_base.FUSED_MLP = False
+    try:
+        with torch.no_grad():
+            lib = dec(feats.to(dev), xyz.reshape(-1, 3).to(dev), idx.to(dev)).cpu().double().view(-1)
+    finally:
+        occ_base.FUSED_MLP = True
+    assert float((out - ref).norm()) <= 1.5 * float((lib - ref).norm()) + 1e-6   # no further from the reference than it
+
+
+@pytest.mark.parametrize('rows', [1, 63, 64, 1000, 20011])
+@pytest.mark.parametrize('drop', [0, 6554])
+def test_whole_mlp_launch_is_the_three_layer_launches(dev, rows, drop):
+    """ococc_occ_mlp_fwd_bf16 against three ococc_mlp_layer_fwd_bf16 calls: bit-identical logits and hidden activations,
+    with and without dropout (same seeds -> same masks); ragged last tile."""
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    g = torch.Generator().manual_seed(rows)
+    W = [torch.randn(n, k, generator=g) / k ** 0.5 for k, n in ((64, 512), (512, 1024), (1024, 1024))]
+    gam = [(1 + 0.2 * torch.randn(n, generator=g)).to(dev) for n in (512, 1024, 1024)]
+    bet = [(0.2 * torch.randn(n, generator=g)).to(dev) for n in (512, 1024, 1024)]
+    hw, hb = (torch.randn(1024, generator=g) / 32).to(dev), torch.tensor([-0.1]).to(dev)
+    xyz = ((torch.rand(rows, 3, generator=g) * 2 - 1) * torch.tensor([8., 8., 4.])).to(dev)
+    R = 7
+    add = torch.randn(R, 512, generator=g).to(dev)
+    idx = torch.randint(0, R, (rows,), generator=g).int().to(dev)
+    frags = fm.linear_fragments32([w.to(dev) for w in W], [64, 512, 1024])
+    pe = fm.pos_encode_bf16(xyz, 10, [-8.0, -8.0, -4.0, 8.0, 8.0, 4.0])
+    seeds = [11, 2 ** 40 + 5, 77]
+    out, y0, y1 = fm.occ_mlp(pe, add, idx, frags, gam, bet, 1e-3, hw, hb, drop, seeds, want_hidden=True)
+    out_only = fm.occ_mlp(pe, add, idx, frags, gam, bet, 1e-3, hw, hb, drop, seeds)
+    e0, _ = fm.mlp_layer(pe, frags[0], 512, gam[0], bet[0], 1e-3, 'gelu', add_rows=add, add_index=idx, drop_threshold=drop,
+                         seed=seeds[0])
+    e1, _ = fm.mlp_layer(e0, frags[1], 1024, gam[1], bet[1], 1e-3, 'gelu', drop_threshold=drop, seed=seeds[1])
+    _, eo = fm.mlp_layer(e1, frags[2], 1024, gam[2], bet[2], 1e-3, 'gelu', drop_threshold=drop, seed=seeds[2],
+                         head_weight=hw, head_bias=hb, want_y=False)
+    assert torch.equal(y0, e0) and torch.equal(y1, e1) and torch.equal(out, eo) and torch.equal(out_only, eo)
+    if drop:
+        assert 0.08 < float((y1 == 0).float().mean()) < 0.12
