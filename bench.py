@@ -254,6 +254,40 @@ def cpu_baseline_ococcnet(frames):
                       f'repetitions, torch {torch.__version__.split("+")[0]} CPU with {cores} threads, oracle/cpu_port.py'}
 
 
+class BlockProbe(object):
+    """HIP events around the fused forward kernels (recorded on the launch stream)."""
+
+    def __init__(self):
+        self.items = []
+
+    def wrap(self, name, flops, launch):
+        a, b = _L().Timer(), _L().Timer()
+        a.record()
+        launch()
+        b.record()
+        self.items.append((name, a, b, flops))
+
+
+def _L():
+    from objectcentricocccompletion_amd import _lib
+    return _lib
+
+
+def probe_summary(probe):
+    """(total ms, total flops, per-kernel detail) of the launches a BlockProbe bracketed"""
+    per = {}
+    for name, a, b, f in probe.items:
+        t = per.setdefault(name, [0.0, 0.0, 0])
+        t[0] += a.elapsed_ms(b)
+        t[1] += f
+        t[2] += 1
+    ms = sum(t[0] for t in per.values())
+    fl = sum(t[1] for t in per.values())
+    detail = {k: {'launches': t[2], 'avg_us': round(t[0] / t[2] * 1e3, 1), 'tflops': round(t[1] / (t[0] * 1e-3) / 1e12, 1)}
+              for k, t in per.items() if t[0] > 0}
+    return ms, fl, detail
+
+
 def bench_sst(args, world, rank, dev):
     """configs[4], one GPU's share: 32 object grids of 80x80x64 cells at 0.1 m (the reference's window
     partition asserts z < x, sst_ops.py:283, so the cube is cut to 6.4 m in z; ~8 000 active voxels each),
@@ -284,19 +318,6 @@ def bench_sst(args, world, rank, dev):
     buckets = GradBuckets(params)
     xyz, feats, bidx = synthetic_object_grids(G, P, seed=rank, device=dev)
     xyz[:, 2] *= 0.8
-
-    class BlockProbe(object):
-        """HIP events around the fused forward kernels (recorded on the launch stream)."""
-
-        def __init__(self):
-            self.items = []
-
-        def wrap(self, name, flops, launch):
-            a, b = L_.Timer(), L_.Timer()
-            a.record()
-            launch()
-            b.record()
-            self.items.append((name, a, b, flops))
 
     from objectcentricocccompletion_amd import _lib as L_
 
@@ -339,17 +360,8 @@ def bench_sst(args, world, rank, dev):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     if rank == 0:
-        per = {}
-        for name, a, b, f in probe.items:
-            t = per.setdefault(name, [0.0, 0.0, 0])
-            t[0] += a.elapsed_ms(b)
-            t[1] += f
-            t[2] += 1
-        ms = sum(t[0] for t in per.values())
-        fl = sum(t[1] for t in per.values())
+        ms, fl, detail = probe_summary(probe)
         tflops = fl / (ms * 1e-3) / 1e12 if ms else None
-        detail = {k: {'launches': t[2], 'avg_us': round(t[0] / t[2] * 1e3, 1), 'tflops': round(t[1] / (t[0] * 1e-3) / 1e12, 1)}
-                  for k, t in per.items() if t[0] > 0}
         print(json.dumps({
             'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * G * args.steps / dt, 1),
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -388,6 +400,9 @@ def bench_decode(args, world, rank, dev):
     run = lambda: dec.get_occ(feats, rois, 0.2, [1.0, 1.0, 1.0], [0.5, 0.5, 0.5], transform=True)
     for _ in range(args.warmup):
         occ = run()
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    probe = BlockProbe()
+    fm.set_probe(probe)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -398,6 +413,7 @@ def bench_decode(args, world, rank, dev):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    fm.set_probe(None)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -406,6 +422,16 @@ def bench_decode(args, world, rank, dev):
         from objectcentricocccompletion_amd.occ import occ_ops
         cells = int(occ_ops.dense_voxel_centers_batched(rois[:, 4:7], 0.2, [1.0] * 3, [0.5] * 3)[2].sum())
         flops = cells * 2.0 * (60 * 512 + 512 * 1024 + 1024 * 1024 + 1024) + R * 2.0 * 1536 * 512
+        ms, fl, detail = probe_summary(probe)
+        if ms:   # own kernels ran (bf16): rate of the dominant kernel alone
+            roof = {'kernel': ' + '.join(sorted(detail)), 'bound': 'mfma', 'achieved': round(fl / (ms * 1e-3) / 1e12, 1),
+                    'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(fl / (ms * 1e-3) / 1e12 / 2500.0, 4), 'traffic': None,
+                    'launches_timed': len(probe.items), 'per_kernel': detail,
+                    'whole_step_tflops': round(flops * args.steps / dt / 1e12, 1)}
+        else:    # f32 run: library GEMMs, whole-step rate
+            roof = {'kernel': 'decoder MLP GEMMs (library, f32)', 'bound': 'mfma',
+                    'achieved': round(flops * args.steps / dt / 1e12, 1), 'peak': 157.3, 'unit': 'TFLOP/s',
+                    'frac': round(flops * args.steps / dt / 1e12 / 157.3, 4), 'traffic': None}
         print(json.dumps({
             'metric': 'object-grids/sec (dense occupancy decode)', 'value': round(world * R * args.steps / dt, 1),
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -414,22 +440,24 @@ def bench_decode(args, world, rank, dev):
             'config': {'workload': f'dense-grid decode (occ_base.py:238-342) of {R} RoIs/GPU, {cells} cells of 0.2 m, '
                                    'ococcnet decoder MLP, inference', 'grids_per_gpu': R, 'cells': cells,
                        'occupied': int(sum(len(t) for s_ in occ for t in s_)), 'parallelism': f'dp{world}'},
-            'roofline': {'kernel': 'decoder MLP GEMMs (library)', 'bound': 'mfma',
-                         'achieved': round(flops * args.steps / dt / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                         'frac': round(flops * args.steps / dt / 1e12 / 2500.0, 4), 'traffic': None},
+            # the dominant kernel, timed by HIP events on its stream: occ_mlp_fwd_kernel = the whole per-cell MLP
+            # (2 (64 x 512 + 512 x 1024 + 1024 x 1024) flops per cell, 60 -> 64 input columns padded) in one launch
+            'roofline': roof,
             'cpu_baseline': None}), flush=True)
 
 
 def also_workloads():
     """Short runs (5 timed steps) of the other workloads, each in a child process of its own, so that the one JSON line the
-    driver records also carries configs[2] (at the config's 4 tracklets per GPU and at 64) and configs[4]'s SST path.
+    driver records also carries configs[2] (at the config's 4 tracklets per GPU and at 64), configs[4]'s SST path and the
+    dense-grid decode of 64 tracklets' RoIs (8 M cells: the decoder kernel back to back, at sustained clocks).
     Not part of the timed region above; a failure is recorded, it never fails the run."""
     import subprocess
     out = {}
     here = os.path.abspath(__file__)
     for key, extra in (('ococcnet_b4', ['--workload', 'ococcnet', '--tracklets', '4']),
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
-                       ('sst', ['--workload', 'sst'])):
+                       ('sst', ['--workload', 'sst']),
+                       ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
         cmd = [sys.executable, here, '--steps', '5', '--warmup', '3', '--no-cpu-baseline'] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

@@ -62,6 +62,20 @@ def main():
         t = timed(lambda: fm.occ_mlp(pe, add, idx, frags, gam, bet, 1e-3, hw, hb, want_hidden=hidden))
         print(f'whole MLP, one launch, hidden activations {"stored" if hidden else "on chip"}: {t:7.3f} ms '
               f'{fl / t / 1e9:7.1f} TF/s', flush=True)
+    # one launch at a time with the device idle in between (how a decode step meets the kernel)
+    import time
+    for gap in (0.0, 0.002, 0.02, 0.2):
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            time.sleep(gap)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fm.occ_mlp(pe, add, idx, frags, gam, bet, 1e-3, hw, hb)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        print(f'single launches, {gap * 1e3:5.1f} ms idle before each: ' + ' '.join(f'{t:6.3f}' for t in ts) + ' ms', flush=True)
 
 
 if __name__ == '__main__':
