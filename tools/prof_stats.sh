@@ -23,3 +23,7 @@ print('steps',n,'kernel us/step',round(tot,1))
 if note: print('* once per step; the other launches in the trace are the roofline probe (8 back-to-back launches per event pair, after the timed region)')
 PY
 tail -c 300 $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/bench.json
+# replay-only accounting: the same trace cut to the graph replays (tools/replay_table.py)
+python3 $GRAFT_REPO_ROOT/tools/replay_table.py $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/${tag}_kernel_trace.csv ${PROF_MIN_US:-6} | tee $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/${tag}_replay_table.txt
+# (the raw trace is tens of MB; the table and the stats csv are what is kept)
+rm -f $GRAFT_REPO_ROOT/gpurun_out/prof_$tag/${tag}_kernel_trace.csv
