@@ -447,7 +447,7 @@ def bench_decode(args, world, rank, dev):
 
 
 def also_workloads():
-    """Short runs (5 timed steps) of the other workloads, each in a child process of its own, so that the one JSON line the
+    """Short runs (10 timed steps after 8 warm-up steps) of the other workloads, each in a child process of its own, so that the one JSON line the
     driver records also carries configs[2] (at the config's 4 tracklets per GPU and at 64), configs[4]'s SST path and the
     dense-grid decode of 64 tracklets' RoIs (8 M cells: the decoder kernel back to back, at sustained clocks).
     Not part of the timed region above; a failure is recorded, it never fails the run."""
@@ -458,7 +458,7 @@ def also_workloads():
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('sst', ['--workload', 'sst']),
                        ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
-        cmd = [sys.executable, here, '--steps', '5', '--warmup', '3', '--no-cpu-baseline'] + extra
+        cmd = [sys.executable, here, '--steps', '10', '--warmup', '8', '--no-cpu-baseline'] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]

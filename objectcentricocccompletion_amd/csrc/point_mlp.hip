@@ -552,23 +552,18 @@ point_mlp_pack_kernel(const float* __restrict__ w, int n, int k, int64_t rs, int
 __global__ void __launch_bounds__(256)
 segment_argmax_kernel(const float* __restrict__ y, const float* __restrict__ vmax, const int32_t* __restrict__ inv,
                       int64_t rows, int n, int32_t* __restrict__ arg) {
-  const int64_t row0 = (int64_t)blockIdx.x * TR;
-  for (int ch = threadIdx.x; ch < n; ch += 256) {
-    int cur = -1;
-    float top = 0.f;
-    bool found = false;
-    for (int r = 0; r < TR && row0 + r < rows; ++r) {
-      const int seg = inv[row0 + r];
-      if (seg != cur) {
-        cur = seg;
-        top = vmax[(int64_t)seg * n + ch];
-        found = false;
-      }
-      if (!found && y[(row0 + r) * n + ch] == top) {
-        atomicMin(arg + (int64_t)seg * n + ch, (int32_t)(row0 + r));
-        found = true;
-      }
-    }
+  // one thread per (row, 4 channels): a row that attains its segment's maximum in a channel proposes itself; the smallest
+  // proposal stands.  (Few rows per segment attain it: the atomics are rare and spread over all segments.)
+  const int q = (n + 3) >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * q) return;
+  const int64_t row = i / q;
+  const int c0 = (int)(i - row * q) * 4;
+  const int seg = inv[row];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ch = c0 + c;
+    if (ch < n && y[row * n + ch] == vmax[(int64_t)seg * n + ch]) atomicMin(arg + (int64_t)seg * n + ch, (int32_t)row);
   }
 }
 
@@ -691,8 +686,8 @@ extern "C" int ococc_point_mlp_segment_argmax(const float* y, const float* seg_m
   OCOCC_REQUIRE(y && seg_max && inv && seg_arg, "null pointer");
   OCOCC_HIP(hipMemsetAsync(seg_arg, 0x7f, (size_t)num_segments * n * 4, stream));
   if (rows == 0) return OCOCC_OK;
-  hipLaunchKernelGGL(segment_argmax_kernel, dim3((unsigned)ococc_cdiv(rows, TR)), dim3(256), 0, stream, y, seg_max, inv,
-                     rows, (int)n, seg_arg);
+  hipLaunchKernelGGL(segment_argmax_kernel, dim3((unsigned)ococc_cdiv(rows * ((n + 3) / 4), 256)), dim3(256), 0, stream, y,
+                     seg_max, inv, rows, (int)n, seg_arg);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -5,6 +5,8 @@
 one launch where SIRLayer.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832) runs torch.cat / products,
 nn.Linear, LayerNorm, GELU, scatter_v2(max) and the gather-back one after the other.  f32 like the reference
 (force_fp32); the backward launch recomputes the layer from its inputs."""
+import weakref
+
 import torch
 
 from . import _lib as L
@@ -13,11 +15,26 @@ from .linear import TALL_ROWS, sliced_wgrad
 ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
 
-def pack_weight(w):
-    """nn.Linear weight [n, k] (or a transposed view) -> f32 MFMA fragment tensor"""
+_packed = {}   # (id of the parameter, transposed) -> (weak reference, version, storage pointer, fragments)
+
+
+def pack_weight(w, owner=None, transposed=False):
+    """nn.Linear weight [n, k] (or a transposed view) -> f32 MFMA fragment tensor.  With ``owner`` (the parameter the
+    view was taken from) the fragments are cached until the parameter is written to (version counter), moves or dies --
+    identity by weak reference: a new tensor at a recycled address is a different tensor."""
     n, k = w.shape
+    key = None
+    if owner is not None and not torch.cuda.is_current_stream_capturing():
+        key = (id(owner), bool(transposed))
+        hit = _packed.get(key)
+        if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[2] == w.data_ptr():
+            return hit[3]
     out = torch.empty(int(L.lib.ococc_point_mlp_fragment_floats(n, k)), dtype=torch.float32, device=w.device)
     L.check(L.lib.ococc_point_mlp_pack_f32(L.ptr(w), n, k, w.stride(0), w.stride(1), L.ptr(out), L.stream()), 'point_mlp_pack')
+    if key is not None:
+        if len(_packed) > 512:
+            _packed.clear()
+        _packed[key] = (weakref.ref(owner), owner._version, w.data_ptr(), out)
     return out
 
 
@@ -37,7 +54,8 @@ class _PointLayer(torch.autograd.Function):
         n = weight.shape[0]
         assert weight.shape[1] == ka + kb + kv, (weight.shape, ka, kb, kv)
         dev = a_.device
-        wf = pack_weight(weight.detach().float())
+        own = weight if weight.dtype == torch.float32 else None
+        wf = pack_weight(weight.detach().float(), own)
         g, be = _f32(ln_w), _f32(ln_b)
         y = torch.empty((rows, n), dtype=torch.float32, device=dev)
         vmax = torch.empty((num_segments, n), dtype=torch.float32, device=dev) if want_max else None
@@ -69,7 +87,7 @@ class _PointLayer(torch.autograd.Function):
                                                          L.stream()), 'segment_argmax')
         else:
             dvmax = None
-        wtf = pack_weight(weight.detach().float().t())
+        wtf = pack_weight(weight.detach().float().t(), weight if weight.dtype == torch.float32 else None, transposed=True)
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         dz = new(rows, n)
         xcat = new(rows, k) if need[4] else None
@@ -86,7 +104,7 @@ class _PointLayer(torch.autograd.Function):
             L.ptr(db), L.ptr(dv), L.ptr(lnp), L.stream()), 'point_mlp_bwd')
         dw = None
         if need[4]:
-            dw = (sliced_wgrad(dz, xcat) if rows >= TALL_ROWS else dz.t() @ xcat).to(weight.dtype)
+            dw = (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
         dg = dbeta = None
         if g is not None:
             sums = lnp.sum(0)
