@@ -520,11 +520,13 @@ def main():
     with torch.no_grad():
         ref_out = model(xyz, feats, bidx, B)
         n_act = ref_out.features.shape[0]
-        n_pairs = int(ref_out.indice_dict['subm1'][3].sum().item())
+        n_pairs = int(ref_out.indice_dict['subm1'][3].sum().item())   # (reporting only: the roofline's algorithmic bytes)
         del ref_out
-    # measured once on the host: lets the sub-manifold convolutions pick their kernel for this density
-    # (compact-then-multiply below ~6 rulebook pairs per row) without any device read-back inside the step
-    sp_ops.DEFAULT_PAIRS_PER_ROW = n_pairs / max(n_act, 1)
+    # The sub-manifold convolutions pick their kernel from the rulebook density (compact-then-multiply below ~2-3 pairs
+    # per row).  Nothing is set here: spconv.ops.density measured it on the device while that first forward built its
+    # rulebook (an asynchronous copy behind an event); harvest it now, before the warm-up steps and the graph capture.
+    torch.cuda.synchronize()
+    sp_ops.density.poll()
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     d_act = (torch.randn(n_act, 128, generator=gen, device=dev) / n_act).to(torch.bfloat16)
 

@@ -168,18 +168,76 @@ def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padd
     dilated = any(int(d) != 1 for d in dilation)
     # (a dilated sub-manifold rulebook of the reference is not its own mirror image -- it keeps padding = k/2 --
     # so it is handled like a user-supplied one: the input-gradient table is derived from the pairs on demand)
-    rb = attach_subm_tables(pairs, nbr_t, mask, n, kvol, symmetric=not dilated)
+    rb = attach_subm_tables(pairs, nbr_t, mask, n, kvol, symmetric=not dilated, num=num)
     if dilated and n > 0:
         _own_row_offset(rb, num, nbr_t, mask, n)
     return indices, pairs, num
 
 
-def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True):
+class DensityTracker(object):
+    """Rulebook pairs per output row of the sub-manifold rulebooks built recently -- what the kernel choice below keys on
+    -- MEASURED ON THE DEVICE and read back without a host synchronisation: every rulebook build outside a graph capture
+    queues the sum of its per-offset pair counts as an asynchronous copy into pinned memory behind an event, and the
+    NEXT build (or ``poll()``) harvests it once the event has passed.  The estimate therefore lags the data by one
+    build; a rulebook built before the first harvest carries no hint and runs on the output-stationary kernels (every
+    kernel is correct for every table: a stale or missing estimate costs time, never results).  A captured HIP graph
+    bakes in the choice made at capture time; ``regime(shape)`` tells a training loop when a re-capture would pay."""
+
+    def __init__(self):
+        self.value = None       # pairs per row, exponentially averaged over the observed builds
+        self.samples = 0
+        self._host = None
+        self._pending = None
+
+    def observe(self, num, rows):
+        if rows <= 0 or num is None or not num.is_cuda or torch.cuda.is_current_stream_capturing():
+            return
+        self.poll()
+        if self._pending is not None:
+            return                   # one observation in flight at a time
+        if self._host is None:
+            self._host = torch.empty((1,), dtype=torch.int64).pin_memory()
+        self._host.copy_(num.sum(dtype=torch.int64).view(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (ev, int(rows))
+
+    def poll(self, wait=False):
+        """harvest the observation in flight if it has landed (``wait``: block for it -- set-up code only)"""
+        if self._pending is None:
+            return self.value
+        ev, rows = self._pending
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            v = float(self._host[0]) / rows
+            self.value = v if self.value is None else 0.5 * self.value + 0.5 * v
+            self.samples += 1
+            self._pending = None
+        return self.value
+
+    def reset(self):
+        self.value, self.samples, self._pending = None, 0, None
+
+
+density = DensityTracker()
+
+
+def current_density():
+    """the density new rulebooks are assumed to have: an explicit DEFAULT_PAIRS_PER_ROW wins, else the device-measured
+    estimate (None until the first observation has landed)"""
+    return float(DEFAULT_PAIRS_PER_ROW) if DEFAULT_PAIRS_PER_ROW is not None else density.value
+
+
+def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None):
     """Hang the device-side companions of a sub-manifold rulebook (offset-major gather table, 16-row block masks) on
-    its indice_pairs tensor, where indice_conv / indice_conv_backward look for them."""
+    its indice_pairs tensor, where indice_conv / indice_conv_backward look for them.  ``num``: the per-offset pair counts
+    (device), observed by the density tracker."""
     rb = RulebookTables(symmetric, kvol)
-    if DEFAULT_PAIRS_PER_ROW is not None:
-        rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+    if AUTO_DENSITY and DEFAULT_PAIRS_PER_ROW is None:
+        density.observe(num, rows)
+    if current_density() is not None:
+        rb.pairs_per_row = current_density()
     rb.tables[(False, 'fwd')] = (nbr_t, mask, rows)
     if symmetric:
         rb.tables[(False, 'bwd')] = (nbr_t, mask, rows)  # symmetric: same table, offset-flipped weights
@@ -380,11 +438,11 @@ def prepare_weights(items):
         if filters.dtype != torch.float32 or not filters.is_contiguous() or cin not in _KD_OK or cout not in _KD_OK:
             continue
         kd, nc = (cin, cout) if mode == 0 else (cout, cin)
-        if mode in (0, 1) and DEFAULT_PAIRS_PER_ROW is not None:
+        if mode in (0, 1) and current_density() is not None:
             # the layer will go through the tile kernel (same test as in indice_conv / indice_conv_backward for a
             # rulebook built under the current default density): fragment-major order
             probe_rb = RulebookTables(True, filters.numel() // (cin * cout))
-            probe_rb.pairs_per_row = float(DEFAULT_PAIRS_PER_ROW)
+            probe_rb.pairs_per_row = current_density()
             if _fragment_major(probe_rb, kd, nc):
                 mode += 4
         kvol = filters.numel() // (cin * cout)
@@ -433,9 +491,19 @@ def _prep_weights(filters, mode, kd_pad, nc_pad):
 # (set_rulebook_density / DEFAULT_PAIRS_PER_ROW) against the per-shape thresholds of _TILE_SHAPES,
 # True / False = force.
 SPARSE_TILE_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_SPARSE_TILE_CONV'))  # env: force on / off
-# density assumed for rulebooks built from now on (None: unknown); a training loop sets it once from a
-# measured step, e.g. bench.py before it captures the HIP graph
+# density assumed for rulebooks built from now on.  None (default): the device-measured estimate of ``density``
+# (DensityTracker above; AUTO_DENSITY = False switches the measurement off); a number overrides it.
 DEFAULT_PAIRS_PER_ROW = None
+AUTO_DENSITY = os.environ.get('OCOCC_AUTO_DENSITY', '1') == '1'
+
+
+def density_regime(kd, ncols):
+    """'tile' / 'stationary' / None: the kernel family the CURRENT density estimate selects for a sub-manifold layer of
+    this shape -- compare with what a captured graph was built under to decide on a re-capture"""
+    v = current_density()
+    if v is None or (kd, ncols) not in _TILE_SHAPES:
+        return None
+    return 'tile' if v <= _TILE_SHAPES[(kd, ncols)] else 'stationary'
 # (contraction channels, columns) -> rulebook pairs per output row up to which the tile kernel measured faster
 # (tools/density_sweep.py: random cells per 40^3 grid, 64 grids; 128 -> 64: 85 vs 109 us at 2.5 pairs / row, 249 vs
 # 224 us at 4.1; 32 <-> 64: 31 vs 32 us at 1.8, 58 vs 48 us at 2.5)

@@ -299,7 +299,7 @@ def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid
     L.check(L.lib.ococc_grid_unique_workspace_layout(4, L.i4(dims), bo, po), 'grid_unique_layout')
     coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), True)
     inv._ococc_counts = counts
-    sp_ops.attach_subm_tables(pairs, nbr_t, mask, cap, 27)
+    sp_ops.attach_subm_tables(pairs, nbr_t, mask, cap, 27, num=num)   # (num: observed by the density tracker)
     pairs._ococc_keepalive = ws
     return vfeats, coors, inv, counts, meta, pairs, num
 

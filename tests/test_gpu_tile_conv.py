@@ -325,3 +325,4 @@ def test_ln_backward_link_refuses_a_second_consumer(dev):
             (c.features.float().sum() + b.features.float().sum()).backward()
     finally:
         ops.SPARSE_TILE_CONV = None
+
