@@ -84,9 +84,9 @@ class TilePlan(object):
         L.check(L.lib.ococc_window_tile_plan(L.ptr(win_len), L.ptr(win_off), L.ptr(tok), n, TILE, n, L.ptr(self.rows),
                                              L.ptr(self.span), L.ptr(count), L.ptr(ws), nbytes, L.stream()),
                 'window_tile_plan')
-        self.num_tiles = int(count.item())      # one read-back per batch and shift (the input layer has several)
-        stats = torch.stack([win_len.sum(), (win_len.double() ** 2).sum().long()]).tolist()   # (one read-back)
-        self.tokens, self.sum_sq = int(stats[0]), float(stats[1])   # sum_sq: sum of squared populations (attention flops)
+        # ONE read-back per batch and shift: tile count, token count, sum of squared populations (attention flops)
+        stats = torch.stack([count[0].long(), win_len.sum(), (win_len.double() ** 2).sum().long()]).tolist()
+        self.num_tiles, self.tokens, self.sum_sq = int(stats[0]), int(stats[1]), float(stats[2])
         self.rows, self.span = self.rows[:self.num_tiles * TILE], self.span[:self.num_tiles * TILE]
 
 

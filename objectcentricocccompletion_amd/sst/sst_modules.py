@@ -12,7 +12,7 @@ from torch import nn
 from .. import _lib as L
 from ..norm import layer_norm_act
 from ..registry import BACKBONES, MIDDLE_ENCODERS, build_conv_layer, build_norm_layer
-from .sst_ops import (LazyWindowDict, flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
+from .sst_ops import (LazyWindowDict, flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors, group_rank,
                       window2flat_v2)
 
 
@@ -33,9 +33,24 @@ class SSTInputLayerV2(nn.Module):
         meta = self.meta_drop_info
         self.drop_info = (meta[0] if self.training else meta[1]) if isinstance(meta, tuple) else meta
 
+    def _window_id_bound(self, voxel_coors, batch_size):
+        """an upper bound of every window id of get_window_coors (the group-rank kernel sizes its key table by it): with
+        the batch size given it is host arithmetic, without it ONE read-back of the largest batch index for both shifts
+        (it was one per group-rank call: four)"""
+        import math
+        ws, ss = self.window_shape, self.sparse_shape
+        wz = ws[2] if len(ws) == 3 else ss[-1]
+        per_batch = 1
+        for s_, w_ in ((ss[0], ws[0]), (ss[1], ws[1]), (ss[2], wz)):
+            per_batch *= int(math.ceil(s_ / w_) + 1)
+        if batch_size is None:
+            batch_size = (int(voxel_coors[:, 0].max().item()) + 1) if voxel_coors.numel() else 1
+        return int(batch_size) * per_batch
+
     def forward(self, voxel_feats, voxel_coors, batch_size=None):
         self.set_drop_info()
         voxel_coors = voxel_coors.long()
+        self._key_bound = self._window_id_bound(voxel_coors, batch_size)
         if self.shuffle_voxels:
             shuffle_inds = torch.randperm(len(voxel_feats), device=voxel_feats.device)
             voxel_feats, voxel_coors = voxel_feats[shuffle_inds], voxel_coors[shuffle_inds]
@@ -45,7 +60,8 @@ class SSTInputLayerV2(nn.Module):
         voxel_feats, voxel_coors = info['voxel_feats'], info['voxel_coors']
         for i in range(2):
             info[f'flat2win_inds_shift{i}'] = get_flat2win_inds_v2(
-                info[f'batch_win_inds_shift{i}'], info[f'voxel_drop_level_shift{i}'], self.drop_info, debug=self.debug)
+                info[f'batch_win_inds_shift{i}'], info[f'voxel_drop_level_shift{i}'], self.drop_info, debug=self.debug,
+                key_bound=self._key_bound)
             info[f'pos_dict_shift{i}'] = self.get_pos_embed(
                 info[f'flat2win_inds_shift{i}'], info[f'coors_in_win_shift{i}'], voxel_feats.size(1), voxel_feats.dtype)
             info[f'key_mask_shift{i}'] = self.get_key_padding_mask(info[f'flat2win_inds_shift{i}'])
@@ -56,8 +72,11 @@ class SSTInputLayerV2(nn.Module):
     def drop_single_shift(self, batch_win_inds):
         """keep mask + drop level of every voxel from the population of its window (:128-148)."""
         drop_lvl = -torch.ones_like(batch_win_inds)
-        inner = get_inner_win_inds(batch_win_inds)
-        num_per_voxel = torch.bincount(batch_win_inds)[batch_win_inds]
+        # one group-rank pass gives the rank inside the window AND the window populations (the reference's bincount is a
+        # second pass with a host read-back of its own)
+        conti, inner, counts = group_rank(batch_win_inds, self._key_bound)
+        inner = inner.to(batch_win_inds.dtype)
+        num_per_voxel = counts.to(batch_win_inds.dtype)[conti.long()]
         target = torch.zeros_like(batch_win_inds)
         for dl in self.drop_info:
             lower, upper = self.drop_info[dl]['drop_range']
@@ -72,9 +91,11 @@ class SSTInputLayerV2(nn.Module):
         n_all = win0.shape[0]
         keep_inds = torch.arange(n_all, device=win0.device, dtype=torch.long)
         keep0, lvl0 = self.drop_single_shift(win0)
+        keep0 = torch.where(keep0)[0]          # (index lists: ONE read-back per mask instead of one per masked tensor)
         lvl0, keep_inds, win0 = lvl0[keep0], keep_inds[keep0], win0[keep0]
         win1 = info['batch_win_inds_shift1'][keep0]
         keep1, lvl1 = self.drop_single_shift(win1)
+        keep1 = torch.where(keep1)[0]
         info['voxel_keep_inds'] = keep_inds[keep1]
         info['voxel_drop_level_shift0'], info['batch_win_inds_shift0'] = lvl0[keep1], win0[keep1]
         info['voxel_drop_level_shift1'], info['batch_win_inds_shift1'] = lvl1[keep1], win1[keep1]

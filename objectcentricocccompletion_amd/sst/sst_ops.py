@@ -195,28 +195,29 @@ def get_window_coors(coors, sparse_shape, window_shape, do_shift):
 
 
 @torch.no_grad()
-def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, populations=None):
+def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, populations=None, key_bound=None):
     """Per drop level: slot of every voxel in the padded [num_windows * max_tokens] layout and the
     voxel positions of that level (sst_ops.py:26-63).  ``populations`` (a dict) receives per level the tokens of every
-    window, which the group-rank kernel counts anyway: the key padding mask as a length."""
+    window, which the group-rank kernel counts anyway: the key padding mask as a length.  ``key_bound``: an upper bound
+    of the window ids when the caller knows one (saves the read-back of their maximum)."""
     out = {}
     for dl in drop_info:
-        dl_mask = voxel_drop_lvl == dl
-        if not dl_mask.any():
+        where = torch.where(voxel_drop_lvl == dl)   # (the one read-back of this level: its voxel list)
+        if where[0].numel() == 0:
             continue
-        conti, inner, counts = group_rank(batch_win_inds[dl_mask])
+        conti, inner, counts = group_rank(batch_win_inds[where[0]], key_bound)
         max_tokens = drop_info[dl]['max_tokens']
         if debug:
             assert int(inner.max()) < max_tokens, f'Max inner inds({int(inner.max())}) larger(equal) than {max_tokens}'
-        out[dl] = ((conti.long() * max_tokens + inner.long()), torch.where(dl_mask))
+        out[dl] = ((conti.long() * max_tokens + inner.long()), where)
         if populations is not None:
             populations[dl] = counts.to(torch.int32)
     return out
 
 
-def get_flat2win_inds_v2(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
+def get_flat2win_inds_v2(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, key_bound=None):
     pop = {}
-    d = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug, populations=pop)
+    d = get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug, populations=pop, key_bound=key_bound)
     d['voxel_drop_level'] = voxel_drop_lvl
     d['batching_info'] = drop_info
     d['_ococc_populations'] = pop
