@@ -683,6 +683,29 @@ int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const float* add_ro
                            const uint64_t* dropout_seeds, uint16_t* y0_out, uint16_t* y1_out, float* out,
                            ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * B6, element-wise halves of the SST input layer, one launch each (the mirror ran 20-50 torch operators per call):
+ * ococc_sst_window_coors_i64: get_window_coors (mmdet3d/ops/sst/sst_ops.py:266-313) for BOTH window shifts.
+ *   coors int64 [n, 4] (b, z, y, x); shapes as (x, y, z) HOST triples (2-D windows: pass window z = sparse z);
+ *   win_ids int64 [2, n] (shift 0 = unshifted, 1 = shifted by half a window), coors_in_win int64 [2, n, 3] (z, y, x).
+ * ococc_sst_drop_level_i64: the level / keep decision of SSTInputLayerV2.drop_single_shift
+ *   (mmdet3d/models/middle_encoders/sst_input_layer_v2.py:128-148) from one group-rank pass: window population =
+ *   counts[conti[i]]; the LAST table row whose [lower, upper) holds it gives level_ids[r] and max_tokens[r] (none: -1,
+ *   0); keep[i] = inner[i] < max_tokens.  Table rows are HOST arrays (<= 8).
+ * ococc_sst_pos_embed: get_pos_embed (sst_input_layer_v2.py:239-305) in flat token order: out [n, feat_dim] f32 / bf16,
+ *   columns [x | y | z] blocks of pos_length (sin at even, cos at odd columns of e = p / inv_freq), zero padded;
+ *   inv_freq: DEVICE f32 [pos_length], the table the reference builds with torch.pow.
+ * ------------------------------------------------------------------------ */
+int ococc_sst_window_coors_i64(const int64_t* coors, int64_t n, const int32_t* sparse_shape_xyz,
+                               const int32_t* window_shape_xyz, int64_t* win_ids, int64_t* coors_in_win,
+                               ococc_stream_t stream);
+int ococc_sst_drop_level_i64(const int32_t* conti, const int32_t* inner, const int32_t* counts, int64_t n,
+                             int32_t num_levels, const int64_t* lower, const int64_t* upper, const int64_t* max_tokens,
+                             const int64_t* level_ids, uint8_t* keep, int64_t* level, ococc_stream_t stream);
+int ococc_sst_pos_embed(const int64_t* coors_in_win, int64_t n, const int32_t* window_shape_xyz, int32_t ndim,
+                        int32_t normalize_pos, const float* inv_freq, int32_t pos_length, int32_t feat_dim, void* out,
+                        int32_t out_dtype, ococc_stream_t stream);
+
 /* f32 <-> bf16 row casts (round to nearest even) */
 int ococc_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, ococc_stream_t stream);
 int ococc_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, ococc_stream_t stream);

@@ -12,7 +12,8 @@ from torch import nn
 from .. import _lib as L
 from ..norm import layer_norm_act
 from ..registry import BACKBONES, MIDDLE_ENCODERS, build_conv_layer, build_norm_layer
-from .sst_ops import (LazyWindowDict, flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors, group_rank,
+from .sst_ops import (LazyWindowDict, flat2window_v2, get_flat2win_inds_v2, get_inner_win_inds, get_window_coors,
+                      get_window_coors_both, group_rank,
                       window2flat_v2)
 
 
@@ -71,19 +72,31 @@ class SSTInputLayerV2(nn.Module):
 
     def drop_single_shift(self, batch_win_inds):
         """keep mask + drop level of every voxel from the population of its window (:128-148)."""
-        drop_lvl = -torch.ones_like(batch_win_inds)
         # one group-rank pass gives the rank inside the window AND the window populations (the reference's bincount is a
-        # second pass with a host read-back of its own)
+        # second pass with a host read-back of its own); level and keep decision in one launch
         conti, inner, counts = group_rank(batch_win_inds, self._key_bound)
-        inner = inner.to(batch_win_inds.dtype)
-        num_per_voxel = counts.to(batch_win_inds.dtype)[conti.long()]
-        target = torch.zeros_like(batch_win_inds)
-        for dl in self.drop_info:
-            lower, upper = self.drop_info[dl]['drop_range']
-            m = (num_per_voxel >= lower) & (num_per_voxel < upper)
-            target[m] = self.drop_info[dl]['max_tokens']
-            drop_lvl[m] = dl
-        return inner < target, drop_lvl
+        n = batch_win_inds.numel()
+        if not batch_win_inds.is_cuda:   # (CPU stand-ins of oracle/cpu_port.py)
+            num_per_voxel = counts.to(batch_win_inds.dtype)[conti.long()]
+            drop_lvl = -torch.ones_like(batch_win_inds)
+            target = torch.zeros_like(batch_win_inds)
+            for dl in self.drop_info:
+                lower, upper = self.drop_info[dl]['drop_range']
+                m = (num_per_voxel >= lower) & (num_per_voxel < upper)
+                target[m] = self.drop_info[dl]['max_tokens']
+                drop_lvl[m] = dl
+            return inner.to(batch_win_inds.dtype) < target, drop_lvl
+        import ctypes
+        levels = list(self.drop_info)
+        i64 = lambda v: (ctypes.c_int64 * len(v))(*[int(a) for a in v])
+        keep = torch.empty((n,), dtype=torch.uint8, device=batch_win_inds.device)
+        drop_lvl = torch.empty((n,), dtype=torch.int64, device=batch_win_inds.device)
+        L.check(L.lib.ococc_sst_drop_level_i64(
+            L.ptr(conti), L.ptr(inner), L.ptr(counts), n, len(levels), i64([self.drop_info[d]['drop_range'][0] for d in levels]),
+            i64([min(self.drop_info[d]['drop_range'][1], 2 ** 62) for d in levels]),
+            i64([self.drop_info[d]['max_tokens'] for d in levels]), i64(levels), L.ptr(keep), L.ptr(drop_lvl), L.stream()),
+            'sst_drop_level')
+        return keep.bool(), drop_lvl.to(batch_win_inds.dtype)
 
     def drop_voxel(self, info, num_shifts):
         """Two sequential drops: shift 0, then shift 1 on the survivors (:150-220)."""
@@ -110,9 +123,12 @@ class SSTInputLayerV2(nn.Module):
     @torch.no_grad()
     def window_partition(self, coors):
         info = {}
+        if coors.is_cuda and coors.dtype == torch.int64:
+            both = get_window_coors_both(coors, self.sparse_shape, self.window_shape)   # one launch for the two shifts
+        else:
+            both = [get_window_coors(coors, self.sparse_shape, self.window_shape, i == 1) for i in range(2)]
         for i in range(2):
-            info[f'batch_win_inds_shift{i}'], info[f'coors_in_win_shift{i}'] = get_window_coors(
-                coors, self.sparse_shape, self.window_shape, i == 1)
+            info[f'batch_win_inds_shift{i}'], info[f'coors_in_win_shift{i}'] = both[i]
         return info
 
     @torch.no_grad()
@@ -128,8 +144,22 @@ class SSTInputLayerV2(nn.Module):
         if self.normalize_pos:
             x, y, z = x / win_x * 2 * 3.1415, y / win_y * 2 * 3.1415, z / win_z * 2 * 3.1415
         pos_length = feat_dim // ndim
-        inv_freq = torch.arange(pos_length, dtype=torch.float32, device=coors_in_win.device)
-        inv_freq = self.pos_temperature ** (2 * (inv_freq // 2) / pos_length)
+        key = (pos_length, float(self.pos_temperature), str(coors_in_win.device))
+        if getattr(self, '_inv_freq_key', None) != key:   # (the frequency table: the reference's own expression, built once)
+            inv = torch.arange(pos_length, dtype=torch.float32, device=coors_in_win.device)
+            self._inv_freq, self._inv_freq_key = self.pos_temperature ** (2 * (inv // 2) / pos_length), key
+        inv_freq = self._inv_freq
+        if (coors_in_win.is_cuda and coors_in_win.dtype == torch.int64 and dtype in (torch.float32, torch.bfloat16)
+                and pos_length % 2 == 0):
+            import ctypes
+            ciw = coors_in_win.contiguous()
+            pos = torch.empty((ciw.size(0), feat_dim), dtype=dtype, device=ciw.device)
+            win3 = (ctypes.c_int32 * 3)(int(win_x), int(win_y), int(win_z))
+            L.check(L.lib.ococc_sst_pos_embed(L.ptr(ciw), ciw.size(0), win3, ndim, int(bool(self.normalize_pos)),
+                                              L.ptr(inv_freq), pos_length, feat_dim, L.ptr(pos), L.dtype_code(dtype), L.stream()),
+                    'sst_pos_embed')
+            inds_dict['_ococc_pos_flat_f32'] = pos   # flat token order: what the fused encoder layers read
+            return LazyWindowDict(lambda: flat2window_v2(pos, inds_dict))
         emb = []
         for a in ([x, y, z] if ndim == 3 else [x, y]):
             e = a[:, None] / inv_freq[None, :]

@@ -167,9 +167,31 @@ def make_continuous_inds(inds):
 
 
 @torch.no_grad()
+def get_window_coors_both(coors, sparse_shape, window_shape):
+    """get_window_coors for the unshifted and the shifted partition in ONE launch (ococc_sst_window_coors_i64):
+    [(batch_win_inds, coors_in_win)] for shift 0 and 1.  coors [N,4] int64 (b,z,y,x) on the device."""
+    from .. import _lib as L
+    L.require_device(coors)
+    import ctypes
+    c = coors.contiguous()
+    assert c.dtype == torch.int64 and c.dim() == 2 and c.size(1) == 4
+    n = c.size(0)
+    win = list(window_shape) if len(window_shape) == 3 else [window_shape[0], window_shape[1], sparse_shape[-1]]
+    assert sparse_shape[2] < sparse_shape[0], 'Usually holds... in case of wrong order'
+    ids = torch.empty((2, n), dtype=torch.int64, device=c.device)
+    ciw = torch.empty((2, n, 3), dtype=torch.int64, device=c.device)
+    i3 = lambda v: (ctypes.c_int32 * 3)(*[int(a) for a in v])
+    L.check(L.lib.ococc_sst_window_coors_i64(L.ptr(c), n, i3(sparse_shape), i3(win), L.ptr(ids), L.ptr(ciw), L.stream()),
+            'sst_window_coors')
+    return [(ids[0], ciw[0]), (ids[1], ciw[1])]
+
+
+@torch.no_grad()
 def get_window_coors(coors, sparse_shape, window_shape, do_shift):
     """Window id of every voxel (unique in the batch) and its coordinate inside the window
     (sst_ops.py:266-313).  coors [N,4] = (b,z,y,x); integer elementwise math."""
+    if coors.is_cuda and coors.dtype == torch.int64:
+        return get_window_coors_both(coors, sparse_shape, window_shape)[1 if do_shift else 0]
     if len(window_shape) == 2:
         win_shape_x, win_shape_y = window_shape
         win_shape_z = sparse_shape[-1]
