@@ -78,11 +78,12 @@ inline bool make_layout(int64_t n, int64_t bound, Layout* L) {
   L->words = (bound + 31) / 32;
   int64_t off = 0;
   auto take = [&](int64_t b) { int64_t o = off; off += ococc_align_up(b > 0 ? b : 4, 256); return o; };
+  // (bitmap | counts | cursor are what has to start at zero: contiguous, one memset)
   L->o_bitmap = take(L->words * 4);
-  L->o_prefix = take(L->words * 4);
   L->o_counts = take(n * 4);
-  L->o_off = take(n * 4);
   L->o_cursor = take(n * 4);
+  L->o_prefix = take(L->words * 4);
+  L->o_off = take(n * 4);
   L->o_members = take(n * 4);
   const int64_t s1 = ococc_scan::scratch_words(L->words, 1), s2 = ococc_scan::scratch_words(n > 0 ? n : 1, 1);
   L->o_scratch = take((s1 > s2 ? s1 : s2) * 4);
@@ -105,8 +106,12 @@ extern "C" int ococc_group_rank_i32(const int32_t* keys, int64_t n, int64_t key_
   Layout L;
   OCOCC_REQUIRE(make_layout(n, key_bound, &L), "need 1 <= key_bound < 2^31");
   OCOCC_REQUIRE(num_groups && status, "null num_groups/status");
-  OCOCC_HIP(hipMemsetAsync(num_groups, 0, 4, stream));
-  OCOCC_HIP(hipMemsetAsync(status, 0, 4, stream));
+  if (status == num_groups + 1) {
+    OCOCC_HIP(hipMemsetAsync(num_groups, 0, 8, stream));   // (the usual {num_groups, status} pair: one memset)
+  } else {
+    OCOCC_HIP(hipMemsetAsync(num_groups, 0, 4, stream));
+    OCOCC_HIP(hipMemsetAsync(status, 0, 4, stream));
+  }
   if (n == 0) return OCOCC_OK;
   OCOCC_REQUIRE(keys && conti && inner, "null pointer");
   OCOCC_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small");
@@ -119,9 +124,7 @@ extern "C" int ococc_group_rank_i32(const int32_t* keys, int64_t n, int64_t key_
   int32_t* members = (int32_t*)(ws + L.o_members);
   uint32_t* scratch = (uint32_t*)(ws + L.o_scratch);
   const int g1 = ococc_grid_1d(n, 256);
-  OCOCC_HIP(hipMemsetAsync(bitmap, 0, L.words * 4, stream));
-  OCOCC_HIP(hipMemsetAsync(cnt, 0, n * 4, stream));
-  OCOCC_HIP(hipMemsetAsync(cursor, 0, n * 4, stream));
+  OCOCC_HIP(hipMemsetAsync(bitmap, 0, (size_t)(L.o_prefix - L.o_bitmap), stream));   // bitmap, counts, cursor
   hipLaunchKernelGGL(gr_mark_kernel, dim3(g1), dim3(256), 0, stream, keys, n, (int32_t)key_bound, bitmap, status);
   OCOCC_CHECK_LAUNCH();
   OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bitmap, L.words, L.words, 1, prefix, L.words, scratch,
