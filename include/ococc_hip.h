@@ -626,6 +626,10 @@ int64_t ococc_point_mlp_fragment_floats(int32_t n, int32_t k);
 int64_t ococc_point_mlp_tiles(int64_t rows);
 int ococc_point_mlp_pack_f32(const float* w, int32_t n, int32_t k, int64_t row_stride, int64_t col_stride, float* frag,
                              ococc_stream_t stream);
+/* the same for up to 32 matrices in one launch (HOST tables) */
+int ococc_point_mlp_pack_multi_f32(int32_t count, const void* const* w, const int32_t* n, const int32_t* k,
+                                   const int64_t* row_stride, const int64_t* col_stride, void* const* frag,
+                                   ococc_stream_t stream);
 int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, const float* mul, int32_t ldm, const float* colscale,
                             const float* b, int32_t kb, int32_t ldb, float bscale, const float* v, int32_t kv,
                             const int32_t* inv, int64_t rows, const float* w_frag, int32_t n, const float* ln_weight,

@@ -124,6 +124,7 @@ SIGNATURES = {
     'ococc_point_mlp_fragment_floats': (c_i64, [c_i32, c_i32]),
     'ococc_point_mlp_tiles': (c_i64, [c_i64]),
     'ococc_point_mlp_pack_f32': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    'ococc_point_mlp_pack_multi_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), ctypes.POINTER(c_vp), c_vp]),
     'ococc_point_mlp_fwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
                                         c_i64, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_point_mlp_segment_argmax': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),

@@ -546,6 +546,28 @@ point_mlp_pack_kernel(const float* __restrict__ w, int n, int k, int64_t rs, int
   }
 }
 
+// the same for up to kMaxPack matrices in one launch (a SIR layer packs its four or five weights, both orientations, once
+// per optimizer step: 120 launches of 4 us per step otherwise)
+constexpr int kMaxPack = 32;
+struct PackMulti {
+  const float* w[kMaxPack];
+  float* dst[kMaxPack];
+  int64_t rs[kMaxPack], cs[kMaxPack];
+  int32_t n[kMaxPack], k[kMaxPack], first_block[kMaxPack + 1];
+  int32_t count;
+};
+__global__ void __launch_bounds__(256) point_mlp_pack_multi_kernel(PackMulti pk) {
+  int t = 0;
+  while (t + 1 < pk.count && (int)blockIdx.x >= pk.first_block[t + 1]) ++t;
+  const int n = pk.n[t], k = pk.k[t];
+  const int ksteps = pad_k(k) >> 2, nblocks = (n + 15) >> 4, total = nblocks * ksteps * 64;
+  const int i = ((int)blockIdx.x - pk.first_block[t]) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63, blk = i >> 6, ks = blk % ksteps, nb = blk / ksteps;
+  const int row = 16 * nb + (lane & 15), col = 4 * ks + (lane >> 4);
+  pk.dst[t][i] = (row < n && col < k) ? pk.w[t][row * pk.rs[t] + col * pk.cs[t]] : 0.f;
+}
+
 // arg[seg][ch] = smallest row whose y equals the segment maximum (the rule of the reference's own DynamicScatter,
 // scatter_points_cuda.cu:136-160; torch_scatter's tie rule is unpinned): rows are sorted by segment, so the
 // first hit of a run is its smallest row; runs of one segment in different tiles meet in an integer atomicMin.
@@ -585,6 +607,32 @@ extern "C" int ococc_point_mlp_pack_f32(const float* w, int32_t n, int32_t k, in
   const int64_t total = ococc_point_mlp_fragment_floats(n, k);
   hipLaunchKernelGGL(point_mlp_pack_kernel, dim3(ococc_grid_1d(total, 256, 256)), dim3(256), 0, (hipStream_t)stream, w, (int)n,
                      (int)k, row_stride, col_stride, frag);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_point_mlp_pack_multi_f32(int32_t count, const void* const* w, const int32_t* n, const int32_t* k,
+                                              const int64_t* row_stride, const int64_t* col_stride, void* const* frag,
+                                              ococc_stream_t stream) {
+  OCOCC_REQUIRE(count >= 0 && count <= kMaxPack, "at most 32 matrices per call");
+  if (count == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(w && n && k && row_stride && col_stride && frag, "null pointer table");
+  PackMulti pk;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    OCOCC_REQUIRE(w[i] && frag[i] && n[i] > 0 && k[i] > 0, "bad matrix");
+    pk.w[i] = (const float*)w[i];
+    pk.dst[i] = (float*)frag[i];
+    pk.rs[i] = row_stride[i];
+    pk.cs[i] = col_stride[i];
+    pk.n[i] = n[i];
+    pk.k[i] = k[i];
+    pk.first_block[i] = blocks;
+    blocks += (int)ococc_cdiv(ococc_point_mlp_fragment_floats(n[i], k[i]), 256);
+  }
+  pk.first_block[count] = blocks;
+  pk.count = count;
+  hipLaunchKernelGGL(point_mlp_pack_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pk);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

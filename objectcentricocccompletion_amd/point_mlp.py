@@ -38,6 +38,39 @@ def pack_weight(w, owner=None, transposed=False):
     return out
 
 
+def prepack(weights, backward=True):
+    """Pack the f32 weights of several layers (and, with ``backward``, their transposed views) in ONE launch, into the
+    cache pack_weight reads: a SIR layer calls this with all its Linears before it runs them."""
+    import ctypes
+    if torch.cuda.is_current_stream_capturing():
+        return
+    todo = []
+    for w in weights:
+        if w.dtype != torch.float32 or not w.is_cuda:
+            continue
+        for tr in ((False, True) if backward else (False,)):
+            key = (id(w), tr)
+            hit = _packed.get(key)
+            view = w.detach().t() if tr else w.detach()
+            if hit is not None and hit[0]() is w and hit[1] == w._version and hit[2] == view.data_ptr():
+                continue
+            todo.append((key, w, view))
+    for lo in range(0, len(todo), 32):
+        part = todo[lo:lo + 32]
+        outs = [torch.empty(int(L.lib.ococc_point_mlp_fragment_floats(v.shape[0], v.shape[1])), dtype=torch.float32,
+                            device=v.device) for _, _, v in part]
+        c = len(part)
+        vp, i32, i64 = ctypes.c_void_p * c, ctypes.c_int32 * c, ctypes.c_int64 * c
+        L.check(L.lib.ococc_point_mlp_pack_multi_f32(
+            c, vp(*[v.data_ptr() for _, _, v in part]), i32(*[v.shape[0] for _, _, v in part]),
+            i32(*[v.shape[1] for _, _, v in part]), i64(*[v.stride(0) for _, _, v in part]),
+            i64(*[v.stride(1) for _, _, v in part]), vp(*[o.data_ptr() for o in outs]), L.stream()), 'point_mlp_pack_multi')
+        if len(_packed) > 512:
+            _packed.clear()
+        for (key, w, v), o in zip(part, outs):
+            _packed[key] = (weakref.ref(w), w._version, v.data_ptr(), o)
+
+
 def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 

@@ -15,7 +15,7 @@ from torch import nn
 
 from ._lib import const_tensor
 from .linear import Linear
-from .point_mlp import point_layer
+from .point_mlp import point_layer, prepack
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import build_mlp, fuse_norm_act, get_activation_layer, unique_with_inverse
 from .voxel.scatter_points import gather_rows, segment_reduce
@@ -138,6 +138,9 @@ class SIRLayer(nn.Module):
         dev = features.device
         raw = self.in_channels - 3 * (self._with_cluster_center + self._with_voxel_center)   # columns of `features`
         scale = 1.0 / float(self.rel_dist_scaler)
+        # all Linears of this layer (and their transposes, when a backward pass will follow) packed in one launch
+        lins = [v.linear.weight for v in self.vfe_layers] + ([blk[0].weight for blk in self.rel_mlp] if self._with_rel_mlp else [])
+        prepack(lins, backward=torch.is_grad_enabled())
         gate = None
         if self._with_rel_mlp:   # gate = rel_mlp(f_cluster / rel_dist_scaler), one launch per Linear -> LN -> act
             gate = f_cluster
