@@ -183,7 +183,7 @@ struct Epilogue {
 };
 // Contains workgroup barriers when has_ln or head_s (kernel-uniform).  Nothing is written to y_lds before the first of
 // them, so with a LayerNorm the tile the GEMM phase read may be the one y_lds overwrites.
-template <int NPW, bool ADD>
+template <int NPW, bool ADD, bool MAY_DROP = true>
 __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epilogue& e) {
   constexpr int N = NPW * 32 * kWaves;
   // The per-lane indices are loop invariant in the persistent kernels; left alone the compiler computes every one of them
@@ -278,7 +278,7 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
           v0 = ln_gelu2_rcp(v0);
           v1 = ln_gelu2_rcp(v1);
         }
-        if (e.drop.thr) {
+        if (MAY_DROP && e.drop.thr) {
           v0 = v0 * ln_dropout_mask2(e.drop, rows_of[mb], n >> 1, N >> 1);
           v1 = v1 * ln_dropout_mask2(e.drop, rows_of[mb], (n >> 1) + 1, N >> 1);
         }
@@ -292,7 +292,7 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
         if (e.y_lds) *(u32x2*)(e.y_lds + (32 * mb + m) * e.ld_lds + n) = o;
         if (e.y_global && rows_of[mb] < e.rows) *(u32x2*)(e.y_global + rows_of[mb] * N + n) = o;
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (q & 1) __builtin_amdgcn_sched_barrier(0);   // (two 8-channel pieces per scheduling region: their chains interleave)
     }
   if (e.head_s) {
     __syncthreads();   // (red0 was last read behind the second LayerNorm barrier)
@@ -405,6 +405,7 @@ __device__ __forceinline__ void copy_tile_out(const uint16_t* ys, int ld, uint16
     if (row0 + r < rows) *(u32x4*)(dst + (row0 + r) * N + p * 8) = *(const u32x4*)(ys + r * ld + p * 8);
   }
 }
+template <bool DROP>   // (inference instantiation: no dropout test per channel pair in the epilogues)
 __global__ void __launch_bounds__(kThreads, 2)
 occ_mlp_fwd_kernel(OccMlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -466,7 +467,7 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.y_lds = ys;
       e.ld_lds = kLd1;
       e.drop = a.drop[0];
-      layer_epilogue<2, true>(acc, e);
+      layer_epilogue<2, true, DROP>(acc, e);
     }
     __syncthreads();   // y0 complete
     if (a.y_out[0]) copy_tile_out<kN0>(ys, kLd1, a.y_out[0], row0, a.rows);
@@ -478,7 +479,7 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.y_lds = ys;
       e.ld_lds = kLd2;
       e.drop = a.drop[1];
-      layer_epilogue<4, false>(acc, e);
+      layer_epilogue<4, false, DROP>(acc, e);
     }
     __syncthreads();   // y1 complete
     if (a.y_out[1]) copy_tile_out<kN1>(ys, kLd2, a.y_out[1], row0, a.rows);
@@ -490,7 +491,7 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.head_s = head_s;
       e.y_lds = nullptr;
       e.drop = a.drop[2];
-      layer_epilogue<4, false>(acc, e);   // ends with the head's barriers: every wave is past its reads of y1
+      layer_epilogue<4, false, DROP>(acc, e);   // ends with the head's barriers: every wave is past its reads of y1
     }
   }
 }
@@ -718,8 +719,13 @@ extern "C" int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const fl
   a.rows = rows;
   const int64_t tiles = ococc_cdiv(rows, TM);
   const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
-  OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
-  hipLaunchKernelGGL(occ_mlp_fwd_kernel, dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
+  if (drop_threshold) {
+    OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
+    hipLaunchKernelGGL(occ_mlp_fwd_kernel<true>, dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
+  } else {
+    OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
+    hipLaunchKernelGGL(occ_mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
+  }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
