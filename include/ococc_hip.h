@@ -738,6 +738,17 @@ int ococc_adamw_lr_dev_f32(int32_t num_tensors, void* const* params, const void*
                            void* const* exp_avg, void* const* exp_avg_sq, const int64_t* numel,
                            const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
                            float* step, int32_t bump_step, ococc_stream_t stream);
+/* The same update that ALSO refreshes the bf16 kernel operands of convolution weights it has just written (what
+ * ococc_weight_prepare_multi_bf16 would compute at the start of the next step: one launch less per step).  lr_dev null:
+ * lr is used.  Operand o belongs to tensor operand_tensor[o] (an index into params, a contiguous f32 [kvol, cin, cout]),
+ * is written in layout operand_mode[o] (the modes of ococc_weight_prepare_bf16, + 4 = fragment-major) to operand_dst[o]
+ * (bf16, kvol * cin * cout elements); at most 8 operands per call.  All tables are HOST arrays. */
+int ococc_adamw_operands_f32(int32_t num_tensors, void* const* params, const void* const* grads, void* const* exp_avg,
+                             void* const* exp_avg_sq, const int64_t* numel, float lr, const float* lr_dev, float beta1,
+                             float beta2, float eps, float weight_decay, float* step, int32_t bump_step,
+                             int32_t num_operands, const int32_t* operand_tensor, const int32_t* operand_mode,
+                             const int32_t* operand_kvol, const int32_t* operand_cin, const int32_t* operand_cout,
+                             void* const* operand_dst, ococc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stream timers (HIP events) for the measurement harness (bench.py roofline line).  No reference

@@ -150,6 +150,11 @@ SIGNATURES = {
     'ococc_adamw_lr_dev_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                        ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), c_vp, c_f32, c_f32, c_f32, c_f32,
                                        c_vp, c_i32, c_vp]),
+    'ococc_adamw_operands_f32': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                         ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), c_f32, c_vp, c_f32, c_f32, c_f32, c_f32,
+                                         c_vp, c_i32, c_i32, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                         ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                         ctypes.POINTER(c_vp), c_vp]),
     'ococc_timer_create': (c_i32, [ctypes.POINTER(c_vp)]),
     'ococc_timer_record': (c_i32, [c_vp, c_i32, c_vp]),
     'ococc_timer_elapsed_ms': (c_i32, [c_vp, c_vp, ctypes.POINTER(c_f32)]),

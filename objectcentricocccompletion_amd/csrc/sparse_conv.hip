@@ -33,6 +33,7 @@
 // over pairs.  Partial sums are written to per-workgroup slabs and added in a
 // fixed order (deterministic, no float atomics).
 #include "common.hpp"
+#include "weight_layout.hpp"
 #include "ln_math.hpp"
 #include "param_reduce.hpp"
 #include <cstdlib>
@@ -795,16 +796,9 @@ int dispatch_cs(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
 }
 
 // ---------------------------------------------------------------- weights
-// Destination index of element (k, r, c) of the prepared matrix wn[k][ncols][kd].  Bit 2 of the mode
-// (value 4) asks for the MFMA-FRAGMENT-major order of ococc_sparse_conv_tile_bf16, whose waves load
-// their weight fragments straight from global memory: fragment (column block r/16, k-step c/32) is 64
-// lanes x 16 bytes, lane = 16 * ((c % 32) / 8) + r % 16, so that one load instruction reads 1 KB of
-// consecutive bytes instead of 64 pieces of 16 bytes from 16 rows.
+// (index maps of the operand layouts: weight_layout.hpp)
 __device__ __forceinline__ int64_t prep_dest(int mode, int64_t i, int k, int r, int c, int ncols, int kd) {
-  if (!(mode & 4)) return i;
-  const int nb = ncols / 16, ksteps = kd / 32;
-  const int lane = 16 * ((c % 32) / 8) + (r % 16);
-  return ((((int64_t)k * nb + r / 16) * ksteps + c / 32) * 64 + lane) * 8 + (c % 8);
+  return ococc_prep_dest(mode, i, k, r, c, ncols, kd);
 }
 template <typename T>
 __global__ void __launch_bounds__(256)

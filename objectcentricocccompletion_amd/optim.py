@@ -16,6 +16,7 @@ import torch
 
 from . import _lib as L
 
+REFRESH_CONV_OPERANDS = __import__('os').environ.get('OCOCC_ADAMW_OPERANDS', '1') == '1'   # see AdamW.step
 _MAX = 48
 
 
@@ -73,12 +74,36 @@ class AdamW(torch.optim.Optimizer):
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise L.OcoccError('AdamW kernel takes contiguous parameters and gradients')
             b1, b2 = group['betas']
+            refreshed = []
             # every launch of one step must see the same step count: only the last one bumps it
             for lo in range(0, len(ps), _MAX):
                 chunk = ps[lo:lo + _MAX]
                 n = len(chunk)
                 arr = ctypes.c_void_p * n
                 last = lo + _MAX >= len(ps)
+                # convolution weights whose bf16 kernel operands are cached for the current step: the update rewrites the
+                # operands too (ococc_adamw_operands_f32) and the preparation launch of the next step disappears
+                targets = []
+                if REFRESH_CONV_OPERANDS:
+                    from .spconv import ops as sp_ops
+                    for i, p in enumerate(chunk):
+                        for mode, kvol, cin, cout, wn in sp_ops.refresh_targets(p):
+                            targets.append((i, mode, kvol, cin, cout, wn, p))
+                if targets and len(targets) <= 8:
+                    no = len(targets)
+                    i32 = ctypes.c_int32 * no
+                    L.check(L.lib.ococc_adamw_operands_f32(
+                        n, arr(*[p.data_ptr() for p in chunk]), arr(*[p.grad.data_ptr() for p in chunk]),
+                        arr(*[self.state[p]['exp_avg'].data_ptr() for p in chunk]),
+                        arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
+                        (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']),
+                        group['lr_dev'].data_ptr() if self.device_lr else None, float(b1), float(b2), float(group['eps']),
+                        float(group['weight_decay']), group['step_dev'].data_ptr(), 2 if last else 0, no,
+                        i32(*[t[0] for t in targets]), i32(*[t[1] for t in targets]), i32(*[t[2] for t in targets]),
+                        i32(*[t[3] for t in targets]), i32(*[t[4] for t in targets]),
+                        (ctypes.c_void_p * no)(*[t[5].data_ptr() for t in targets]), L.stream()), 'adamw_operands')
+                    refreshed += [t[6] for t in targets]
+                    continue
                 fn, lr_arg = ((L.lib.ococc_adamw_lr_dev_f32, group['lr_dev'].data_ptr()) if self.device_lr
                               else (L.lib.ococc_adamw_f32, float(group['lr'])))
                 L.check(fn(
@@ -90,6 +115,10 @@ class AdamW(torch.optim.Optimizer):
                     2 if last else 0, L.stream()), 'adamw')
             for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
                 torch.autograd.graph.increment_version(p)
+            if refreshed:
+                from .spconv import ops as sp_ops
+                for p in refreshed:
+                    sp_ops.operands_refreshed(p)
         return loss
 
 

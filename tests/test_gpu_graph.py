@@ -160,3 +160,59 @@ def test_adamw_device_learning_rate_schedule_and_checkpoint(dev):
         oc.step()
     for p, q in zip(mc.parameters(), mb.parameters()):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+
+
+def test_adamw_refreshes_the_cached_conv_operands(dev):
+    """optim.AdamW rewrites the bf16 kernel operands of the convolution weights together with the weights
+    (ococc_adamw_operands_f32): after a step the cached layouts -- row-major and fragment-major, forward and input
+    gradient -- equal a fresh preparation of the updated weights bit for bit, the next step launches no preparation, and
+    the parameters equal those of the plain update."""
+    import ctypes
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd import optim
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    from objectcentricocccompletion_amd.spconv import ops
+    torch.manual_seed(0)
+    xyz, feats, bidx = synthetic_object_grids(4, 600, seed=1, device=dev)
+    results = {}
+    for fused in (True, False):
+        optim.REFRESH_CONV_OPERANDS = fused
+        ops.density.reset()
+        torch.manual_seed(1)
+        model = SubMOccEncoder().to(dev)
+        opt = optim.AdamW(model.parameters(), lr=1e-2)
+        launches = []
+        orig = L.lib.ococc_weight_prepare_multi_bf16
+
+        class Spy(object):
+            def __call__(self, *a):
+                launches.append(a[0])
+                return orig(*a)
+        try:
+            L.lib.ococc_weight_prepare_multi_bf16 = Spy()
+            for step in range(3):
+                opt.zero_grad(set_to_none=True)
+                out = model(xyz, feats, bidx, 4)
+                out.features.float().pow(2).mean().backward()
+                opt.step()
+                torch.cuda.synchronize()
+                ops.density.poll()
+        finally:
+            L.lib.ococc_weight_prepare_multi_bf16 = orig
+            optim.REFRESH_CONV_OPERANDS = True
+        results[fused] = ([p.detach().clone() for p in model.parameters()], list(launches))
+        if fused:
+            checked = 0
+            for layer in model.conv_layers:
+                w = layer[0].weight
+                for mode, kvol, cin, cout, wn in ops.refresh_targets(w):
+                    fresh = torch.empty_like(wn)
+                    L.check(L.lib.ococc_weight_prepare_bf16(L.ptr(w.detach()), L.dtype_code(torch.float32), kvol, cin, cout, mode,
+                                                            L.ptr(fresh), L.stream()), 'weight_prepare')
+                    assert torch.equal(wn.view(-1), fresh.view(-1)), (cin, cout, mode)
+                    checked += 1
+            assert checked >= 5   # three forward operands + two input-gradient operands
+    # (the density estimate arrives after the first step: the layouts chosen there are prepared once more)
+    assert sum(results[True][1]) < sum(results[False][1]) and len(results[True][1]) <= 2 and len(results[False][1]) == 3
+    for a, b in zip(results[True][0], results[False][0]):
+        assert torch.equal(a, b)
