@@ -27,6 +27,16 @@ def rotation_3d_in_axis(points, angles, axis=0):
     return torch.einsum('aij,jka->aik', (points, rot_mat_T))
 
 
+def box_corners(boxes):
+    """[N, 7+] (x, y, z_bottom, dx, dy, dz, yaw) -> [N, 8, 3], the corner order of LiDARInstance3DBoxes.corners
+    (mmdet3d/core/bbox/structures/lidar_box3d.py:54-92): (x0y0z0, x0y0z1, x0y1z1, x0y1z0, x1y0z0, x1y0z1, x1y1z1, x1y1z0)
+    about the bottom centre, turned about z with rotation_3d_in_axis."""
+    unit = boxes.new_tensor([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]])
+    unit = unit - boxes.new_tensor([0.5, 0.5, 0.0])
+    corners = boxes[:, 3:6].reshape(-1, 1, 3) * unit[None]
+    return rotation_3d_in_axis(corners, boxes[:, 6], axis=2) + boxes[:, :3].reshape(-1, 1, 3)
+
+
 @BBOX_CODERS.register_module()
 class DeltaXYZWLHRBBoxCoder(object):
     """(x, y, z_bottom, w, l, h, r) deltas normalised by the anchor diagonal / height."""

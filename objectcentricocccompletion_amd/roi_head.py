@@ -32,7 +32,6 @@ class TrackletRoIHeadOCC(nn.Module):
         self.general_cfg, self.num_classes = general_cfg, num_classes
         self.with_roi_scores = general_cfg.get('with_roi_scores', False)
         self.with_roi_corners = general_cfg.get('with_roi_corners', False)
-        assert not self.with_roi_corners, 'with_roi_corners is off in ococcnet.py and not built'
         self.roi_extractor = ROI_EXTRACTORS.build(roi_extractor)
         bh = dict(bbox_head)
         bh['train_cfg'], bh['test_cfg'] = train_cfg, test_cfg
@@ -157,7 +156,18 @@ class TrackletRoIHeadOCC(nn.Module):
         new_feats, new_xyz = pts_feats[inds], pts_xyz[inds]
         if self.with_roi_scores:
             new_feats = torch.cat([new_feats, roi_scores[roi_inds].unsqueeze(1)], 1)
+        if self.with_roi_corners:
+            new_feats = torch.cat([new_feats, self.roi_corner_offsets(rois, roi_inds, new_xyz).to(new_feats.dtype)], 1)
         return self.bbox_head(new_xyz, new_feats, info, roi_inds, rois, roi_frame_inds)
+
+    @staticmethod
+    def roi_corner_offsets(rois, roi_inds, xyz):
+        """27 extra point features of general_cfg.with_roi_corners (tracklet_roi_head_occ.py:861-868): the offsets from
+        the point to the 8 corners of its RoI and to a ninth "centre" row, over 10.  The reference takes that ninth row
+        from the first three RoI COLUMNS, (batch index, x, y) -- reproduced as is (tests/golden/roi_corners.npz)."""
+        from .bbox import box_corners
+        c = torch.cat([box_corners(rois[:, 1:]).to(xyz.dtype), rois[:, :3].to(xyz.dtype)[:, None, :]], 1)   # [R, 9, 3]
+        return (c[roi_inds.long()] - xyz[:, None, :]).reshape(xyz.size(0), 27) / 10
 
     # ------------------------------------------------------------------ inference
     def tracklets2rois(self, tracklets):
