@@ -9,7 +9,9 @@ import weakref
 
 import torch
 
+from . import _deferred
 from . import _lib as L
+from . import norm as _norm  # noqa: F401 (registers the 'ln' flusher of _deferred)
 from .linear import TALL_ROWS, sliced_wgrad
 
 ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
@@ -97,6 +99,7 @@ class _PointLayer(torch.autograd.Function):
             0 if b_ is None else b_.stride(0), float(bscale), L.ptr(v_), kv, L.ptr(inv), rows, L.ptr(wf), n, L.ptr(g),
             L.ptr(be), float(eps), ACT[act], L.ptr(y), L.ptr(vmax), int(num_segments), L.stream()), 'point_mlp_fwd')
         ctx.save_for_backward(a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf)
+        ctx.ln_params = (ln_w, ln_b)   # the parameters themselves: their gradient sums may join the end-of-backward launch
         ctx.misc = (float(bscale), float(eps), act, int(num_segments))
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (a, mul, b, v))
         return y, vmax
@@ -140,8 +143,17 @@ class _PointLayer(torch.autograd.Function):
             dw = (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
         dg = dbeta = None
         if g is not None:
-            sums = lnp.sum(0)
-            dg, dbeta = sums[0], sums[1]
+            ln_w, ln_b = ctx.ln_params
+            dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+            # per-tile partial rows [tiles][d gamma | d beta]: the layout of the LayerNorm kernels' partials, so the
+            # column sums can ride on the pass's end-of-backward launch (_deferred, norm._flush_param_reduce) instead
+            # of one reduction launch per layer
+            if (tiles > 0 and need[5] and need[6] and ln_w is not ln_b and _deferred.deferrable(ln_w, ln_b)
+                    and _deferred.defer('ln', (lnp, tiles, n, dgb), [(ln_w, dgb[0]), (ln_b, dgb[1])])):
+                dg = dbeta = None
+            else:
+                sums = lnp.sum(0)
+                dg, dbeta = sums[0], sums[1]
         cast = lambda t, dt: None if t is None else t.to(dt)
         dts = ctx.in_dtypes
         return (cast(da, dts[0]), cast(dmul, dts[1]), cast(db, dts[2]), cast(dv, dts[3]), dw, dg, dbeta, None, None, None,
