@@ -244,8 +244,13 @@ class OccDecoder(nn.Module):
             return []
         assert roi_feats.size(0) == rois.size(0), f'{roi_feats.size(0)}, {rois.size(0)}'
         assert rois.size(1) in (8, 10)
-        roi_batch_idx = rois[:, 0]
-        batch_size = int(roi_batch_idx.max().item() + 1)
+        # which RoIs belong to which sample: ONE read-back of the batch column, grouped on the host (the reference's
+        # torch.nonzero(roi_batch_idx == i) per sample is a synchronisation per sample)
+        batch_of = rois[:, 0].long().tolist()
+        batch_size = max(batch_of) + 1
+        rois_of = [[] for _ in range(batch_size)]
+        for j, b in enumerate(batch_of):
+            rois_of[b].append(j)
         sizes, yaw, ctr = rois[:, 4:7], rois[:, 7], rois[:, 1:4]
         if local_xyz is not None and not return_full:
             assert len(local_xyz) == len(local_pts_roi_inds), f'{len(local_xyz)}, {len(local_pts_roi_inds)}'
@@ -263,8 +268,7 @@ class OccDecoder(nn.Module):
         counts = torch.bincount(pbox, minlength=rois.size(0)).tolist()
         per_roi = list(torch.split(pts, counts))
         res = []
-        for i in range(batch_size):
-            ids = torch.nonzero(roi_batch_idx == i).squeeze(1).tolist()
+        for ids in rois_of:
             cur = [per_roi[j] for j in ids]
             res.append(torch.cat(cur, 0) if concat_batch else cur)
         return res
