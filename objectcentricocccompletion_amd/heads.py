@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ._lib import const_tensor
 from .bbox import build_bbox_coder, rotation_3d_in_axis
 from .losses import build_loss, reduce_mean
 from .occ import occ_ops
@@ -45,21 +46,20 @@ class SparseHeadMixin(object):
 
     def get_nonempty_roi_mask(self, out_coors, num_rois):
         """fsd_bbox_head.py:238-250."""
-        out_coors = out_coors[out_coors >= 0].long()
-        mask = torch.zeros(num_rois, dtype=torch.bool, device=out_coors.device)
-        mask[out_coors] = True
-        return mask
+        # (-1 entries go to a spare slot instead of being compacted away: no read-back)
+        idx = torch.where(out_coors >= 0, out_coors, torch.full_like(out_coors, num_rois)).long()
+        mask = torch.zeros(num_rois + 1, dtype=torch.bool, device=out_coors.device)
+        mask.index_fill_(0, idx, True)
+        return mask[:num_rois]
 
     def align_roi_feature_and_rois(self, features, out_coors, num_rois):
         """Rows of `features` follow the sorted non-empty RoIs; put them at their RoI index,
         zeros for empty RoIs (fsd_bbox_head.py:252-272)."""
-        new_feature = features.new_zeros((num_rois, features.size(1)))
-        coors_mask = out_coors >= 0
-        if not coors_mask.any():
-            new_feature[:len(features), :] = features * 0
-            return new_feature
-        new_feature[out_coors[coors_mask].long()] = features[coors_mask]
-        return new_feature
+        # rows whose coordinate is -1 land in a spare row that is cut off again: no mask compaction, no read-back, and
+        # `features` stays connected to the result whether or not any RoI is non-empty
+        idx = torch.where(out_coors >= 0, out_coors, torch.full_like(out_coors, num_rois)).long()
+        new_feature = features.new_zeros((num_rois + 1, features.size(1))).index_copy(0, idx, features)
+        return new_feature[:num_rois]
 
     def filter_pos_assigned_but_empty_rois(self, pos_data, pos_batch_idx, filtered_pos_mask, roi_batch_idx):
         """fsd_bbox_head.py:442-455: per sample b, the rows of `pos_data` that belong to b, picked at the in-sample
@@ -183,7 +183,7 @@ class OccAutoEncoder(nn.Module, SparseHeadMixin):
         distributions with torch's device RNG instead of per-RoI torch.multinomial calls."""
         assert rois.size(1) in (8, 10)
         if not self.compensate_encoder_coors:
-            r = local_xyz.new_tensor((np.pi / 2,))
+            r = const_tensor((np.pi / 2,), local_xyz.device, local_xyz.dtype)
             local_xyz = rotation_3d_in_axis(local_xyz[None, :, :], r, axis=2).squeeze(0)
         R = rois.size(0)
         dev = local_xyz.device
@@ -360,7 +360,7 @@ class OccAutoEncoder(nn.Module, SparseHeadMixin):
         """occ_ae_head.py:203-264 -> (local_roi_feats [R,D], nonempty mask [R], rotated local xyz)."""
         local_xyz = pts_info['local_xyz']
         if self.compensate_encoder_coors:  # the pi/2 frame fix the pooling op leaves to callers
-            r = local_xyz.new_tensor((np.pi / 2,))
+            r = const_tensor((np.pi / 2,), local_xyz.device, local_xyz.dtype)
             local_xyz = rotation_3d_in_axis(local_xyz[None, :, :], r, axis=2).squeeze(0)
         boundary_offset, is_in_margin = pts_info['boundary_offset'], pts_info['is_in_margin']
         parts = [boundary_offset, is_in_margin[:, None]]
@@ -542,9 +542,11 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         return self.transformer_forward_various_length(rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc)
 
     def reorder_feats(self, feats, roi_frame_inds, roi_batch_inds, sort_batch_indices=None,
-                      sort_frame_indices=None):
-        """Rows -> [B, L, C] sorted by (batch, frame) (ococc_bbox_head.py:997-1019)."""
-        B = int(roi_batch_inds.max().item() + 1)
+                      sort_frame_indices=None, batch_size=None):
+        """Rows -> [B, L, C] sorted by (batch, frame) (ococc_bbox_head.py:997-1019).  ``batch_size``: the caller's B when
+        it has read it back already (one read-back per forward instead of one per call)."""
+        B = (batch_size if batch_size is not None else sort_frame_indices.shape[0] if sort_frame_indices is not None
+             else int(roi_batch_inds.max().item() + 1))
         L = roi_frame_inds.numel() // B
         if sort_batch_indices is None or sort_frame_indices is None:
             sort_batch_indices = torch.argsort(roi_batch_inds)
@@ -576,7 +578,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         B = int(rois_batch_idx.max().item() + 1)
         L = roi_frame_inds.numel() // B
         assert L * B == roi_frame_inds.numel()
-        re_feats, sb, sf = self.reorder_feats(roi_feats, roi_frame_inds, rois_batch_idx)
+        re_feats, sb, sf = self.reorder_feats(roi_feats, roi_frame_inds, rois_batch_idx, batch_size=B)
         re_frames = self.reorder_feats(roi_frame_inds.clone(), roi_frame_inds, rois_batch_idx, sb, sf)[0].squeeze(-1)
         re_feats = re_feats.view(B, L, re_feats.shape[-1]).permute(1, 0, 2)  # [L, B, D]
         pos_embed = self.pos_enc(re_frames.transpose(0, 1))
@@ -817,24 +819,25 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         reg_mask[~nonempty] = 0
         cls_avg = n_total * 1.0
         if self.train_cfg.get('sync_cls_avg_factor', False):
-            cls_avg = reduce_mean(bbox_weights.new_tensor([cls_avg]))
+            cls_avg = reduce_mean(torch.full((1,), cls_avg, dtype=bbox_weights.dtype, device=bbox_weights.device))
         losses['loss_rcnn_cls'] = self.loss_cls(cls_score.view(-1), labels, label_weights, avg_factor=cls_avg)
         pos_inds = reg_mask > 0
         losses['num_pos_rois'] = pos_inds.sum().float()
         losses['num_neg_rois'] = (reg_mask <= 0).sum().float()
-        reg_avg = pos_inds.sum().item()
+        pos_rows = torch.where(pos_inds)[0]   # the ONE read-back of the positives (count, emptiness, row lists below)
+        reg_avg = pos_rows.numel()
         if self.train_cfg.get('sync_reg_avg_factor', False):
-            reg_avg = reduce_mean(bbox_weights.new_tensor([reg_avg]))
-        if not pos_inds.any():
+            reg_avg = reduce_mean(torch.full((1,), float(reg_avg), dtype=bbox_weights.dtype, device=bbox_weights.device))
+        if pos_rows.numel() == 0:
             losses['loss_rcnn_bbox'] = bbox_pred.sum() * 0
         else:
-            pos_pred = bbox_pred[pos_inds]
+            pos_pred = bbox_pred[pos_rows]
             bbox_targets = self.filter_pos_assigned_but_empty_rois(bbox_targets, pos_batch_idx, pos_inds,
                                                                    rois[:, 0].int())
-            w = bbox_weights[pos_inds].view(-1, 1).repeat(1, pos_pred.shape[-1])
+            w = bbox_weights[pos_rows].view(-1, 1).repeat(1, pos_pred.shape[-1])
             code_weights = self.train_cfg.get('rcnn_code_weights', None)
             if code_weights is not None:
-                w = w * torch.tensor(code_weights, dtype=w.dtype, device=w.device)[None, :]
+                w = w * const_tensor(code_weights, w.device, w.dtype)[None, :]
             assert pos_pred.size(0) == bbox_targets.size(0)
             losses['loss_rcnn_bbox'] = self.loss_bbox(pos_pred, bbox_targets, w, avg_factor=reg_avg)
         losses.update(self.loss_occ(rois, results_dict['fused_roi_feats'], results_dict['ori_roi_feats'],
@@ -855,19 +858,20 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         num_occupied = (gt_smp_occ_labels == 1).sum().float()
         losses['num_occupied'] = num_occupied
         losses['num_free'] = gt_smp_occ_labels.numel() - num_occupied
-        if not pos_inds.any():
+        pos_rows = torch.where(pos_inds)[0]   # one read-back for emptiness and the row lists below
+        if pos_rows.numel() == 0:
             idx = torch.arange(roi_features.size(0), device=roi_features.device)
             losses['loss_rcnn_occ'] = decoder(roi_features, roi_features.new_zeros(roi_features.size(0), 3), idx) * 0
             for k in ('recall_neg', 'recall_pos', 'precision_neg', 'precision_pos'):
                 losses[k] = roi_features.new_ones(1)
             return losses
-        pos_roi_features = roi_features[pos_inds]  # [M, D]
+        pos_roi_features = roi_features[pos_rows]  # [M, D]
         rb = rois[:, 0].int()
         occ_targets = self.filter_pos_assigned_but_empty_rois(gt_smp_occ_labels, pos_batch_idx, pos_inds, rb)
         occ_smp_xyz = self.filter_pos_assigned_but_empty_rois(gt_smp_local_coords, pos_batch_idx, pos_inds, rb)
         pos_gt_bboxes = self.filter_pos_assigned_but_empty_rois(pos_gt_bboxes, pos_batch_idx, pos_inds, rb)
         if transform_occ:
-            pr = rois[pos_inds][:, 1:]
+            pr = rois[pos_rows][:, 1:]
             with torch.no_grad():
                 occ_smp_xyz = rotation_3d_in_axis(occ_smp_xyz, pos_gt_bboxes[:, 6], axis=2)
                 occ_smp_xyz += pos_gt_bboxes[..., None, 0:3]
@@ -888,11 +892,12 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         with torch.no_grad():
             pred_cls = decoder.get_cls_from_pred(occ_preds.view(-1, 1)) if decoder.cls_dim == 1 \
                 else decoder.get_cls_from_pred(occ_preds)
-            lab, valid = occ_labels.view(-1), occ_weights.view(-1) > 0
-            neg_tp = ((lab[valid] == 0) & (pred_cls[valid] == 0)).sum()
-            pos_tp = ((lab[valid] == 1) & (pred_cls[valid] == 1)).sum()
-            losses['recall_neg'] = neg_tp / ((lab[valid] == 0).sum() + 1e-6)
-            losses['recall_pos'] = pos_tp / ((lab[valid] == 1).sum() + 1e-6)
-            losses['precision_neg'] = neg_tp / ((pred_cls[valid] == 0).sum() + 1e-6)
-            losses['precision_pos'] = pos_tp / ((pred_cls[valid] == 1).sum() + 1e-6)
+            # (the same counts with the validity mask ANDed in instead of eight boolean compactions and their read-backs)
+            lab, valid, pred_cls = occ_labels.view(-1), occ_weights.view(-1) > 0, pred_cls.view(-1)
+            l0, l1, p0, p1 = (lab == 0) & valid, (lab == 1) & valid, (pred_cls == 0) & valid, (pred_cls == 1) & valid
+            neg_tp, pos_tp = (l0 & p0).sum(), (l1 & p1).sum()
+            losses['recall_neg'] = neg_tp / (l0.sum() + 1e-6)
+            losses['recall_pos'] = pos_tp / (l1.sum() + 1e-6)
+            losses['precision_neg'] = neg_tp / (p0.sum() + 1e-6)
+            losses['precision_pos'] = pos_tp / (p1.sum() + 1e-6)
         return losses

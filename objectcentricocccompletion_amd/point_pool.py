@@ -61,8 +61,7 @@ class TrackletPointRoIExtractor(nn.Module):
         if self.combined:
             pts_inds, roi_inds = batch_inds.int(), rois[:, 0].int()
         else:
-            max_frames = int(roi_frame_inds.max().item()) + 1
-            pts_max_frames = int(pts_frame_inds.max().item()) + 1
+            max_frames, pts_max_frames = (int(v) + 1 for v in torch.stack([roi_frame_inds.max(), pts_frame_inds.max()]).tolist())   # one read-back
             assert pts_max_frames <= max_frames, f'{pts_max_frames} > {max_frames}'
             pts_inds = (batch_inds * max_frames + pts_frame_inds).int()
             roi_inds = (rois[:, 0].int() * max_frames + roi_frame_inds).int()
