@@ -35,9 +35,9 @@ __device__ __forceinline__ ln_f32x2 ln_gelu_grad2(ln_f32x2 z) {
   return cdf + z * (e * 0.39894228040143267794f);
 }
 
-// GELU(z) = z Phi(z) for two channels, the same Phi (the forward kernels used libm's erff: ~25 scalar instructions with
-// a branch per element)
-__device__ __forceinline__ ln_f32x2 ln_gelu2(ln_f32x2 z) {
+// GELU(z) = z Phi(z) for two channels through the Phi of ln_gelu_grad2 (exp + rcp): rounds 1-2's forward GELU, kept as the
+// reference form of ln_gelu2 below (which every forward kernel uses since round 3)
+__device__ __forceinline__ ln_f32x2 ln_gelu2_exp(ln_f32x2 z) {
   const ln_f32x2 zz = z * z;
   ln_f32x2 e, t, az;
   e.x = __builtin_amdgcn_exp2f(zz.x * -0.72134752044448170368f);
@@ -57,14 +57,14 @@ __device__ __forceinline__ ln_f32x2 ln_gelu2(ln_f32x2 z) {
   cdf.y = 0.5f + __builtin_copysignf(q.y, z.y);
   return z * cdf;
 }
-__device__ __forceinline__ float ln_gelu1(float z) { return ln_gelu2(ln_f32x2{z, z}).x; }
 
-// GELU with ONE transcendental per element, for epilogues that are VALU-bound next to the matrix pipe (mlp_layer.hip):
+// GELU with ONE transcendental per element -- the forward GELU of every kernel here (VALU-bound epilogues next to the
+// matrix pipe: mlp_layer.hip, window_block.hip; the LayerNorm kernels; the convolution epilogues):
 //   GELU(z) = max(z, 0) - |z| u(|z|),   u(a) = (1 - erf(a / sqrt 2)) / 2 = 1 / (2 P(a)^16)
 // Abramowitz & Stegun 7.1.28, erf(x) = 1 - (1 + a1 x + ... + a6 x^6)^-16, |error| <= 3e-7 (x >= 0); the coefficients
 // below are a_i / sqrt(2)^i.  No exponential, no sign select: 12 packed operations, 2 reciprocals and 4 single ones per
 // pair against 14 + 4 + 6 above.  |GELU error| <= 1.5e-7 |z|.
-__device__ __forceinline__ ln_f32x2 ln_gelu2_rcp(ln_f32x2 z) {
+__device__ __forceinline__ ln_f32x2 ln_gelu2(ln_f32x2 z) {
   ln_f32x2 a, r, relu;
   a.x = __builtin_fabsf(z.x);
   a.y = __builtin_fabsf(z.y);
@@ -84,6 +84,10 @@ __device__ __forceinline__ ln_f32x2 ln_gelu2_rcp(ln_f32x2 z) {
   relu.y = __builtin_fmaxf(z.y, 0.f);
   return relu - (a * r) * 0.5f;
 }
+// One value at a time (the convolution epilogues, the generic LayerNorm kernel): the exp + rcp form -- its two short
+// dependency chains finish sooner than the single long one above where there is no second channel to interleave with
+// (the 32 -> 64 tile convolution with LN + GELU epilogue: 23.4 us against 25.0 us).  The two forms agree to 1e-6.
+__device__ __forceinline__ float ln_gelu1(float z) { return ln_gelu2_exp(ln_f32x2{z, z}).x; }
 
 // Dropout behind the activation (build_mlp's Sequential(Linear, norm, act, Dropout), sst_ops.py:333-360), folded into
 // the LN kernels: the keep mask is a counter-based hash of (seed, element index) -- one 32-bit hash per channel pair,

@@ -275,8 +275,8 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
         ln_f32x2 v0 = {acc[nb][mb][4 * q] * rstd[mb] * gm[0] + bt[0], acc[nb][mb][4 * q + 1] * rstd[mb] * gm[1] + bt[1]};
         ln_f32x2 v1 = {acc[nb][mb][4 * q + 2] * rstd[mb] * gm[2] + bt[2], acc[nb][mb][4 * q + 3] * rstd[mb] * gm[3] + bt[3]};
         if (e.act == 1) {
-          v0 = ln_gelu2_rcp(v0);
-          v1 = ln_gelu2_rcp(v1);
+          v0 = ln_gelu2(v0);
+          v1 = ln_gelu2(v1);
         }
         if (MAY_DROP && e.drop.thr) {
           v0 = v0 * ln_dropout_mask2(e.drop, rows_of[mb], n >> 1, N >> 1);
