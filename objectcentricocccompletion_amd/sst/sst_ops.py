@@ -223,6 +223,34 @@ def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, pop
     window, which the group-rank kernel counts anyway: the key padding mask as a length.  ``key_bound``: an upper bound
     of the window ids when the caller knows one (saves the read-back of their maximum)."""
     out = {}
+    levels = [int(dl) for dl in drop_info]
+    if (key_bound is not None and batch_win_inds.is_cuda and batch_win_inds.numel() > 0 and min(levels) >= 0
+            and (max(levels) + 1) * int(key_bound) < 2 ** 31):
+        # ONE group-rank pass over the composite key (level, window) serves every level: its groups come out level by
+        # level, so a level's windows are a contiguous range of ranks and its populations a slice of the counts; the
+        # voxel lists of the levels are the pieces of one stable sort.  Two read-backs (group count; voxels and windows
+        # per level) where the per-level loop below has two per level.
+        nl = max(levels) + 1
+        lv = voxel_drop_lvl.long()
+        conti, inner, counts = group_rank(lv * int(key_bound) + batch_win_inds.long(), nl * int(key_bound))
+        order = torch.argsort(lv, stable=True)
+        ids = torch.arange(nl, device=lv.device)
+        glvl = torch.zeros(counts.numel(), dtype=torch.long, device=lv.device).scatter_(0, conti.long(), lv)
+        tally = torch.stack([(lv[:, None] == ids[None, :]).sum(0), (glvl[:, None] == ids[None, :]).sum(0)]).tolist()
+        vo = wo = 0
+        for dl in range(nl):
+            nv, nw = tally[0][dl], tally[1][dl]
+            if dl in drop_info and nv > 0:
+                idx = order[vo:vo + nv]
+                max_tokens = drop_info[dl]['max_tokens']
+                inner_l = inner[idx].long()
+                if debug:
+                    assert int(inner_l.max()) < max_tokens, f'Max inner inds({int(inner_l.max())}) larger(equal) than {max_tokens}'
+                out[dl] = (((conti[idx].long() - wo) * max_tokens + inner_l), (idx,))
+                if populations is not None:
+                    populations[dl] = counts[wo:wo + nw].to(torch.int32)
+            vo, wo = vo + nv, wo + nw
+        return {dl: out[dl] for dl in drop_info if dl in out}   # (the reference's dict order)
     for dl in drop_info:
         where = torch.where(voxel_drop_lvl == dl)   # (the one read-back of this level: its voxel list)
         if where[0].numel() == 0:
