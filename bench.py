@@ -522,6 +522,14 @@ def main():
         ref_out = model(xyz, feats, bidx, B)
         n_act = ref_out.features.shape[0]
         n_pairs = int(ref_out.indice_dict['subm1'][3].sum().item())   # (reporting only: the roofline's algorithmic bytes)
+        # (reporting only) matrix-instruction over-issue of the output-stationary kernel: it multiplies every 16-row block
+        # that has ANY neighbour at an offset (the block masks), useful are the rulebook pairs
+        over_issue = None
+        rb = getattr(ref_out.indice_dict['subm1'][2], '_ococc', None)
+        if rb is not None and rb.tables.get((False, 'fwd'), (None, None))[1] is not None:
+            mask = rb.tables[(False, 'fwd')][1].to(torch.int64) & 0xffffffff
+            active = int(((mask[:, None] >> torch.arange(27, device=mask.device)[None, :]) & 1).sum().item())
+            over_issue = round(active * 16 / max(n_pairs, 1), 2)
         del ref_out
     # The sub-manifold convolutions pick their kernel from the rulebook density (compact-then-multiply below ~2-3 pairs
     # per row).  Nothing is set here: spconv.ops.density measured it on the device while that first forward built its
@@ -727,6 +735,7 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 'traffic': pmc_traffic(),
                 'algorithmic_bytes_per_launch': alg_bytes,
+                'mfma_over_issue': over_issue,   # rows the kernel multiplies / rows that have a neighbour (16-row blocks)
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
                 'timed_in': 'timed region' if not use_graph else
