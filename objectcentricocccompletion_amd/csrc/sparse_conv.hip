@@ -427,10 +427,14 @@ __device__ __forceinline__ void stream_keep(const T& v) {
   asm volatile("" ::"v"(v));
 }
 
-// (the LayerNorm epilogue needs a few more registers; a spill inside the loop would put scratch traffic into
-// the hand-counted vmcnt queue, so that variant is built for one workgroup per CU and never spills)
+// (the LayerNorm epilogue needs a few more registers: at two workgroups per CU the 64 -> 128 and 128 -> 64 variants
+// park two values (lane row / k-group) in scratch AROUND the loop -- stored before it, reloaded in its exit block
+// ahead of the explicit vmcnt(0); nothing inside the loop, which tools/check_stream_isa.py verifies.  Loads return in
+// order among themselves, so the two stores only make the hand-counted waits more conservative.  Fused at two
+// workgroups per CU the 64 -> 128 layer takes ~6 us MORE than conv + separate LayerNorm launch (0.298 against 0.292 ms
+// per step): the epilogue's 128 GELUs per lane run at 8 waves per CU; it stays opt-in, OCOCC_FUSE_CONV_LN=1)
 template <int KD, int NC, bool OUT_BF16, bool LN = false>
-__global__ void __launch_bounds__(kStreamThreads, LN ? 1 : 2)
+__global__ void __launch_bounds__(kStreamThreads, 2)
 gather_gemm_stream_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes,
                           const uint16_t* __restrict__ wn, int kvol, const int32_t* __restrict__ table,
                           const uint32_t* __restrict__ blockmask, int64_t n_out,

@@ -73,8 +73,132 @@ def prepack(weights, backward=True):
             _packed[key] = (weakref.ref(w), w._version, v.data_ptr(), o)
 
 
+class PackPlan(object):
+    """prepack for a fixed set of parameters (the Linears of one SIR layer) with everything that does not change from
+    step to step built once: the argument arrays of the pack launch and the fragment buffers themselves, rewritten in
+    place when a parameter's version moves (stream order keeps earlier readers ahead of the rewrite; a graph that still
+    needs the OLD values of a parameter written to in place is an error autograd reports on its own).  ~10 us of host
+    time per call instead of ~80."""
+
+    def __init__(self, weights):
+        import ctypes
+        self.weights = list(weights)
+        self.views = []
+        for w in self.weights:
+            d = w.detach()
+            self.views += [(w, False, d), (w, True, d.t())]
+        self.outs = [torch.empty(int(L.lib.ococc_point_mlp_fragment_floats(v.shape[0], v.shape[1])), dtype=torch.float32,
+                                 device=v.device) for _, _, v in self.views]
+        self.ptrs = tuple(w.data_ptr() for w in self.weights)
+        self.state = None   # (versions, with transposes) of the last pack
+        self._args = {}
+        for tr_too in (False, True):
+            idx = [i for i, (_, tr, _) in enumerate(self.views) if tr_too or not tr]
+            c = len(idx)
+            vp, i32, i64 = ctypes.c_void_p * c, ctypes.c_int32 * c, ctypes.c_int64 * c
+            vs = [self.views[i][2] for i in idx]
+            self._args[tr_too] = (c, vp(*[v.data_ptr() for v in vs]), i32(*[v.shape[0] for v in vs]),
+                                  i32(*[v.shape[1] for v in vs]), i64(*[v.stride(0) for v in vs]),
+                                  i64(*[v.stride(1) for v in vs]), vp(*[self.outs[i].data_ptr() for i in idx]), idx)
+
+    def valid_for(self, weights):
+        return (len(weights) == len(self.weights) and all(a is b for a, b in zip(weights, self.weights))
+                and tuple(w.data_ptr() for w in weights) == self.ptrs)
+
+    def refresh(self, backward=True):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        versions = tuple(w._version for w in self.weights)
+        if self.state is not None and self.state[0] == versions and (self.state[1] or not backward):
+            # (still ours in the cache?  pack_weight may have cleared it)
+            first = _packed.get((id(self.weights[0]), False))
+            if first is not None and first[3] is self.outs[0]:
+                return
+        c, src, n, k, s0, s1, dst, idx = self._args[bool(backward)]
+        for lo in range(0, c, 32):
+            if c <= 32:
+                L.check(L.lib.ococc_point_mlp_pack_multi_f32(c, src, n, k, s0, s1, dst, L.stream()), 'point_mlp_pack_multi')
+            else:   # (more than one launch: slices of the argument arrays)
+                import ctypes
+                m = min(32, c - lo)
+                sl = lambda arr, ty: (ty * m)(*arr[lo:lo + m])
+                L.check(L.lib.ococc_point_mlp_pack_multi_f32(
+                    m, sl(src, ctypes.c_void_p), sl(n, ctypes.c_int32), sl(k, ctypes.c_int32), sl(s0, ctypes.c_int64),
+                    sl(s1, ctypes.c_int64), sl(dst, ctypes.c_void_p), L.stream()), 'point_mlp_pack_multi')
+        if len(_packed) > 512:
+            _packed.clear()
+        for i in idx:
+            w, tr, v = self.views[i]
+            _packed[(id(w), tr)] = (weakref.ref(w), w._version, v.data_ptr(), self.outs[i])
+        self.state = (versions, bool(backward))
+
+
 def _f32(t):
     return None if t is None else t.detach().float().contiguous()
+
+
+def layer_forward(a_, mul_, b_, v_, wf, n, g, be, colscale, inv, bscale, eps, act, want_max, num_segments):
+    """The forward launch on prepared operands (f32, row-contiguous; ``wf`` the packed weight): (y, segment maxima)."""
+    rows, ka = a_.shape
+    kb = 0 if b_ is None else b_.shape[1]
+    kv = 0 if v_ is None else v_.shape[1]
+    dev = a_.device
+    y = torch.empty((rows, n), dtype=torch.float32, device=dev)
+    vmax = torch.empty((num_segments, n), dtype=torch.float32, device=dev) if want_max else None
+    L.check(L.lib.ococc_point_mlp_fwd_f32(
+        a_.data_ptr(), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
+        0 if b_ is None else b_.stride(0), bscale, L.ptr(v_), kv, L.ptr(inv), rows, wf.data_ptr(), n, L.ptr(g),
+        L.ptr(be), eps, ACT[act], y.data_ptr(), L.ptr(vmax), num_segments, L.stream()), 'point_mlp_fwd')
+    return y, vmax
+
+
+def layer_backward(a_, mul_, b_, v_, weight, wf, g, be, colscale, inv, y, vmax, bscale, eps, act, G, dy, dvmax,
+                   need_a, need_mul, need_b, need_v, need_w):
+    """The backward launch (+ the weight-gradient GEMM): (da, dmul, db, dv, dw, ln partials [tiles, 2, n], tiles).
+    ``dy`` / ``dvmax``: f32 contiguous or None (dvmax)."""
+    rows, ka = a_.shape
+    kb = 0 if b_ is None else b_.shape[1]
+    kv = 0 if v_ is None else v_.shape[1]
+    n, k = weight.shape
+    dev = a_.device
+    arg = None
+    if vmax is not None and dvmax is not None:
+        arg = torch.empty((G, n), dtype=torch.int32, device=dev)
+        L.check(L.lib.ococc_point_mlp_segment_argmax(y.data_ptr(), vmax.data_ptr(), inv.data_ptr(), rows, n, G, arg.data_ptr(),
+                                                     L.stream()), 'segment_argmax')
+    else:
+        dvmax = None
+    wtf = pack_weight(weight.detach().float().t(), weight if weight.dtype == torch.float32 else None, transposed=True)
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    dz = new(rows, n)
+    xcat = new(rows, k) if need_w else None
+    da = new(rows, ka) if need_a else None
+    dmul = new(rows, ka) if (mul_ is not None and need_mul) else None
+    db = new(rows, kb) if (b_ is not None and need_b) else None
+    dv = torch.zeros((G, kv), dtype=torch.float32, device=dev) if (v_ is not None and need_v) else None
+    tiles = int(L.lib.ococc_point_mlp_tiles(rows))
+    lnp = new(tiles, 2, n) if g is not None else None
+    L.check(L.lib.ococc_point_mlp_bwd_f32(
+        a_.data_ptr(), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
+        0 if b_ is None else b_.stride(0), bscale, L.ptr(v_), kv, L.ptr(inv), rows, wf.data_ptr(), wtf.data_ptr(), n, L.ptr(g),
+        L.ptr(be), eps, ACT[act], dy.data_ptr(), L.ptr(dvmax), L.ptr(arg), dz.data_ptr(), L.ptr(xcat), L.ptr(da), L.ptr(dmul),
+        L.ptr(db), L.ptr(dv), L.ptr(lnp), L.stream()), 'point_mlp_bwd')
+    dw = None
+    if need_w:
+        dw = (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
+    return da, dmul, db, dv, dw, lnp, tiles
+
+
+def ln_param_grads(ln_w, ln_b, lnp, tiles, n, need):
+    """(d gamma, d beta) of one layer from its per-tile partial rows [tiles][d gamma | d beta] -- the layout of the
+    LayerNorm kernels' partials, so the column sums can ride on the pass's end-of-backward launch (_deferred,
+    norm._flush_param_reduce) instead of one reduction launch per layer; (None, None) then."""
+    if (tiles > 0 and need and ln_w is not ln_b and _deferred.deferrable(ln_w, ln_b)):
+        dgb = torch.empty((2, n), dtype=torch.float32, device=lnp.device)
+        if _deferred.defer('ln', (lnp, tiles, n, dgb), [(ln_w, dgb[0]), (ln_b, dgb[1])]):
+            return None, None
+    sums = lnp.sum(0)
+    return sums[0], sums[1]
 
 
 class _PointLayer(torch.autograd.Function):
@@ -83,21 +207,14 @@ class _PointLayer(torch.autograd.Function):
     def forward(ctx, a, mul, b, v, weight, ln_w, ln_b, colscale, inv, bscale, eps, act, want_max, num_segments):
         L.require_device(a, weight)
         a_, mul_, b_, v_ = _f32(a), _f32(mul), _f32(b), _f32(v)
-        rows, ka = a_.shape
-        kb = 0 if b_ is None else b_.shape[1]
-        kv = 0 if v_ is None else v_.shape[1]
         n = weight.shape[0]
-        assert weight.shape[1] == ka + kb + kv, (weight.shape, ka, kb, kv)
-        dev = a_.device
+        assert weight.shape[1] == a_.shape[1] + (0 if b_ is None else b_.shape[1]) + (0 if v_ is None else v_.shape[1]), \
+            (weight.shape, a_.shape)
         own = weight if weight.dtype == torch.float32 else None
         wf = pack_weight(weight.detach().float(), own)
         g, be = _f32(ln_w), _f32(ln_b)
-        y = torch.empty((rows, n), dtype=torch.float32, device=dev)
-        vmax = torch.empty((num_segments, n), dtype=torch.float32, device=dev) if want_max else None
-        L.check(L.lib.ococc_point_mlp_fwd_f32(
-            L.ptr(a_), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
-            0 if b_ is None else b_.stride(0), float(bscale), L.ptr(v_), kv, L.ptr(inv), rows, L.ptr(wf), n, L.ptr(g),
-            L.ptr(be), float(eps), ACT[act], L.ptr(y), L.ptr(vmax), int(num_segments), L.stream()), 'point_mlp_fwd')
+        y, vmax = layer_forward(a_, mul_, b_, v_, wf, n, g, be, colscale, inv, float(bscale), float(eps), act, want_max,
+                                int(num_segments))
         ctx.save_for_backward(a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf)
         ctx.ln_params = (ln_w, ln_b)   # the parameters themselves: their gradient sums may join the end-of-backward launch
         ctx.misc = (float(bscale), float(eps), act, int(num_segments))
@@ -108,52 +225,14 @@ class _PointLayer(torch.autograd.Function):
     def backward(ctx, dy, dvmax):
         a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf = ctx.saved_tensors
         bscale, eps, act, G = ctx.misc
-        rows, ka = a_.shape
-        kb = 0 if b_ is None else b_.shape[1]
-        kv = 0 if v_ is None else v_.shape[1]
-        n, k = weight.shape
-        dev = a_.device
         need = ctx.needs_input_grad
-        dy = _f32(dy)
-        arg = None
-        if vmax is not None and dvmax is not None:
-            dvmax = _f32(dvmax)
-            arg = torch.empty((G, n), dtype=torch.int32, device=dev)
-            L.check(L.lib.ococc_point_mlp_segment_argmax(L.ptr(y), L.ptr(vmax), L.ptr(inv), rows, n, G, L.ptr(arg),
-                                                         L.stream()), 'segment_argmax')
-        else:
-            dvmax = None
-        wtf = pack_weight(weight.detach().float().t(), weight if weight.dtype == torch.float32 else None, transposed=True)
-        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        dz = new(rows, n)
-        xcat = new(rows, k) if need[4] else None
-        da = new(rows, ka) if need[0] else None
-        dmul = new(rows, ka) if (mul_ is not None and need[1]) else None
-        db = new(rows, kb) if (b_ is not None and need[2]) else None
-        dv = torch.zeros((G, kv), dtype=torch.float32, device=dev) if (v_ is not None and need[3]) else None
-        tiles = int(L.lib.ococc_point_mlp_tiles(rows))
-        lnp = new(tiles, 2, n) if g is not None else None
-        L.check(L.lib.ococc_point_mlp_bwd_f32(
-            L.ptr(a_), ka, a_.stride(0), L.ptr(mul_), 0 if mul_ is None else mul_.stride(0), L.ptr(colscale), L.ptr(b_), kb,
-            0 if b_ is None else b_.stride(0), bscale, L.ptr(v_), kv, L.ptr(inv), rows, L.ptr(wf), L.ptr(wtf), n, L.ptr(g),
-            L.ptr(be), eps, ACT[act], L.ptr(dy), L.ptr(dvmax), L.ptr(arg), L.ptr(dz), L.ptr(xcat), L.ptr(da), L.ptr(dmul),
-            L.ptr(db), L.ptr(dv), L.ptr(lnp), L.stream()), 'point_mlp_bwd')
-        dw = None
-        if need[4]:
-            dw = (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
+        da, dmul, db, dv, dw, lnp, tiles = layer_backward(
+            a_, mul_, b_, v_, weight, wf, g, be, colscale, inv, y, vmax, bscale, eps, act, G, _f32(dy), _f32(dvmax),
+            need[0], need[1], need[2], need[3], need[4])
         dg = dbeta = None
         if g is not None:
             ln_w, ln_b = ctx.ln_params
-            dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
-            # per-tile partial rows [tiles][d gamma | d beta]: the layout of the LayerNorm kernels' partials, so the
-            # column sums can ride on the pass's end-of-backward launch (_deferred, norm._flush_param_reduce) instead
-            # of one reduction launch per layer
-            if (tiles > 0 and need[5] and need[6] and ln_w is not ln_b and _deferred.deferrable(ln_w, ln_b)
-                    and _deferred.defer('ln', (lnp, tiles, n, dgb), [(ln_w, dgb[0]), (ln_b, dgb[1])])):
-                dg = dbeta = None
-            else:
-                sums = lnp.sum(0)
-                dg, dbeta = sums[0], sums[1]
+            dg, dbeta = ln_param_grads(ln_w, ln_b, lnp, tiles, weight.shape[0], need[5] and need[6])
         cast = lambda t, dt: None if t is None else t.to(dt)
         dts = ctx.in_dtypes
         return (cast(da, dts[0]), cast(dmul, dts[1]), cast(db, dts[2]), cast(dv, dts[3]), dw, dg, dbeta, None, None, None,

@@ -9,13 +9,15 @@ gather-backs that build its input and the segment maximum behind it, is one laun
 run the same chain from separate operators.
 """
 import os
+import weakref
 
 import torch
 from torch import nn
 
 from ._lib import const_tensor
 from .linear import Linear
-from .point_mlp import point_layer, prepack
+from . import _lib as L
+from .point_mlp import PackPlan, layer_backward, layer_forward, ln_param_grads, pack_weight, point_layer, prepack
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import build_mlp, fuse_norm_act, get_activation_layer, unique_with_inverse
 from .voxel.scatter_points import gather_rows, segment_reduce
@@ -26,6 +28,115 @@ POINT_LAYER_KERNEL = True   # False: every Linear / LayerNorm / segment reductio
 # LayerNorm / segment kernels, each tuned for throughput, are faster (measured on MI355X, whole ococcnet step: 25.4 / 35.8 / 51.1 ms fused against
 # 33.5 / 41.9 / 53.6 ms at 4 / 16 / 32 tracklets = 8 k / 33 k / 65 k points, but 98 against 79 ms at 64 tracklets).  Above this many points the per-operator chain runs.
 POINT_LAYER_MAX_ROWS = int(os.environ.get('OCOCC_POINT_LAYER_MAX_ROWS', 80000))
+# One autograd node per SIRLayer (the launches are the same: at 4 tracklets the step is bound by the host, and a layer as
+# five Functions + the concatenations between them costs ~0.4 ms of interpreter / autograd time per direction).
+WHOLE_LAYER_NODE = os.environ.get('OCOCC_SIR_WHOLE_LAYER', '1') == '1'
+
+
+_PACK_PLANS = weakref.WeakKeyDictionary()   # SIRLayer -> PackPlan of its Linears (not on the module: it holds ctypes arrays)
+
+
+def _f32c(t):
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class _SirLayerFn(torch.autograd.Function):
+    """SIRLayer._forward_fused as ONE node: forward = its point_mlp launches in order, backward = their backward
+    launches in reverse (the gradient of a layer's input is the next call's dy; the gradient of the maxima a layer
+    gathered joins the one that arrives from outside).  ``spec`` = (rel blocks, vfe blocks, acts, eps, rel scale
+    constant, column scale constant, bscale, with cluster centre, shortcut); ``params`` = (weight, ln weight, ln bias)
+    per block, rel_mlp first."""
+
+    @staticmethod
+    def forward(ctx, spec, features, f_cluster, inv, G, *params):
+        nr, nv, acts, epss, rel_cs, col, bscale, with_cc, shortcut = spec
+        feats, fc = _f32c(features), _f32c(f_cluster)
+        ws = [params[3 * i] for i in range(nr + nv)]
+        gs = [_f32c(params[3 * i + 1]) for i in range(nr + nv)]
+        bs = [_f32c(params[3 * i + 2]) for i in range(nr + nv)]
+        wfs = [pack_weight(w.detach(), w) for w in ws]
+        ys, ms = [], []
+        x = fc
+        for j in range(nr):   # gate = rel_mlp(f_cluster / rel_dist_scaler)
+            x, _ = layer_forward(x, None, None, None, wfs[j], ws[j].shape[0], gs[j], bs[j], rel_cs if j == 0 else None, None,
+                                 1.0, epss[j], acts[j], False, 0)
+            ys.append(x)
+        gate = x if nr else None
+        y = None
+        for i in range(nv):
+            q = nr + i
+            if i == 0:
+                y, m = layer_forward(feats, gate, fc if with_cc else None, None, wfs[q], ws[q].shape[0], gs[q], bs[q], col, inv,
+                                     bscale, epss[q], acts[q], True, G)
+            else:
+                y, m = layer_forward(y, None, None, ms[-1], wfs[q], ws[q].shape[0], gs[q], bs[q], None, inv, 1.0, epss[q],
+                                     acts[q], True, G)
+            ys.append(y)
+            ms.append(m)
+        ctx.spec = spec
+        ctx.G = G
+        ctx.ln_params = [(params[3 * i + 1], params[3 * i + 2]) for i in range(nr + nv)]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(feats, fc, inv, *ws, *gs, *bs, *wfs, *ys, *ms)
+        out = y + feats[:, 3:] if shortcut else y
+        groups = torch.cat(ms, dim=1) if nv > 1 else ms[0]
+        return out, groups
+
+    @staticmethod
+    def backward(ctx, dy, dM):
+        nr, nv, acts, epss, rel_cs, col, bscale, with_cc, shortcut = ctx.spec
+        G, nl = ctx.G, nr + nv
+        t = ctx.saved_tensors
+        feats, fc, inv = t[0], t[1], t[2]
+        ws, gs, bs, wfs, ys = (t[3 + k * nl: 3 + (k + 1) * nl] for k in range(5))
+        ms = t[3 + 5 * nl:]
+        need = ctx.needs_input_grad
+        rows = feats.shape[0]
+        if dy is None:
+            dy = torch.zeros((rows, ys[-1].shape[1]), dtype=torch.float32, device=feats.device)
+        dy_out = dy = _f32c(dy)
+        grads = [None] * (3 * nl)
+
+        def param_grads(q, dw, lnp, tiles):
+            grads[3 * q] = dw
+            lw, lb = ctx.ln_params[q]
+            dg, db = ln_param_grads(lw, lb, lnp, tiles, ws[q].shape[0], need[5 + 3 * q + 1] and need[5 + 3 * q + 2])
+            grads[3 * q + 1], grads[3 * q + 2] = dg, db
+
+        off = [0]
+        for m in ms:
+            off.append(off[-1] + m.shape[1])
+        carry, dfeat, dgate = None, None, None
+        for i in reversed(range(nv)):
+            q = nr + i
+            dm = None if dM is None else dM[:, off[i]:off[i + 1]]
+            if carry is not None:
+                dm = carry if dm is None else torch.add(dm, carry)
+            if dm is not None:
+                dm = _f32c(dm)
+            if i == 0:
+                gate = ys[nr - 1] if nr else None
+                da, dmul, _, _, dw, lnp, tiles = layer_backward(
+                    feats, gate, fc if with_cc else None, None, ws[q], wfs[q], gs[q], bs[q], col, inv, ys[q], ms[i], bscale,
+                    epss[q], acts[q], G, dy, dm, need[1], True, False, False, need[5 + 3 * q])
+                dfeat, dgate = da, dmul
+            else:
+                da, _, _, dv, dw, lnp, tiles = layer_backward(
+                    ys[q - 1], None, None, ms[i - 1], ws[q], wfs[q], gs[q], bs[q], None, inv, ys[q], ms[i], 1.0, epss[q],
+                    acts[q], G, dy, dm, True, False, False, True, need[5 + 3 * q])
+                dy, carry = da, dv
+            param_grads(q, dw, lnp, tiles)
+        if shortcut and dfeat is not None:
+            dfeat[:, 3:] += dy_out
+        for j in reversed(range(nr)):
+            x_in = ys[j - 1] if j > 0 else fc
+            da, _, _, _, dw, lnp, tiles = layer_backward(
+                x_in, None, None, None, ws[j], wfs[j], gs[j], bs[j], rel_cs if j == 0 else None, None, ys[j], None, 1.0,
+                epss[j], acts[j], 0, dgate, None, j > 0, False, False, False, need[5 + 3 * j])
+            dgate = da
+            param_grads(j, dw, lnp, tiles)
+        return (None, dfeat, None, None, None, *grads)
 
 
 class DynamicVFELayerV2(nn.Module):
@@ -134,34 +245,67 @@ class SIRLayer(nn.Module):
     def _act_of(norm, act):
         return 'gelu' if norm.fused_act == 'gelu' else ('relu' if isinstance(act, nn.ReLU) else 'none')
 
-    def _forward_fused(self, features, f_cluster, inv, num_groups):
+    def _blocks(self):
+        """(Linear, norm, act name) of every block, rel_mlp first -- and whether the point_mlp kernels cover them; per
+        training mode (dropout only counts while training), kept until the kernel switch is flipped."""
+        key = (self.training, POINT_LAYER_KERNEL)
+        cache = self.__dict__.setdefault('_block_cache', {})
+        if key not in cache:
+            ok = self._fusable()
+            rel = [(b[0], b[1], self._act_of(b[1], b[2])) for b in self.rel_mlp] if (ok and self._with_rel_mlp) else []
+            vfe = [(v.linear, v.norm, self._act_of(v.norm, v.act)) for v in self.vfe_layers] if ok else []
+            cache[key] = (ok, rel, vfe)
+        return cache[key]
+
+    def _forward_fused(self, features, f_cluster, inv, num_groups, shortcut=False):
         dev = features.device
+        _, rel, vfe = self._blocks()
         raw = self.in_channels - 3 * (self._with_cluster_center + self._with_voxel_center)   # columns of `features`
         scale = 1.0 / float(self.rel_dist_scaler)
         # all Linears of this layer (and their transposes, when a backward pass will follow) packed in one launch
-        lins = [v.linear.weight for v in self.vfe_layers] + ([blk[0].weight for blk in self.rel_mlp] if self._with_rel_mlp else [])
-        prepack(lins, backward=torch.is_grad_enabled())
-        gate = None
-        if self._with_rel_mlp:   # gate = rel_mlp(f_cluster / rel_dist_scaler), one launch per Linear -> LN -> act
-            gate = f_cluster
-            for i, blk in enumerate(self.rel_mlp):
-                lin, norm = blk[0], blk[1]
-                cs = const_tensor([scale] * lin.in_features, dev) if i == 0 else None
-                gate = point_layer(gate, lin.weight, norm.weight, norm.bias, norm.eps, self._act_of(norm, blk[2]), colscale=cs)
+        lins = [lin.weight for lin, _, _ in vfe] + [lin.weight for lin, _, _ in rel]
+        if all(w.dtype == torch.float32 and w.is_cuda for w in lins):
+            plan = _PACK_PLANS.get(self)
+            if plan is None or not plan.valid_for(lins):
+                plan = _PACK_PLANS[self] = PackPlan(lins)
+            plan.refresh(backward=torch.is_grad_enabled())
+        else:
+            prepack(lins, backward=torch.is_grad_enabled())
         col = const_tensor([1.0 / v for v in self.xyz_normalizer] + [1.0] * (raw - 3), dev)
+        rel_cs = const_tensor([scale] * rel[0][0].in_features, dev) if rel else None
+        if inv.dtype != torch.int32:   # (the blocks of a SIR stack share one inverse: converted once, kept on the tensor)
+            i32 = getattr(inv, '_ococc_i32', None)
+            if i32 is None:
+                i32 = inv.to(torch.int32)
+                inv._ococc_i32 = i32
+            inv = i32
+        blocks = rel + vfe
+        if (WHOLE_LAYER_NODE and features.dtype == torch.float32 and f_cluster.dtype == torch.float32
+                and not f_cluster.requires_grad and all(lin.weight.dtype == torch.float32 for lin, _, _ in blocks)):
+            spec = (len(rel), len(vfe), tuple(a for _, _, a in blocks), tuple(float(n.eps) for _, n, _ in blocks), rel_cs, col,
+                    scale / 10.0, bool(self._with_cluster_center), bool(shortcut))
+            params = []
+            for lin, norm, _ in blocks:
+                params += [lin.weight, norm.weight, norm.bias]
+            y, groups = _SirLayerFn.apply(spec, features, f_cluster, inv, int(num_groups), *params)
+            return y, groups, shortcut
+        gate = None
+        if rel:   # gate = rel_mlp(f_cluster / rel_dist_scaler), one launch per Linear -> LN -> act
+            gate = f_cluster
+            for i, (lin, norm, act) in enumerate(rel):
+                gate = point_layer(gate, lin.weight, norm.weight, norm.bias, norm.eps, act, colscale=rel_cs if i == 0 else None)
         extra = f_cluster if self._with_cluster_center else None
         maxima = []
         y = None
-        for i, vfe in enumerate(self.vfe_layers):
-            act = self._act_of(vfe.norm, vfe.act)
+        for i, (lin, norm, act) in enumerate(vfe):
             if i == 0:
-                y, m = point_layer(features, vfe.linear.weight, vfe.norm.weight, vfe.norm.bias, vfe.norm.eps, act, mul=gate,
+                y, m = point_layer(features, lin.weight, norm.weight, norm.bias, norm.eps, act, mul=gate,
                                    colscale=col, b=extra, bscale=scale / 10.0, inv=inv, num_segments=num_groups, seg_max=True)
             else:
-                y, m = point_layer(y, vfe.linear.weight, vfe.norm.weight, vfe.norm.bias, vfe.norm.eps, act, v=maxima[-1],
+                y, m = point_layer(y, lin.weight, norm.weight, norm.bias, norm.eps, act, v=maxima[-1],
                                    inv=inv, num_segments=num_groups, seg_max=True)
             maxima.append(m)
-        return y, torch.cat(maxima, dim=1)
+        return y, torch.cat(maxima, dim=1), False
 
     def _forward_ops(self, features, f_cluster, inv, num_groups):
         xyz = features[:, :3]
@@ -189,11 +333,16 @@ class SIRLayer(nn.Module):
         inv, group_coors = self._groups(coors, unq_inv_once, new_coors_once)
         num_groups = group_coors.size(0)
         f_cluster = self._cluster_offsets(features[:, :3], f_cluster, inv, num_groups)
-        fused = self._fusable() and features.shape[0] <= POINT_LAYER_MAX_ROWS
-        run = self._forward_fused if fused else self._forward_ops
-        point_feats, group_feats = run(features, f_cluster, inv, num_groups)
-        if return_both or self.return_point_feats:
-            if self.with_shortcut and point_feats.shape[1] == features.shape[1] - 3:
+        want_points = return_both or self.return_point_feats
+        if self._blocks()[0] and features.shape[0] <= POINT_LAYER_MAX_ROWS:
+            n_out = self.vfe_layers[-1].linear.out_features
+            shortcut = bool(want_points and self.with_shortcut and n_out == features.shape[1] - 3)
+            point_feats, group_feats, shortcut_done = self._forward_fused(features, f_cluster, inv, num_groups, shortcut)
+        else:
+            point_feats, group_feats = self._forward_ops(features, f_cluster, inv, num_groups)
+            shortcut_done = False
+        if want_points:
+            if not shortcut_done and self.with_shortcut and point_feats.shape[1] == features.shape[1] - 3:
                 point_feats = point_feats + features[:, 3:]
             return (point_feats, group_feats, group_coors) if return_both else (point_feats, group_feats)
         return (group_feats, group_coors, inv) if return_inv else (group_feats, group_coors)

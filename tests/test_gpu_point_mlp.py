@@ -152,3 +152,53 @@ def test_sir_layer_fused_equals_operator_path(dev, cfg):
     assert rel(a[0], b[0]) < 1e-4 and rel(a[1], b[1]) < 1e-4 and rel(a[2], b[2]) < 1e-3
     for p, q in zip(a[3], b[3]):
         assert rel(p, q) < 1e-3
+
+
+@pytest.mark.parametrize('use', ['both', 'groups', 'points'])
+@pytest.mark.parametrize('in_channels', [131, 24])
+def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
+    """The whole-layer node (one Function per SIRLayer, the shortcut inside) against the chain of per-block Functions: the
+    same launches in the same order, so outputs and gradients agree to the bit; and against the per-operator path."""
+    from objectcentricocccompletion_amd import sir
+    g = torch.Generator().manual_seed(11)
+    layer = sir.SIRLayer(in_channels=in_channels, feat_channels=[128, 128], with_cluster_center=False,
+                         rel_mlp_hidden_dims=[16, 32], rel_mlp_in_channel=13, norm_cfg=dict(type='LN', eps=1e-3),
+                         mode='max', return_point_feats=True, rel_dist_scaler=10.0, xyz_normalizer=[20, 20, 4], act='gelu',
+                         dropout=0).to(dev)
+    G = 37
+    sizes = torch.randint(1, 150, (G,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(G), sizes).to(dev)
+    M = inv.numel()
+    feats = torch.randn(M, in_channels, generator=g).to(dev)
+    fc = torch.randn(M, 13, generator=g).to(dev)
+    dp, dg = torch.randn(M, 128, generator=g).to(dev), torch.randn(G, 256, generator=g).to(dev)
+
+    def run(whole, kernel=True):
+        sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL = whole, kernel
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = feats.clone().requires_grad_(True)
+            pf, gf = layer(x, inv, fc)
+            loss = 0
+            if use in ('both', 'points'):
+                loss = loss + (pf * dp).sum()
+            if use in ('both', 'groups'):
+                loss = loss + (gf * dg).sum()
+            loss.backward()
+            return pf.detach(), gf.detach(), x.grad.clone(), [None if p.grad is None else p.grad.clone() for p in layer.parameters()]
+        finally:
+            sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL = True, True
+
+    a, b, c = run(True), run(False), run(True, kernel=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    rel = lambda p, q: float((p - q).abs().max() / q.abs().max().clamp(min=1e-30))
+    # (the chain adds the shortcut's and the gathered maxima's gradients through autograd's accumulation: another order)
+    assert rel(a[2], b[2]) < 1e-6
+    for p, q in zip(a[3], b[3]):
+        assert (p is None) == (q is None)
+        if p is not None:
+            assert rel(p, q) < 1e-5
+    assert rel(a[0], c[0]) < 1e-4 and rel(a[1], c[1]) < 1e-4 and rel(a[2], c[2]) < 1e-3
+    for p, q in zip(a[3], c[3]):
+        if p is not None and q is not None:
+            assert rel(p, q) < 1e-3

@@ -58,12 +58,17 @@ for m in re.finditer(r'\n(_ZN12_GLOBAL__N_125gather_gemm_stream_kernel(\w+)):', 
     queue, bad, scratch = [], [], 0
 
     def check_out_of_line(start, inflight):
+        # (a block without the 'in Loop' note is the loop's EXIT: there the compiler may reload what it spilled
+        # around the loop -- into registers that are not the target of a load still in flight, checked below; the
+        # explicit vmcnt(0) follows before anything is used)
+        leaving = 'in Loop' not in body[start]
         for l in body[start + 1:end]:
             t = l.strip()
             if not t or t[0] == ';': continue
             if t[0] == '.': continue
             op = t.split()[0]
-            if op.startswith(('buffer_', 'global_', 'scratch_')) or (op == 's_waitcnt' and 'vmcnt' in t):
+            reload = leaving and op.startswith('scratch_load')
+            if (op.startswith(('buffer_', 'global_', 'scratch_')) and not reload) or (op == 's_waitcnt' and 'vmcnt' in t):
                 bad.append('memory operation in an out-of-line block: ' + t[:60])
             if regs_of(t) & inflight and not op.startswith('v_mfma'): bad.append(t[:90])
             if op == 's_branch': return
