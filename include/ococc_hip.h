@@ -637,6 +637,13 @@ int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, const float
                             ococc_stream_t stream);
 int ococc_point_mlp_segment_argmax(const float* y, const float* seg_max, const int32_t* inv, int64_t rows, int32_t n,
                                    int64_t num_segments, int32_t* seg_arg, ococc_stream_t stream);
+/* weight gradient of a layer from the backward call's dz [rows, n] and x_cat [rows, k]: partial [slices][n][k], one
+ * product per row slice (slices = ococc_point_mlp_wgrad_slices(rows), <= 64); dW = their sum -- e.g. through
+ * ococc_layernorm_param_reduce_multi with the slab read as [slices][2][n k / 2].  Replaces the torch.mm of
+ * nn.Linear's backward (voxel_encoders/utils.py:147-189 DynamicVFELayerV2.linear). */
+int32_t ococc_point_mlp_wgrad_slices(int64_t rows);
+int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, int64_t rows, int32_t n, int32_t k, float* partial,
+                              ococc_stream_t stream);
 int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float* mul, int32_t ldm, const float* colscale,
                             const float* b, int32_t kb, int32_t ldb, float bscale, const float* v, int32_t kv,
                             const int32_t* inv, int64_t rows, const float* w_frag, const float* wt_frag, int32_t n,

@@ -69,10 +69,28 @@ def register_joint(kinds, fn):
     _joint[tuple(kinds)] = fn
 
 
-def _accumulates_into_grad(p):
-    """True when the running backward pass will execute p's AccumulateGrad node (p.grad gets the result)."""
+_acc_nodes = {}   # id(param) -> (weak reference to it, its AccumulateGrad node)
+
+
+def _accumulate_node(p):
+    """p's AccumulateGrad node.  Finding it takes a throw-away view (~10 us; a SIR layer asks for 15 parameters per
+    backward), and the node stays the same object while somebody holds it: kept per parameter -- in a table of bounded
+    size, since the node in turn keeps its parameter alive."""
+    hit = _acc_nodes.get(id(p))
+    if hit is not None and hit[0]() is p:
+        return hit[1]
     with torch.enable_grad():
         node = p.view_as(p).grad_fn.next_functions[0][0]
+    if len(_acc_nodes) >= 8192:
+        _acc_nodes.clear()
+    import weakref
+    _acc_nodes[id(p)] = (weakref.ref(p), node)
+    return node
+
+
+def _accumulates_into_grad(p):
+    """True when the running backward pass will execute p's AccumulateGrad node (p.grad gets the result)."""
+    node = _accumulate_node(p)
     try:
         return bool(torch._C._will_engine_execute_node(node))
     except RuntimeError:  # autograd.grad(..., inputs=[p]) captures the gradient instead / no pass is running

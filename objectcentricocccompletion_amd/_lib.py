@@ -128,6 +128,8 @@ SIGNATURES = {
     'ococc_point_mlp_fwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
                                         c_i64, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_point_mlp_segment_argmax': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),
+    'ococc_point_mlp_wgrad_slices': (c_i32, [c_i64]),
+    'ococc_point_mlp_wgrad_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'ococc_point_mlp_bwd_f32': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_i32, c_vp,
                                         c_i64, c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -589,6 +589,73 @@ segment_argmax_kernel(const float* __restrict__ y, const float* __restrict__ vma
   }
 }
 
+// dW partials of a layer: partial[s] = dz[rows of slice s]^T  x_cat[rows of slice s], one [n, k] matrix per row slice; the
+// column sums over the slices ride on the pass's end-of-backward reduction (ococc_layernorm_param_reduce_multi reads
+// the slab as [slices][2][n k / 2]).  Replaces a batched library GEMM + sum + remainder GEMM + add: the arithmetic is
+// nothing (2 rows n k = 0.5 GFLOP at 8 k rows), the four library calls were ~70 us of host time per layer in a
+// host-bound step.  Workgroup = one 64 x 64 tile of the product over one row slice, 32 rows per pass through LDS;
+// wave w owns the 32 x 32 quadrant (w >> 1, w & 1) as 2 x 2 v_mfma_f32_16x16x4_f32 tiles.
+constexpr int kWgLd = 80;   // LDS row stride in floats: the 4 k-groups of an operand read start 16 banks apart
+__global__ void __launch_bounds__(256)
+point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ xc, int64_t rows, int n, int k,
+                       int64_t rows_per_slice, float* __restrict__ partial) {
+  __shared__ float zs[32 * kWgLd];
+  __shared__ float xs[32 * kWgLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+  const int64_t r_lo = (int64_t)blockIdx.x * rows_per_slice;
+  const int64_t r_hi = r_lo + rows_per_slice < rows ? r_lo + rows_per_slice : rows;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int col = tid & 63, rsub = tid >> 6;          // loader: thread -> (column, row mod 4)
+  const bool zc_ok = n0 + col < n, xc_ok = k0 + col < k;
+  const int l16 = lane & 15, kg = lane >> 4;
+  const int nq = (wave >> 1) * 32, kq = (wave & 1) * 32;
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += 32) {
+    float zv[8], xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = r0 + rsub + 4 * j;
+      const bool ok = r < r_hi;
+      zv[j] = (ok && zc_ok) ? dz[r * n + n0 + col] : 0.f;
+      xv[j] = (ok && xc_ok) ? xc[r * k + k0 + col] : 0.f;
+    }
+    __syncthreads();   // the previous pass has read its tile
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      zs[(rsub + 4 * j) * kWgLd + col] = zv[j];
+      xs[(rsub + 4 * j) * kWgLd + col] = xv[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = zs[(kk + kg) * kWgLd + nq + 16 * i + l16];   // A[m = out channel][contraction row]
+        b[i] = xs[(kk + kg) * kWgLd + kq + 16 * i + l16];   // B[contraction row][input channel]
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = partial + (int64_t)blockIdx.x * n * k;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = n0 + nq + 16 * i + 4 * kg + q, in = k0 + kq + 16 * j + l16;
+        if (ch < n && in < k) out[(int64_t)ch * k + in] = acc[i][j][q];
+      }
+}
+
 __global__ void __launch_bounds__(256) fill_kernel(float* p, int64_t count, float v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
@@ -665,8 +732,12 @@ extern "C" int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, 
   const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
 #define OCOCC_PM_FWD(NBW)                                                                                             \
   do {                                                                                                                \
-    OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_fwd_kernel<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  lds));                                                                              \
+    static int lds_set = 0;  /* (the attribute sticks: raised once per instantiation, not per launch) */              \
+    if (lds > lds_set) {                                                                                              \
+      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_fwd_kernel<NBW>,                                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
+      lds_set = lds;                                                                                                  \
+    }                                                                                                                 \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_fwd_kernel<NBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,     \
                        (int)n, ln_weight, ln_bias, eps, (int)act, y, seg_max);                                        \
   } while (0)
@@ -700,8 +771,12 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
   const int kbw = (((k + 15) >> 4) + 3) / 4;
 #define OCOCC_PM_BWD(NBW, KBW)                                                                                            \
   do {                                                                                                                    \
-    OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  lds));                                                                                  \
+    static int lds_set = 0;                                                                                               \
+    if (lds > lds_set) {                                                                                                  \
+      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW>,                                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                    \
+      lds_set = lds;                                                                                                      \
+    }                                                                                                                     \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_bwd_kernel<NBW, KBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,    \
                        wt_frag, (int)n, ln_weight, ln_bias, eps, (int)act, dy, d_seg_max, seg_arg, dz, x_cat, da, dmul,   \
                        db, dv, ln_partial);                                                                               \
@@ -720,6 +795,25 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
   }
 #undef OCOCC_PM_BWD_N
 #undef OCOCC_PM_BWD
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int32_t ococc_point_mlp_wgrad_slices(int64_t rows) {
+  if (rows <= 0) return 0;
+  int64_t s = rows / 256;
+  return (int32_t)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+extern "C" int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, int64_t rows, int32_t n, int32_t k,
+                                         float* partial, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(rows >= 0 && n >= 1 && k >= 1, "bad sizes");
+  if (rows == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(dz && x_cat && partial, "null pointer");
+  const int slices = ococc_point_mlp_wgrad_slices(rows);
+  const int64_t per = ococc_align_up(ococc_cdiv(rows, slices), 32);   // (the last slice may come out short or empty: zeros)
+  hipLaunchKernelGGL(point_mlp_wgrad_kernel, dim3(slices, (n + 63) / 64, (k + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream_, dz, x_cat, rows, (int)n, (int)k, per, partial);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -5,6 +5,7 @@
 one launch where SIRLayer.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832) runs torch.cat / products,
 nn.Linear, LayerNorm, GELU, scatter_v2(max) and the gather-back one after the other.  f32 like the reference
 (force_fp32); the backward launch recomputes the layer from its inputs."""
+import os
 import weakref
 
 import torch
@@ -153,9 +154,10 @@ def layer_forward(a_, mul_, b_, v_, wf, n, g, be, colscale, inv, bscale, eps, ac
 
 
 def layer_backward(a_, mul_, b_, v_, weight, wf, g, be, colscale, inv, y, vmax, bscale, eps, act, G, dy, dvmax,
-                   need_a, need_mul, need_b, need_v, need_w):
-    """The backward launch (+ the weight-gradient GEMM): (da, dmul, db, dv, dw, ln partials [tiles, 2, n], tiles).
-    ``dy`` / ``dvmax``: f32 contiguous or None (dvmax)."""
+                   need_a, need_mul, need_b, need_v, need_w, weight_param=None):
+    """The backward launch (+ the weight gradient): (da, dmul, db, dv, dw, ln partials [tiles, 2, n], tiles).
+    ``dy`` / ``dvmax``: f32 contiguous or None (dvmax); ``weight_param``: the parameter itself when the caller's saved
+    tensor is not it (its gradient may then be queued for the end of the pass: dw is None)."""
     rows, ka = a_.shape
     kb = 0 if b_ is None else b_.shape[1]
     kv = 0 if v_ is None else v_.shape[1]
@@ -185,8 +187,30 @@ def layer_backward(a_, mul_, b_, v_, weight, wf, g, be, colscale, inv, y, vmax, 
         L.ptr(db), L.ptr(dv), L.ptr(lnp), L.stream()), 'point_mlp_bwd')
     dw = None
     if need_w:
-        dw = (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
+        dw = weight_grad(weight_param if weight_param is not None else weight, dz, xcat)
     return da, dmul, db, dv, dw, lnp, tiles
+
+
+WGRAD_KERNEL = os.environ.get('OCOCC_POINT_WGRAD', '1') == '1'
+
+
+def weight_grad(weight, dz, xcat):
+    """dW = dz^T x_cat [n, k]: per-row-slice products from ococc_point_mlp_wgrad_f32, summed at the end of the backward
+    pass together with the LayerNorm parameter sums (None is returned then: the sum reaches weight.grad there) or right
+    away; OCOCC_POINT_WGRAD=0: the library GEMMs."""
+    rows, n = dz.shape
+    k = xcat.shape[1]
+    if not WGRAD_KERNEL or rows == 0 or (n * k) % 2:
+        return (sliced_wgrad(dz, xcat) if rows >= 4096 else dz.t() @ xcat).to(weight.dtype)
+    slices = int(L.lib.ococc_point_mlp_wgrad_slices(rows))
+    partial = torch.empty((slices, n, k), dtype=torch.float32, device=dz.device)
+    L.check(L.lib.ococc_point_mlp_wgrad_f32(dz.data_ptr(), xcat.data_ptr(), rows, n, k, partial.data_ptr(), L.stream()),
+            'point_mlp_wgrad')
+    if weight.dtype == torch.float32 and weight.shape == (n, k) and _deferred.deferrable(weight):
+        out = torch.empty((2, n * k // 2), dtype=torch.float32, device=dz.device)
+        if _deferred.defer('ln', (partial, slices, n * k // 2, out), [(weight, out.view(n, k))]):
+            return None
+    return (partial.sum(0) if slices > 1 else partial[0]).to(weight.dtype)
 
 
 def ln_param_grads(ln_w, ln_b, lnp, tiles, n, need):
@@ -217,6 +241,7 @@ class _PointLayer(torch.autograd.Function):
                                 int(num_segments))
         ctx.save_for_backward(a_, mul_, b_, v_, weight, g, be, colscale, inv, y, vmax, wf)
         ctx.ln_params = (ln_w, ln_b)   # the parameters themselves: their gradient sums may join the end-of-backward launch
+        ctx.weight_param = weight
         ctx.misc = (float(bscale), float(eps), act, int(num_segments))
         ctx.in_dtypes = tuple(None if t is None else t.dtype for t in (a, mul, b, v))
         return y, vmax
@@ -228,7 +253,7 @@ class _PointLayer(torch.autograd.Function):
         need = ctx.needs_input_grad
         da, dmul, db, dv, dw, lnp, tiles = layer_backward(
             a_, mul_, b_, v_, weight, wf, g, be, colscale, inv, y, vmax, bscale, eps, act, G, _f32(dy), _f32(dvmax),
-            need[0], need[1], need[2], need[3], need[4])
+            need[0], need[1], need[2], need[3], need[4], ctx.weight_param)
         dg = dbeta = None
         if g is not None:
             ln_w, ln_b = ctx.ln_params

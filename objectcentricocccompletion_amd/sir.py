@@ -77,6 +77,7 @@ class _SirLayerFn(torch.autograd.Function):
         ctx.spec = spec
         ctx.G = G
         ctx.ln_params = [(params[3 * i + 1], params[3 * i + 2]) for i in range(nr + nv)]
+        ctx.w_params = [params[3 * i] for i in range(nr + nv)]
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(feats, fc, inv, *ws, *gs, *bs, *wfs, *ys, *ms)
         out = y + feats[:, 3:] if shortcut else y
@@ -119,12 +120,12 @@ class _SirLayerFn(torch.autograd.Function):
                 gate = ys[nr - 1] if nr else None
                 da, dmul, _, _, dw, lnp, tiles = layer_backward(
                     feats, gate, fc if with_cc else None, None, ws[q], wfs[q], gs[q], bs[q], col, inv, ys[q], ms[i], bscale,
-                    epss[q], acts[q], G, dy, dm, need[1], True, False, False, need[5 + 3 * q])
+                    epss[q], acts[q], G, dy, dm, need[1], True, False, False, need[5 + 3 * q], ctx.w_params[q])
                 dfeat, dgate = da, dmul
             else:
                 da, _, _, dv, dw, lnp, tiles = layer_backward(
                     ys[q - 1], None, None, ms[i - 1], ws[q], wfs[q], gs[q], bs[q], None, inv, ys[q], ms[i], 1.0, epss[q],
-                    acts[q], G, dy, dm, True, False, False, True, need[5 + 3 * q])
+                    acts[q], G, dy, dm, True, False, False, True, need[5 + 3 * q], ctx.w_params[q])
                 dy, carry = da, dv
             param_grads(q, dw, lnp, tiles)
         if shortcut and dfeat is not None:
@@ -133,7 +134,7 @@ class _SirLayerFn(torch.autograd.Function):
             x_in = ys[j - 1] if j > 0 else fc
             da, _, _, _, dw, lnp, tiles = layer_backward(
                 x_in, None, None, None, ws[j], wfs[j], gs[j], bs[j], rel_cs if j == 0 else None, None, ys[j], None, 1.0,
-                epss[j], acts[j], 0, dgate, None, j > 0, False, False, False, need[5 + 3 * j])
+                epss[j], acts[j], 0, dgate, None, j > 0, False, False, False, need[5 + 3 * j], ctx.w_params[j])
             dgate = da
             param_grads(j, dw, lnp, tiles)
         return (None, dfeat, None, None, None, *grads)
@@ -375,6 +376,11 @@ class SIR(nn.Module):
         """points [M, 3], features [M, C] -> (point features of the last block, [group maxima of all blocks], group coors);
         the groups are found once when ``unique_once`` (backbones/sir.py:67-88)."""
         group_coors, inv = unique_with_inverse(coors, dims) if self.unique_once else (None, None)
+        if f_cluster is None and inv is not None and not points.requires_grad:
+            # every block would derive the same offsets from the same xyz columns and the same groups (voxel_encoder.py:
+            # 777-781) -- and, taken from the concatenated input, they would formally require a gradient nobody uses
+            centre = segment_reduce(points.float(), inv, group_coors.size(0), 'mean')
+            f_cluster = points - gather_rows(centre, inv)
         feats, per_block = features, []
         last = len(self.block_list) - 1
         for i, block in enumerate(self.block_list):

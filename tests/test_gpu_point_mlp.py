@@ -202,3 +202,20 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
     for p, q in zip(a[3], c[3]):
         if p is not None and q is not None:
             assert rel(p, q) < 1e-3
+
+
+@pytest.mark.parametrize('rows,n,k', [(1, 16, 13), (31, 32, 3), (300, 128, 131), (5000, 144, 256), (70001, 64, 24),
+                                       (8192, 128, 259 - 3)])
+def test_weight_gradient_kernel(dev, rows, n, k):
+    """ococc_point_mlp_wgrad_f32: the per-slice products sum to dz^T x_cat (f32 MFMA against an f64 product)."""
+    from objectcentricocccompletion_amd import _lib as L
+    g = torch.Generator().manual_seed(rows + n + k)
+    dz, xc = torch.randn(rows, n, generator=g).to(dev), torch.randn(rows, k, generator=g).to(dev)
+    slices = int(L.lib.ococc_point_mlp_wgrad_slices(rows))
+    assert 1 <= slices <= 64
+    partial = torch.full((slices, n, k), float('nan'), device=dev)
+    L.check(L.lib.ococc_point_mlp_wgrad_f32(dz.data_ptr(), xc.data_ptr(), rows, n, k, partial.data_ptr(), L.stream()), 'wgrad')
+    got = partial.double().sum(0)
+    exp = dz.double().t() @ xc.double()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - exp).abs().max()) <= 2e-6 * float(exp.abs().max()) * max(1.0, rows ** 0.5 / 8)

@@ -47,10 +47,40 @@ def main():
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per = []
     for _ in range(steps):
+        t = time.perf_counter()
         step()
+        per.append(time.perf_counter() - t)
     torch.cuda.synchronize()
-    print(f'unprofiled: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step')
+    per.sort()
+    print(f'unprofiled: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms/step   (host issue time per step: median '
+          f'{per[len(per) // 2] * 1e3:.2f}, min {per[0] * 1e3:.2f} ms)')
+    # host time the phases take to ISSUE (no synchronisation inside) and device time between their event marks
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    host = [0.0, 0.0, 0.0]
+    torch.cuda.synchronize()
+    for i in range(steps):
+        t = time.perf_counter()
+        ev[i][0].record()
+        opt.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **batch)
+        total = losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()
+        ev[i][1].record()
+        t1 = time.perf_counter()
+        total.backward()
+        ev[i][2].record()
+        t2 = time.perf_counter()
+        opt.step()
+        ev[i][3].record()
+        t3 = time.perf_counter()
+        host[0] += t1 - t
+        host[1] += t2 - t1
+        host[2] += t3 - t2
+    torch.cuda.synchronize()
+    dev_ms = [sum(e[j].elapsed_time(e[j + 1]) for e in ev) / steps for j in range(3)]
+    print('host ms  fwd %.2f  bwd %.2f  opt %.2f   |  device span ms  fwd %.2f  bwd %.2f  opt %.2f' % (
+        host[0] / steps * 1e3, host[1] / steps * 1e3, host[2] / steps * 1e3, *dev_ms))
     # forward and backward apart (the backward runs in autograd's thread: cProfile sees only its Python callbacks
     # through the main thread's run_backward call)
     if os.environ.get('OCOCC_HOST_PROFILE') == 'torch':   # the autograd thread too: per-operator / per-node CPU time
