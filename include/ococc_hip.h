@@ -652,6 +652,44 @@ int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float
                             float* dmul, float* db, float* dv, float* ln_partial, ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A whole SIRLayer per call: SIRLayer.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832) with LayerNorm
+ * blocks and max pooling, as the sequence of ococc_point_mlp_* launches above plus the joins between them.
+ * Blocks are numbered rel_mlp first, then vfe_layers; block b is Linear(k_b -> n[b], no bias) -> LayerNorm -> act[b]
+ * (0 none, 1 GELU, 2 ReLU) with k_b = cluster_cols | n[b-1] (rel), feat_cols (+ cluster_cols) (first vfe), 2 n[b-1] (later
+ * vfe).  features [rows, feat_cols] (xyz first), f_cluster [rows, cluster_cols], inv int32 non-decreasing.
+ *   fwd: y_out [rows, n[last]] (+ features[:, 3:] when shortcut), groups_out [groups, sum of the vfe widths]; slab: the
+ *        intermediates the backward call reads (ococc_sir_layer_fwd_floats floats).
+ *   bwd: dy [rows, n[last]] / d_groups [groups, sum] (either may be null = zero) -> dfeat [rows, feat_cols] (may be null),
+ *        and per block the LayerNorm partial rows [tiles][2][n] and weight-gradient slices [slices][n][k] inside slab at
+ *        the offsets ococc_sir_layer_bwd_layout reports (finish with ococc_layernorm_param_reduce_multi).  y_out: the
+ *        forward's output when there is no shortcut (it is the last block's y), else unused. */
+typedef struct {
+  int32_t n_rel, n_vfe;
+  int32_t feat_cols, cluster_cols;
+  int32_t with_cluster_center, shortcut;
+  float bscale;                      /* factor of the f_cluster columns appended to the first vfe block's input */
+  int32_t reserved;
+  const float* rel_colscale;         /* [cluster_cols] scale of the rel_mlp input, or null */
+  const float* colscale;             /* [feat_cols] scale of the feature columns, or null */
+  int32_t n[8];
+  int32_t act[8];
+  float eps[8];
+  const float* w_frag[8];            /* ococc_point_mlp_pack_f32 of the weight ... */
+  const float* wt_frag[8];           /* ... and of its transposed view (backward only) */
+  const float* ln_weight[8];
+  const float* ln_bias[8];
+} ococc_sir_layer;
+int64_t ococc_sir_layer_fwd_floats(const ococc_sir_layer* layer, int64_t rows, int64_t groups);
+int ococc_sir_layer_fwd_f32(const ococc_sir_layer* layer, const float* features, const float* f_cluster, const int32_t* inv,
+                            int64_t rows, int64_t groups, float* slab, float* y_out, float* groups_out,
+                            ococc_stream_t stream);
+int ococc_sir_layer_bwd_layout(const ococc_sir_layer* layer, int64_t rows, int64_t groups, int64_t* ln_partial_off,
+                               int64_t* w_partial_off, int64_t* tiles, int32_t* slices, int64_t* total_floats);
+int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features, const float* f_cluster, const int32_t* inv,
+                            int64_t rows, int64_t groups, const float* fwd_slab, const float* y_out, const float* dy,
+                            const float* d_groups, float* slab, float* dfeat, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A11 / A10, fused  the occupancy decoder's per-query MLP, one launch per layer (or one for the whole MLP):
  *   y = dropout(act(LayerNorm(x W^T + bias + add_rows[add_index]))),  optionally  head = y . head_weight + head_bias
  * replaces OccDecoder.forward's conv_occ (mmdet3d/models/occ/occ_base.py:99-153): build_mlp's

@@ -137,6 +137,24 @@ def defer(kind, job, grads):
     return True
 
 
+def defer_many(kind, jobs, grads):
+    """``defer`` for several jobs of one kind at once (a whole SIR layer's LayerNorm and weight sums); ``grads`` buffers
+    must be plain tensors outside any graph (they are stored as they are)."""
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush)
+    except RuntimeError:
+        return False
+    global _pass_id
+    task = torch._C._current_graph_task_id()
+    if task != _pass_id:
+        if not _held and (_jobs or _grads):
+            discard()
+        _pass_id = task
+    _jobs.setdefault(kind, []).extend(jobs)
+    _grads.extend(grads)
+    return True
+
+
 def pending():
     return sum(len(v) for v in _jobs.values())
 

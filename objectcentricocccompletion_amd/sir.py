@@ -8,6 +8,7 @@ gather-backs that build its input and the segment maximum behind it, is one laun
 (csrc/point_mlp.hip, f32 MFMA); options the kernel does not cover (batch norm, mean pooling, distance decoration)
 run the same chain from separate operators.
 """
+import ctypes
 import os
 import weakref
 
@@ -16,6 +17,7 @@ from torch import nn
 
 from ._lib import const_tensor
 from .linear import Linear
+from . import _deferred
 from . import _lib as L
 from .point_mlp import PackPlan, layer_backward, layer_forward, ln_param_grads, pack_weight, point_layer, prepack
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
@@ -34,11 +36,161 @@ WHOLE_LAYER_NODE = os.environ.get('OCOCC_SIR_WHOLE_LAYER', '1') == '1'
 
 
 _PACK_PLANS = weakref.WeakKeyDictionary()   # SIRLayer -> PackPlan of its Linears (not on the module: it holds ctypes arrays)
+_NATIVE_PLANS = weakref.WeakKeyDictionary()   # SIRLayer -> _NativePlan
 
 
 def _f32c(t):
     t = t.detach()
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+# ... and one library call per direction for the whole layer (csrc/sir_layer.hip issues the launches the node below issues
+# from Python): the rest of the ~0.3 + 0.5 ms per layer.
+NATIVE_LAYER = os.environ.get('OCOCC_SIR_NATIVE_LAYER', '1') == '1'
+
+
+class _SirLayerDesc(ctypes.Structure):   # ococc_sir_layer of include/ococc_hip.h
+    _fields_ = [('n_rel', ctypes.c_int32), ('n_vfe', ctypes.c_int32), ('feat_cols', ctypes.c_int32),
+                ('cluster_cols', ctypes.c_int32), ('with_cluster_center', ctypes.c_int32), ('shortcut', ctypes.c_int32),
+                ('bscale', ctypes.c_float), ('reserved', ctypes.c_int32), ('rel_colscale', ctypes.c_void_p),
+                ('colscale', ctypes.c_void_p), ('n', ctypes.c_int32 * 8), ('act', ctypes.c_int32 * 8),
+                ('eps', ctypes.c_float * 8), ('w_frag', ctypes.c_void_p * 8), ('wt_frag', ctypes.c_void_p * 8),
+                ('ln_weight', ctypes.c_void_p * 8), ('ln_bias', ctypes.c_void_p * 8)]
+
+
+class _Ptr(object):
+    """a device address inside a slab (which it keeps alive) -- what the end-of-pass reduction needs of a tensor"""
+    __slots__ = ('base', 'p')
+
+    def __init__(self, base, p):
+        self.base, self.p = base, p
+
+    def data_ptr(self):
+        return self.p
+
+
+class _NativePlan(object):
+    """Per SIRLayer: the descriptor the library calls read (rebuilt when a parameter moves), the weight-fragment plan
+    and the sizes that follow from the block shapes."""
+
+    def __init__(self, blocks, n_rel, feat_cols, cluster_cols, with_cc, bscale, rel_cs, col):
+        self.params = []
+        for lin, norm, _ in blocks:
+            self.params += [lin.weight, norm.weight, norm.bias]
+        self.weights = [lin.weight for lin, _, _ in blocks]
+        self.pack = PackPlan(self.weights, private=True)
+        self.consts = (rel_cs, col)
+        d = _SirLayerDesc()
+        d.n_rel, d.n_vfe = n_rel, len(blocks) - n_rel
+        d.feat_cols, d.cluster_cols, d.with_cluster_center, d.shortcut = feat_cols, cluster_cols, int(with_cc), 0
+        d.bscale = bscale
+        d.rel_colscale = None if rel_cs is None else rel_cs.data_ptr()
+        d.colscale = None if col is None else col.data_ptr()
+        for b, (lin, norm, act) in enumerate(blocks):
+            d.n[b] = lin.out_features
+            d.act[b] = {'none': 0, 'gelu': 1, 'relu': 2}[act]
+            d.eps[b] = float(norm.eps)
+            d.w_frag[b] = self.pack.outs[2 * b].data_ptr()
+            d.wt_frag[b] = self.pack.outs[2 * b + 1].data_ptr()
+            d.ln_weight[b] = norm.weight.data_ptr()
+            d.ln_bias[b] = norm.bias.data_ptr()
+        self.desc = d
+        self.ref = ctypes.byref(d)
+        self.ptrs = tuple(p.data_ptr() for p in self.params)
+        self.nl = len(blocks)
+        self.ns = [lin.out_features for lin, _, _ in blocks]
+        self.ks = [lin.in_features for lin, _, _ in blocks]
+        self.n_last = self.ns[-1]
+        self.sum_n = sum(self.ns[n_rel:])
+        # gradient buffers of one backward: per block [2, n] (LayerNorm) then [n k] (weight), one allocation
+        self.grad_sizes = []
+        for n, k in zip(self.ns, self.ks):
+            self.grad_sizes += [n * k, n, n]       # the order of self.params
+        n_vfe = len(blocks) - n_rel
+        expect = [cluster_cols if j == 0 else self.ns[j - 1] for j in range(n_rel)]
+        expect += [feat_cols + (cluster_cols if with_cc else 0)] + [2 * self.ns[n_rel + i - 1] for i in range(1, n_vfe)]
+        self.ok = (expect == self.ks and all((n * k) % 2 == 0 for n, k in zip(self.ns, self.ks))
+                   and all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params)
+                   and (n_rel == 0 or self.ns[n_rel - 1] == feat_cols))
+        self._layouts = {}
+
+    def valid_for(self, params):
+        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params)) \
+            and tuple(p.data_ptr() for p in params) == self.ptrs
+
+    def bwd_layout(self, rows, groups):
+        key = (rows, groups)
+        hit = self._layouts.get(key)
+        if hit is None:
+            ln_off, w_off = (ctypes.c_int64 * 8)(), (ctypes.c_int64 * 8)()
+            tiles, slices, total = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+            L.check(L.lib.ococc_sir_layer_bwd_layout(self.ref, rows, groups, ln_off, w_off, ctypes.byref(tiles),
+                                                     ctypes.byref(slices), ctypes.byref(total)), 'sir_layer_bwd_layout')
+            if len(self._layouts) > 64:
+                self._layouts.clear()
+            hit = self._layouts[key] = (list(ln_off)[:self.nl], list(w_off)[:self.nl], tiles.value, slices.value, total.value)
+        return hit
+
+
+class _SirLayerNative(torch.autograd.Function):
+    """_SirLayerFn with the launch sequences inside the library (ococc_sir_layer_fwd_f32 / _bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, plan, shortcut, features, f_cluster, inv, G, *params):
+        feats, fc = _f32c(features), _f32c(f_cluster)
+        rows, dev = feats.shape[0], feats.device
+        d = plan.desc
+        d.shortcut = int(shortcut)
+        slab = torch.empty((int(L.lib.ococc_sir_layer_fwd_floats(plan.ref, rows, G)),), dtype=torch.float32, device=dev)
+        y = torch.empty((rows, plan.n_last), dtype=torch.float32, device=dev)
+        groups = torch.empty((G, plan.sum_n), dtype=torch.float32, device=dev)
+        L.check(L.lib.ococc_sir_layer_fwd_f32(plan.ref, feats.data_ptr(), fc.data_ptr(), inv.data_ptr(), rows, G,
+                                              slab.data_ptr(), y.data_ptr(), groups.data_ptr(), L.stream()), 'sir_layer_fwd')
+        ctx.plan, ctx.shortcut, ctx.G = plan, bool(shortcut), G
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(feats, fc, inv, slab, y, *params)   # (the parameters: for autograd's version check)
+        return y, groups
+
+    @staticmethod
+    def backward(ctx, dy, dM):
+        plan, G = ctx.plan, ctx.G
+        t = ctx.saved_tensors
+        feats, fc, inv, fslab, y = t[:5]
+        rows, dev = feats.shape[0], feats.device
+        need = ctx.needs_input_grad
+        d = plan.desc
+        d.shortcut = int(ctx.shortcut)
+        ln_off, w_off, tiles, slices, total = plan.bwd_layout(rows, G)
+        slab = torch.empty((total,), dtype=torch.float32, device=dev)
+        dfeat = torch.empty_like(feats) if need[2] else None
+        dy = None if dy is None else _f32c(dy)
+        dM = None if dM is None else _f32c(dM)
+        L.check(L.lib.ococc_sir_layer_bwd_f32(plan.ref, feats.data_ptr(), fc.data_ptr(), inv.data_ptr(), rows, G,
+                                              fslab.data_ptr(), y.data_ptr(), L.ptr(dy), L.ptr(dM), slab.data_ptr(),
+                                              L.ptr(dfeat), L.stream()), 'sir_layer_bwd')
+        grads = [None] * len(plan.params)
+        if rows == 0:
+            return (None, None, dfeat, None, None, None, *[torch.zeros_like(p) for p in plan.params])
+        base = slab.data_ptr()
+        if all(need[6:]) and _deferred.deferrable(*plan.params):
+            out = torch.empty((sum(plan.grad_sizes),), dtype=torch.float32, device=dev)
+            views = out.split(plan.grad_sizes)
+            jobs, o = [], out.data_ptr()
+            for b in range(plan.nl):
+                n, k = plan.ns[b], plan.ks[b]
+                half = n * k // 2
+                jobs.append((_Ptr(slab, base + 4 * w_off[b]), slices, half, (_Ptr(out, o), _Ptr(out, o + 4 * half))))
+                o += 4 * n * k
+                jobs.append((_Ptr(slab, base + 4 * ln_off[b]), tiles, n, (_Ptr(out, o), _Ptr(out, o + 4 * n))))
+                o += 8 * n
+            if _deferred.defer_many('ln', jobs, list(zip(plan.params, views))):
+                return (None, None, dfeat, None, None, None, *grads)
+        for b in range(plan.nl):   # the sums right away, handed back through the engine
+            n, k = plan.ns[b], plan.ks[b]
+            grads[3 * b] = slab[w_off[b]: w_off[b] + slices * n * k].view(slices, n, k).sum(0)
+            lnp = slab[ln_off[b]: ln_off[b] + tiles * 2 * n].view(tiles, 2, n).sum(0)
+            grads[3 * b + 1], grads[3 * b + 2] = lnp[0], lnp[1]
+        return (None, None, dfeat, None, None, None, *grads)
 
 
 class _SirLayerFn(torch.autograd.Function):
@@ -263,15 +415,6 @@ class SIRLayer(nn.Module):
         _, rel, vfe = self._blocks()
         raw = self.in_channels - 3 * (self._with_cluster_center + self._with_voxel_center)   # columns of `features`
         scale = 1.0 / float(self.rel_dist_scaler)
-        # all Linears of this layer (and their transposes, when a backward pass will follow) packed in one launch
-        lins = [lin.weight for lin, _, _ in vfe] + [lin.weight for lin, _, _ in rel]
-        if all(w.dtype == torch.float32 and w.is_cuda for w in lins):
-            plan = _PACK_PLANS.get(self)
-            if plan is None or not plan.valid_for(lins):
-                plan = _PACK_PLANS[self] = PackPlan(lins)
-            plan.refresh(backward=torch.is_grad_enabled())
-        else:
-            prepack(lins, backward=torch.is_grad_enabled())
         col = const_tensor([1.0 / v for v in self.xyz_normalizer] + [1.0] * (raw - 3), dev)
         rel_cs = const_tensor([scale] * rel[0][0].in_features, dev) if rel else None
         if inv.dtype != torch.int32:   # (the blocks of a SIR stack share one inverse: converted once, kept on the tensor)
@@ -281,8 +424,30 @@ class SIRLayer(nn.Module):
                 inv._ococc_i32 = i32
             inv = i32
         blocks = rel + vfe
-        if (WHOLE_LAYER_NODE and features.dtype == torch.float32 and f_cluster.dtype == torch.float32
-                and not f_cluster.requires_grad and all(lin.weight.dtype == torch.float32 for lin, _, _ in blocks)):
+        whole = (WHOLE_LAYER_NODE and features.dtype == torch.float32 and f_cluster.dtype == torch.float32
+                 and not f_cluster.requires_grad and all(lin.weight.dtype == torch.float32 for lin, _, _ in blocks))
+        if whole and NATIVE_LAYER and len(blocks) <= 8 and not torch.cuda.is_current_stream_capturing():
+            plan = _NATIVE_PLANS.get(self)
+            params = []
+            for lin, norm, _ in blocks:
+                params += [lin.weight, norm.weight, norm.bias]
+            if plan is None or not plan.valid_for(params) or plan.consts[0] is not rel_cs or plan.consts[1] is not col:
+                plan = _NATIVE_PLANS[self] = _NativePlan(blocks, len(rel), features.shape[1], f_cluster.shape[1],
+                                                         self._with_cluster_center, scale / 10.0, rel_cs, col)
+            if plan.ok and all(p.is_cuda for p in params):
+                plan.pack.refresh(backward=torch.is_grad_enabled())
+                y, groups = _SirLayerNative.apply(plan, bool(shortcut), features, f_cluster, inv, int(num_groups), *params)
+                return y, groups, shortcut
+        # all Linears of this layer (and their transposes, when a backward pass will follow) packed in one launch
+        lins = [lin.weight for lin, _, _ in blocks]
+        if all(w.dtype == torch.float32 and w.is_cuda for w in lins):
+            plan = _PACK_PLANS.get(self)
+            if plan is None or not plan.valid_for(lins):
+                plan = _PACK_PLANS[self] = PackPlan(lins)
+            plan.refresh(backward=torch.is_grad_enabled())
+        else:
+            prepack(lins, backward=torch.is_grad_enabled())
+        if whole:
             spec = (len(rel), len(vfe), tuple(a for _, _, a in blocks), tuple(float(n.eps) for _, n, _ in blocks), rel_cs, col,
                     scale / 10.0, bool(self._with_cluster_center), bool(shortcut))
             params = []

@@ -173,8 +173,8 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
     fc = torch.randn(M, 13, generator=g).to(dev)
     dp, dg = torch.randn(M, 128, generator=g).to(dev), torch.randn(G, 256, generator=g).to(dev)
 
-    def run(whole, kernel=True):
-        sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL = whole, kernel
+    def run(whole, kernel=True, native=False):
+        sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL, sir.NATIVE_LAYER = whole, kernel, native
         try:
             layer.zero_grad(set_to_none=True)
             x = feats.clone().requires_grad_(True)
@@ -187,9 +187,16 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
             loss.backward()
             return pf.detach(), gf.detach(), x.grad.clone(), [None if p.grad is None else p.grad.clone() for p in layer.parameters()]
         finally:
-            sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL = True, True
+            sir.WHOLE_LAYER_NODE, sir.POINT_LAYER_KERNEL, sir.NATIVE_LAYER = True, True, True
 
     a, b, c = run(True), run(False), run(True, kernel=False)
+    nat = run(True, native=True)   # the same launches issued by the library (csrc/sir_layer.hip)
+    assert torch.equal(nat[0], a[0]) and torch.equal(nat[1], a[1])
+    assert float((nat[2] - a[2]).abs().max()) <= 1e-6 * float(a[2].abs().max())
+    for p, q in zip(nat[3], a[3]):
+        assert (p is None) == (q is None)
+        if p is not None:
+            assert float((p - q).abs().max()) <= 1e-5 * float(q.abs().max().clamp(min=1e-30))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     rel = lambda p, q: float((p - q).abs().max() / q.abs().max().clamp(min=1e-30))
     # (the chain adds the shortcut's and the gathered maxima's gradients through autograd's accumulation: another order)
