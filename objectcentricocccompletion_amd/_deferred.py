@@ -69,22 +69,28 @@ def register_joint(kinds, fn):
     _joint[tuple(kinds)] = fn
 
 
-_acc_nodes = {}   # id(param) -> (weak reference to it, its AccumulateGrad node)
+_acc_nodes = {}   # id(param) -> (weak reference to it, its AccumulateGrad node, raw stream it was found under)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def _accumulate_node(p):
     """p's AccumulateGrad node.  Finding it takes a throw-away view (~10 us; a SIR layer asks for 15 parameters per
     backward), and the node stays the same object while somebody holds it: kept per parameter -- in a table of bounded
     size, since the node in turn keeps its parameter alive."""
+    # (a node remembers the stream it was created under, and the engine warns -- and may synchronise -- when a kept-alive
+    # node meets gradients from another stream: an entry is only good for the stream it was made on)
+    sid = _raw_stream(p.device.index) if (_raw_stream is not None and p.is_cuda) else 0
     hit = _acc_nodes.get(id(p))
-    if hit is not None and hit[0]() is p:
-        return hit[1]
+    if hit is not None:
+        if hit[0]() is p and hit[2] == sid:
+            return hit[1]
+        del _acc_nodes[id(p)], hit
     with torch.enable_grad():
         node = p.view_as(p).grad_fn.next_functions[0][0]
     if len(_acc_nodes) >= 8192:
         _acc_nodes.clear()
     import weakref
-    _acc_nodes[id(p)] = (weakref.ref(p), node)
+    _acc_nodes[id(p)] = (weakref.ref(p), node, sid)
     return node
 
 
@@ -92,9 +98,12 @@ def _accumulates_into_grad(p):
     """True when the running backward pass will execute p's AccumulateGrad node (p.grad gets the result)."""
     node = _accumulate_node(p)
     try:
-        return bool(torch._C._will_engine_execute_node(node))
+        ok = bool(torch._C._will_engine_execute_node(node))
     except RuntimeError:  # autograd.grad(..., inputs=[p]) captures the gradient instead / no pass is running
-        return False
+        ok = False
+    if not ok:   # not a pass that uses the node (e.g. the warm-up / capture passes of a graphed callable, on their own
+        _acc_nodes.pop(id(p), None)   # stream): do not keep it alive beyond this call
+    return ok
 
 
 def deferrable(*params):

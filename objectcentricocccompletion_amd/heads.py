@@ -12,6 +12,9 @@ and its checkpoints load.  What differs is underneath:
   * the occupancy loss calls the decoder with (RoI features, query points, RoI index) and
     the decoder's first layer is factorised, instead of materialising [R+,K,1536] copies.
 """
+import os
+import weakref
+
 import numpy as np
 import torch
 from torch import nn
@@ -25,6 +28,52 @@ from .occ.occ_base import OccDecoder
 from .registry import BACKBONES, HEADS
 from .sir import SIRLayer
 from .sst.sst_ops import build_mlp, unique_with_inverse
+
+
+# The temporal transformer's shapes are fixed by the batch layout ([L frames, B tracklets, D]): its forward and backward
+# are replayed as two HIP graphs (torch.cuda.make_graphed_callables: static input / output buffers, one graph pair per
+# shape) instead of ~60 + ~120 launches issued one by one -- the step at 4 tracklets is bound by the host.  Training
+# mode with gradients only; anything else (eval, no_grad, a capture already running, ever-changing shapes) takes the
+# eager path.
+GRAPH_TRANSFORMER = os.environ.get('OCOCC_GRAPH_TRANSFORMER', '1') == '1'
+_graphed_encoders = weakref.WeakKeyDictionary()   # encoder -> {shape key: graphed callable}
+
+
+class _EncoderCall(nn.Module):
+    """positional-argument face of TransformerEncoder.forward for make_graphed_callables (which also needs a Module to
+    find the parameters whose gradients the captured backward has to return)"""
+
+    def __init__(self, enc):
+        super().__init__()
+        self.enc = enc
+
+    def forward(self, feats, pos, mask):
+        return self.enc(feats, pos_enc=pos, attn_mask=mask)
+
+
+def run_encoder(enc, feats, pos, mask):
+    ok = (GRAPH_TRANSFORMER and enc.training and torch.is_grad_enabled() and feats.is_cuda and mask is not None
+          and pos is not None and feats.requires_grad and not torch.cuda.is_current_stream_capturing()
+          and all(p.requires_grad for p in enc.parameters()))
+    if ok:
+        key = (tuple(feats.shape), feats.dtype, pos.dtype, bool(pos.requires_grad), tuple(mask.shape))
+        table = _graphed_encoders.get(enc)
+        if table is None:
+            table = _graphed_encoders[enc] = {}
+        g = table.get(key)
+        if g is None and len(table) < 4:   # (a graph pair per shape: not for inputs whose shape keeps changing)
+            sample = (torch.randn_like(feats).requires_grad_(True), torch.randn_like(pos).requires_grad_(pos.requires_grad),
+                      mask.clone())
+            # (warm-up and capture run on a side stream, and the captured backward keeps the autograd graph of its static
+            # outputs: the parameters' AccumulateGrad nodes meet gradients from another stream than the one they were made
+            # on, which the engine reports -- the known, intended consequence of graphing a sub-module)
+            quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if quiet is not None:
+                quiet(False)
+            g = table[key] = torch.cuda.make_graphed_callables(_EncoderCall(enc), sample)
+        if g is not None:
+            return g(feats, pos, mask)
+    return enc(feats, pos_enc=pos, attn_mask=mask)
 
 
 def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx):
@@ -590,7 +639,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         else:
             future_mask = self.get_future_mask(L, re_feats.device)
         enc = self.trans_enc if trans_enc is None else trans_enc
-        out = enc(re_feats, pos_enc=pos_embed, attn_mask=future_mask).transpose(0, 1)
+        out = run_encoder(enc, re_feats, pos_embed, future_mask).transpose(0, 1)
         return self.inverse_reorder_feats(out, sb, sf)
 
     def transformer_forward_various_length(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):

@@ -138,3 +138,37 @@ def test_simple_test_tracklets_and_occupancy_counts_equal_reference(dev, gold, m
     if b == 1:   # the candidate misses timestamps: those frames are not counted; frame 3 has no points and keeps its box
         assert len(inters) == len(samples[1]['candidates'][0][1])
         assert np.allclose(ot.boxes[3].cpu().numpy(), samples[1]['boxes'][3], atol=1e-6)
+
+
+def test_graphed_transformer_equals_eager(dev):
+    """heads.run_encoder: the temporal transformer replayed as a HIP-graph pair (forward / backward) gives what the eager
+    launches give -- output, input gradients and parameter gradients (dropout off: same kernels, same order)."""
+    import copy
+    from objectcentricocccompletion_amd import heads
+    from objectcentricocccompletion_amd.occ.layers import SimpleEncoderLayer, TransformerEncoder
+    torch.manual_seed(0)
+    L_, B, D = 32, 4, 256
+    enc = TransformerEncoder(SimpleEncoderLayer(D, 4, dim_feedforward=512, dropout=0.0, mlp_dropout=0.0), 2).to(dev).train()
+    ref = copy.deepcopy(enc)
+    feats = torch.randn(L_, B, D, device=dev)
+    pos = torch.randn(L_, B, D, device=dev)
+    mask = torch.triu(torch.ones(L_, L_, dtype=torch.bool, device=dev), diagonal=1)
+    dy = torch.randn(L_, B, D, device=dev)
+    outs = []
+    for model, graphed in ((enc, True), (ref, False)):
+        heads.GRAPH_TRANSFORMER = graphed
+        try:
+            for it in range(2):    # (the second call replays what the first captured)
+                model.zero_grad(set_to_none=True)
+                f, p = feats.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+                y = heads.run_encoder(model, f, p, mask)
+                y.backward(dy)
+            outs.append((y.detach().clone(), f.grad.clone(), p.grad.clone(), [q.grad.clone() for q in model.parameters()]))
+        finally:
+            heads.GRAPH_TRANSFORMER = True
+    assert enc in heads._graphed_encoders and ref not in heads._graphed_encoders
+    a, b = outs
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp(min=1e-30))
+    assert rel(a[0], b[0]) < 1e-5 and rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5
+    for x, y in zip(a[3], b[3]):
+        assert rel(x, y) < 1e-4
