@@ -51,29 +51,65 @@ class _EncoderCall(nn.Module):
         return self.enc(feats, pos_enc=pos, attn_mask=mask)
 
 
+def graphed_call(owner, make_wrapper, args, slot=''):
+    """``make_wrapper(owner)(*args)`` replayed as a HIP-graph pair when that is possible (training mode, gradients on,
+    device tensors of which at least one requires a gradient, every parameter trainable when the graph is made, no
+    capture running, at most four shapes seen per owner); None when not -- the caller then runs the eager form."""
+    if not (GRAPH_TRANSFORMER and owner.training and torch.is_grad_enabled() and all(a.is_cuda for a in args)
+            and any(a.requires_grad for a in args) and not torch.cuda.is_current_stream_capturing()):
+        return None
+    key = (slot,) + tuple((tuple(a.shape), a.dtype, bool(a.requires_grad)) for a in args)
+    table = _graphed_encoders.get(owner)
+    if table is None:
+        table = _graphed_encoders[owner] = {}
+    g = table.get(key)
+    if g is None:
+        if len(table) >= 4:   # (a graph pair per shape: not for inputs whose shape keeps changing)
+            return None
+        sample = tuple((torch.randn_like(a) if a.is_floating_point() else a.clone()).requires_grad_(a.requires_grad)
+                       for a in args)
+        # (warm-up and capture run on a side stream, and the captured backward keeps the autograd graph of its static
+        # outputs: the parameters' AccumulateGrad nodes meet gradients from another stream than the one they were made
+        # on, which the engine reports -- the known, intended consequence of graphing a sub-module)
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:
+            quiet(False)
+        wrapper = make_wrapper(owner)
+        if not all(p.requires_grad for p in wrapper.parameters()):   # (the captured backward returns every parameter's
+            table[key] = False                                        # gradient: frozen parameters -> eager, for good)
+            return None
+        g = table[key] = torch.cuda.make_graphed_callables(wrapper, sample, allow_unused_input=True)
+    return g(*args) if g is not False else None
+
+
 def run_encoder(enc, feats, pos, mask):
-    ok = (GRAPH_TRANSFORMER and enc.training and torch.is_grad_enabled() and feats.is_cuda and mask is not None
-          and pos is not None and feats.requires_grad and not torch.cuda.is_current_stream_capturing()
-          and all(p.requires_grad for p in enc.parameters()))
-    if ok:
-        key = (tuple(feats.shape), feats.dtype, pos.dtype, bool(pos.requires_grad), tuple(mask.shape))
-        table = _graphed_encoders.get(enc)
-        if table is None:
-            table = _graphed_encoders[enc] = {}
-        g = table.get(key)
-        if g is None and len(table) < 4:   # (a graph pair per shape: not for inputs whose shape keeps changing)
-            sample = (torch.randn_like(feats).requires_grad_(True), torch.randn_like(pos).requires_grad_(pos.requires_grad),
-                      mask.clone())
-            # (warm-up and capture run on a side stream, and the captured backward keeps the autograd graph of its static
-            # outputs: the parameters' AccumulateGrad nodes meet gradients from another stream than the one they were made
-            # on, which the engine reports -- the known, intended consequence of graphing a sub-module)
-            quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
-            if quiet is not None:
-                quiet(False)
-            g = table[key] = torch.cuda.make_graphed_callables(_EncoderCall(enc), sample)
-        if g is not None:
-            return g(feats, pos, mask)
+    if mask is not None and pos is not None and feats.requires_grad:
+        out = graphed_call(enc, _EncoderCall, (feats, pos, mask))
+        if out is not None:
+            return out
     return enc(feats, pos_enc=pos, attn_mask=mask)
+
+
+class _HeadTail(nn.Module):
+    """what OccBBoxHead.forward does behind the transformer (ococc_bbox_head.py:372-400): latent fusion, the fused
+    feature and the two prediction MLPs -- fixed shapes [R, .], graphed like the encoder"""
+
+    def __init__(self, head):
+        super().__init__()
+        self.conv_latent, self.conv_fused, self.conv_cls, self.conv_reg = (head.conv_latent, head.conv_fused, head.conv_cls,
+                                                                            head.conv_reg)
+        self.fused_mode, self.rcnn_trans = head.fused_mode, head.rcnn_trans
+
+    def forward(self, local_roi_feats, roi_feats_fused, final_cluster_feats):
+        if self.fused_mode == 'residual':
+            shape_latent = local_roi_feats + self.conv_latent(roi_feats_fused)
+        elif self.fused_mode == 'concat':
+            shape_latent = self.conv_latent(torch.cat([local_roi_feats, roi_feats_fused], dim=1))
+        else:  # concat_residual
+            shape_latent = local_roi_feats + self.conv_latent(torch.cat([local_roi_feats, roi_feats_fused], dim=1))
+        second = roi_feats_fused if self.rcnn_trans else final_cluster_feats
+        fused = self.conv_fused(torch.cat([shape_latent, second], dim=1))
+        return shape_latent, self.conv_cls(fused), self.conv_reg(fused)
 
 
 def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx):
@@ -563,6 +599,13 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         local_roi_feats, _, local_xyz = self.occ_ae_head.encode(pts_xyz, pts_features[:, :2], pts_info,
                                                                 roi_inds, rois)
         roi_feats_fused = self.transformer_forward(rois, roi_frame_inds, final_cluster_feats, nonempty_roi_mask)
+        tail = None
+        if local_roi_feats.requires_grad and roi_feats_fused.requires_grad and final_cluster_feats.requires_grad:
+            tail = graphed_call(self, _HeadTail, (local_roi_feats, roi_feats_fused, final_cluster_feats), slot='tail')
+        if tail is not None:
+            shape_latent, cls_score, bbox_pred = tail
+            return dict(fused_roi_feats=shape_latent, nonempty_roi_mask=nonempty_roi_mask, ori_roi_feats=local_roi_feats,
+                        cls_score=cls_score, bbox_pred=bbox_pred)
         if self.fused_mode == 'residual':
             shape_latent = local_roi_feats + self.conv_latent(roi_feats_fused)
         elif self.fused_mode == 'concat':

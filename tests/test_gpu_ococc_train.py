@@ -172,3 +172,44 @@ def test_graphed_transformer_equals_eager(dev):
     assert rel(a[0], b[0]) < 1e-5 and rel(a[1], b[1]) < 1e-5 and rel(a[2], b[2]) < 1e-5
     for x, y in zip(a[3], b[3]):
         assert rel(x, y) < 1e-4
+
+
+def test_graphed_head_tail_equals_eager(dev):
+    """heads._HeadTail (latent fusion + fused feature + cls / reg MLPs behind the transformer) as a graph pair against
+    the same module called eagerly (dropout off)."""
+    import copy
+    from torch import nn
+    from objectcentricocccompletion_amd import heads
+    from objectcentricocccompletion_amd.sst.sst_ops import build_mlp
+    torch.manual_seed(1)
+    R, D = 128, 256
+    ln = dict(type='LN', eps=1e-3)
+
+    class Stub(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv_latent = build_mlp(2 * D, [D, D], ln, act='gelu')
+            self.conv_fused = build_mlp(2 * D, [D], ln, act='gelu')
+            self.conv_cls = build_mlp(D, [D, 1], ln, is_head=True, act='gelu')
+            self.conv_reg = build_mlp(D, [D, 7], ln, is_head=True, act='gelu')
+            self.fused_mode, self.rcnn_trans = 'concat_residual', True
+
+    a = Stub().to(dev).train()
+    b = copy.deepcopy(a)
+    xs = [torch.randn(R, D, device=dev) for _ in range(3)]
+    ds = [torch.randn(R, D, device=dev), torch.randn(R, 1, device=dev), torch.randn(R, 7, device=dev)]
+    outs = []
+    for model, graphed in ((a, True), (b, False)):
+        for it in range(2):
+            model.zero_grad(set_to_none=True)
+            ins = [x.clone().requires_grad_(True) for x in xs]
+            res = heads.graphed_call(model, heads._HeadTail, tuple(ins), slot='tail') if graphed else heads._HeadTail(model)(*ins)
+            assert res is not None
+            sum((r * d).sum() for r, d in zip(res, ds)).backward()
+        outs.append(([r.detach().clone() for r in res], [i.grad.clone() for i in ins if i.grad is not None],
+                     [q.grad.clone() for q in model.parameters()]))
+        assert len(outs[-1][1]) == 2   # (rcnn_trans: the per-frame cluster features are not an input of the tail)
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp(min=1e-30))
+    for k in range(3):
+        for x, y in zip(outs[0][k], outs[1][k]):
+            assert rel(x, y) < 1e-4, k
