@@ -449,13 +449,14 @@ def bench_decode(args, world, rank, dev):
 
 def also_workloads():
     """Short runs (10 timed steps after 8 warm-up steps) of the other workloads, each in a child process of its own, so that the one JSON line the
-    driver records also carries configs[2] (at the config's 4 tracklets per GPU and at 64), configs[4]'s SST path and the
+    driver records also carries configs[2] (at the config's 4 tracklets per GPU, at 16 and at 64: SURVEY 8d), configs[4]'s SST path and the
     dense-grid decode of 64 tracklets' RoIs (8 M cells: the decoder kernel back to back, at sustained clocks).
     Not part of the timed region above; a failure is recorded, it never fails the run."""
     import subprocess
     out = {}
     here = os.path.abspath(__file__)
     for key, extra in (('ococcnet_b4', ['--workload', 'ococcnet', '--tracklets', '4']),
+                       ('ococcnet_b16', ['--workload', 'ococcnet', '--tracklets', '16']),
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('sst', ['--workload', 'sst']),
                        ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
