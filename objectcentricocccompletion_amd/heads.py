@@ -667,7 +667,9 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
     def transformer_forward_fixed_length(self, rois, roi_frame_inds, roi_feats, nonempty_roi_mask, trans_enc=None):
         """ococc_bbox_head.py:849-908."""
         rois_batch_idx = rois[:, 0]
-        B = int(rois_batch_idx.max().item() + 1)
+        B = getattr(rois, '_ococc_batch_size', None)   # (set by bbox3d2roi from the list's shapes: no read-back)
+        if not B:
+            B = int(rois_batch_idx.max().item() + 1)
         L = roi_frame_inds.numel() // B
         assert L * B == roi_frame_inds.numel()
         re_feats, sb, sf = self.reorder_feats(roi_feats, roi_frame_inds, rois_batch_idx, batch_size=B)

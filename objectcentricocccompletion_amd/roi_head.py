@@ -19,7 +19,11 @@ def bbox3d2roi(bbox_list):
     for i, b in enumerate(bbox_list):
         out.append(torch.cat([b.new_full((b.size(0), 1), i), b], dim=-1) if b.size(0) > 0
                    else torch.zeros_like(b[:, :1].expand(0, b.size(1) + 1)))
-    return torch.cat(out, 0)
+    rois = torch.cat(out, 0)
+    # (largest sample index present + 1, known from the list's shapes: what the head would otherwise read back from
+    # column 0 -- ococc_bbox_head.py:851 ``int(rois_batch_idx.max().item() + 1)``)
+    rois._ococc_batch_size = max((i + 1 for i, b in enumerate(bbox_list) if b.size(0) > 0), default=0)
+    return rois
 
 
 @HEADS.register_module()

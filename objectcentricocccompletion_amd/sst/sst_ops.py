@@ -13,12 +13,19 @@ def unique_with_inverse(coors, dims=None, return_counts=False):
     """torch.unique(coors, return_inverse=True, dim=0) for integer keys >= -1 (the reference
     feeds RoI / voxel indices where -1 marks "no group" and is kept as a group of its own,
     sorted first -- ococc_bbox_head.py:255-260).  Returns int32 tensors."""
-    shifted = coors + 1  # -1 -> 0: the bitmap ranks only non-negative keys
-    if dims is not None:
-        dims = [int(d) + 1 for d in dims]
-    new_coors, inv, counts = grid_unique(shifted, dims)
-    new_coors = new_coors - 1
-    inv._ococc_counts = counts
+    # (the two point encoders of OccBBoxHead group the same pooled points by the same RoI index: the second call finds
+    # the first one's result on the key tensor -- one grouping pass and one read-back of the group count less per step)
+    key = None if dims is None else tuple(int(d) for d in dims)
+    memo = getattr(coors, '_ococc_unique', None)
+    if memo is not None and memo[0] == key and memo[1] == coors._version:
+        new_coors, inv, counts = memo[2]
+    else:
+        shifted = coors + 1  # -1 -> 0: the bitmap ranks only non-negative keys
+        new_coors, inv, counts = grid_unique(shifted, None if dims is None else [int(d) + 1 for d in dims])
+        new_coors = new_coors - 1
+        inv._ococc_counts = counts
+        if not coors.requires_grad:
+            coors._ococc_unique = (key, coors._version, (new_coors, inv, counts))
     if return_counts:
         return new_coors, inv, counts
     return new_coors, inv
