@@ -112,7 +112,15 @@ class _HeadTail(nn.Module):
         return shape_latent, self.conv_cls(fused), self.conv_reg(fused)
 
 
-def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx):
+def _true_rows(mask, count=None):
+    """Row numbers where ``mask`` is set.  With ``count`` (the number of set entries, already on the host) the output
+    size is known and nothing is read back."""
+    if count is not None and hasattr(torch, 'nonzero_static'):
+        return torch.nonzero_static(mask, size=int(count)).reshape(-1)
+    return torch.nonzero(mask).reshape(-1)
+
+
+def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx, count=None):
     """Row numbers into pos_data for SparseHeadMixin.filter_pos_assigned_but_empty_rois."""
     rb = roi_batch_idx.long()
     pb = pos_batch_idx.long()
@@ -121,7 +129,7 @@ def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx):
     n = rb.numel()
     # position of every RoI among the RoIs of its sample = sorted position - first sorted position of the sample
     local = torch.arange(n, device=rb.device) - torch.searchsorted(srb, srb)
-    sel = torch.nonzero(filtered_pos_mask[order_r]).reshape(-1)          # the one read-back (output size)
+    sel = _true_rows(filtered_pos_mask[order_r], count)                  # (a read-back of the output size without `count`)
     at = torch.searchsorted(spb, srb[sel]) + local[sel]                    # sorted position inside pos_data
     return order_p[at]
 
@@ -146,7 +154,7 @@ class SparseHeadMixin(object):
         new_feature = features.new_zeros((num_rois + 1, features.size(1))).index_copy(0, idx, features)
         return new_feature[:num_rois]
 
-    def filter_pos_assigned_but_empty_rois(self, pos_data, pos_batch_idx, filtered_pos_mask, roi_batch_idx):
+    def filter_pos_assigned_but_empty_rois(self, pos_data, pos_batch_idx, filtered_pos_mask, roi_batch_idx, count=None):
         """fsd_bbox_head.py:442-455: per sample b, the rows of `pos_data` that belong to b, picked at the in-sample
         positions where `filtered_pos_mask` (over the RoIs of b) is set; samples concatenated in order.  The
         reference loops over the samples with three boolean-mask indexings (= three host read-backs) each; here
@@ -158,7 +166,7 @@ class SparseHeadMixin(object):
                 and cached[1] == tuple(t._version for t in key):
             rows = cached[2]
         else:
-            rows = _filter_rows(*key)
+            rows = _filter_rows(*key, count=count)
             self._filter_rows_cache = (key, tuple(t._version for t in key), rows)
         return pos_data[rows]
 
@@ -918,7 +926,12 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         pos_inds = reg_mask > 0
         losses['num_pos_rois'] = pos_inds.sum().float()
         losses['num_neg_rois'] = (reg_mask <= 0).sum().float()
-        pos_rows = torch.where(pos_inds)[0]   # the ONE read-back of the positives (count, emptiness, row lists below)
+        # the ONE read-back of the loss: how many RoIs are positive for the box loss and for the occupancy loss (the row
+        # lists below and in loss_occ are then built at a known size)
+        occ_reg_mask = occ_reg_mask.clone()
+        occ_reg_mask[~nonempty] = 0
+        n_pos, n_occ = torch.stack([pos_inds.sum(), (occ_reg_mask > 0).sum()]).tolist()
+        pos_rows = _true_rows(pos_inds, n_pos)
         reg_avg = pos_rows.numel()
         if self.train_cfg.get('sync_reg_avg_factor', False):
             reg_avg = reduce_mean(torch.full((1,), float(reg_avg), dtype=bbox_weights.dtype, device=bbox_weights.device))
@@ -927,7 +940,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         else:
             pos_pred = bbox_pred[pos_rows]
             bbox_targets = self.filter_pos_assigned_but_empty_rois(bbox_targets, pos_batch_idx, pos_inds,
-                                                                   rois[:, 0].int())
+                                                                   rois[:, 0].int(), count=n_pos)
             w = bbox_weights[pos_rows].view(-1, 1).repeat(1, pos_pred.shape[-1])
             code_weights = self.train_cfg.get('rcnn_code_weights', None)
             if code_weights is not None:
@@ -935,14 +948,14 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             assert pos_pred.size(0) == bbox_targets.size(0)
             losses['loss_rcnn_bbox'] = self.loss_bbox(pos_pred, bbox_targets, w, avg_factor=reg_avg)
         losses.update(self.loss_occ(rois, results_dict['fused_roi_feats'], results_dict['ori_roi_feats'],
-                                    occ_pos_batch_idx, pos_gt_bboxes_occ, occ_reg_mask.clone(), nonempty,
+                                    occ_pos_batch_idx, pos_gt_bboxes_occ, occ_reg_mask, nonempty,
                                     pos_roi_local_xyz, gt_occ, occ_scores, transform_occ=transform_occ,
-                                    roi_frame_inds=roi_frame_inds))
+                                    roi_frame_inds=roi_frame_inds, num_pos=n_occ))
         return losses
 
     def loss_occ(self, rois, roi_features, ori_roi_feats, pos_batch_idx, pos_gt_bboxes, reg_mask,
                  nonempty_roi_mask, gt_smp_local_coords, gt_smp_occ_labels, gt_occ_label_scores,
-                 transform_occ=False, roi_frame_inds=None, do_aug=False):
+                 transform_occ=False, roi_frame_inds=None, do_aug=False, num_pos=None):
         """ococc_bbox_head.py:608-811 (default train_cfg switches of ococcnet.py: no residual /
         contrastive / outside / observed-feature variants)."""
         losses = {}
@@ -952,7 +965,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         num_occupied = (gt_smp_occ_labels == 1).sum().float()
         losses['num_occupied'] = num_occupied
         losses['num_free'] = gt_smp_occ_labels.numel() - num_occupied
-        pos_rows = torch.where(pos_inds)[0]   # one read-back for emptiness and the row lists below
+        pos_rows = _true_rows(pos_inds, num_pos)   # (``num_pos``: the caller has counted them; else one read-back)
+        num_pos = pos_rows.numel()
         if pos_rows.numel() == 0:
             idx = torch.arange(roi_features.size(0), device=roi_features.device)
             losses['loss_rcnn_occ'] = decoder(roi_features, roi_features.new_zeros(roi_features.size(0), 3), idx) * 0
@@ -961,7 +975,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             return losses
         pos_roi_features = roi_features[pos_rows]  # [M, D]
         rb = rois[:, 0].int()
-        occ_targets = self.filter_pos_assigned_but_empty_rois(gt_smp_occ_labels, pos_batch_idx, pos_inds, rb)
+        occ_targets = self.filter_pos_assigned_but_empty_rois(gt_smp_occ_labels, pos_batch_idx, pos_inds, rb, count=num_pos)
         occ_smp_xyz = self.filter_pos_assigned_but_empty_rois(gt_smp_local_coords, pos_batch_idx, pos_inds, rb)
         pos_gt_bboxes = self.filter_pos_assigned_but_empty_rois(pos_gt_bboxes, pos_batch_idx, pos_inds, rb)
         if transform_occ:
