@@ -662,6 +662,13 @@ __global__ void __launch_bounds__(256) fill_kernel(float* p, int64_t count, floa
 
 inline int nbw_of(int n) { return (((n + 15) >> 4) + 3) / 4; }
 
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % kMaxDevices;
+}
+
 }  // namespace
 
 extern "C" int64_t ococc_point_mlp_fragment_floats(int32_t n, int32_t k) {
@@ -730,13 +737,14 @@ extern "C" int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, 
   const int k = ka + kb + kv, kp = pad_k(k), np = pad_k(n);
   const int lds = lds_floats(kp, np) * 4;
   const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
+  const int dev = current_device_slot();
 #define OCOCC_PM_FWD(NBW)                                                                                             \
   do {                                                                                                                \
-    static int lds_set = 0;  /* (the attribute sticks: raised once per instantiation, not per launch) */              \
-    if (lds > lds_set) {                                                                                              \
+    static int lds_set[kMaxDevices] = {};  /* (the attribute sticks: raised once per instantiation and device) */     \
+    if (lds > lds_set[dev]) {                                                                                         \
       OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_fwd_kernel<NBW>,                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
-      lds_set = lds;                                                                                                  \
+      lds_set[dev] = lds;                                                                                             \
     }                                                                                                                 \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_fwd_kernel<NBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,     \
                        (int)n, ln_weight, ln_bias, eps, (int)act, y, seg_max);                                        \
@@ -769,13 +777,14 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
   const int lds = lds_floats(kp, np) * 4;
   const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
   const int kbw = (((k + 15) >> 4) + 3) / 4;
+  const int dev = current_device_slot();
 #define OCOCC_PM_BWD(NBW, KBW)                                                                                            \
   do {                                                                                                                    \
-    static int lds_set = 0;                                                                                               \
-    if (lds > lds_set) {                                                                                                  \
+    static int lds_set[kMaxDevices] = {};                                                                                 \
+    if (lds > lds_set[dev]) {                                                                                             \
       OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW>,                                          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                    \
-      lds_set = lds;                                                                                                      \
+      lds_set[dev] = lds;                                                                                                 \
     }                                                                                                                     \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_bwd_kernel<NBW, KBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,    \
                        wt_frag, (int)n, ln_weight, ln_bias, eps, (int)act, dy, d_seg_max, seg_arg, dz, x_cat, da, dmul,   \
