@@ -731,6 +731,15 @@ int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const float* add_ro
                            const float* head_weight, const float* head_bias, uint32_t drop_threshold,
                            const uint64_t* dropout_seeds, uint16_t* y0_out, uint16_t* y1_out, float* out,
                            ococc_stream_t stream);
+/* the same launch in a training step: per layer l it also writes the LayerNorm input z_out[l] (bf16 [rows, n_l]; the
+ * LayerNorm works on these rounded values), its row statistics stats_out[l] (f32 [rows, 2]: mean, rstd) and the activation
+ * y_out[l] (bf16, after GELU and dropout) -- what the backward pass of OccDecoder.forward's conv_occ reads
+ * (ococc_layernorm_act_bwd / _dropout_bwd_bf16 with the same (threshold, seed) per layer). */
+int ococc_occ_mlp_train_fwd_bf16(const uint16_t* pe, int64_t rows, const float* add_rows, const int32_t* add_index,
+                                 const void* const* w_frag, const void* const* ln_weight, const void* const* ln_bias,
+                                 float eps, const float* head_weight, const float* head_bias, uint32_t drop_threshold,
+                                 const uint64_t* dropout_seeds, void* const* z_out, void* const* y_out,
+                                 void* const* stats_out, float* out, ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * B6, element-wise halves of the SST input layer, one launch each (the mirror ran 20-50 torch operators per call):

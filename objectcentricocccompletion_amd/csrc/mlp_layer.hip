@@ -172,6 +172,8 @@ struct Epilogue {
   float* red0;              // LDS [8 waves][64 rows] each
   float* red1;
   uint16_t* y_global;       // bf16 [rows, N] or null
+  uint16_t* z_global;       // TRAIN: bf16 [rows, N], the LayerNorm input as the backward pass reads it
+  float* stats_global;      // TRAIN: f32 [rows, 2] (mean, rstd)
   uint16_t* y_lds;          // bf16 tile [64][ld_lds] or null
   float* head_out;          // f32 [rows] (with head_s)
   const float* head_b;
@@ -183,7 +185,10 @@ struct Epilogue {
 };
 // Contains workgroup barriers when has_ln or head_s (kernel-uniform).  Nothing is written to y_lds before the first of
 // them, so with a LayerNorm the tile the GEMM phase read may be the one y_lds overwrites.
-template <int NPW, bool ADD, bool MAY_DROP = true>
+// TRAIN: what a backward pass needs is written out as well -- z rounded to bf16 (and the LayerNorm then works on the
+// ROUNDED values, as it does when a library GEMM hands it a bf16 tensor: forward and backward see the same numbers)
+// and the row statistics.
+template <int NPW, bool ADD, bool MAY_DROP = true, bool TRAIN = false>
 __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epilogue& e) {
   constexpr int N = NPW * 32 * kWaves;
   // The per-lane indices are loop invariant in the persistent kernels; left alone the compiler computes every one of them
@@ -218,6 +223,25 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
         if (q == 3) __builtin_amdgcn_sched_barrier(0);
       }
   }
+  if (TRAIN) {
+#pragma unroll
+    for (int nb = 0; nb < NPW; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * (nb0 + nb) + 8 * q + 4 * h;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          u32x2 o;
+          o.x = ln_pack2(ln_f32x2{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1]});
+          o.y = ln_pack2(ln_f32x2{acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]});
+          acc[nb][mb][4 * q] = __uint_as_float(o.x << 16);
+          acc[nb][mb][4 * q + 1] = __uint_as_float(o.x & 0xffff0000u);
+          acc[nb][mb][4 * q + 2] = __uint_as_float(o.y << 16);
+          acc[nb][mb][4 * q + 3] = __uint_as_float(o.y & 0xffff0000u);
+          if (rows_of[mb] < e.rows) *(u32x2*)(e.z_global + rows_of[mb] * N + n) = o;
+        }
+      }
+  }
   float rstd[2] = {1.f, 1.f};
   if (e.has_ln) {
     float s[2] = {0.f, 0.f};
@@ -231,13 +255,14 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
       if (h == 0) e.red0[wave * TM + 32 * mb + m] = s[mb];
     }
     __syncthreads();
-    float q2[2];
+    float q2[2], mean_[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) t += e.red0[w * TM + 32 * mb + m];
       const float mean = t / (float)N;
+      mean_[mb] = mean;
       q2[mb] = 0.f;
 #pragma unroll
       for (int nb = 0; nb < NPW; ++nb)
@@ -256,6 +281,10 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) t += e.red1[w * TM + 32 * mb + m];
       rstd[mb] = rsqrtf(t / (float)N + e.eps);
+      if (TRAIN && wave == 0 && h == 0 && rows_of[mb] < e.rows) {
+        e.stats_global[rows_of[mb] * 2] = mean_[mb];
+        e.stats_global[rows_of[mb] * 2 + 1] = rstd[mb];
+      }
     }
   }
   float dot[2] = {0.f, 0.f};
@@ -334,6 +363,8 @@ mlp_layer_fwd_kernel(MlpLayerArgs a) {
   }
   const int64_t tiles = (a.rows + TM - 1) / TM;
   Epilogue e;
+  e.z_global = nullptr;
+  e.stats_global = nullptr;
   e.gam_s = gam_s;
   e.bet_s = bet_s;
   e.bias_s = a.bias ? bias_s : nullptr;
@@ -392,6 +423,9 @@ struct OccMlpArgs {
   const float* head_b;      // [1] or null
   float* out;               // [rows]
   uint16_t* y_out[2];       // optional copies of y0 [rows, 512], y1 [rows, 1024] (what a backward pass starts from)
+  uint16_t* y2_out;         // TRAIN: y2 [rows, 1024]
+  uint16_t* z_out[3];       // TRAIN: LayerNorm inputs (bf16) ...
+  float* stats_out[3];      // ... and row statistics [rows, 2] of the three layers
   float eps;
   int64_t rows;
   LnDropout drop[3];
@@ -405,7 +439,7 @@ __device__ __forceinline__ void copy_tile_out(const uint16_t* ys, int ld, uint16
     if (row0 + r < rows) *(u32x4*)(dst + (row0 + r) * N + p * 8) = *(const u32x4*)(ys + r * ld + p * 8);
   }
 }
-template <bool DROP>   // (inference instantiation: no dropout test per channel pair in the epilogues)
+template <bool DROP, bool TRAIN = false>   // (inference instantiation: no dropout test per channel pair in the epilogues)
 __global__ void __launch_bounds__(kThreads, 2)
 occ_mlp_fwd_kernel(OccMlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -439,6 +473,8 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
   e.red0 = red0;
   e.red1 = red1;
   e.y_global = nullptr;
+  e.z_global = nullptr;
+  e.stats_global = nullptr;
   e.head_out = a.out;
   e.head_b = a.head_b;
   e.rows = a.rows;
@@ -467,7 +503,9 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.y_lds = ys;
       e.ld_lds = kLd1;
       e.drop = a.drop[0];
-      layer_epilogue<2, true, DROP>(acc, e);
+      e.z_global = a.z_out[0];
+      e.stats_global = a.stats_out[0];
+      layer_epilogue<2, true, DROP, TRAIN>(acc, e);
     }
     __syncthreads();   // y0 complete
     if (a.y_out[0]) copy_tile_out<kN0>(ys, kLd1, a.y_out[0], row0, a.rows);
@@ -479,7 +517,9 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.y_lds = ys;
       e.ld_lds = kLd2;
       e.drop = a.drop[1];
-      layer_epilogue<4, false, DROP>(acc, e);
+      e.z_global = a.z_out[1];
+      e.stats_global = a.stats_out[1];
+      layer_epilogue<4, false, DROP, TRAIN>(acc, e);
     }
     __syncthreads();   // y1 complete
     if (a.y_out[1]) copy_tile_out<kN1>(ys, kLd2, a.y_out[1], row0, a.rows);
@@ -491,7 +531,11 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.head_s = head_s;
       e.y_lds = nullptr;
       e.drop = a.drop[2];
-      layer_epilogue<4, false, DROP>(acc, e);   // ends with the head's barriers: every wave is past its reads of y1
+      e.z_global = a.z_out[2];
+      e.stats_global = a.stats_out[2];
+      e.y_global = TRAIN ? a.y2_out : nullptr;
+      layer_epilogue<4, false, DROP, TRAIN>(acc, e);   // ends with the head's barriers: every wave is past its reads of y1
+      e.y_global = nullptr;
     }
   }
 }
@@ -715,6 +759,11 @@ extern "C" int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const fl
   a.out = out;
   a.y_out[0] = y0_out;
   a.y_out[1] = y1_out;
+  a.y2_out = nullptr;
+  for (int l = 0; l < 3; ++l) {
+    a.z_out[l] = nullptr;
+    a.stats_out[l] = nullptr;
+  }
   a.eps = eps;
   a.rows = rows;
   const int64_t tiles = ococc_cdiv(rows, TM);
@@ -725,6 +774,58 @@ extern "C" int ococc_occ_mlp_fwd_bf16(const uint16_t* pe, int64_t rows, const fl
   } else {
     OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
     hipLaunchKernelGGL(occ_mlp_fwd_kernel<false>, dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
+  }
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+// The same launch for a training step: besides the logits it leaves what the backward pass reads -- per layer the
+// LayerNorm input z (bf16), its row statistics and the activation y (bf16, after GELU and dropout).
+extern "C" int ococc_occ_mlp_train_fwd_bf16(const uint16_t* pe, int64_t rows, const float* add_rows, const int32_t* add_index,
+                                            const void* const* w_frag, const void* const* ln_weight,
+                                            const void* const* ln_bias, float eps, const float* head_weight,
+                                            const float* head_bias, uint32_t drop_threshold, const uint64_t* dropout_seeds,
+                                            void* const* z_out, void* const* y_out, void* const* stats_out, float* out,
+                                            ococc_stream_t stream) {
+  OCOCC_REQUIRE(rows >= 0 && drop_threshold < 65536u && (drop_threshold == 0 || dropout_seeds), "bad arguments");
+  if (rows == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(pe && add_rows && add_index && w_frag && ln_weight && ln_bias && head_weight && out && z_out && y_out &&
+                    stats_out, "null pointer");
+  OccMlpArgs a;
+  uintptr_t align = (uintptr_t)pe | (uintptr_t)add_rows | (uintptr_t)head_weight;
+  for (int l = 0; l < 3; ++l) {
+    OCOCC_REQUIRE(w_frag[l] && ln_weight[l] && ln_bias[l] && z_out[l] && y_out[l] && stats_out[l], "null pointer");
+    a.w[l] = (const uint16_t*)w_frag[l];
+    a.ln_w[l] = (const float*)ln_weight[l];
+    a.ln_b[l] = (const float*)ln_bias[l];
+    a.z_out[l] = (uint16_t*)z_out[l];
+    a.stats_out[l] = (float*)stats_out[l];
+    align |= (uintptr_t)w_frag[l] | (uintptr_t)ln_weight[l] | (uintptr_t)ln_bias[l] | (uintptr_t)z_out[l] | (uintptr_t)y_out[l];
+    a.drop[l].thr = drop_threshold;
+    a.drop[l].scale = drop_threshold ? 65536.f / (65536.f - (float)drop_threshold) : 1.f;
+    a.drop[l].seed_lo = drop_threshold ? (uint32_t)dropout_seeds[l] : 0u;
+    a.drop[l].seed_hi = drop_threshold ? (uint32_t)(dropout_seeds[l] >> 32) : 0u;
+  }
+  OCOCC_REQUIRE((align & 15) == 0, "pointers must be 16-byte aligned");
+  a.pe = pe;
+  a.add = add_rows;
+  a.add_idx = add_index;
+  a.head_w = head_weight;
+  a.head_b = head_bias;
+  a.out = out;
+  a.y_out[0] = (uint16_t*)y_out[0];
+  a.y_out[1] = (uint16_t*)y_out[1];
+  a.y2_out = (uint16_t*)y_out[2];
+  a.eps = eps;
+  a.rows = rows;
+  const int64_t tiles = ococc_cdiv(rows, TM);
+  const unsigned grid = (unsigned)(tiles < cu_count() ? tiles : cu_count());
+  if (drop_threshold) {
+    OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(occ_mlp_fwd_kernel<true, true>), dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
+  } else {
+    OCOCC_HIP(hipFuncSetAttribute((const void*)occ_mlp_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOccMlpLds));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(occ_mlp_fwd_kernel<false, true>), dim3(grid), dim3(kThreads), kOccMlpLds, (hipStream_t)stream, a);
   }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;

@@ -141,3 +141,84 @@ class DecoderWeights(object):
             self.frags = linear_fragments32([w.detach() for w in weights], pads)
             self._key = key
         return self.frags
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training: the forward is the same single launch (ococc_occ_mlp_train_fwd_bf16 also leaves z, the row statistics and
+# y of every layer), the backward is the chain the separate operators ran -- LayerNorm backward kernels with the
+# dropout masks regenerated from (threshold, seed), library GEMMs for dX and dW -- issued from one autograd node.
+class _OccMlpTrain(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, pe, roi_part, idx, w_pe, w1, w2, g0, b0, g1, b1, g2, b2, head_w, head_b, eps, drop_threshold, seeds,
+                cache):
+        """pe bf16 [M, 64] (no gradient), roi_part f32 [K, 512], idx int32 [M] non-decreasing, w_pe [512, pe columns],
+        w1 [1024, 512], w2 [1024, 1024] f32 parameters (views allowed), LayerNorm parameters, head_w [1, 1024], head_b [1]."""
+        from ..norm import layernorm_act_backward  # noqa: F401 (imported here: norm imports nothing from this module)
+        M, dev = pe.size(0), pe.device
+        frags = cache.get([w_pe, w1, w2], [pe.shape[1], w1.shape[1], w2.shape[1]])
+        f32 = lambda t: t.detach().float().contiguous()
+        gs, bs = [f32(g0), f32(g1), f32(g2)], [f32(b0), f32(b1), f32(b2)]
+        add = f32(roi_part)
+        hw, hb = f32(head_w).view(-1), f32(head_b).view(-1)
+        widths = OCC_MLP_WIDTHS[1:]
+        zs = [torch.empty((M, n), dtype=torch.bfloat16, device=dev) for n in widths]
+        ys = [torch.empty((M, n), dtype=torch.bfloat16, device=dev) for n in widths]
+        stats = [torch.empty((M, 2), dtype=torch.float32, device=dev) for _ in widths]
+        out = torch.empty((M,), dtype=torch.float32, device=dev)
+        sd = (ctypes.c_uint64 * 3)(*[int(v) for v in seeds]) if drop_threshold else None
+        flops = 2.0 * M * sum(OCC_MLP_WIDTHS[i + 1] * OCC_MLP_WIDTHS[i] for i in range(3))
+        _run('occ_mlp_fwd_kernel (training)', flops, lambda: L.check(L.lib.ococc_occ_mlp_train_fwd_bf16(
+            L.ptr(pe), M, L.ptr(add), L.ptr(idx), _vp([w.data_ptr() for w in frags]), _vp([g.data_ptr() for g in gs]),
+            _vp([b.data_ptr() for b in bs]), float(eps), L.ptr(hw), L.ptr(hb), int(drop_threshold), sd,
+            _vp([z.data_ptr() for z in zs]), _vp([y.data_ptr() for y in ys]), _vp([t.data_ptr() for t in stats]), L.ptr(out),
+            L.stream()), 'occ_mlp_train_fwd'))
+        ctx.save_for_backward(pe, idx, w_pe, w1, w2, head_w, *gs, *bs, *zs, *ys, *stats)
+        ctx.ln_params = ((g0, b0), (g1, b1), (g2, b2))
+        ctx.misc = (float(eps), int(drop_threshold), tuple(int(v) for v in seeds), roi_part.size(0))
+        return out.view(M, 1)
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        from ..linear import sliced_wgrad
+        from ..norm import layernorm_act_backward
+        t = ctx.saved_tensors
+        pe, idx, w_pe, w1, w2, head_w = t[:6]
+        gs, bs, zs, ys, stats = t[6:9], t[9:12], t[12:15], t[15:18], t[18:21]
+        eps, thr, seeds, K = ctx.misc
+        M, dev = pe.size(0), pe.device
+        bf = torch.bfloat16
+        d = dlogit.reshape(M, 1).to(bf)
+        # head: logit = y2 . w_head + b_head
+        d_head_w = (d.t() @ ys[2]).float().to(head_w.dtype)
+        d_head_b = dlogit.sum().reshape(1)
+        dy = d @ head_w.detach().to(bf).view(1, -1)                                  # [M, 1024]
+        weights = (w_pe, w1, w2)
+        grads_ln, dws = [None] * 6, [None] * 3
+        dz0 = None
+        for l in (2, 1, 0):
+            dz = torch.empty_like(zs[l])
+            lw, lb = ctx.ln_params[l]
+            dg, db = layernorm_act_backward(zs[l], dy.contiguous(), gs[l], bs[l], stats[l], 1, dz, lw, lb,
+                                            drop=(thr, seeds[l]) if thr else (0, 0))
+            grads_ln[2 * l], grads_ln[2 * l + 1] = (None if dg is None else dg.to(lw.dtype)), (None if db is None else db.to(lb.dtype))
+            if l > 0:
+                dws[l] = (dz.t() @ ys[l - 1]).float().to(weights[l].dtype)           # [n_l, n_{l-1}]
+                dy = dz @ weights[l].detach().to(bf)                                 # [M, n_{l-1}]
+            else:
+                dz0 = dz.float()
+        # first layer: z0 = pe W_pe^T + roi_part[idx]
+        pe32 = pe[:, :w_pe.shape[1]].float()
+        dws[0] = sliced_wgrad(dz0, pe32).to(w_pe.dtype)
+        d_roi = torch.empty((K, dz0.shape[1]), dtype=torch.float32, device=dev)
+        L.check(L.lib.ococc_segment_reduce_f32(L.ptr(dz0), L.ptr(idx), M, dz0.shape[1], 0, None, L.ptr(d_roi), None, K,
+                                               L.stream()), 'occ_mlp_train_bwd: roi_part')
+        return (None, d_roi, None, dws[0], dws[1], dws[2], grads_ln[0], grads_ln[1], grads_ln[2], grads_ln[3], grads_ln[4],
+                grads_ln[5], d_head_w, d_head_b, None, None, None, None)
+
+
+def occ_mlp_train(pe, roi_part, idx, w_pe, w1, w2, ln_weights, ln_biases, eps, head_w, head_b, drop_threshold, seeds, cache):
+    """logits f32 [M, 1] with a backward pass; see _OccMlpTrain."""
+    assert pe.dtype == torch.bfloat16 and pe.shape[1] == OCC_MLP_WIDTHS[0] and idx.dtype == torch.int32
+    return _OccMlpTrain.apply(pe, roi_part, idx, w_pe, w1, w2, ln_weights[0], ln_biases[0], ln_weights[1], ln_biases[1],
+                              ln_weights[2], ln_biases[2], head_w, head_b, eps, drop_threshold, seeds, cache)

@@ -10,6 +10,8 @@ so   W0 . cat(LN(f_roi), pe)  =  W_roi . LN(f_roi)  (once per RoI)  +  W_pe . pe
 the 400 MB repeated tensor and 96 % of the first layer's FLOPs disappear; the sum is
 mathematically identical (fp32 rounding differs in the last bits).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -23,6 +25,7 @@ from . import occ_ops
 
 
 FUSED_WHOLE_MLP = True   # ... and in ONE launch when the widths are the reference's 60 -> 512 -> 1024 -> 1024 -> 1
+FUSED_TRAIN_MLP = os.environ.get('OCOCC_FUSED_TRAIN_MLP', '1') == '1'   # ... and the bf16 TRAINING forward on that launch too (fused_mlp.occ_mlp_train)
 FUSED_MLP = True   # bf16 inference of OccDecoder on the per-layer kernels of occ/fused_mlp.py (False: library GEMMs + LN kernels)
 
 
@@ -133,6 +136,39 @@ class OccDecoder(nn.Module):
                                   head_bias=head.bias if last else None, want_y=not last)
         return out.view(-1, 1)
 
+    def _forward_fused_train(self, roi_features, smp_xyzs, pts_roi_inds):
+        """Training form on the whole-MLP kernel (fused_mlp.occ_mlp_train): one launch forward, which also leaves what the
+        backward chain reads.  None when the MLP is not the shape that kernel takes."""
+        from . import fused_mlp as fm
+        fused = self._fused_layers()
+        if fused is None:
+            return None
+        layers, head = fused
+        D = self.roi_feature_channels
+        lin0 = layers[0][0]
+        pe_cols = lin0.in_features - D
+        widths = (fm.pad64(pe_cols),) + tuple(l.out_features for l, _ in layers)
+        if not (len(layers) == 3 and widths == fm.OCC_MLP_WIDTHS and all(l.bias is None for l, _ in layers)
+                and len({ln.eps for _, ln in layers}) == 1 and head.bias is not None
+                and all(p.dtype == torch.float32 for l, ln in layers for p in (l.weight, ln.weight, ln.bias))):
+            return None
+        ps = {float(ln.fused_dropout) if self.training else 0.0 for _, ln in layers}
+        if len(ps) != 1:
+            return None
+        p = ps.pop()
+        thr = int(round(p * 65536)) if p > 0 else 0
+        # (CPU generator: reproducible under manual_seed, no device synchronisation -- as norm.layer_norm_act draws its seed)
+        seeds = [int(v) for v in torch.randint(0, 2 ** 62, (3,)).tolist()] if thr else (0, 0, 0)
+        if not hasattr(self, '_train_weights'):
+            self._train_weights = fm.DecoderWeights()
+        roi_part = torch.mm(self._ln(roi_features).float(), lin0.weight[:, :D].t())           # [K, 512] f32, once per RoI
+        bound = self.pos_encode.norm_bound if self.pos_encode.use_norm else None
+        pe = fm.pos_encode_bf16(smp_xyzs, self.pos_encode.L, bound)
+        idx = pts_roi_inds if pts_roi_inds.dtype == torch.int32 else pts_roi_inds.to(torch.int32)
+        return fm.occ_mlp_train(pe, roi_part, idx.contiguous(), lin0.weight[:, D:], layers[1][0].weight, layers[2][0].weight,
+                                [ln.weight for _, ln in layers], [ln.bias for _, ln in layers], layers[0][1].eps,
+                                head.weight, head.bias, thr, seeds, self._train_weights)
+
     def forward(self, roi_features, smp_xyzs, pts_roi_inds):
         """roi_features [K,D], smp_xyzs [N,3], pts_roi_inds [N] in [0,K) -> logits [N, cls_dim]
         (occ_base.py:100-118), first layer factorised as described in the module docstring."""
@@ -143,6 +179,11 @@ class OccDecoder(nn.Module):
             fused = self._fused_layers()
             if fused is not None and not (self.training and any(ln.fused_dropout for _, ln in fused[0])):
                 return self._forward_fused(fused[0], fused[1], roi_features, smp_xyzs, pts_roi_inds)
+        if (self.compute_dtype == torch.bfloat16 and FUSED_MLP and FUSED_TRAIN_MLP and smp_xyzs.is_cuda
+                and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
+            out = self._forward_fused_train(roi_features, smp_xyzs, pts_roi_inds)
+            if out is not None:
+                return out
         first = self.conv_occ[0]
         lin = first[0] if isinstance(first, nn.Sequential) else first
         D = self.roi_feature_channels

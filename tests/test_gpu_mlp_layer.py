@@ -213,3 +213,72 @@ def test_whole_mlp_launch_is_the_three_layer_launches(dev, rows, drop):
     assert torch.equal(y0, e0) and torch.equal(y1, e1) and torch.equal(out, eo) and torch.equal(out_only, eo)
     if drop:
         assert 0.08 < float((y1 == 0).float().mean()) < 0.12
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_fused_decoder_training_step(dev, golden_dir, dropout, monkeypatch):
+    """OccDecoder's bf16 TRAINING forward on the one-launch kernel (fused_mlp.occ_mlp_train: it also leaves z, the row
+    statistics and y of every layer for the backward chain) against the operator-by-operator bf16 path it replaces:
+    logits, the gradient of the RoI features and every parameter gradient.  With dropout both paths are given the same
+    seeds (the masks are a function of (seed, row, channel pair) in both)."""
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    from objectcentricocccompletion_amd.occ import occ_base
+    from objectcentricocccompletion_amd.occ.occ_base import OccDecoder
+    gold = np.load(os.path.join(golden_dir, 'ococc_head.npz'))
+    P = decoder_params()
+    feats = torch.from_numpy(gold['out_fused_roi_feats']).to(dev)
+    xyz = torch.from_numpy(gold['dec_xyz'])
+    R, K, _ = xyz.shape
+    idx = torch.arange(R).repeat_interleave(K).to(dev)
+    xyz = xyz.reshape(-1, 3).to(dev)
+    g = torch.Generator().manual_seed(5)
+    dl = torch.randn(R * K, 1, generator=g).to(dev)
+    real_randint = torch.randint
+
+    def fixed_randint(*a, **k):   # every seed drawn while the decoder runs is 12345 (shape as asked for)
+        return torch.full_like(real_randint(*a, **k), 12345)
+
+    runs, calls = [], []
+
+    class Probe:
+        def wrap(self, name, flops, launch):
+            calls.append(name)
+            launch()
+
+    for fused in (True, False, None):   # None: the f32 decoder (dropout off only: torch's mask is another one)
+        if fused is None and dropout:
+            continue
+        dec = OccDecoder(1536, [512, 1024, 1024], pos_encode_L=10, norm_cfg=dict(type='LN', eps=1e-3), act='gelu',
+                         occ_dropout=dropout, use_ln=True)
+        dec.load_state_dict({k[len(PREFIX):]: v for k, v in P.items()})
+        dec = dec.to(dev).train()
+        dec.compute_dtype = torch.bfloat16 if fused is not None else None
+        monkeypatch.setattr(occ_base, 'FUSED_TRAIN_MLP', bool(fused))
+        monkeypatch.setattr(torch, 'randint', fixed_randint)
+        fm.set_probe(Probe())
+        try:
+            f = feats.clone().requires_grad_(True)
+            out = dec(f, xyz, idx)
+            out.backward(dl)
+        finally:
+            fm.set_probe(None)
+            monkeypatch.setattr(torch, 'randint', real_randint)
+        runs.append((out.detach().float(), f.grad.clone(), {k: v.grad.clone() for k, v in dec.named_parameters()}))
+    assert calls == ['occ_mlp_fwd_kernel (training)']
+    a, b = runs[0], runs[1]
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp(min=1e-30))
+    # (the operator path runs the first layer's GEMM in f32 and rounds z to bf16 afterwards; here its operands are bf16)
+    errs = {'logits': rel(a[0], b[0]), 'd roi feats': rel(a[1], b[1]), **{k: rel(a[2][k], b[2][k]) for k in a[2]}}
+    print('fused training step vs operator path (norm-wise):', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert errs['logits'] < 1e-2 and errs['d roi feats'] < 3e-2
+    for k in a[2]:
+        assert errs[k] < 3e-2, k
+    if len(runs) == 3:   # both bf16 realisations are equally far from the f32 decoder (two roundings of the same thing)
+        c = runs[2]
+        for name, i in (('logits', 0), ('d roi feats', 1)):
+            ea, eb = rel(a[i], c[i]), rel(b[i], c[i])
+            print(f'{name}: fused vs f32 {ea:.2e}, operator bf16 path vs f32 {eb:.2e}')
+            assert ea < 1.5 * eb + 2e-3, (name, ea, eb)
+        for k in a[2]:
+            ea, eb = rel(a[2][k], c[2][k]), rel(b[2][k], c[2][k])
+            assert ea < 1.5 * eb + 2e-3, (k, ea, eb)
