@@ -213,3 +213,54 @@ def test_graphed_head_tail_equals_eager(dev):
     for k in range(3):
         for x, y in zip(outs[0][k], outs[1][k]):
             assert rel(x, y) < 1e-4, k
+
+
+def test_training_step_host_fast_paths_equal_plain_paths(dev, monkeypatch):
+    """One whole configs[2] training step (train mode, every dropout probability set to zero so that both runs are
+    deterministic) with the round-3 host-side machinery on -- SIR layers as one library call per direction with their own
+    weight-gradient kernel and queued parameter sums, the temporal transformer and the head's tail replayed as graph
+    pairs -- against the same step with all of it off (per-block autograd nodes sequenced from Python, library GEMMs for
+    the weight gradients, eager launches): the same losses, the same gradients."""
+    import copy
+    from objectcentricocccompletion_amd import heads, point_mlp, point_pool, roi_head, sir  # noqa: F401
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
+    cfg = ococcnet_model_cfg()
+    cfg['train_cfg']['random_shift_frame_inds'] = False
+    bh = cfg['roi_head']['bbox_head']
+    for k in ('attn_dropout', 'cls_dropout', 'reg_dropout', 'latent_dropout', 'fusion_dropout', 'dropout'):
+        bh[k] = 0
+    bh['occ_ae_head']['occ_decoder']['occ_dropout'] = 0
+    torch.manual_seed(0)
+    fast = DETECTORS.build(cfg).to(dev).train()
+    plain = copy.deepcopy(fast)
+    batch = synthetic_training_batch(2, 32, pts_per_frame=48, occ_queries=128, seed=3, device=dev)
+
+    def run(model):
+        outs = None
+        for _ in range(2):   # (the second step replays what the first captured)
+            model.zero_grad(set_to_none=True)
+            losses = model(return_loss=True, **batch)
+            total = losses['loss_rcnn_cls'] + losses['loss_rcnn_bbox'] + losses['loss_rcnn_occ'].mean()
+            total.backward()
+            outs = ({k: v.detach().float().mean().item() for k, v in losses.items()},
+                    {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        return outs
+
+    a = run(fast)
+    assert fast.roi_head.bbox_head in heads._graphed_encoders and fast.roi_head.bbox_head.trans_enc in heads._graphed_encoders
+    for mod, name in ((sir, 'NATIVE_LAYER'), (sir, 'WHOLE_LAYER_NODE'), (point_mlp, 'WGRAD_KERNEL'), (heads, 'GRAPH_TRANSFORMER')):
+        monkeypatch.setattr(mod, name, False)
+    b = run(plain)
+    assert plain.roi_head.bbox_head not in heads._graphed_encoders
+    for k in b[0]:
+        assert abs(a[0][k] - b[0][k]) <= 1e-5 * max(1.0, abs(b[0][k])), (k, a[0][k], b[0][k])
+    assert set(a[1]) == set(b[1])
+    worst = 0.0
+    for k in b[1]:
+        ref = float(b[1][k].abs().max())
+        err = float((a[1][k] - b[1][k]).abs().max())
+        worst = max(worst, err / max(ref, 1e-12))
+        assert err <= 2e-4 * max(ref, 1e-9), (k, err, ref)
+    print('largest gradient deviation (relative to the tensor\'s largest entry):', worst)
