@@ -129,6 +129,7 @@ SIGNATURES = {
                                         c_i64, c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_point_mlp_segment_argmax': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp]),
     'ococc_point_mlp_wgrad_slices': (c_i32, [c_i64]),
+    'ococc_point_mlp_force_tile': (c_i32, [c_i32]),
     'ococc_sir_layer_fwd_floats': (c_i64, [c_vp, c_i64, c_i64]),
     'ococc_sir_layer_fwd_f32': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sir_layer_bwd_layout': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),

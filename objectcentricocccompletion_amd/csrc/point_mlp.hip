@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int TR = 64;          // rows per tile
+constexpr int TR = 64;          // rows per tile (MB = 4 row blocks of 16); small inputs run 32-row tiles (MB = 2), see tile_mb()
 constexpr int kT = 256;         // threads
 constexpr int kMaxK = 256, kMaxN = 144;
 
@@ -53,18 +53,20 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {   // dest
 __host__ __device__ constexpr int pad_k(int k) { return (k + 31) & ~31; }
 __host__ __device__ constexpr int pad_n(int n) { return (n + 15) & ~15; }
 
-// x tile -> LDS.  Wave w builds rows 16 w .. 16 w + 15; the 64 lanes of a wave read consecutive columns of one row
+// x tile -> LDS.  Wave w builds rows RW w .. RW w + RW - 1 (RW = a quarter of the tile); the 64 lanes of a wave read consecutive columns of one row
 // (coalesced).  A lane's columns (lane, lane + 64, ...) keep their source for all rows, so the source pointers are
 // worked out once and the row loop is branch-free straight-line code: the loads of four rows are in flight together.
-// inv of the wave's rows sits in lanes 0..15 and is handed out by shuffles.
+// inv of the wave's rows sits in lanes 0..RW-1 and is handed out by shuffles.
+template <int MB>
 __device__ __forceinline__ void assemble(const PointMlpIn& in, int64_t row0, int kp, int ld, float* xs, int* inv_s) {
+  constexpr int RW = 4 * MB;   // rows a wave builds
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = in.ka + in.kb + in.kv, kab = in.ka + in.kb;
   int my_inv = 0;
-  if (in.inv && lane < 16) {
-    const int64_t row = row0 + 16 * wave + lane;
+  if (in.inv && lane < RW) {
+    const int64_t row = row0 + RW * wave + lane;
     my_inv = row < in.rows ? in.inv[row] : -1;
-    inv_s[16 * wave + lane] = my_inv;
+    inv_s[RW * wave + lane] = my_inv;
   }
   const float* src[4];     // element (row or segment) 0 of the lane's column in chunk j; a valid address even when unused
   const float* gate[4];
@@ -99,8 +101,8 @@ __device__ __forceinline__ void assemble(const PointMlpIn& in, int64_t row0, int
   }
   const bool gated = in.mul != nullptr;
 #pragma unroll 4
-  for (int rr = 0; rr < 16; ++rr) {
-    const int r = 16 * wave + rr;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int r = RW * wave + rr;
     const int64_t row = row0 + r;
     const bool ok = row < in.rows;
     const int64_t rc = ok ? row : 0;
@@ -117,13 +119,14 @@ __device__ __forceinline__ void assemble(const PointMlpIn& in, int64_t row0, int
   }
 }
 
-// rows of an LDS tile -> rows of a global [rows, width] tensor, a wave per 16 rows, lanes along the columns
+// rows of an LDS tile -> rows of a global [rows, width] tensor, a wave per quarter of the tile, lanes along the columns
+template <int MB>
 __device__ __forceinline__ void store_rows(const float* ts, int ld, float* __restrict__ dst, int width, int64_t row0,
                                            int64_t rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll 4
-  for (int rr = 0; rr < 16; ++rr) {
-    const int r = 16 * wave + rr;
+  for (int rr = 0; rr < 4 * MB; ++rr) {
+    const int r = 4 * MB * wave + rr;
     if (row0 + r < rows)
       for (int col = lane; col < width; col += 64) dst[(row0 + r) * width + col] = ts[r * ld + col];
   }
@@ -148,9 +151,9 @@ __device__ __forceinline__ void frag_wait() {
 }
 __device__ __forceinline__ void frag_tie(float& v) { asm volatile("" : "+v"(v)); }
 
-template <int NBW>
+template <int NBW, int MB>
 __device__ __forceinline__ void gemm_f32(const float* __restrict__ wf, int nb0, int nblocks, int ksteps, const float* xs,
-                                         int ld, f32x4 (&acc)[NBW][4]) {
+                                         int ld, f32x4 (&acc)[NBW][MB]) {
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const float* wp[NBW];
 #pragma unroll
@@ -174,13 +177,13 @@ __device__ __forceinline__ void gemm_f32(const float* __restrict__ wf, int nb0, 
   auto compute = [&](const float (&a)[NBW][8], int ks0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float b[4];
+      float b[MB];
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) b[mb] = xb[mb * 16 * ld + 4 * (ks0 + j)];
+      for (int mb = 0; mb < MB; ++mb) b[mb] = xb[mb * 16 * ld + 4 * (ks0 + j)];
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][j], b[mb], acc[nb][mb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nb][j], b[mb], acc[nb][mb], 0, 0, 0);
     }
   };
   issue(a0, 0);
@@ -198,21 +201,23 @@ __device__ __forceinline__ void gemm_f32(const float* __restrict__ wf, int nb0, 
   landed(a0);
 }
 
-// sum over the channels of each of the lane's 4 rows (row mb*16 + c), across lanes and waves; one barrier
-__device__ __forceinline__ void row_sums(float (&part)[4], float* red) {
+// sum over the channels of each of the lane's MB rows (row mb*16 + c), across lanes and waves; one barrier
+template <int MB>
+__device__ __forceinline__ void row_sums(float (&part)[MB], float* red) {
+  constexpr int TRM = 16 * MB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MB; ++mb) {
     float p = part[mb];
     p += __shfl_xor(p, 16, 64);
     p += __shfl_xor(p, 32, 64);
-    if (g == 0) red[wave * TR + mb * 16 + c] = p;
+    if (g == 0) red[wave * TRM + mb * 16 + c] = p;
   }
   __syncthreads();
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MB; ++mb) {
     const int t = mb * 16 + c;
-    part[mb] = (red[t] + red[TR + t]) + (red[2 * TR + t] + red[3 * TR + t]);
+    part[mb] = (red[t] + red[TRM + t]) + (red[2 * TRM + t] + red[3 * TRM + t]);
   }
 }
 
@@ -233,12 +238,12 @@ struct Slice {   // the wave's channel blocks and which of the lane's channels a
 };
 
 // z -> xhat (LayerNorm statistics over the n real channels, two passes), rstd per row block
-template <int NBW>
-__device__ __forceinline__ void layernorm_rows(f32x4 (&z)[NBW][4], const Slice<NBW>& sl, int n, float eps, float* red0,
-                                               float* red1, float (&rstd)[4]) {
-  float s[4], q[4];
+template <int NBW, int MB>
+__device__ __forceinline__ void layernorm_rows(f32x4 (&z)[NBW][MB], const Slice<NBW>& sl, int n, float eps, float* red0,
+                                               float* red1, float (&rstd)[MB]) {
+  float s[MB], q[MB];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MB; ++mb) {
     s[mb] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -248,7 +253,7 @@ __device__ __forceinline__ void layernorm_rows(f32x4 (&z)[NBW][4], const Slice<N
   row_sums(s, red0);
   const float inv_n = 1.f / (float)n;
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MB; ++mb) {
     const float mean = s[mb] * inv_n;
     q[mb] = 0.f;
 #pragma unroll
@@ -261,7 +266,7 @@ __device__ __forceinline__ void layernorm_rows(f32x4 (&z)[NBW][4], const Slice<N
   }
   row_sums(q, red1);
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
+  for (int mb = 0; mb < MB; ++mb) {
     rstd[mb] = rsqrtf(q[mb] * inv_n + eps);
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
@@ -283,35 +288,36 @@ __device__ __forceinline__ float act_g(int act, float v) {
   return act == 1 ? ln_gelu_grad2(ln_f32x2{v, v}).x : (act == 2 ? (v > 0.f ? 1.f : 0.f) : 1.f);
 }
 
-// one LDS tile [64][max(kp, np) + 2] used in turn for x, y / dz and dx, + the LayerNorm exchange + inv
-__host__ __device__ constexpr int lds_floats(int kp, int np) { return TR * ((kp > np ? kp : np) + 2) + 2 * 4 * TR + TR; }
+// one LDS tile [tile rows][max(kp, np) + 2] used in turn for x, y / dz and dx, + the LayerNorm exchange + inv
+__host__ __device__ constexpr int lds_floats(int kp, int np, int tr) { return tr * ((kp > np ? kp : np) + 2) + 2 * 4 * tr + tr; }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NBW>
+template <int NBW, int MB>
 __global__ void __launch_bounds__(kT, 2)
 point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const float* __restrict__ ln_w,
                      const float* __restrict__ ln_b, float eps, int act, float* __restrict__ y, float* __restrict__ vmax) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int k = in.ka + in.kb + in.kv, kp = pad_k(k), np = pad_k(n), ld = (kp > np ? kp : np) + 2;
+  constexpr int TRM = 16 * MB;       // rows of this instantiation's tile
   float* xs = smem_f;                // x, then y
-  float* red0 = xs + TR * ld;
-  float* red1 = red0 + 4 * TR;
-  int* inv_s = (int*)(red1 + 4 * TR);
+  float* red0 = xs + TRM * ld;
+  float* red1 = red0 + 4 * TRM;
+  int* inv_s = (int*)(red1 + 4 * TRM);
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TR;
-  assemble(in, row0, kp, ld, xs, inv_s);
+  const int64_t row0 = (int64_t)blockIdx.x * TRM;
+  assemble<MB>(in, row0, kp, ld, xs, inv_s);
   __syncthreads();
   const Slice<NBW> sl(n);
-  f32x4 z[NBW][4];
+  f32x4 z[NBW][MB];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<NBW>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
+    for (int mb = 0; mb < MB; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_f32<NBW, MB>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
   __syncthreads();   // x has been read by every wave: the tile now receives y
   if (ln_w) {
-    float rstd[4];
-    layernorm_rows<NBW>(z, sl, n, eps, red0, red1, rstd);
+    float rstd[MB];
+    layernorm_rows<NBW, MB>(z, sl, n, eps, red0, red1, rstd);
   }
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
@@ -326,7 +332,7 @@ point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const f
             bt[r] = ln_b[ch + r];
           }
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
+      for (int mb = 0; mb < MB; ++mb) {
         const f32x4 pre = z[nb][mb] * gm + bt;
         const f32x4 o = act == 1 ? act_f4<1>(pre) : (act == 2 ? act_f4<2>(pre) : pre);
 #pragma unroll
@@ -335,12 +341,12 @@ point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const f
     }
   }
   __syncthreads();
-  store_rows(xs, ld, y, n, row0, in.rows);
+  store_rows<MB>(xs, ld, y, n, row0, in.rows);
   if (vmax && threadIdx.x < n) {   // segment maxima: one thread per channel walks the tile's rows
     int cur = -1;
     float acc = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < TR; ++r) {
+    for (int r = 0; r < TRM; ++r) {
       const int seg = inv_s[r];
       const float v = xs[r * ld + threadIdx.x];
       if (seg != cur) {
@@ -360,7 +366,7 @@ point_mlp_fwd_kernel(PointMlpIn in, const float* __restrict__ wf, int n, const f
 // null).  Writes dz [rows, n] (gradient at the Linear's output), xcat [rows, k] (the assembled input, for dW = dz^T xcat;
 // may be null), da / dmul [rows, ka], db [rows, kb] (each may be null), adds into dv [segments, kv] (zeroed by the caller)
 // and leaves one row [dgamma(n) | dbeta(n)] of LayerNorm partial sums per tile.
-template <int NBW, int KBW>
+template <int NBW, int KBW, int MB>
 __global__ void __launch_bounds__(kT, 2)
 point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* __restrict__ wtf, int n,
                      const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int act,
@@ -369,38 +375,43 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
                      float* __restrict__ db, float* __restrict__ dv, float* __restrict__ ln_partial) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int k = in.ka + in.kb + in.kv, kp = pad_k(k), np = pad_k(n), ld = (kp > np ? kp : np) + 2;
+  constexpr int TRM = 16 * MB;
   float* xs = smem_f;              // x, then dz, then dx
-  float* red0 = xs + TR * ld;
-  float* red1 = red0 + 4 * TR;
-  int* inv_s = (int*)(red1 + 4 * TR);
+  float* red0 = xs + TRM * ld;
+  float* red1 = red0 + 4 * TRM;
+  int* inv_s = (int*)(red1 + 4 * TRM);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * TR;
-  assemble(in, row0, kp, ld, xs, inv_s);
+  const int64_t row0 = (int64_t)blockIdx.x * TRM;
+  assemble<MB>(in, row0, kp, ld, xs, inv_s);
   __syncthreads();
-  if (xcat) store_rows(xs, ld, xcat, k, row0, in.rows);
+  if (xcat) store_rows<MB>(xs, ld, xcat, k, row0, in.rows);
   const Slice<NBW> sl(n);
-  f32x4 z[NBW][4];
+  f32x4 z[NBW][MB];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<NBW>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
+    for (int mb = 0; mb < MB; ++mb) z[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_f32<NBW, MB>(wf, sl.nb0, (n + 15) >> 4, kp >> 2, xs, ld, z);
   __syncthreads();   // x has been read (GEMM, xcat copy): the tile now receives dz
-  float rstd[4] = {1.f, 1.f, 1.f, 1.f};
-  if (ln_w) layernorm_rows<NBW>(z, sl, n, eps, red0, red1, rstd);   // z = xhat
-  // d(pre-activation) = (dy + routed dvmax) * act'(pre), LayerNorm parameter sums, then the LayerNorm backward
-  f32x4 d[NBW][4];
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  int segs[4];
+  float rstd[MB];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) segs[mb] = inv_s[mb * 16 + c];
+  for (int mb = 0; mb < MB; ++mb) rstd[mb] = 1.f;
+  if (ln_w) layernorm_rows<NBW, MB>(z, sl, n, eps, red0, red1, rstd);   // z = xhat
+  // d(pre-activation) = (dy + routed dvmax) * act'(pre), LayerNorm parameter sums, then the LayerNorm backward
+  f32x4 d[NBW][MB];
+  float s1[MB], s2[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) s1[mb] = s2[mb] = 0.f;
+  int segs[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) segs[mb] = inv_s[mb * 16 + c];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) {
     const int ch = 16 * (sl.nb0 + nb) + 4 * g;
     // upstream gradients of the lane's 4 x 4 positions of this block, asked for together
-    f32x4 up[4];
+    f32x4 up[MB];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
       const int64_t row = row0 + mb * 16 + c;
       up[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (nb < sl.nbn && row < in.rows) {
@@ -419,7 +430,7 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
       const float gm = (ln_w && live) ? ln_w[ch + r] : 1.f, bt = (ln_w && live) ? ln_b[ch + r] : 0.f;
       float dg = 0.f, dbt = 0.f;
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
+      for (int mb = 0; mb < MB; ++mb) {
         const float xh = z[nb][mb][r];
         const float dpre = up[mb][r] * act_g(act, ln_w ? xh * gm + bt : xh);
         dg += dpre * xh;
@@ -443,20 +454,20 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
     }
   }
   if (ln_w) {
-    row_sums(s1, red0);
-    row_sums(s2, red1);
+    row_sums<MB>(s1, red0);
+    row_sums<MB>(s2, red1);
     const float inv_n = 1.f / (float)n;
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           d[nb][mb][r] = sl.live[nb][r] ? ((d[nb][mb][r] - s1[mb] * inv_n) - z[nb][mb][r] * (s2[mb] * inv_n)) * rstd[mb] : 0.f;
   }
   // dz -> LDS, zero up to pad_k(n) columns: the contraction of the second GEMM runs over that range
   const int nk = pad_k(n);
-  for (int i = threadIdx.x; i < TR * (nk - n); i += kT) {
+  for (int i = threadIdx.x; i < TRM * (nk - n); i += kT) {
     const int r = i / (nk - n), col = n + i % (nk - n);
     xs[r * ld + col] = 0.f;
   }
@@ -465,28 +476,28 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
     if (nb < sl.nbn) {
       const int ch = 16 * (sl.nb0 + nb) + 4 * g;
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (sl.live[nb][r]) xs[(mb * 16 + c) * ld + ch + r] = d[nb][mb][r];
     }
   }
   __syncthreads();
-  store_rows(xs, ld, dz_out, n, row0, in.rows);
+  store_rows<MB>(xs, ld, dz_out, n, row0, in.rows);
   // dx^T[kk][m] = sum_n W^T[kk][n] dz[m][n]: the wave's KBW blocks of 16 input channels
   const int kblocks = (k + 15) >> 4, kb0 = wave * KBW, kbn = max(0, min(KBW, kblocks - kb0));
-  f32x4 gx[KBW][4];
+  f32x4 gx[KBW][MB];
 #pragma unroll
   for (int nb = 0; nb < KBW; ++nb)
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) gx[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_f32<KBW>(wtf, kb0, kblocks, nk >> 2, xs, ld, gx);
+    for (int mb = 0; mb < MB; ++mb) gx[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_f32<KBW, MB>(wtf, kb0, kblocks, nk >> 2, xs, ld, gx);
   __syncthreads();   // dz has been read (GEMM, dz_out copy): the tile now receives dx
 #pragma unroll
   for (int nb = 0; nb < KBW; ++nb) {
     if (nb < kbn) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int col = 16 * (kb0 + nb) + 4 * g + r;
@@ -495,11 +506,11 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
     }
   }
   __syncthreads();
-  {   // gradients of the direct parts: a wave per 16 rows, lanes along the columns
+  {   // gradients of the direct parts: a wave per quarter of the tile, lanes along the columns
     const int kab = in.ka + in.kb;
 #pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-      const int r = 16 * wave + rr;
+    for (int rr = 0; rr < 4 * MB; ++rr) {
+      const int r = 4 * MB * wave + rr;
       const int64_t row = row0 + r;
       if (row >= in.rows) continue;
       for (int col = lane; col < kab; col += 64) {
@@ -519,7 +530,7 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
     int cur = -1;
     float acc = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < TR; ++r) {
+    for (int r = 0; r < TRM; ++r) {
       const int seg = inv_s[r];
       const float v = xs[r * ld + col];
       if (seg != cur) {
@@ -662,6 +673,19 @@ __global__ void __launch_bounds__(256) fill_kernel(float* p, int64_t count, floa
 
 inline int nbw_of(int n) { return (((n + 15) >> 4) + 3) / 4; }
 
+// Rows per tile.  A tile's work is one long dependent chain (assemble, GEMM, LayerNorm, ... ~40 us forward, ~85 us
+// backward at 64 rows), and configs[2]'s own batch (4 tracklets, 8-10 k points) is 128-160 tiles of 64 rows on 256
+// CUs.  32-row tiles -- twice the workgroups, half the chain, the weight fragments streamed once more per row from
+// L2 -- are faster over the whole range the fused layer is used in (whole configs[2] step, MI355X: 17.4 -> 16.0 ms at 4
+// tracklets = 8 k points, 28.9 -> 27.5 at 16, 46.7 -> 44.8 at 32, 84.6 -> 82.6 at 64 = 131 k points); beyond that
+// (not measured) the 64-row tile's halved weight traffic is kept.  g_force_tile: tests pin either form.
+int g_force_tile = 0;
+inline int tile_mb(int64_t rows) {
+  if (g_force_tile == 32) return 2;
+  if (g_force_tile == 64) return 4;
+  return ococc_cdiv(rows, TR) <= 2048 ? 2 : 4;
+}
+
 constexpr int kMaxDevices = 64;
 inline int current_device_slot() {
   int d = 0;
@@ -735,24 +759,33 @@ extern "C" int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, 
                        num_segments * n, -INFINITY);
   if (rows == 0) return OCOCC_OK;
   const int k = ka + kb + kv, kp = pad_k(k), np = pad_k(n);
-  const int lds = lds_floats(kp, np) * 4;
-  const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
+  const int mb = tile_mb(rows);
+  const int lds = lds_floats(kp, np, 16 * mb) * 4;
+  const unsigned grid = (unsigned)ococc_cdiv(rows, 16 * mb);
   const int dev = current_device_slot();
-#define OCOCC_PM_FWD(NBW)                                                                                             \
+#define OCOCC_PM_FWD(NBW, MB)                                                                                             \
   do {                                                                                                                \
     static int lds_set[kMaxDevices] = {};  /* (the attribute sticks: raised once per instantiation and device) */     \
     if (lds > lds_set[dev]) {                                                                                         \
-      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_fwd_kernel<NBW>,                                           \
+      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_fwd_kernel<NBW, MB>,                                        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                \
       lds_set[dev] = lds;                                                                                             \
     }                                                                                                                 \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_fwd_kernel<NBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_fwd_kernel<NBW, MB>), dim3(grid), dim3(kT), lds, stream, in, w_frag, \
                        (int)n, ln_weight, ln_bias, eps, (int)act, y, seg_max);                                        \
   } while (0)
-  switch (nbw_of(n)) {
-    case 1: OCOCC_PM_FWD(1); break;
-    case 2: OCOCC_PM_FWD(2); break;
-    default: OCOCC_PM_FWD(3); break;
+  if (mb == 2) {
+    switch (nbw_of(n)) {
+      case 1: OCOCC_PM_FWD(1, 2); break;
+      case 2: OCOCC_PM_FWD(2, 2); break;
+      default: OCOCC_PM_FWD(3, 2); break;
+    }
+  } else {
+    switch (nbw_of(n)) {
+      case 1: OCOCC_PM_FWD(1, 4); break;
+      case 2: OCOCC_PM_FWD(2, 4); break;
+      default: OCOCC_PM_FWD(3, 4); break;
+    }
   }
 #undef OCOCC_PM_FWD
   OCOCC_CHECK_LAUNCH();
@@ -774,34 +807,42 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
   OCOCC_REQUIRE(!ln_weight || ln_partial, "LayerNorm partial rows missing");
   if (rows == 0) return OCOCC_OK;
   const int k = ka + kb + kv, kp = pad_k(k), np = pad_k(n);
-  const int lds = lds_floats(kp, np) * 4;
-  const unsigned grid = (unsigned)ococc_cdiv(rows, TR);
+  const int mb = tile_mb(rows);
+  const int lds = lds_floats(kp, np, 16 * mb) * 4;
+  const unsigned grid = (unsigned)ococc_cdiv(rows, 16 * mb);
   const int kbw = (((k + 15) >> 4) + 3) / 4;
   const int dev = current_device_slot();
-#define OCOCC_PM_BWD(NBW, KBW)                                                                                            \
+#define OCOCC_PM_BWD(NBW, KBW, MB)                                                                                            \
   do {                                                                                                                    \
     static int lds_set[kMaxDevices] = {};                                                                                 \
     if (lds > lds_set[dev]) {                                                                                             \
-      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW>,                                          \
+      OCOCC_HIP(hipFuncSetAttribute((const void*)point_mlp_bwd_kernel<NBW, KBW, MB>,                                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                    \
       lds_set[dev] = lds;                                                                                                 \
     }                                                                                                                     \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_bwd_kernel<NBW, KBW>), dim3(grid), dim3(kT), lds, stream, in, w_frag,    \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_bwd_kernel<NBW, KBW, MB>), dim3(grid), dim3(kT), lds, stream, in, w_frag, \
                        wt_frag, (int)n, ln_weight, ln_bias, eps, (int)act, dy, d_seg_max, seg_arg, dz, x_cat, da, dmul,   \
                        db, dv, ln_partial);                                                                               \
   } while (0)
-#define OCOCC_PM_BWD_N(KBW)                     \
+#define OCOCC_PM_BWD_N(KBW, MB)                 \
   switch (nbw_of(n)) {                          \
-    case 1: OCOCC_PM_BWD(1, KBW); break;        \
-    case 2: OCOCC_PM_BWD(2, KBW); break;        \
-    default: OCOCC_PM_BWD(3, KBW); break;       \
+    case 1: OCOCC_PM_BWD(1, KBW, MB); break;    \
+    case 2: OCOCC_PM_BWD(2, KBW, MB); break;    \
+    default: OCOCC_PM_BWD(3, KBW, MB); break;   \
   }
-  switch (kbw) {
-    case 1: OCOCC_PM_BWD_N(1); break;
-    case 2: OCOCC_PM_BWD_N(2); break;
-    case 3: OCOCC_PM_BWD_N(3); break;
-    default: OCOCC_PM_BWD_N(4); break;
+#define OCOCC_PM_BWD_K(MB)                      \
+  switch (kbw) {                                \
+    case 1: OCOCC_PM_BWD_N(1, MB); break;       \
+    case 2: OCOCC_PM_BWD_N(2, MB); break;       \
+    case 3: OCOCC_PM_BWD_N(3, MB); break;       \
+    default: OCOCC_PM_BWD_N(4, MB); break;      \
   }
+  if (mb == 2) {
+    OCOCC_PM_BWD_K(2)
+  } else {
+    OCOCC_PM_BWD_K(4)
+  }
+#undef OCOCC_PM_BWD_K
 #undef OCOCC_PM_BWD_N
 #undef OCOCC_PM_BWD
   OCOCC_CHECK_LAUNCH();
@@ -827,7 +868,14 @@ extern "C" int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, in
   return OCOCC_OK;
 }
 
-extern "C" int64_t ococc_point_mlp_tiles(int64_t rows) { return rows < 0 ? -1 : ococc_cdiv(rows, TR); }
+extern "C" int64_t ococc_point_mlp_tiles(int64_t rows) { return rows < 0 ? -1 : ococc_cdiv(rows, 16 * tile_mb(rows)); }
+
+// tests: rows per tile pinned to 32 or 64 (0: by input size)
+extern "C" int ococc_point_mlp_force_tile(int32_t tile_rows) {
+  OCOCC_REQUIRE(tile_rows == 0 || tile_rows == 32 || tile_rows == 64, "0 (automatic), 32 or 64");
+  g_force_tile = tile_rows;
+  return OCOCC_OK;
+}
 
 extern "C" int ococc_point_mlp_segment_argmax(const float* y, const float* seg_max, const int32_t* inv, int64_t rows,
                                               int32_t n, int64_t num_segments, int32_t* seg_arg, ococc_stream_t stream_) {

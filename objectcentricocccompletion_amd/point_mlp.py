@@ -17,6 +17,9 @@ from .linear import TALL_ROWS, sliced_wgrad
 
 ACT = {None: 0, 'none': 0, 'gelu': 1, 'relu': 2}
 
+if os.environ.get('OCOCC_POINT_TILE'):   # 32 / 64: pin the rows per workgroup tile of the fwd / bwd launches (default: by input size)
+    L.check(L.lib.ococc_point_mlp_force_tile(int(os.environ['OCOCC_POINT_TILE'])), 'point_mlp_force_tile')
+
 
 _packed = {}   # (id of the parameter, transposed) -> (weak reference, version, storage pointer, fragments)
 

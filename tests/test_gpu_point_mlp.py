@@ -8,6 +8,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[32, 64], ids=['tile32', 'tile64'])
+def tile_rows(request):
+    """every test of this file runs with the fwd / bwd launches pinned to 32-row and to 64-row tiles (the library picks
+    by input size otherwise: small inputs, as these tests' are, would never reach the 64-row instantiations)"""
+    from objectcentricocccompletion_amd import _lib as L
+    L.check(L.lib.ococc_point_mlp_force_tile(request.param), 'force_tile')
+    yield request.param
+    L.check(L.lib.ococc_point_mlp_force_tile(0), 'force_tile')
+
+
 def _ref_layer(a, w, g, be, eps, act, mul, cs, b, bs, v, inv, G, seg_max):
     x = a
     if mul is not None:
