@@ -624,8 +624,8 @@ int ococc_partial_rows_sum_f32(int32_t count, const void* const* src, const int6
  * ------------------------------------------------------------------------ */
 int64_t ococc_point_mlp_fragment_floats(int32_t n, int32_t k);
 int64_t ococc_point_mlp_tiles(int64_t rows);
-/* rows per workgroup tile of the fwd / bwd launches: 0 = by input size (32 up to 131 k rows, else 64),
- * 32 or 64 pinned (tests); ococc_point_mlp_tiles follows. */
+/* rows per workgroup tile of the fwd / bwd launches: 0 = by input size (16 up to 4 k rows, 32 up to 131 k rows, else 64),
+ * 16, 32 or 64 pinned (tests); ococc_point_mlp_tiles follows. */
 int ococc_point_mlp_force_tile(int32_t tile_rows);
 int ococc_point_mlp_pack_f32(const float* w, int32_t n, int32_t k, int64_t row_stride, int64_t col_stride, float* frag,
                              ococc_stream_t stream);

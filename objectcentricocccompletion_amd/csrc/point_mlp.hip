@@ -678,11 +678,13 @@ inline int nbw_of(int n) { return (((n + 15) >> 4) + 3) / 4; }
 // CUs.  32-row tiles -- twice the workgroups, half the chain, the weight fragments streamed once more per row from
 // L2 -- are faster over the whole range the fused layer is used in (whole configs[2] step, MI355X: 17.4 -> 16.0 ms at 4
 // tracklets = 8 k points, 28.9 -> 27.5 at 16, 46.7 -> 44.8 at 32, 84.6 -> 82.6 at 64 = 131 k points); beyond that
-// (not measured) the 64-row tile's halved weight traffic is kept.  g_force_tile: tests pin either form.
+// (not measured) the 64-row tile's halved weight traffic is kept.  g_force_tile: tests pin any of the three forms.
 int g_force_tile = 0;
 inline int tile_mb(int64_t rows) {
+  if (g_force_tile == 16) return 1;
   if (g_force_tile == 32) return 2;
   if (g_force_tile == 64) return 4;
+  if (rows <= 4096) return 1;   // (one or two tracklets: 16-row tiles, ~1 ms of a 15 ms step in two of two A/B pairs; a wash at 8 k rows)
   return ococc_cdiv(rows, TR) <= 2048 ? 2 : 4;
 }
 
@@ -774,7 +776,13 @@ extern "C" int ococc_point_mlp_fwd_f32(const float* a, int32_t ka, int32_t lda, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(point_mlp_fwd_kernel<NBW, MB>), dim3(grid), dim3(kT), lds, stream, in, w_frag, \
                        (int)n, ln_weight, ln_bias, eps, (int)act, y, seg_max);                                        \
   } while (0)
-  if (mb == 2) {
+  if (mb == 1) {
+    switch (nbw_of(n)) {
+      case 1: OCOCC_PM_FWD(1, 1); break;
+      case 2: OCOCC_PM_FWD(2, 1); break;
+      default: OCOCC_PM_FWD(3, 1); break;
+    }
+  } else if (mb == 2) {
     switch (nbw_of(n)) {
       case 1: OCOCC_PM_FWD(1, 2); break;
       case 2: OCOCC_PM_FWD(2, 2); break;
@@ -837,7 +845,9 @@ extern "C" int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, 
     case 3: OCOCC_PM_BWD_N(3, MB); break;       \
     default: OCOCC_PM_BWD_N(4, MB); break;      \
   }
-  if (mb == 2) {
+  if (mb == 1) {
+    OCOCC_PM_BWD_K(1)
+  } else if (mb == 2) {
     OCOCC_PM_BWD_K(2)
   } else {
     OCOCC_PM_BWD_K(4)
@@ -872,7 +882,7 @@ extern "C" int64_t ococc_point_mlp_tiles(int64_t rows) { return rows < 0 ? -1 : 
 
 // tests: rows per tile pinned to 32 or 64 (0: by input size)
 extern "C" int ococc_point_mlp_force_tile(int32_t tile_rows) {
-  OCOCC_REQUIRE(tile_rows == 0 || tile_rows == 32 || tile_rows == 64, "0 (automatic), 32 or 64");
+  OCOCC_REQUIRE(tile_rows == 0 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64, "0 (automatic), 16, 32 or 64");
   g_force_tile = tile_rows;
   return OCOCC_OK;
 }

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[32, 64], ids=['tile32', 'tile64'])
+@pytest.fixture(autouse=True, params=[16, 32, 64], ids=['tile16', 'tile32', 'tile64'])
 def tile_rows(request):
     """every test of this file runs with the fwd / bwd launches pinned to 32-row and to 64-row tiles (the library picks
     by input size otherwise: small inputs, as these tests' are, would never reach the 64-row instantiations)"""
@@ -159,7 +159,11 @@ def test_sir_layer_fused_equals_operator_path(dev, cfg):
             sir.POINT_LAYER_KERNEL = True
     rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
     a, b = runs
-    assert rel(a[0], b[0]) < 1e-4 and rel(a[1], b[1]) < 1e-4 and rel(a[2], b[2]) < 1e-3
+    # (input gradient: norm-wise.  Where two rows of a group agree in a channel to the last bits, the two paths -- whose y
+    # differ by f32 summation order -- may name different rows the maximum and route that gradient to different rows: an
+    # element-wise bound then fails once in a dozen runs by a few 1e-3 of the largest entry, on both sides legitimately)
+    nrel = lambda a, b: float((a - b).norm() / b.norm().clamp(min=1e-30))
+    assert rel(a[0], b[0]) < 1e-4 and rel(a[1], b[1]) < 1e-4 and nrel(a[2], b[2]) < 1e-3
     for p, q in zip(a[3], b[3]):
         assert rel(p, q) < 1e-3
 
@@ -215,7 +219,8 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
         assert (p is None) == (q is None)
         if p is not None:
             assert rel(p, q) < 1e-5
-    assert rel(a[0], c[0]) < 1e-4 and rel(a[1], c[1]) < 1e-4 and rel(a[2], c[2]) < 1e-3
+    nrel = lambda p, q: float((p - q).norm() / q.norm().clamp(min=1e-30))   # (see test_sir_layer_fused_equals_operator_path)
+    assert rel(a[0], c[0]) < 1e-4 and rel(a[1], c[1]) < 1e-4 and nrel(a[2], c[2]) < 1e-3
     for p, q in zip(a[3], c[3]):
         if p is not None and q is not None:
             assert rel(p, q) < 1e-3
