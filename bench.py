@@ -460,7 +460,8 @@ def also_workloads():
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('sst', ['--workload', 'sst']),
                        ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
-        cmd = [sys.executable, here, '--steps', '10', '--warmup', '8', '--no-cpu-baseline'] + extra
+        steps = '30' if key in ('ococcnet_b4', 'ococcnet_b16') else '10'   # (the short steps: more of them, the host's load shows)
+        cmd = [sys.executable, here, '--steps', steps, '--warmup', '8', '--no-cpu-baseline'] + extra
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
