@@ -13,7 +13,6 @@ and its checkpoints load.  What differs is underneath:
     the decoder's first layer is factorised, instead of materialising [R+,K,1536] copies.
 """
 import os
-import weakref
 
 import numpy as np
 import torch
@@ -36,7 +35,38 @@ from .sst.sst_ops import build_mlp, unique_with_inverse
 # mode with gradients only; anything else (eval, no_grad, a capture already running, ever-changing shapes) takes the
 # eager path.
 GRAPH_TRANSFORMER = os.environ.get('OCOCC_GRAPH_TRANSFORMER', '1') == '1'
-_graphed_encoders = weakref.WeakKeyDictionary()   # encoder -> {shape key: graphed callable}
+
+
+class _GraphTable(dict):
+    """{shape key: graphed callable} of one owner module, kept ON the module (a graphed callable references its owner:
+    in a table keyed weakly by the owner that reference would keep the entry -- graphs, static buffers -- alive for
+    ever).  Copies and pickles of the module start with an empty table."""
+
+    def __deepcopy__(self, memo):
+        return _GraphTable()
+
+    def __reduce__(self):
+        return (_GraphTable, ())
+
+
+class _Graphed(object):
+    """`owner in _graphed_encoders` / `_graphed_encoders.get(owner)`: the owner's table, if it has replayed anything"""
+
+    def get(self, owner, default=None):
+        t = owner.__dict__.get('_ococc_graphs')
+        return t if t else default
+
+    def __contains__(self, owner):
+        return bool(owner.__dict__.get('_ococc_graphs'))
+
+    def table(self, owner):
+        t = owner.__dict__.get('_ococc_graphs')
+        if t is None:
+            t = owner.__dict__['_ococc_graphs'] = _GraphTable()
+        return t
+
+
+_graphed_encoders = _Graphed()
 
 
 class _EncoderCall(nn.Module):
@@ -59,9 +89,7 @@ def graphed_call(owner, make_wrapper, args, slot=''):
             and any(a.requires_grad for a in args) and not torch.cuda.is_current_stream_capturing()):
         return None
     key = (slot,) + tuple((tuple(a.shape), a.dtype, bool(a.requires_grad)) for a in args)
-    table = _graphed_encoders.get(owner)
-    if table is None:
-        table = _graphed_encoders[owner] = {}
+    table = _graphed_encoders.table(owner)
     g = table.get(key)
     if g is None:
         if len(table) >= 4:   # (a graph pair per shape: not for inputs whose shape keeps changing)
