@@ -120,6 +120,11 @@ def pmc_traffic():
         return None
 
 
+def occ_base_fused_train():
+    from objectcentricocccompletion_amd.occ import occ_base
+    return bool(occ_base.FUSED_MLP and occ_base.FUSED_TRAIN_MLP)
+
+
 def bench_ococcnet(args, world, rank, dev):
     """configs[2]: full ococcnet.py model on synthetic Waymo-shaped tracklets, B tracklets x 32 frames
     (= B*32 object grids) per GPU per step, K = 512 occupancy queries, fwd + bwd + AdamW, fp32 as the
@@ -205,10 +210,13 @@ def bench_ococcnet(args, world, rank, dev):
             'config': {'workload': f'configs[2]: full ococcnet.py model (66.55 M parameters), {B} tracklets x {L} '
                                    f'frames = {B * L} object grids/GPU/step, 64 points/frame, K=512 occupancy '
                                    'queries, fwd+bwd+AdamW, all-reduce of 266 MB gradients at N>1',
-                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}', 'launch': 'eager (host-bound at 4 tracklets: '
-                       '~2.5 k launches per step; --tracklets 64 leaves that regime)'},
-            'roofline': {'kernel': 'OccDecoder forward (MLP 60|1536 -> 512 -> 1024 -> 1024 -> 1 over all query points, '
-                                   'library GEMMs + fused LN/GELU kernels)',
+                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}', 'launch': 'eager, ~1.5 k launches per step (the temporal transformer and the head\'s tail '
+                       'replayed as HIP-graph pairs); on its device time from 4 tracklets on'},
+            'roofline': {'kernel': 'OccDecoder forward (MLP 60|1536 -> 512 -> 1024 -> 1024 -> 1 over all query points: '
+                                   + ('library f32 GEMMs + LN/GELU kernels)' if args.f32_decoder else
+                                      'positional encoding, weight fragments, per-RoI GEMM and the one-launch bf16 MLP kernel in its '
+                                      'training instantiation, which also writes z / row statistics / y of every layer -- 10 KB '
+                                      'per query row)' if occ_base_fused_train() else 'library bf16 GEMMs + fused LN/GELU kernels)'),
                          'bound': 'mfma', 'achieved': round(flops / (dec_ms * 1e-3) / 1e12, 2) if dec_ms else None,
                          'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(flops / (dec_ms * 1e-3) / 1e12 / peak, 4) if dec_ms else None, 'traffic': None,
