@@ -162,6 +162,10 @@ __device__ __forceinline__ void gemm_rows64(f32x16 (&acc)[NPW][2], const uint16_
 
 // ---- the epilogue shared by the kernels below.  Register i of block nb, row block mb holds
 //   channel 32 (NPW wave + nb) + (i & 3) + 8 (i >> 2) + 4 h  of row 32 mb + m        (m = lane & 31, h = lane >> 5)
+// rows of an LDS tile -> global, full rows per wave instruction group (defined with the whole-MLP kernel below)
+template <int N>
+__device__ __forceinline__ void copy_tile_out(const uint16_t* ys, int ld, uint16_t* dst, int64_t row0, int64_t rows);
+
 struct Epilogue {
   const float* gam_s;       // LDS, [N] each; bias_s / head_s null: absent
   const float* bet_s;
@@ -174,6 +178,8 @@ struct Epilogue {
   uint16_t* y_global;       // bf16 [rows, N] or null
   uint16_t* z_global;       // TRAIN: bf16 [rows, N], the LayerNorm input as the backward pass reads it
   float* stats_global;      // TRAIN: f32 [rows, 2] (mean, rstd)
+  uint16_t* stage;          // TRAIN: LDS tile [64][stage_ld] z is staged through on its way out (the tile the GEMM phase
+  int32_t stage_ld;         //        read: free behind the first LayerNorm barrier)
   uint16_t* y_lds;          // bf16 tile [64][ld_lds] or null
   float* head_out;          // f32 [rows] (with head_s)
   const float* head_b;
@@ -238,7 +244,6 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
           acc[nb][mb][4 * q + 1] = __uint_as_float(o.x & 0xffff0000u);
           acc[nb][mb][4 * q + 2] = __uint_as_float(o.y << 16);
           acc[nb][mb][4 * q + 3] = __uint_as_float(o.y & 0xffff0000u);
-          if (rows_of[mb] < e.rows) *(u32x2*)(e.z_global + rows_of[mb] * N + n) = o;
         }
       }
   }
@@ -255,6 +260,24 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
       if (h == 0) e.red0[wave * TM + 32 * mb + m] = s[mb];
     }
     __syncthreads();
+    if (TRAIN) {
+      // every wave is past its GEMM reads of the tile: z (the accumulators hold bf16 values) goes into it, and leaves
+      // behind the second barrier as full rows -- written from here, 8 bytes per lane and 32 rows per instruction, the
+      // three z tensors and y2 cost more than the whole arithmetic
+#pragma unroll
+      for (int nb = 0; nb < NPW; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = 32 * (nb0 + nb) + 8 * q + 4 * h;
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            u32x2 o;
+            o.x = (__float_as_uint(acc[nb][mb][4 * q]) >> 16) | (__float_as_uint(acc[nb][mb][4 * q + 1]) & 0xffff0000u);
+            o.y = (__float_as_uint(acc[nb][mb][4 * q + 2]) >> 16) | (__float_as_uint(acc[nb][mb][4 * q + 3]) & 0xffff0000u);
+            *(u32x2*)(e.stage + (32 * mb + m) * e.stage_ld + n) = o;
+          }
+        }
+    }
     float q2[2], mean_[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -275,6 +298,10 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
       if (h == 0) e.red1[wave * TM + 32 * mb + m] = q2[mb];
     }
     __syncthreads();
+    if (TRAIN) {
+      copy_tile_out<N>(e.stage, e.stage_ld, e.z_global, e.row0, e.rows);
+      __syncthreads();   // (the tile receives y next)
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       float t = 0.f;
@@ -365,6 +392,8 @@ mlp_layer_fwd_kernel(MlpLayerArgs a) {
   Epilogue e;
   e.z_global = nullptr;
   e.stats_global = nullptr;
+  e.stage = nullptr;
+  e.stage_ld = 0;
   e.gam_s = gam_s;
   e.bet_s = bet_s;
   e.bias_s = a.bias ? bias_s : nullptr;
@@ -475,6 +504,8 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
   e.y_global = nullptr;
   e.z_global = nullptr;
   e.stats_global = nullptr;
+  e.stage = nullptr;
+  e.stage_ld = 0;
   e.head_out = a.out;
   e.head_b = a.head_b;
   e.rows = a.rows;
@@ -505,6 +536,8 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.drop = a.drop[0];
       e.z_global = a.z_out[0];
       e.stats_global = a.stats_out[0];
+      e.stage = ys;
+      e.stage_ld = kLd1;
       layer_epilogue<2, true, DROP, TRAIN>(acc, e);
     }
     __syncthreads();   // y0 complete
@@ -519,6 +552,7 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.drop = a.drop[1];
       e.z_global = a.z_out[1];
       e.stats_global = a.stats_out[1];
+      e.stage_ld = kLd2;
       layer_epilogue<4, false, DROP, TRAIN>(acc, e);
     }
     __syncthreads();   // y1 complete
@@ -529,13 +563,15 @@ occ_mlp_fwd_kernel(OccMlpArgs a) {
       e.gam_s = gam2;
       e.bet_s = bet2;
       e.head_s = head_s;
-      e.y_lds = nullptr;
+      e.y_lds = TRAIN ? ys : nullptr;   // (training: y2 leaves through the tile as well)
       e.drop = a.drop[2];
       e.z_global = a.z_out[2];
       e.stats_global = a.stats_out[2];
-      e.y_global = TRAIN ? a.y2_out : nullptr;
       layer_epilogue<4, false, DROP, TRAIN>(acc, e);   // ends with the head's barriers: every wave is past its reads of y1
-      e.y_global = nullptr;
+      if (TRAIN) {
+        copy_tile_out<kN2>(ys, kLd2, a.y2_out, row0, a.rows);
+        __syncthreads();   // (the next tile's positional encodings land inside this region)
+      }
     }
   }
 }
