@@ -5,12 +5,17 @@ _select_one2one_candidates :993-1030, tracklets2rois :1045-1060, get_gt_rois :10
 mmdet3d/models/detectors/tracklet_detector_occ.py (:96-198, :313-345).  Same type strings,
 constructor arguments, loss-dict keys and result-dict keys; tracklets are the plain-tensor
 ``Tracklet`` of tracklet.py."""
+import os
+
 import torch
 from torch import nn
 
 from .bbox import rotation_3d_in_axis
 from .registry import BBOX_ASSIGNERS, DETECTORS, HEADS, ROI_EXTRACTORS
 from .tracklet import SamplingResult, Tracklet
+
+
+BATCHED_ASSIGN = os.environ.get('OCOCC_BATCHED_ASSIGN', '1') == '1'   # assignment / sampling of all tracklets at once
 
 
 def bbox3d2roi(bbox_list):
@@ -103,10 +108,100 @@ class TrackletRoIHeadOCC(nn.Module):
             trk._self_iou_cache = (cands[c], trk.boxes, over, trk.boxes._version, cands[c].boxes._version)
         return out_trks, out_occs, out_scores
 
+    def _assign_and_sample_batched(self, tracklet_list, gts, occs, occ_scores, pts_batch_idx, pts_frame_inds):
+        """The loop below for TrackletAssigner without object_centric / keep_frame_inds, where everything but the box,
+        score and IoU rows themselves follows from timestamps, i.e. is known on the host: the index lists of the whole
+        batch go up in ONE copy, the rows are gathered from the concatenated tensors in one launch per field, and the
+        per-tracklet SamplingResults are views of those (the reference's per-tracklet form costs ~25 launches and 3-4
+        small uploads per tracklet: half of the launches of a 64-tracklet step).  Same fields, same values."""
+        from .tracklet import host_index
+        dev = tracklet_list[0].device
+        shift_on = bool(self.train_cfg.get('random_shift_frame_inds', False))
+        n_of, m_of, idx_of, pos_of, neg_of, shifts = [], [], [], [], [], []
+        for trk, gt in zip(tracklet_list, gts):
+            n, m = len(trk), len(gt)
+            if m == 0 or n == 0:
+                idx = [0 if m == 0 else -1] * n
+            else:
+                idx = [gt.get_index_from_ts(ts) + 1 for ts in trk.ts_list]
+            n_of.append(n)
+            m_of.append(m)
+            idx_of.append(idx)
+            pos_of.append([i for i, g in enumerate(idx) if g > 0])
+            neg_of.append([i for i, g in enumerate(idx) if g == 0])
+            shifts.append(int(torch.randint(0, 200 - n + 1, (1,)).item()) if shift_on else 0)   # (CPU generator)
+        # global row numbers into the concatenated tensors
+        big, cuts = [], []
+
+        def part(values):
+            cuts.append((len(big), len(big) + len(values)))
+            big.extend(values)
+            return len(cuts) - 1
+
+        box_off, gt_off = 0, 0
+        pos_g, neg_g, order_g, pos_gt_g, pos_assigned, frame_inds, labels_pos = [], [], [], [], [], [], []
+        pos_loc = [i for p in pos_of for i in p]      # the indices the reference's fields hold: local to the tracklet
+        neg_loc = [i for q in neg_of for i in q]
+        for t, trk in enumerate(tracklet_list):
+            order = pos_of[t] + neg_of[t]
+            pos_g += [box_off + i for i in pos_of[t]]
+            neg_g += [box_off + i for i in neg_of[t]]
+            order_g += [box_off + i for i in order]
+            pos_gt_g += [gt_off + idx_of[t][i] - 1 for i in pos_of[t]]
+            pos_assigned += [idx_of[t][i] - 1 for i in pos_of[t]]
+            frame_inds += [i + shifts[t] for i in order]
+            labels_pos += [gts[t].type] * len(pos_of[t])
+            box_off += n_of[t]
+            gt_off += m_of[t]
+        k_pos, k_neg, k_ord, k_pgt, k_pas, k_fr, k_lab, k_shift, k_ploc, k_nloc = (part(v) for v in (
+            pos_g, neg_g, order_g, pos_gt_g, pos_assigned, frame_inds, labels_pos, shifts, pos_loc, neg_loc))
+        up = host_index(big, dev)
+        take = lambda k: up[cuts[k][0]:cuts[k][1]]
+        cur_all = torch.cat([t.concated_boxes() for t in tracklet_list], 0)
+        scores_all = torch.cat([t.concated_scores().detach() for t in tracklet_list], 0)
+        over_all = torch.cat([trk.self_ious(gt) if (m and n) else trk.boxes.new_zeros(n)
+                              for trk, gt, n, m in zip(tracklet_list, gts, n_of, m_of)], 0)
+        have_gt = [gt.concated_boxes() for gt, m in zip(gts, m_of) if m > 0]
+        n_pos = [len(p) for p in pos_of]
+        n_neg = [len(q) for q in neg_of]
+        n_ord = [a + b for a, b in zip(n_pos, n_neg)]
+        pos_boxes = cur_all[take(k_pos)].split(n_pos)
+        neg_boxes = cur_all[take(k_neg)].split(n_neg)
+        if have_gt:
+            gt_all = torch.cat(have_gt, 0)
+            pos_gt_boxes = gt_all[take(k_pgt)].split(n_pos)
+        iou = over_all[take(k_ord)].detach().split(n_ord)
+        scores = scores_all[take(k_ord)].split(n_ord)
+        pos_local = take(k_ploc).split(n_pos)
+        neg_local = take(k_nloc).split(n_neg)
+        pas = take(k_pas).split(n_pos)
+        frames = take(k_fr).split(n_ord)
+        labels = take(k_lab).split(n_pos)
+        if shift_on:   # the points of tracklet t move by the same shift as its boxes (one gather + one add for the batch)
+            pts_frame_inds += take(k_shift)[pts_batch_idx.long()].to(pts_frame_inds.dtype)
+        results = []
+        for t, (trk, gt) in enumerate(zip(tracklet_list, gts)):
+            s = SamplingResult.__new__(SamplingResult)
+            s.pos_inds, s.neg_inds = pos_local[t], neg_local[t]
+            s.pos_bboxes, s.neg_bboxes = pos_boxes[t], neg_boxes[t]
+            s.num_gts = m_of[t]
+            s.pos_assigned_gt_inds = pas[t]
+            gtb = gt.concated_boxes()
+            s.pos_gt_bboxes = gtb.new_zeros((0, 7)) if gtb.numel() == 0 else pos_gt_boxes[t]
+            s.pos_gt_labels = labels[t]
+            s.iou, s.scores, s.bboxes_frame_inds = iou[t], scores[t], frames[t]
+            s.occ_labels, s.occ_scores = occs[t], occ_scores[t]
+            results.append(s)
+        return results
+
     def _assign_and_sample(self, tracklet_list, candidates_list, gt_occs_list, gt_occ_scores_list, pts_batch_idx,
                            pts_frame_inds):
         gts, occs, occ_scores = self._select_one2one_candidates(tracklet_list, candidates_list, gt_occs_list,
                                                                 gt_occ_scores_list)
+        from .tracklet import TrackletAssigner
+        if (BATCHED_ASSIGN and type(self.bbox_assigner) is TrackletAssigner and not self.bbox_assigner.object_centric
+                and not self.train_cfg.get('keep_frame_inds', True) and all(len(t) > 0 for t in tracklet_list)):
+            return self._assign_and_sample_batched(tracklet_list, gts, occs, occ_scores, pts_batch_idx, pts_frame_inds)
         results = []
         for tid, (trk, gt) in enumerate(zip(tracklet_list, gts)):
             cur = trk.concated_boxes()

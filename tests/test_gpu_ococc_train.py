@@ -264,3 +264,31 @@ def test_training_step_host_fast_paths_equal_plain_paths(dev, monkeypatch):
         worst = max(worst, err / max(ref, 1e-12))
         assert err <= 2e-4 * max(ref, 1e-9), (k, err, ref)
     print('largest gradient deviation (relative to the tensor\'s largest entry):', worst)
+
+
+@pytest.mark.parametrize('shift', [False, True])
+def test_batched_assignment_equals_per_tracklet_loop(dev, gold, model, monkeypatch, shift):
+    """roi_head._assign_and_sample_batched (index lists of the whole batch in one upload, one gather per field, results as
+    views) gives every field of every SamplingResult the per-tracklet loop gives (which the golden test above pins to the
+    reference), including the frame-index shift and what it does to the points' frame indices."""
+    from objectcentricocccompletion_amd import roi_head as rh
+    samples, points, frames, trks, cands, occs, occ_scores = _scene(dev)
+    batch_idx = torch.cat([torch.full((len(p),), i, dtype=torch.long, device=dev) for i, p in enumerate(points)])
+    monkeypatch.setitem(model.roi_head.train_cfg, 'random_shift_frame_inds', shift)
+    monkeypatch.setitem(model.roi_head.train_cfg, 'keep_frame_inds', False)
+    outs = []
+    for batched in (True, False):
+        monkeypatch.setattr(rh, 'BATCHED_ASSIGN', batched)
+        fi = torch.cat(frames).clone()
+        torch.manual_seed(123)
+        res = model.roi_head._assign_and_sample(trks, cands, occs, occ_scores, batch_idx, fi)
+        outs.append((res, fi))
+    (a, fa), (b, fb) = outs
+    assert torch.equal(fa, fb)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        for name in ('pos_inds', 'neg_inds', 'pos_bboxes', 'neg_bboxes', 'pos_assigned_gt_inds', 'pos_gt_bboxes', 'pos_gt_labels',
+                     'iou', 'scores', 'bboxes_frame_inds', 'bboxes'):
+            u, v = getattr(x, name), getattr(y, name)
+            assert u.dtype == v.dtype and u.shape == v.shape and torch.equal(u, v), name
+        assert x.num_gts == y.num_gts and x.occ_labels is y.occ_labels and x.occ_scores is y.occ_scores
