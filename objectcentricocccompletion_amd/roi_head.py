@@ -20,11 +20,14 @@ BATCHED_ASSIGN = os.environ.get('OCOCC_BATCHED_ASSIGN', '1') == '1'   # assignme
 
 def bbox3d2roi(bbox_list):
     """[N_i, 7] per sample -> [sum N_i, 8] with the sample index in column 0."""
-    out = []
-    for i, b in enumerate(bbox_list):
-        out.append(torch.cat([b.new_full((b.size(0), 1), i), b], dim=-1) if b.size(0) > 0
-                   else torch.zeros_like(b[:, :1].expand(0, b.size(1) + 1)))
-    rois = torch.cat(out, 0)
+    # (the sample index column for the whole list at once: the per-sample fill + concatenation was three launches per
+    # tracklet, ~200 of a 64-tracklet step's)
+    from .tracklet import host_index
+    boxes = torch.cat(list(bbox_list), 0)
+    col = [float(i) for i, b in enumerate(bbox_list) for _ in range(b.size(0))]
+    idx = host_index(col, boxes.device, dtype=boxes.dtype) if boxes.is_floating_point() else host_index(
+        [int(v) for v in col], boxes.device, dtype=boxes.dtype)
+    rois = torch.cat([idx.view(-1, 1), boxes], dim=-1)
     # (largest sample index present + 1, known from the list's shapes: what the head would otherwise read back from
     # column 0 -- ococc_bbox_head.py:851 ``int(rois_batch_idx.max().item() + 1)``)
     rois._ococc_batch_size = max((i + 1 for i, b in enumerate(bbox_list) if b.size(0) > 0), default=0)
@@ -101,9 +104,12 @@ class TrackletRoIHeadOCC(nn.Module):
             out_trks.append(cands[c])
             out_occs.append(occs[c] if occs is not None else None)
             out_scores.append(scores[c] if scores is not None else None)
-            over = trk.boxes.new_zeros(len(trk))
-            if hi > lo:
-                over = ious[lo:hi] if own == list(range(len(trk))) else over.index_copy(0, host_index(own, dev), ious[lo:hi])
+            if hi > lo and own == list(range(len(trk))):
+                over = ious[lo:hi]
+            else:
+                over = trk.boxes.new_zeros(len(trk))
+                if hi > lo:
+                    over = over.index_copy(0, host_index(own, dev), ious[lo:hi])
             # valid for this candidate object and for the box tensors as they are now (in-place transforms bump _version)
             trk._self_iou_cache = (cands[c], trk.boxes, over, trk.boxes._version, cands[c].boxes._version)
         return out_trks, out_occs, out_scores
@@ -171,6 +177,7 @@ class TrackletRoIHeadOCC(nn.Module):
             gt_all = torch.cat(have_gt, 0)
             pos_gt_boxes = gt_all[take(k_pgt)].split(n_pos)
         iou = over_all[take(k_ord)].detach().split(n_ord)
+        boxes_ord = cur_all[take(k_ord)].split(n_ord)     # (= cat(pos_bboxes, neg_bboxes) per tracklet, without the cats)
         scores = scores_all[take(k_ord)].split(n_ord)
         pos_local = take(k_ploc).split(n_pos)
         neg_local = take(k_nloc).split(n_neg)
@@ -184,6 +191,7 @@ class TrackletRoIHeadOCC(nn.Module):
             s = SamplingResult.__new__(SamplingResult)
             s.pos_inds, s.neg_inds = pos_local[t], neg_local[t]
             s.pos_bboxes, s.neg_bboxes = pos_boxes[t], neg_boxes[t]
+            s._bboxes = boxes_ord[t]
             s.num_gts = m_of[t]
             s.pos_assigned_gt_inds = pas[t]
             gtb = gt.concated_boxes()

@@ -319,7 +319,8 @@ class SamplingResult(object):
 
     @property
     def bboxes(self):
-        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+        ready = self.__dict__.get('_bboxes')   # (the batched assignment gathers the rows in this order once for the batch)
+        return ready if ready is not None else torch.cat([self.pos_bboxes, self.neg_bboxes])
 
 
 @BBOX_ASSIGNERS.register_module()
