@@ -435,7 +435,11 @@ class TrackletDetectorOCC(nn.Module):
     def _cat_points(points, pts_frame_inds):
         xyz = torch.cat([p[:, :3] for p in points], 0)
         feats = torch.cat([p[:, 3:] for p in points], 0)
-        batch = torch.cat([torch.full((p.size(0),), i, dtype=torch.long, device=p.device) for i, p in enumerate(points)])
+        # (sample index of every point: one repeat with the counts known on the host -- no fill per sample, no read-back)
+        from .tracklet import host_index
+        dev = points[0].device
+        counts = [int(p.size(0)) for p in points]
+        batch = torch.repeat_interleave(torch.arange(len(points), device=dev), host_index(counts, dev), output_size=sum(counts))
         return xyz.contiguous(), feats.contiguous(), batch, torch.cat(pts_frame_inds, 0).long()
 
     @staticmethod
