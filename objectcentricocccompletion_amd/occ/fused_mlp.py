@@ -147,6 +147,23 @@ class DecoderWeights(object):
 # Training: the forward is the same single launch (ococc_occ_mlp_train_fwd_bf16 also leaves z, the row statistics and
 # y of every layer), the backward is the chain the separate operators ran -- LayerNorm backward kernels with the
 # dropout masks regenerated from (threshold, seed), library GEMMs for dX and dW -- issued from one autograd node.
+def wgrad_rows_bf16(dz, y, slices=32):
+    """dz^T y -> f32 [n, k] for bf16 dz [M, n], y [M, k] with M in the 1e5..1e6: as ONE GEMM the library runs the
+    [n, k] output as a few dozen macro tiles over a contraction of M (1024 x 1024 at 1 M rows: 4.1 ms, 0.54 PFLOP/s; 1024 x
+    512: 3.4 ms) -- as a batched GEMM over row slices with f32 outputs, summed, 2.05 and 1.08 ms (tools/probe/
+    dec_gemm_bench.py), and the partial sums are not rounded to bf16."""
+    M = dz.shape[0]
+    per = M // slices
+    if per < 512 or dz.shape[1] < 16 or y.shape[1] < 16:   # (a 1-wide side -- the head -- takes a batched path that costs 11 ms
+        return (dz.t() @ y).float()                         # of HOST time per call here: one GEMM for those)
+    main = per * slices
+    out = torch.bmm(dz[:main].view(slices, per, dz.shape[1]).transpose(1, 2), y[:main].view(slices, per, y.shape[1]),
+                    out_dtype=torch.float32).sum(0)
+    if main < M:
+        out = out + torch.mm(dz[main:].t(), y[main:], out_dtype=torch.float32)
+    return out
+
+
 class _OccMlpTrain(torch.autograd.Function):
 
     @staticmethod
@@ -190,7 +207,7 @@ class _OccMlpTrain(torch.autograd.Function):
         bf = torch.bfloat16
         d = dlogit.reshape(M, 1).to(bf)
         # head: logit = y2 . w_head + b_head
-        d_head_w = (d.t() @ ys[2]).float().to(head_w.dtype)
+        d_head_w = wgrad_rows_bf16(d, ys[2]).to(head_w.dtype)
         d_head_b = dlogit.sum().reshape(1)
         dy = d @ head_w.detach().to(bf).view(1, -1)                                  # [M, 1024]
         weights = (w_pe, w1, w2)
@@ -203,7 +220,7 @@ class _OccMlpTrain(torch.autograd.Function):
                                             drop=(thr, seeds[l]) if thr else (0, 0))
             grads_ln[2 * l], grads_ln[2 * l + 1] = (None if dg is None else dg.to(lw.dtype)), (None if db is None else db.to(lb.dtype))
             if l > 0:
-                dws[l] = (dz.t() @ ys[l - 1]).float().to(weights[l].dtype)           # [n_l, n_{l-1}]
+                dws[l] = wgrad_rows_bf16(dz, ys[l - 1]).to(weights[l].dtype)         # [n_l, n_{l-1}]
                 dy = dz @ weights[l].detach().to(bf)                                 # [M, n_{l-1}]
             else:
                 dz0 = dz.float()
