@@ -9,6 +9,7 @@
 One launch per layer, LayerNorm / GELU / dropout in the GEMM's epilogue; bf16 operands and activations, f32
 accumulation and statistics."""
 import ctypes
+import os
 
 import torch
 
@@ -152,10 +153,14 @@ def wgrad_rows_bf16(dz, y, slices=32):
     [n, k] output as a few dozen macro tiles over a contraction of M (1024 x 1024 at 1 M rows: 4.1 ms, 0.54 PFLOP/s; 1024 x
     512: 3.4 ms) -- as a batched GEMM over row slices with f32 outputs, summed, 2.05 and 1.08 ms (tools/probe/
     dec_gemm_bench.py), and the partial sums are not rounded to bf16."""
-    M = dz.shape[0]
+    M, n = dz.shape
     per = M // slices
-    if per < 512 or dz.shape[1] < 16 or y.shape[1] < 16:   # (a 1-wide side -- the head -- takes a batched path that costs 11 ms
-        return (dz.t() @ y).float()                         # of HOST time per call here: one GEMM for those)
+    if per < 512 or y.shape[1] < 16:
+        return (dz.t() @ y).float()
+    if n < 16:   # (the head's 1-wide gradient: as it is, the batched form takes a path that costs 11 ms of HOST time per call;
+        wide = torch.zeros((M, 16), dtype=dz.dtype, device=dz.device)   # padded to 16 columns it is the fast one -- 1.4 ms
+        wide[:, :n] = dz                                               # less per 64-tracklet step than one skinny GEMM)
+        return wgrad_rows_bf16(wide, y, slices)[:n]
     main = per * slices
     out = torch.bmm(dz[:main].view(slices, per, dz.shape[1]).transpose(1, 2), y[:main].view(slices, per, y.shape[1]),
                     out_dtype=torch.float32).sum(0)
