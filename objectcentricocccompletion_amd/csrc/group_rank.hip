@@ -17,10 +17,17 @@ namespace {
 __global__ void __launch_bounds__(256)
 gr_mark_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t bound, uint32_t* __restrict__ bitmap,
                int32_t* __restrict__ status) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t k = keys[i];
-    if (k < 0) continue;
-    if (k >= bound) { *status = 1; continue; }
+  // (whole waves walk the keys, so that neighbouring lanes can compare notes: voxels arrive in coordinate order and
+  // the lanes of a wave name a handful of windows -- only the first lane of a run of equal keys marks it, csrc/grid_unique.hip)
+  const int64_t n_up = (n + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t k = i < n ? keys[i] : -1;
+    if (k >= bound) {
+      *status = 1;
+      k = -1;
+    }
+    const int32_t left = __shfl_up(k, 1, 64);
+    if (k < 0 || ((threadIdx.x & 63) != 0 && left == k)) continue;
     // (most keys of a group find their bit set already: a plain read first keeps ~30 atomics per word off the L2 --
     // 40 -> a few us for 260 k window ids; a stale read only costs the atomic it would have saved)
     const uint32_t bit = 1u << (k & 31);
