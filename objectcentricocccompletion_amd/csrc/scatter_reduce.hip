@@ -62,16 +62,30 @@ segment_reduce_kernel(const float* __restrict__ feats, const int32_t* __restrict
     for (int ch = ch0; ch < c; ch += cp) {
       int32_t cur = -1;
       float acc = 0.f;
-      for (int64_t r = r0 + s; r < r1; r += sub) {
-        const int32_t seg = inv[r];
-        if (seg < 0) continue;
-        const float v = feats[r * c + ch];
-        if (seg != cur) {
-          if (cur >= 0) flush<MODE>(out, cur, c, ch, acc, counts);
-          cur = seg;
-          acc = v;
-        } else {
-          acc = (MODE == OCOCC_REDUCE_MAX) ? fmaxf(acc, v) : acc + v;
+      // four rows per trip, their loads issued together: the walk is a chain of dependent compares, and with one row
+      // per trip every step paid a global round trip (96 us for 131 k rows x 128 channels, 0.7 TB/s)
+      for (int64_t r = r0 + s; r < r1; r += 4 * sub) {
+        int32_t sg[4];
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t rr = r + (int64_t)u * sub;
+          const bool ok = rr < r1;
+          sg[u] = ok ? inv[rr] : -1;
+          vv[u] = ok ? feats[rr * c + ch] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int32_t seg = sg[u];
+          if (seg < 0) continue;
+          const float v = vv[u];
+          if (seg != cur) {
+            if (cur >= 0) flush<MODE>(out, cur, c, ch, acc, counts);
+            cur = seg;
+            acc = v;
+          } else {
+            acc = (MODE == OCOCC_REDUCE_MAX) ? fmaxf(acc, v) : acc + v;
+          }
         }
       }
       if (cur >= 0) flush<MODE>(out, cur, c, ch, acc, counts);
