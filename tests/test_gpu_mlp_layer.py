@@ -270,7 +270,7 @@ def test_fused_decoder_training_step(dev, golden_dir, dropout, monkeypatch):
     # (the operator path runs the first layer's GEMM in f32 and rounds z to bf16 afterwards; here its operands are bf16)
     errs = {'logits': rel(a[0], b[0]), 'd roi feats': rel(a[1], b[1]), **{k: rel(a[2][k], b[2][k]) for k in a[2]}}
     print('fused training step vs operator path (norm-wise):', {k: f'{v:.2e}' for k, v in errs.items()})
-    assert errs['logits'] < 1e-2 and errs['d roi feats'] < 3e-2
+    assert errs['logits'] < 2e-2 and errs['d roi feats'] < 3e-2   # (observed 6e-3 .. 7e-3 and 5e-3: two bf16 roundings of the same MLP)
     for k in a[2]:
         assert errs[k] < 3e-2, k
     if len(runs) == 3:   # both bf16 realisations are equally far from the f32 decoder (two roundings of the same thing)
