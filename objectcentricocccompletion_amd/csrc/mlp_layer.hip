@@ -234,7 +234,6 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NPW][2], const Epil
     for (int nb = 0; nb < NPW; ++nb)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = 32 * (nb0 + nb) + 8 * q + 4 * h;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
           u32x2 o;
