@@ -88,6 +88,11 @@ def graphed_call(owner, make_wrapper, args, slot=''):
     if not (GRAPH_TRANSFORMER and owner.training and torch.is_grad_enabled() and all(a.is_cuda for a in args)
             and any(a.requires_grad for a in args) and not torch.cuda.is_current_stream_capturing()):
         return None
+    # ROCm 7.2: with the runtime's graph packet-capture fast path on, replaying a graph after new device allocations
+    # faults (graph.GraphedStep refuses to run then; here the eager form runs instead).  The variable has to be in the
+    # environment before the HIP runtime loads, i.e. before `import torch`: bench.py and tests/conftest.py set it.
+    if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '') != '0':
+        return None
     key = (slot,) + tuple((tuple(a.shape), a.dtype, bool(a.requires_grad)) for a in args)
     table = _graphed_encoders.table(owner)
     g = table.get(key)

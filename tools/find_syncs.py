@@ -1,6 +1,8 @@
 """Host synchronisations of one --workload ococcnet training step, by call site (torch sync-debug warnings)."""
 import collections
 import os
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime loads: objectcentricocccompletion_amd/graph.py
 import sys
 import traceback
 import warnings

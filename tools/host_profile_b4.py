@@ -7,6 +7,8 @@ usage: python tools/host_profile_b4.py [tracklets=4] [steps=10]"""
 import cProfile
 import io
 import os
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime loads: objectcentricocccompletion_amd/graph.py
 import pstats
 import sys
 import time

@@ -15,6 +15,8 @@ reference's on-disk formats (tools/make_synthetic_dataset.py writes a small set 
 data/waymo tree prepared by the reference's converters has the same layout), sharded over the ranks."""
 import argparse
 import os
+
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # before the HIP runtime loads: objectcentricocccompletion_amd/graph.py
 import sys
 import time
 
