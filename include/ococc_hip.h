@@ -314,15 +314,6 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
 int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                 int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
                                 const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
-/* The same contract once more, for WIDE outputs on sparse active sets (64 -> 128 channels, where the tile kernel's LDS
- * accumulators allow one workgroup per CU and two rounds of them): f32 accumulators in the registers of the waves that
- * own the rows, the rows of a 256-row tile that have a neighbour at an offset compacted into one 16-row block,
- * multiplied by a pair of waves, the products left in LDS and PULLED by the row owners in ascending offset order
- * (deterministic).  kvol <= 27; (kd, ncols) in {(64, 128), (64, 64), (32, 64), (128, 64), (128, 128)}; wn in
- * fragment-major order (ococc_weight_prepare_bf16 mode + 4), as for ococc_sparse_conv_tile_bf16. */
-int ococc_sparse_conv_pull_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
-                                int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
-                                const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
 /* The same kernel with the LayerNorm (+ GELU) that follows the convolution in the reference's
  * make_sparse_convmodule block (mmdet3d/ops/sparse_block.py:216-289: conv -> LN(eps) -> GELU) applied in the
  * epilogue, where the finished f32 row sits in LDS: conv_out [n_out, ncols] bf16 (what the LN backward needs), y =

@@ -62,8 +62,6 @@ SIGNATURES = {
     'ococc_backward_param_reduce_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_tile_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,
                                             c_i32, c_vp]),
-    'ococc_sparse_conv_pull_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,
-                                            c_i32, c_vp]),
     'ococc_sparse_conv_tile_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,
                                                c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_tile_lnbwd_partial_rows': (c_i64, [c_i64, c_i32, c_i32]),

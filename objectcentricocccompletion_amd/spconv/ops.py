@@ -564,38 +564,15 @@ def _use_tile_kernel(rb, kd, ncols):
     return ppr is not None and ppr <= _TILE_SHAPES.get((kd, ncols), -1.0)
 
 
-# Wide outputs on sparse active sets: register accumulators + compacted products pulled by the row owners
-# (ococc_sparse_conv_pull_bf16, csrc/sparse_conv_pull.hip).  Correct and tested, but measured SLOWER than the streamed-
-# weights kernel on configs[1] (59 vs 39 us for 64 -> 128): opt-in only (True / env OCOCC_PULL_CONV=1 forces
-# it for the shapes below; _PULL_SHAPES gives the density up to which a hint would select it -- none by default).
-PULL_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_PULL_CONV'))  # env: force on / off
-_PULL_KERNEL_SHAPES = {(64, 128)}
-_PULL_SHAPES = {}
-
-
-def _use_pull_kernel(rb, kd, ncols):
-    if rb is None or not rb.subm or rb.kvol % 2 == 0 or rb.kvol > 27 or (kd, ncols) not in _PULL_KERNEL_SHAPES:
-        return False
-    if PULL_CONV is not None:
-        return bool(PULL_CONV)
-    ppr = getattr(rb, 'pairs_per_row', None)
-    return ppr is not None and ppr <= _PULL_SHAPES.get((kd, ncols), -1.0)
-
-
 def _fragment_major(rb, kd, ncols):
-    """the kernels that load weight fragments straight from L2 want them in fragment-major order (prepare mode + 4)"""
-    return _use_tile_kernel(rb, kd, ncols) or _use_pull_kernel(rb, kd, ncols)
+    """the tile kernel loads its weight fragments straight from L2 and wants them in fragment-major order (prepare
+    mode + 4)"""
+    return _use_tile_kernel(rb, kd, ncols)
 
 
 def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
     kvol, ncols, kd = wn.shape
     out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
-    if _use_pull_kernel(rb, kd, ncols):
-        L.check(L.lib.ococc_sparse_conv_pull_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
-                                                  L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
-                                                  L.dtype_code(out_dtype), L.stream()),
-                'sparse_conv_pull')
-        return out
     if _use_tile_kernel(rb, kd, ncols):  # (the caller prepared wn in fragment-major order under the same test)
         L.check(L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
                                                   L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
@@ -673,7 +650,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     nc = (cout + 15) // 16 * 16
     x = _to_bf16_padded(features, kd)
     tile = _fragment_major(rb if subm else None, kd, nc)
-    wn = _prep_weights(filters, 4 if tile else 0, kd, nc)  # +4: fragment-major order for the tile / pull kernels
+    wn = _prep_weights(filters, 4 if tile else 0, kd, nc)  # +4: fragment-major order for the tile kernel
     b = None
     if bias is not None:
         b = torch.zeros((nc,), dtype=torch.float32, device=features.device)
@@ -818,7 +795,7 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
         nc = (cin + 15) // 16 * 16
         mode = 1 if (rb.subm and subm) else 2
         if mode == 1 and _fragment_major(rb, kd_out, nc):
-            mode = 5  # fragment-major order for the tile / pull kernels
+            mode = 5  # fragment-major order for the tile kernel
         wn = _prep_weights(filters, mode, kd_out, nc)
         out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
         if (_ln_link is not None and FUSE_LN_BACKWARD and mode == 5 and nc == cin and nc in (32, 64)
