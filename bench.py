@@ -67,12 +67,21 @@ def parse():
                          'convolutions they run beside, 0.346-0.360 vs 0.335 ms/step)')
     ap.add_argument('--no-graph', action='store_true',
                     help='launch every kernel eagerly from Python instead of replaying the captured HIP graph')
+    ap.add_argument('--dump-params', default=None,
+                    help='test hook: every rank saves its parameters (one flat f32 vector) to <path>.rank<r>.pt when the timed '
+                         'steps are done, i.e. after exactly warmup + steps optimizer steps (tests/test_gpu_bench_ranks.py)')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 500 if args.workload == 'submconv' else 50
     if args.warmup is None:
         args.warmup = 20 if args.workload == 'submconv' else 10
     return args
+
+
+def dump_params(args, rank, params):
+    if args.dump_params:
+        torch.cuda.synchronize()
+        torch.save(torch.cat([p.detach().float().reshape(-1) for p in params]).cpu(), f'{args.dump_params}.rank{rank}.pt')
 
 
 def cpu_baseline(sample_grids, points, model):
@@ -190,6 +199,7 @@ def bench_ococcnet(args, world, rank, dev):
         dist.barrier()
     dt = time.perf_counter() - t0
     decoder.forward = real_forward
+    dump_params(args, rank, params)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -687,6 +697,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     sp_ops.set_probe(None)
+    dump_params(args, rank, params)
     # host cost of queueing one step on an idle device (one hipGraphLaunch, or the eager launch sequence): when it
     # approaches ms_per_step the number above is the host's, not the GPU's
     host_us = []

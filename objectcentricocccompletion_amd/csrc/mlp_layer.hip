@@ -9,8 +9,9 @@
 //   * x tile [64][K] bf16 in LDS (row stride K + 16 elements: the 32 rows of an MFMA operand read hit different banks);
 //     the NEXT tile's rows are copied global -> LDS by DMA (global_load_lds_dwordx4, no registers) while this tile's
 //     epilogue runs;
-//   * out^T = W x^T on v_mfma_f32_32x32x16_bf16 -- measured 1.9-2.0 PFLOP/s issue rate on this part against 1.15 for
-//     the 16x16x32 shape (tools/probe/mfma_rate.hip) -- weights as the A operand in fragment order (one wave load = 1 KB
+//   * out^T = W x^T on v_mfma_f32_32x32x16_bf16 (32 cycles per instruction and SIMD; the same FLOP per clock as the
+//     16x16x32 shape at 16 -- tools/probe/mfma_rate.hip, corrected in round 4 -- with half the A-operand fragments per
+//     FLOP, which is what this L2-bound kernel is short of) -- weights as the A operand in fragment order (one wave load = 1 KB
 //     of consecutive bytes, ococc_linear_fragments32_bf16), streamed from L2 through a 4-deep register ring by inline
 //     asm loads with hand-counted waits (the compiler sinks plain loads to their uses, csrc/point_mlp.hip);
 //   * a wave owns N / 8 channels of all 64 rows: 4 (or 2) x 2 accumulator tiles of 32 x 32;

@@ -8,8 +8,9 @@
 * <proposals file minus .pkl>_database/<segment>--<id>.npy: the tracklet's points (LoadTrackletPoints);
 * occ_anno_root/<segment>/<id>.npz, key ``occ``: the GT occupancy grid of a candidate (LoadAnnotationsOcc).
 
-The evaluation that needs waymo_open_dataset protos (format_results / 'waymo' metric, :315-484) is not built; the
-occupancy-IoU metric is roi_head.occupancy_iou_metrics."""
+``evaluate`` (:315-428) writes the Waymo-format result file (waymo_io.convert_tracklet_to_waymo: the metrics.Objects
+protobuf encoded without the waymo_open_dataset package) and parses the metrics tool's output when the caller names the
+tool's executable; the occupancy-IoU metric is roi_head.occupancy_iou_metrics."""
 import os.path as osp
 import pickle
 
@@ -116,6 +117,17 @@ class WaymoTrackletDataset(Dataset):
                 idx = np.random.choice(np.where(self.flag == self.flag[idx])[0])
                 continue
             return data
+
+    def evaluate(self, results, metric='waymo', logger=None, pklfile_prefix=None, submission_prefix=None, show=False,
+                 out_dir=None, pipeline=None, metrics_main=None):
+        """:315-428 -- results: the refined tracklets (``id`` str, ``segment_name``, ``type`` = class index); writes
+        ``pklfile_prefix``.bin and evaluates it against <waymo_format>/gt.bin (train_gt.bin for 'result_train' prefixes)
+        with the Waymo tool ``metrics_main`` (waymo_io.evaluate: without the tool, the .bin is written and the call
+        raises)."""
+        from . import waymo_io
+        waymo_root = osp.join(self.data_root.split('kitti_format')[0], 'waymo_format')
+        gt = osp.join(waymo_root, 'train_gt.bin' if 'result_train' in pklfile_prefix else 'gt.bin')
+        return waymo_io.evaluate(results, pklfile_prefix, gt, self.CLASSES, metrics_main)
 
 
 @DATASETS.register_module()

@@ -35,6 +35,13 @@ from .sst.sst_ops import build_mlp, unique_with_inverse
 # mode with gradients only; anything else (eval, no_grad, a capture already running, ever-changing shapes) takes the
 # eager path.
 GRAPH_TRANSFORMER = os.environ.get('OCOCC_GRAPH_TRANSFORMER', '1') == '1'
+# Round 3 saw ONE segmentation fault inside hipGraphLaunch with these pairs on: the captured BACKWARD graph is replayed by
+# the autograd engine's device thread, i.e. hipGraphLaunch runs on a second host thread while the main thread owns every
+# other launch of the process.  With the engine's worker threads off the backward nodes -- and the replay -- run on the
+# calling thread, like every other launch (one process per GPU: the worker thread buys nothing).  graphed_call() switches
+# them off the first time it makes a pair; OCOCC_GRAPH_AUTOGRAD_THREADS=1 keeps the engine multithreaded
+# (tools/soak_graph_pairs.py soaks either configuration in a fresh process).
+GRAPH_AUTOGRAD_THREADS = os.environ.get('OCOCC_GRAPH_AUTOGRAD_THREADS', '0') == '1'
 
 
 class _GraphTable(dict):
@@ -104,14 +111,20 @@ def graphed_call(owner, make_wrapper, args, slot=''):
         # (warm-up and capture run on a side stream, and the captured backward keeps the autograd graph of its static
         # outputs: the parameters' AccumulateGrad nodes meet gradients from another stream than the one they were made
         # on, which the engine reports -- the known, intended consequence of graphing a sub-module)
-        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
-        if quiet is not None:
-            quiet(False)
         wrapper = make_wrapper(owner)
         if not all(p.requires_grad for p in wrapper.parameters()):   # (the captured backward returns every parameter's
             table[key] = False                                        # gradient: frozen parameters -> eager, for good)
             return None
-        g = table[key] = torch.cuda.make_graphed_callables(wrapper, sample, allow_unused_input=True)
+        if not GRAPH_AUTOGRAD_THREADS and torch.autograd.is_multithreading_enabled():
+            torch.autograd.set_multithreading_enabled(False)   # replays on the calling thread from here on (see above)
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:
+            quiet(False)
+        try:
+            g = table[key] = torch.cuda.make_graphed_callables(wrapper, sample, allow_unused_input=True)
+        finally:
+            if quiet is not None:
+                quiet(True)   # (the warning is about the capture's side stream only; later mismatches are reported again)
     return g(*args) if g is not False else None
 
 

@@ -1,7 +1,8 @@
 """GT-occupancy annotation, device side: the range-image visibility ray test of
 tools/occ/occ_annotate.py (point_cloud_to_range_image_idx :141-207, OccAnnotator.annotate_trk :488-556)
-as one HIP kernel (ococc_occ_visibility_f64).  The file handling around it (Waymo frames, tracklet
-aggregation, .npz writing) is host code outside this path."""
+as one HIP kernel (ococc_occ_visibility_f64), and the file handling around it (OccAnnotator below: tracklets from the
+GT metrics file, per-frame points and raw range images, aggregation in the box frame, voxelisation, the .npz files
+LoadAnnotationsOcc reads)."""
 import ctypes
 import math
 
@@ -98,3 +99,194 @@ def visibility_ray_test(unknown_centers, track_boxes, extrinsics, inclinations, 
     vis, _, _ = _run(unknown_centers, frame_affines_from_boxes(track_boxes), to_sensor, azc,
                      torch.as_tensor(np.asarray(inclinations, dtype=np.float64)).reshape(S * F, -1), imgs, size, True, False)
     return vis
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# File handling around the ray test: tools/occ/occ_annotate.py:103-139 (get_local_point_list), :228-688 (OccAnnotator)
+# and the readers of tools/ctrl/utils.py it uses, on the same directory layout:
+#   <data_root>/kitti_format/idx2timestamp.pkl            {frame index (str): timestamp}
+#   <data_root>/kitti_format/<split>/velodyne/<idx>.bin   float32 [N, 6] points of the frame (get_pc_from_time_stamp)
+#   <data_root>/waymo_raw/<split>/<idx>.pkl               per frame: '<LIDAR>_BEAM_INCLINATION' [H], '<LIDAR>_LIDAR_EXTRINSIC'
+#                                                         [4,4], '<LIDAR>_RANGE_IMAGE_MERGE_VIRTUAL' [H,W] for the five LiDARs
+#   <bin_path>                                            metrics.Objects file of the GT boxes (waymo_io.read_bin)
+# and writes <out_dir>/<split>/<segment>/<track id>.npz with key 'occ' [X,Y,Z] int32: 0 unknown, 1 occupied, 2 empty
+# (what LoadAnnotationsOcc reads).  The Open3D voxelisation branch (--cpu-voxelization) needs open3d, which neither the
+# reference's requirements nor this image carry: NotImplementedError.  One process per GPU: a multi-GPU run shards the
+# segments by rank (``rank`` / ``world``) instead of the reference's worker pool over cuda devices.
+def points_in_box(points, box):
+    """check_pt_in_box3d of mmdet3d/ops/roiaware_pool3d/src/points_in_boxes_cuda.cu:24-49 for ONE box [7] (x, y, z bottom,
+    w, l, h, rz), float32 arithmetic: bool [N]."""
+    p = points[:, :3].float()
+    cx, cy, cz, w, l, h, rz = [box[i].float() for i in range(7)]
+    cz = cz + h / 2.0
+    rot = rz + math.pi / 2
+    cosa, sina = torch.cos(rot), torch.sin(rot)
+    dx, dy = p[:, 0] - cx, p[:, 1] - cy
+    lx, ly = dx * cosa + dy * (-sina), dx * sina + dy * cosa
+    return ~((p[:, 2] - cz).abs() > h / 2.0) & (lx > -l / 2.0) & (lx < l / 2.0) & (ly > -w / 2.0) & (ly < w / 2.0)
+
+
+def get_local_point_list(trk, load_points, box_mode='avg', device='cuda'):
+    """occ_annotate.py:103-139: the points inside every frame's box, moved into the box frame (origin at the bottom centre,
+    x along the heading), and the aggregate box size.  load_points(ts) -> float32 [N, >=3] ndarray."""
+    local_pc_list, box_sizes = [], []
+    boxes = trk.boxes.to(device).float()
+    for i in range(len(trk)):
+        pc = torch.from_numpy(np.ascontiguousarray(load_points(trk.ts_list[i])[:, :3])).to(device)
+        inside = pc[points_in_box(pc, boxes[i])]
+        if len(inside) == 0:
+            continue
+        rz = boxes[i, 6]
+        c, s = torch.cos(-rz), torch.sin(-rz)
+        rot_mat_T = torch.stack([torch.stack([c, -s, c.new_zeros(())]), torch.stack([s, c, c.new_zeros(())]),
+                                 c.new_tensor([0., 0., 1.])])
+        local_pc_list.append((inside - boxes[i, :3]) @ rot_mat_T)
+        box_sizes.append(boxes[i:i + 1, 3:6])
+    assert len(local_pc_list) > 0, 'no points in the tracklet'
+    sizes = torch.cat(box_sizes, 0)
+    return local_pc_list, (sizes.mean(0) if box_mode == 'avg' else sizes.max(0).values)
+
+
+class OccAnnotator(object):
+    """occ_annotate.py:228-688 with the reference's constructor arguments (``workers`` / ``ngpus`` are accepted and
+    replaced by ``rank`` / ``world``: one process per GPU)."""
+    type_mapping = {'vehicle': 1, 'pedestrian': 2, 'cyclist': 3}
+    LiDAR_NAME_LIST = ['TOP', 'FRONT', 'SIDE_LEFT', 'SIDE_RIGHT', 'REAR']
+
+    def __init__(self, data_root, out_dir, split, voxel_size, bin_path, object_type='vehicle', workers=1, debug=False,
+                 cpu_voxelization=False, overwrite=False, save_mean_var=False, ngpus=1, rank=0, world=1, device='cuda'):
+        import os.path as osp
+        import pickle
+        if cpu_voxelization:
+            raise NotImplementedError('the Open3D voxelisation branch needs open3d (absent here as in the reference\'s requirements)')
+        self.data_root, self.out_dir, self.split, self.voxel_size = data_root, out_dir, split, voxel_size
+        self.kitti_format_root = osp.join(data_root, 'kitti_format')
+        self.raw_format_root = osp.join(data_root, 'waymo_raw', split)
+        self.debug, self.overwrite, self.save_mean_var = debug, overwrite, save_mean_var
+        self.rank, self.world, self.device = rank, world, device
+        self.types = {self.type_mapping[object_type]}
+        name = osp.basename(bin_path).split('.')[0]
+        tracklets = self.generate_or_load_tracklet(bin_path, f'{name}_tracklets.pkl')
+        self.trk_dicts = {}
+        for t in tracklets:
+            self.trk_dicts.setdefault(t.segment_name, []).append(t)
+        self.segment_names = sorted(self.trk_dicts)
+        with open(osp.join(self.kitti_format_root, 'idx2timestamp.pkl'), 'rb') as fr:
+            self.idx2ts = pickle.load(fr)
+        self.ts2idx = {ts: idx for idx, ts in self.idx2ts.items()}
+
+    def generate_or_load_tracklet(self, bin_path, file_name):
+        """:268-281 -- the tracklets of the metrics file, cached beside the outputs (as dump-format tuples: the reference
+        pickles its LiDARTracklet objects, which only its own class can load)"""
+        import os
+        import pickle
+        from .. import waymo_io
+        from ..tracklet import Tracklet
+        cache = os.path.join(self.out_dir, file_name)
+        if os.path.isfile(cache):
+            with open(cache, 'rb') as f:
+                return [Tracklet.from_dump_format(t) for t in pickle.load(f)]
+        tracklets = waymo_io.generate_tracklets(waymo_io.read_bin(bin_path), self.types)
+        os.makedirs(self.out_dir, exist_ok=True)
+        with open(cache, 'wb') as f:
+            pickle.dump([t.to_dump_format() for t in tracklets], f)
+        return tracklets
+
+    def load_points(self, ts):
+        """tools/ctrl/utils.py:60-66"""
+        import os.path as osp
+        path = osp.join(self.kitti_format_root, f'{self.split}/velodyne', str(self.ts2idx[ts]) + '.bin')
+        return np.fromfile(path, dtype=np.float32).reshape(-1, 6)
+
+    def annotate_one_seg(self, segname_idx):
+        cache = {}
+
+        def load(ts):
+            if ts not in cache:
+                cache[ts] = self.load_points(ts)
+            return cache[ts]
+        done = 0
+        for trk in self.trk_dicts[self.segment_names[segname_idx]]:
+            done += self.annotate_trk(trk, load) is not None
+        return done
+
+    def annotate_trk(self, trk, load_points=None):
+        """:312-655 (the GPU voxelisation branch).  Returns the path written, or None when the tracklet is skipped (an
+        existing readable file, fewer than 10 frames, no point in any box, a missing raw frame)."""
+        import os
+        import pickle
+        dev = self.device
+        out_path = os.path.join(self.out_dir, self.split, trk.segment_name)
+        os.makedirs(out_path, exist_ok=True)
+        out_name = os.path.join(out_path, f'{trk.id}.npz')
+        if os.path.isfile(out_name) and not self.overwrite:
+            try:
+                np.load(out_name)
+                return None
+            except Exception:
+                print(f'error loading {out_name}, overwrite')
+        if len(trk) < 10:
+            return None
+        try:
+            local_pc_list, bbox_size = get_local_point_list(trk, load_points or self.load_points, 'max', dev)
+        except AssertionError as e:
+            print(e)
+            return None
+        local_pc_agg = torch.cat(local_pc_list, 0)
+        voxel_dims = torch.ceil(bbox_size / self.voxel_size).to(torch.int32)
+        # corners of the local box (origin (0.5, 0.5, 0), yaw 0): x, y centred, z from the bottom face
+        min_bound = torch.stack([-bbox_size[0] / 2, -bbox_size[1] / 2, bbox_size.new_zeros(())])
+        quantized = torch.floor((local_pc_agg - min_bound) / self.voxel_size).to(torch.long)
+        keep = (quantized < voxel_dims[None]).all(1) & (quantized >= 0).all(1)   # (points right on the boundary: dropped)
+        local_pc_agg, quantized = local_pc_agg[keep], quantized[keep]
+        X, Y, Z = (int(v) for v in voxel_dims)
+        occ = torch.zeros((X, Y, Z), dtype=torch.bool, device=dev)
+        occ[quantized[:, 0], quantized[:, 1], quantized[:, 2]] = True
+        gx, gy, gz = torch.meshgrid(torch.arange(X, device=dev), torch.arange(Y, device=dev), torch.arange(Z, device=dev),
+                                    indexing='ij')
+        voxel_coors = torch.stack([gx, gy, gz], -1).view(-1, 3)
+        occ = occ.view(-1)
+        un_occ_coors = voxel_coors[~occ]
+        unknown_centers = un_occ_coors.to(torch.float64) * self.voxel_size + min_bound + self.voxel_size / 2
+        visible_occ = torch.zeros_like(occ, dtype=torch.int32)
+        if un_occ_coors.size(0) > 0:
+            frames = []
+            for ts in trk.ts_list:
+                path = os.path.join(self.raw_format_root, f'{self.ts2idx[ts]}.pkl')
+                if not os.path.isfile(path):
+                    print(f'{path} not found, skip this segment {trk.segment_name}')
+                    return None
+                try:
+                    with open(path, 'rb') as f:
+                        frames.append(pickle.load(f))
+                except Exception:
+                    print(f'error loading {path}, skip this segment {trk.segment_name}')
+                    return None
+            visibility = None
+            for lidar in self.LiDAR_NAME_LIST:   # every LiDAR has its own image size: one ray test per sensor, then the max
+                ext = np.stack([fr[f'{lidar}_LIDAR_EXTRINSIC'] for fr in frames], 0)[None]
+                inc = np.flip(np.stack([fr[f'{lidar}_BEAM_INCLINATION'] for fr in frames], 0), axis=1).copy()[None]
+                imgs = [[torch.as_tensor(np.asarray(fr[f'{lidar}_RANGE_IMAGE_MERGE_VIRTUAL'])) for fr in frames]]
+                vis = visibility_ray_test(unknown_centers, trk.boxes, ext, inc, imgs)
+                visibility = vis if visibility is None else torch.maximum(visibility, vis)
+            visible_occ[~occ] = visibility
+        visible_occ[occ] = 1
+        grid = visible_occ.view(X, Y, Z)
+        if self.save_mean_var:
+            # per occupied cell the mean and the variance of its points (scatter_v2 'mean' twice, :633-651)
+            flat = (quantized[:, 0] * Y + quantized[:, 1]) * Z + quantized[:, 2]
+            cnt = torch.zeros(X * Y * Z, device=dev, dtype=local_pc_agg.dtype).index_add_(0, flat, torch.ones_like(flat, dtype=local_pc_agg.dtype))
+            mean = torch.zeros((X * Y * Z, 3), device=dev, dtype=local_pc_agg.dtype).index_add_(0, flat, local_pc_agg)
+            mean = mean / cnt.clamp(min=1)[:, None]
+            var = torch.zeros_like(mean).index_add_(0, flat, (local_pc_agg - mean[flat]) ** 2) / cnt.clamp(min=1)[:, None]
+            np.savez(out_name, occ=grid.cpu().numpy(), mean_var=torch.cat([mean, var], 1).view(X, Y, Z, 6).cpu().numpy())
+        else:
+            np.savez(out_name, occ=grid.cpu().numpy())
+        return out_name
+
+    def annotate_segment(self, chunksize=-1):
+        """:657-688; segments rank, rank + world, ... of the sorted list"""
+        n = 0
+        for i in range(self.rank, len(self.segment_names), self.world):
+            n += self.annotate_one_seg(i)
+        return n

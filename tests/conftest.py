@@ -1,11 +1,6 @@
 import os
 
 os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')  # see objectcentricocccompletion_amd/graph.py
-# The graph-pair replay of the temporal transformer / head tail (heads.graphed_call) is exercised by its own tests in a
-# CHILD process (tests/test_gpu_ococc_train.py::test_graph_pair_paths_in_a_child_process): one segmentation fault inside
-# hipGraphLaunch (backward graph replayed from autograd's device thread) was seen in ~60 runs of the suite and not again
-# in 40 targeted repeats; every other test runs those modules eagerly, so that such a fault cannot take the suite down.
-os.environ.setdefault('OCOCC_GRAPH_TRANSFORMER', '0')
 
 import os
 import sys

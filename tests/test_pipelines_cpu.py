@@ -35,6 +35,23 @@ def test_tracklet_noise_same_draws():
         assert np.allclose(d['tracklet'].boxes.numpy(), G[f'noise_{int(consistent)}'], rtol=1e-6, atol=1e-6)
 
 
+def test_consistent_yaw_noise_is_one_draw_for_the_whole_tracklet():
+    """LiDARTracklet.add_yaw_noise(consistent=True) (lidar_tracklet.py:544-547) adds a [1] tensor to a 0-dim element in
+    place, which raises in the reference itself on torch >= 1.x ("output with shape [] doesn't match the broadcast shape
+    [1]"; oracle/gen_golden_pipelines.py could not execute that branch).  What it plainly means -- ONE uniform draw in
+    (-max, max), taken with torch.rand(1) after the centre and size draws, added to every frame's yaw -- is what the
+    product does; pinned here to that statement, not to a golden."""
+    d = fresh()
+    before = d['tracklet'].boxes.clone()
+    torch.manual_seed(11)
+    P.TrackletNoise(yaw_noise_cfg=dict(max_noise=0.3, consistent=True))(d)
+    torch.manual_seed(11)
+    draw = (torch.rand(1, dtype=before.dtype) - 0.5) * 2 * 0.3
+    after = d['tracklet'].boxes
+    assert torch.equal(after[:, :6], before[:, :6])
+    assert torch.allclose(after[:, 6], before[:, 6] + draw) and abs(float(draw)) <= 0.3
+
+
 def test_point_decoration_columns():
     d = fresh()
     P.PIPELINES.build(dict(type='PointDecoration', properties=['yaw', 'size', 'score', 'center_offset', 'length'],
