@@ -191,6 +191,19 @@ int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_featur
                                    uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status, int32_t* nbr_t,
                                    uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
                                    int64_t workspace_bytes, ococc_stream_t stream);
+/* The same, also leaving the per-row records of the neighbour-pattern row order (ococc_subm_row_order below) for the
+ * table it writes: order_counters as there (zero on entry), order_rowrec [capacity, 4] int32, 16-byte aligned, capacity
+ * below 2^21.  Follow with ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, ...).  Both NULL: exactly the
+ * call above. */
+int ococc_object_grid_geometry_order_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
+                                         int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
+                                         const float host_coors_range[6], int32_t batch_size,
+                                         const int32_t host_grid_zyx[3], int32_t slices, int32_t* voxel_coors,
+                                         int64_t capacity, int32_t* inv, int32_t* counts, float* voxel_feats,
+                                         uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status, int32_t* nbr_t,
+                                         uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
+                                         int64_t workspace_bytes, void* order_counters, int32_t* order_rowrec,
+                                         ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * visibility ray test of the GT-occupancy annotation
@@ -314,6 +327,35 @@ int ococc_sparse_conv_gather_gemm_bf16(const uint16_t* feat, int64_t n_in, int32
 int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                 int32_t ncols, const int32_t* table, int32_t dense_k, int64_t n_out,
                                 const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
+/* The same convolution with the OUTPUT rows processed in neighbour-pattern order (sub-manifold tables, kvol <= 32).
+ * ococc_subm_row_order buckets the rows of an offset-major gather table by (number of neighbours besides dense_k: 3+,
+ * 2, 1, 0; lowest two neighbour offsets) -- rows that share their offsets become neighbours in the order, so a
+ * workgroup walks only the offsets its rows have and 16-row MFMA blocks are nearly full.  The order is a property of
+ * the table: build it once per rulebook, use it for every layer and direction that gathers through the table.
+ *   counters ococc_subm_row_order_counter_bytes() bytes, ZERO on entry; the call leaves them zero again (one buffer,
+ *            zeroed once, serves every build on a stream -- there is no memset launch per build)
+ *   scratch  ococc_subm_row_order_scratch_bytes(n) bytes, 16-byte aligned (the row records: n below 2^21)
+ *   rec      [n, 4] int32, 16-byte aligned: per slot {row, offset mask (bit k: table[k][row] >= 0), table entries at the
+ *            row's lowest and second lowest neighbour offsets (-1: none)}
+ *   hdr      [8] int32   tile plan read by the kernel (heavy_blocks / mid_blocks: 16-row blocks per workgroup tile
+ *                        for the 3+ / 2 neighbour classes: 4, 8 or 16; the rest uses 16)
+ * Slots inside a bucket are handed out with atomics: the order may differ between two builds, the convolution's
+ * result does not (each output row accumulates its own products in ascending offset order, in f32).
+ * ococc_sparse_conv_sorted_bf16: operands as ococc_sparse_conv_gather_gemm_bf16 (wn row-major [kvol, ncols, kd]), same
+ * result bit for bit; kd, ncols in {32, 64, 128}, not both 128.  Replaces indiceConv's per-offset gather / GEMM /
+ * scatter-add (spconv_ops.h:300-354). */
+int64_t ococc_subm_row_order_counter_bytes(void);
+int64_t ococc_subm_row_order_scratch_bytes(int64_t n);
+int ococc_subm_row_order(const int32_t* table, int32_t kvol, int32_t dense_k, int64_t n, int32_t heavy_blocks,
+                         int32_t mid_blocks, void* counters, void* scratch, int32_t* rec, int32_t* hdr,
+                         ococc_stream_t stream);
+/* The second half of ococc_subm_row_order alone, for row records some other kernel left while it wrote the table
+ * (ococc_object_grid_geometry_order_f32): records -> slots, header, counters back to zero. */
+int ococc_subm_row_order_place(const int32_t* rowrec, int32_t kvol, int32_t dense_k, int64_t n, int32_t heavy_blocks,
+                               int32_t mid_blocks, void* counters, int32_t* rec, int32_t* hdr, ococc_stream_t stream);
+int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
+                                  int32_t ncols, const int32_t* table, const int32_t* rec, const int32_t* hdr,
+                                  int64_t n_out, const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
 /* The same kernel with the LayerNorm (+ GELU) that follows the convolution in the reference's
  * make_sparse_convmodule block (mmdet3d/ops/sparse_block.py:216-289: conv -> LN(eps) -> GELU) applied in the
  * epilogue, where the finished f32 row sits in LDS: conv_out [n_out, ncols] bf16 (what the LN backward needs), y =

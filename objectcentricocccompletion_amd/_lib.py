@@ -39,6 +39,9 @@ SIGNATURES = {
     'ococc_object_grid_geometry_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3, c_i32,
                                                c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                c_vp, c_i64, c_vp]),
+    'ococc_object_grid_geometry_order_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3, c_i32,
+                                                     c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                     c_vp, c_i64, c_vp, c_vp, c_vp]),
     'ococc_voxelize_scatter_mean_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3,
                                                 c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_occ_visibility_f64': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
@@ -69,6 +72,12 @@ SIGNATURES = {
                                                   c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_sparse_conv_gather_gemm_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp,
                                                    c_vp, c_i64, c_vp, c_vp, c_i32, c_vp]),
+    'ococc_subm_row_order_scratch_bytes': (c_i64, [c_i64]),
+    'ococc_subm_row_order_counter_bytes': (c_i64, []),
+    'ococc_subm_row_order_place': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_subm_row_order': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_sparse_conv_sorted_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
+                                              c_vp, c_vp, c_i32, c_vp]),
     'ococc_sparse_conv_gather_gemm_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64,
                                                       c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ococc_weight_prepare_multi_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),

@@ -51,6 +51,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float ococc_bf16_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  (Written as two scalar casts joined with
+// shift / or, hipcc emits two conversions and a v_or_b32_sdwa.)
+typedef __attribute__((ext_vector_type(2))) __bf16 ococc_bf16x2;
+__device__ __forceinline__ unsigned int ococc_pack_bf16x2(float lo, float hi) {
+  const ococc_bf16x2 p = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned int, p);
+}
 // round-to-nearest-even through the compiler's cast (v_cvt_pk_bf16_f32 keeps NaNs)
 __device__ __forceinline__ unsigned short ococc_f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;

@@ -31,6 +31,7 @@
 // Nothing leaves the chip between the phases of a kernel except the outputs; the only global atomics are the float
 // adds of the 1.6 % of points that share a cell and the 32-bit ORs of the block masks.
 #include "common.hpp"
+#include "row_order.hpp"
 
 namespace {
 
@@ -344,8 +345,11 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
                  const int32_t* __restrict__ totals, int32_t* __restrict__ inv, int32_t* __restrict__ out_coors,
                  int32_t* __restrict__ counts, float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int64_t cap,
                  int32_t* __restrict__ nbr_t, uint32_t* __restrict__ blockmask, int32_t* __restrict__ pairs,
-                 int emit_blocks) {
+                 int emit_blocks, uint32_t* __restrict__ order_hist, i32x4_t* __restrict__ order_rowrec) {
   extern __shared__ uint32_t smem[];
+  // (order_hist != null: the rows' neighbour-pattern records of ococc_subm_row_order are written here, where the row's
+  // 27 table entries sit in registers anyway -- the separate counting pass re-read the whole table, 14 us)
+  __shared__ uint32_t s_oh[kOrderBuckets];
   if ((int)blockIdx.x >= emit_blocks) {
     // padding rows of the fixed-capacity form: -1 coordinates, zero count and features, no neighbours
     const int64_t total = totals[27];
@@ -358,6 +362,16 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
       if (out_bf16) out_bf16[r * c + ch] = 0;
     }
     for (int k = 0; k < 27; ++k) nbr_t[(int64_t)k * cap + r] = -1;
+    if (order_hist) {
+      // no offsets at all: the "no neighbour" bucket; the rows of a wave take consecutive places behind ONE atomic
+      const int key = order_key(0u, 13, (int)(blockIdx.x % kHotCopies));
+      const unsigned long long m = __ballot(true);
+      uint32_t first = 0u;
+      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) first = atomicAdd(&order_hist[key], (uint32_t)__popcll(m));
+      first = __shfl(first, __ffsll((long long)m) - 1, 64);
+      const uint32_t place = first + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      order_rowrec[r] = i32x4_t{(int)((uint32_t)key | (place << kOrderKeyBits)), 0, -1, -1};
+    }
     return;
   }
   uint32_t* bm = smem;            // [words]
@@ -391,6 +405,8 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
   }
   if (threadIdx.x < kCols) s_base[threadIdx.x] = bases[((int64_t)b * g.slices + sl) * kCols + threadIdx.x];
   if (threadIdx.x < 27) s_run[threadIdx.x] = 0;
+  if (order_hist)
+    for (int i = threadIdx.x; i < kOrderBuckets; i += kEmitThreads) s_oh[i] = 0u;
   // global row of this grid's first voxel: the slice-0 base of the voxel column
   const int32_t grid_base = bases[((int64_t)b * g.slices) * kCols + 27];
   __syncthreads();
@@ -471,6 +487,18 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
       if (lane == 0) s_wcnt[k][wave] = (int32_t)__popcll(m);
       if (nb[k] >= 0) mbits |= 1u << k;
     }
+    if (order_hist && have && row < cap) {
+      int32_t e1 = -1, e2 = -1;
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (k != 13 && nb[k] >= 0) {
+          if (e1 < 0) e1 = nb[k];
+          else if (e2 < 0) e2 = nb[k];
+        }
+      const int key = order_key(mbits, 13, (int)(blockIdx.x % kHotCopies));
+      const uint32_t rank = atomicAdd(&s_oh[key], 1u);   // place inside this workgroup's share of the bucket
+      order_rowrec[row] = i32x4_t{(int)((uint32_t)key | (rank << kOrderKeyBits)), (int)mbits, e1, e2};
+    }
     STAMP(12);
     // 16-row block masks.  Rows are consecutive along the lanes, so a block is a run of lanes: segmented OR towards
     // the run's first lane, which ORs the result into the mask word (cleared by kernel A; a block that continues in
@@ -516,6 +544,17 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     LDS_BARRIER();
   }
 
+  if (order_hist) {
+    // the workgroup's share of every bucket starts where the bucket's counter stood; its rows' records get the start added
+    __syncthreads();
+    order_reserve<kEmitThreads>(s_oh, order_hist);
+    __syncthreads();
+    const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
+    for (int32_t r = row_lo + threadIdx.x; r < hi; r += kEmitThreads) {
+      const uint32_t x = (uint32_t)order_rowrec[r].x;
+      order_rowrec[r].x = (int)(x + (s_oh[x & ((1u << kOrderKeyBits) - 1u)] << kOrderKeyBits));
+    }
+  }
   STAMP(7);
   // ---- points of this grid whose voxel row belongs to the slice, kCodesPerThread * 256 per round ----
   // Every phase first SCANS the round's points (codes -> rank -> "mine?") into a work list in LDS and then serves the
@@ -702,16 +741,19 @@ extern "C" int64_t ococc_object_grid_geometry_workspace_bytes(int64_t n, int32_t
   return L.total;
 }
 
-extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
-                                              int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
-                                              const float host_coors_range[6], int32_t batch_size,
-                                              const int32_t host_grid_zyx[3], int32_t slices, int32_t* voxel_coors,
-                                              int64_t capacity, int32_t* inv, int32_t* counts, float* voxel_feats,
-                                              uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status,
-                                              int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
-                                              int32_t* indice_num, void* workspace, int64_t workspace_bytes,
-                                              ococc_stream_t stream_) {
+extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
+                                                    int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
+                                                    const float host_coors_range[6], int32_t batch_size,
+                                                    const int32_t host_grid_zyx[3], int32_t slices, int32_t* voxel_coors,
+                                                    int64_t capacity, int32_t* inv, int32_t* counts, float* voxel_feats,
+                                                    uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status,
+                                                    int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
+                                                    int32_t* indice_num, void* workspace, int64_t workspace_bytes,
+                                                    void* order_counters, int32_t* order_rowrec, ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE((order_counters == nullptr) == (order_rowrec == nullptr), "order_counters and order_rowrec go together");
+  OCOCC_REQUIRE(!order_rowrec || (capacity < kOrderMaxRows && ((uintptr_t)order_rowrec & 15) == 0),
+                "row records: 16-byte aligned, below 2^21 rows");
   GeoLayout L;
   int64_t gu;
   OCOCC_REQUIRE(n >= 1 && capacity >= 1 && c >= 1 && num_point_features >= 3, "bad sizes");
@@ -766,7 +808,23 @@ extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_p
   const int pad_blocks = (int)ococc_cdiv(capacity, kEmitThreads);
   hipLaunchKernelGGL(grid_emit_kernel, dim3(emit_blocks + pad_blocks), dim3(kEmitThreads), lds, stream, feats, (int)c, n, g,
                      bitmap, lpre, prefix, code_of, seg, bases, totals, inv, voxel_coors, counts, voxel_feats,
-                     voxel_feats_bf16, capacity, nbr_t, blockmask, indice_pairs, emit_blocks);
+                     voxel_feats_bf16, capacity, nbr_t, blockmask, indice_pairs, emit_blocks, (uint32_t*)order_counters,
+                     (i32x4_t*)order_rowrec);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
+}
+
+extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
+                                              int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
+                                              const float host_coors_range[6], int32_t batch_size,
+                                              const int32_t host_grid_zyx[3], int32_t slices, int32_t* voxel_coors,
+                                              int64_t capacity, int32_t* inv, int32_t* counts, float* voxel_feats,
+                                              uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status,
+                                              int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
+                                              int32_t* indice_num, void* workspace, int64_t workspace_bytes,
+                                              ococc_stream_t stream_) {
+  return ococc_object_grid_geometry_order_f32(points, num_point_features, batch_idx, n, feats, c, host_voxel_size,
+                                              host_coors_range, batch_size, host_grid_zyx, slices, voxel_coors, capacity, inv,
+                                              counts, voxel_feats, voxel_feats_bf16, num_voxels, status, nbr_t, blockmask,
+                                              indice_pairs, indice_num, workspace, workspace_bytes, nullptr, nullptr, stream_);
 }

@@ -51,10 +51,7 @@ __device__ __forceinline__ bf16x8 pack_tiles(const f32x4 a, const f32x4 b) {
   return r;
 }
 __device__ __forceinline__ u32x2 pack4(const f32x4 o) {
-  u32x2 v;
-  v.x = (uint32_t)ococc_f32_to_bf16(o[0]) | ((uint32_t)ococc_f32_to_bf16(o[1]) << 16);
-  v.y = (uint32_t)ococc_f32_to_bf16(o[2]) | ((uint32_t)ococc_f32_to_bf16(o[3]) << 16);
-  return v;
+  return u32x2{ococc_pack_bf16x2(o[0], o[1]), ococc_pack_bf16x2(o[2], o[3])};
 }
 __device__ __forceinline__ f32x4 unpack4(const u32x2 v) {
   return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
@@ -79,7 +76,8 @@ __device__ __forceinline__ void load_frags(const int tid_, const uint16_t* __res
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[nb][ks] = wp[(nb * KS + ks) * 64];
 }
-template <int NB, int KS>
+// FRESH: acc is write-only (the first k-step multiplies into a zero literal: no register zeroing in front of the GEMM)
+template <int NB, int KS, bool FRESH = false>
 __device__ __forceinline__ void tile_gemm(const int tid_, const bf16x8 (&a)[NB][KS], const uint16_t* xs, int ldb, f32x4 (&acc)[NB][4]) {
   const int lane = tid_ & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
@@ -91,7 +89,7 @@ __device__ __forceinline__ void tile_gemm(const int tid_, const bf16x8 (&a)[NB][
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
-        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb][ks], b[mb], acc[nb][mb], 0, 0, 0);
+        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb][ks], b[mb], (FRESH && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nb][mb], 0, 0, 0);
   }
 }
 
@@ -267,7 +265,7 @@ struct TilePieces {
 __device__ __forceinline__ uint32_t add_bf16x2(uint32_t a, uint32_t b) {
   const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
   const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-  return (uint32_t)ococc_f32_to_bf16(lo) | ((uint32_t)ococc_f32_to_bf16(hi) << 16);
+  return ococc_pack_bf16x2(lo, hi);
 }
 
 template <int ACT>  // 0 gelu (erf), 1 relu
@@ -319,8 +317,7 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
   bf16x8 fqk[NQK][4];
   {
     f32x4 acc[NV][4];
-    zero_acc(acc);
-    tile_gemm<NV, 4>(tid_, fv, xs, LDX, acc);
+    tile_gemm<NV, 4, true>(tid_, fv, xs, LDX, acc);
     if (!RES) load_frags<NQK, 4>(tid_, wqkv, NQK * wave, fqk);
 #pragma unroll
     for (int nb = 0; nb < NV; ++nb) {
@@ -345,9 +342,8 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
   __syncthreads();
   {
     f32x4 acc[NQK][4];
-    zero_acc(acc);
-    if (RES) tile_gemm<NQK, 4>(tid_, fqk_res, xs, LDX, acc);
-    else tile_gemm<NQK, 4>(tid_, fqk, xs, LDX, acc);
+    if (RES) tile_gemm<NQK, 4, true>(tid_, fqk_res, xs, LDX, acc);
+    else tile_gemm<NQK, 4, true>(tid_, fqk, xs, LDX, acc);
     after_qk();
 #pragma unroll
     for (int nb = 0; nb < NQK; ++nb) {
@@ -378,17 +374,20 @@ __device__ __forceinline__ void tile_range(const int tid_, const TileMeta* tm, i
 // Attention of head h for the 16 queries of tile qt (lane: query c): S^T = K Q^T (16x16x16 MFMA, keys on the rows),
 // softmax over the keys of the query's window in registers, O^T = V^T P^T (16x16x32 MFMA, V^T by transposing reads).
 // Returns o (d = 4g + r of query c) and the log-sum-exp of the query.
-__device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* qs, int h, int qt, int klo, int khi, int span_q,
-                                               float& lse) {
+// madd: the lane's additive key mask (0 for a key of the query's window, -inf otherwise; slot [kt][r] = key 16 kt + 4 g + r),
+// the same for every head: the caller works it out once per query tile.  Scores are kept in base 2 (the 1 / sqrt(16)
+// scale times log2 e goes into one fused multiply-add with the mask), so that an exponential is v_sub + v_exp.
+__device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* qs, int h, int qt, int klo, int khi,
+                                               const f32x4 (&madd)[4], float& lse) {
   const int lane = tid_ & 63, c = lane & 15, g = lane >> 4;
   const int q_ = c >> 2, p_ = c & 3;
   const uint16_t* qh = qs + h * HD;
   const uint16_t* kh = qs + E + h * HD;
   const uint16_t* vh = qs + 2 * E + h * HD;
-  const int lo = span_q & 255, hi = span_q >> 8;
+  constexpr float kScale2 = 0.25f * 1.44269504088896340736f;   // 1 / sqrt(16) * log2(e)
   const s16x4 bq = ld4(qh + (qt * 16 + c) * LDQ + 4 * g);
   f32x4 s[4];
-  float m = -INFINITY;
+  float m = -1e30f;   // (finite: a query without a key -- an empty slot -- ends with weights 0, not NaN)
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
     s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -397,12 +396,8 @@ __device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* q
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bq, acc, 0, 0, 0);   // rows: keys 4g+r, col: query c
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * g + r;
-        const float val = (key >= lo && key < hi) ? acc[r] * 0.25f : -INFINITY;   // 1 / sqrt(16)
-        s[kt][r] = val;
-        m = fmaxf(m, val);
-      }
+      for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(acc[r], kScale2, madd[kt][r]);
+      m = fmaxf(fmaxf(m, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
     }
   }
   m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -413,7 +408,7 @@ __device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* q
     if (kt >= klo && kt <= khi) {   // (a window of ~10 tokens touches one or two of the four key tiles)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = m > -INFINITY ? __expf(s[kt][r] - m) : 0.f;
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);   // (-inf - m -> 0)
         s[kt][r] = e;
         sum += e;
       }
@@ -424,7 +419,7 @@ __device__ __forceinline__ f32x4 attn_head_fwd(const int tid_, const uint16_t* q
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
-  lse = sum > 0.f ? m + __logf(sum) : 0.f;
+  lse = sum > 0.f ? (m + __log2f(sum)) * 0.69314718055994530942f : 0.f;   // natural units, as the backward reads it
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -445,11 +440,20 @@ __device__ __forceinline__ void attn_tile_fwd(const int tid_, const TileMeta* tm
     int klo, khi;
     tile_range(tid_, tm, qt, klo, khi);
     const int sp = tm->span[qt * 16 + c];
+    const int lo = sp & 255, hi = sp >> 8;
+    f32x4 madd[4];   // 0 / -inf per score slot of the lane: keys of the query's window only
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        madd[kt][r] = (key >= lo && key < hi) ? 0.f : -INFINITY;
+      }
 #pragma unroll
     for (int hh = 0; hh < NH / NW; ++hh) {
       const int h = (NH / NW) * wave + hh;
       float lse;
-      const f32x4 o = attn_head_fwd(tid_, qs, h, qt, klo, khi, sp, lse);
+      const f32x4 o = attn_head_fwd(tid_, qs, h, qt, klo, khi, madd, lse);
       *(u32x2*)(os + (qt * 16 + c) * LDX + h * HD + 4 * g) = pack4(o);
       if (lse_s && g == 0) lse_s[h * TM + qt * 16 + c] = lse;
     }
@@ -524,8 +528,7 @@ window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     attn_tile_fwd<NW>(tid_, tm, qs, xs, nullptr);   // o goes where x + pos was (its last reader was the Q | K GEMM)
     __syncthreads();
     f32x4 z[2][4];
-    zero_acc(z);
-    tile_gemm<2, 4>(tid_, fo, xs, LDX, z);
+    tile_gemm<2, 4, true>(tid_, fo, xs, LDX, z);
     load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);    // the next tile's first GEMM
     f32x4 gam[2], bet[2];
 #pragma unroll
@@ -590,8 +593,7 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
     __syncthreads();
     {
       f32x4 acc[4][4];
-      zero_acc(acc);
-      tile_gemm<4, 4>(tid_, f1, xs, LDX, acc);
+      tile_gemm<4, 4, true>(tid_, f1, xs, LDX, acc);
       load_frags<2, 8>(tid_, w2, 2 * wave, f2);
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
@@ -603,8 +605,7 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
     }
     __syncthreads();
     f32x4 z[2][4];
-    zero_acc(z);
-    tile_gemm<2, 8>(tid_, f2, hs, LDH, z);
+    tile_gemm<2, 8, true>(tid_, f2, hs, LDH, z);
     load_frags<4, 4>(tid_, w1, 4 * wave, f1);           // the next tile's first GEMM
     f32x4 gam[2], bet[2];
 #pragma unroll
@@ -680,8 +681,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
       bf16x8 f[2][4];
       load_frags<2, 4>(tid_, w1, 2 * wave, f);
       f32x4 hpre[2][4];
-      zero_acc(hpre);
-      tile_gemm<2, 4>(tid_, f, xs, LDX, hpre);
+      tile_gemm<2, 4, true>(tid_, f, xs, LDX, hpre);
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int n = 16 * (2 * wave + nb) + 4 * g;
@@ -697,11 +697,10 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
     __syncthreads();
     tile_store_rows<NW, FF>(hs, LDH, a_out, nullptr, row0, num_tokens);
     f32x4 z[1][4], dz[1][4];
-    zero_acc(z);
     {
       bf16x8 f[1][8];
       load_frags<1, 8>(tid_, w2, wave, f);
-      tile_gemm<1, 8>(tid_, f, hs, LDH, z);
+      tile_gemm<1, 8, true>(tid_, f, hs, LDH, z);
     }
     {
       const f32x4 b = *(const f32x4*)(b2 + n1);
@@ -725,8 +724,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
       bf16x8 f[2][4];
       load_frags<2, 4>(tid_, w2t, 2 * wave, f);
       f32x4 da[2][4];
-      zero_acc(da);
-      tile_gemm<2, 4>(tid_, f, xs, LDX, da);           // d act(h) = W2^T dz
+      tile_gemm<2, 4, true>(tid_, f, xs, LDX, da);           // d act(h) = W2^T dz
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int n = 16 * (2 * wave + nb) + 4 * g;
@@ -738,11 +736,10 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
     __syncthreads();
     tile_store_rows<NW, FF>(hs, LDH, dh_out, nullptr, row0, num_tokens);
     f32x4 gx[1][4];
-    zero_acc(gx);
     {
       bf16x8 f[1][8];
       load_frags<1, 8>(tid_, w1t, wave, f);
-      tile_gemm<1, 8>(tid_, f, hs, LDH, gx);           // W1^T dh
+      tile_gemm<1, 8, true>(tid_, f, hs, LDH, gx);           // W1^T dh
     }
     // (the dz tile in xs -- B operand of the d act GEMM, source of dz_out -- was last read before the barrier above)
 #pragma unroll
@@ -827,11 +824,10 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     __syncthreads();
     tile_store_rows<NW, E>(xs, LDX, o_out, tm->rows, 0, 0);
     f32x4 z[1][4];
-    zero_acc(z);
     {
       bf16x8 f[1][4];
       load_frags<1, 4>(tid_, wo, wave, f);
-      tile_gemm<1, 4>(tid_, f, xs, LDX, z);
+      tile_gemm<1, 4, true>(tid_, f, xs, LDX, z);
     }
     {
       const f32x4 b = *(const f32x4*)(bo + n1);
@@ -848,10 +844,9 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     tile_store_rows<NW, E>(xs, LDX, dz_out, tm->rows, 0, 0);
     {
       f32x4 go[1][4];
-      zero_acc(go);
       bf16x8 f[1][4];
       load_frags<1, 4>(tid_, wot, wave, f);
-      tile_gemm<1, 4>(tid_, f, xs, LDX, go);    // dO = Wo^T dz1
+      tile_gemm<1, 4, true>(tid_, f, xs, LDX, go);    // dO = Wo^T dz1
       __syncthreads();                     // dz1 tile: read by every wave's GEMM and by the copy above
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(go[0][mb]);
@@ -980,11 +975,10 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     __syncthreads();
     tile_store_rows<NW, 3 * E>(qs, LDQ, dqkv_out, tm->rows, 0, 0);
     f32x4 gx[1][4];
-    zero_acc(gx);
     {
       bf16x8 f[1][12];
       load_frags<1, 12>(tid_, wqkvt, wave, f);
-      tile_gemm<1, 12>(tid_, f, qs, LDQ, gx);   // dx = Wqkv^T dqkv (+ dz1: the residual)
+      tile_gemm<1, 12, true>(tid_, f, qs, LDQ, gx);   // dx = Wqkv^T dqkv (+ dz1: the residual)
     }
     load_frags<1, 4>(tid_, wqkv, 16 + wave, fv);   // the next tile's first GEMM
 #pragma unroll

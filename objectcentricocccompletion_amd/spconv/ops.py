@@ -95,6 +95,7 @@ class RulebookTables(object):
         self.subm = subm
         self.kvol = kvol
         self.tables = {}  # (inverse, direction) -> (table, blockmask, rows)
+        self.orders = {}  # table address -> (rec, hdr, table): the neighbour-pattern row order (row_order)
 
 
 def _ilist(v, ndim):
@@ -229,10 +230,11 @@ def current_density():
     return float(DEFAULT_PAIRS_PER_ROW) if DEFAULT_PAIRS_PER_ROW is not None else density.value
 
 
-def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None):
+def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None, rowrec=None):
     """Hang the device-side companions of a sub-manifold rulebook (offset-major gather table, 16-row block masks) on
     its indice_pairs tensor, where indice_conv / indice_conv_backward look for them.  ``num``: the per-offset pair counts
-    (device), observed by the density tracker."""
+    (device), observed by the density tracker.  ``rowrec``: row records of the neighbour-pattern order, if the kernel
+    that wrote the table left them (new_rulebook_wants_order)."""
     rb = RulebookTables(symmetric, kvol)
     if AUTO_DENSITY and DEFAULT_PAIRS_PER_ROW is None:
         density.observe(num, rows)
@@ -242,6 +244,11 @@ def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None)
     if symmetric:
         rb.tables[(False, 'bwd')] = (nbr_t, mask, rows)  # symmetric: same table, offset-flipped weights
     pairs._ococc = rb
+    if rowrec is not None or (_sorted_regime(rb) and 0 < rows < ORDER_MAX_ROWS):
+        # the neighbour-pattern row order is part of the geometry: built here, it runs wherever the rulebook is built
+        # (bench.py: on the forked stream, beside the previous batch's convolutions) and not in front of the first layer
+        # (row records at hand: the counters they were counted into must be emptied by the placing pass in any case)
+        row_order(rb, nbr_t, rows, rowrec)
     return rb
 
 
@@ -564,6 +571,81 @@ def _use_tile_kernel(rb, kd, ncols):
     return ppr is not None and ppr <= _TILE_SHAPES.get((kd, ncols), -1.0)
 
 
+# Output rows in neighbour-pattern order (csrc/sparse_conv_sorted.hip): sub-manifold layers the tile kernel does not
+# take, on sparse rulebooks.  OCOCC_SORTED_CONV=0 keeps the voxel-order kernels, =1 forces the order whatever the
+# density; unset: by the rulebook's pairs per row.  OCOCC_SORTED_TILES=heavy,mid sets the 16-row blocks per workgroup
+# tile for rows with 3+ / 2 neighbours.
+SORTED_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_SORTED_CONV'))
+SORTED_TILES = tuple(int(v) for v in os.environ.get('OCOCC_SORTED_TILES', '4,8').split(','))
+
+
+# rulebook pairs per output row up to which the order pays (denser: most rows need most offsets whatever the order,
+# and the small tiles only multiply the weight traffic)
+SORTED_MAX_PAIRS_PER_ROW = float(os.environ.get('OCOCC_SORTED_MAX_PAIRS_PER_ROW', '4.0'))
+
+
+def _sorted_regime(rb):
+    if SORTED_CONV is False or rb is None or not rb.subm or rb.kvol > 32:
+        return False
+    if rb.orders or SORTED_CONV:   # (an order that came with the rulebook is used)
+        return True
+    ppr = getattr(rb, 'pairs_per_row', None)
+    return ppr is not None and ppr <= SORTED_MAX_PAIRS_PER_ROW
+
+
+def _use_sorted_kernel(rb, kd, ncols):
+    return (_sorted_regime(rb) and kd in (32, 64, 128) and ncols in (32, 64, 128) and kd * ncols < 128 * 128
+            and not _use_tile_kernel(rb, kd, ncols))
+
+
+_order_counters = {}   # device -> the zero-in / zero-out counters of ococc_subm_row_order
+ORDER_MAX_ROWS = 1 << 21   # a row record holds places below 2^21
+
+
+def order_counters(dev):
+    hit = _order_counters.get(dev)
+    if hit is None:
+        hit = _order_counters[dev] = torch.zeros((int(L.lib.ococc_subm_row_order_counter_bytes()),), dtype=torch.uint8,
+                                                 device=dev)
+    return hit
+
+
+def new_rulebook_wants_order(rows, kvol=27):
+    """will a sub-manifold rulebook built NOW take the neighbour-pattern row order?  (the geometry kernel that writes the
+    gather table can leave the order's row records on the way: scatter_points.object_grid_geometry asks before it
+    launches)"""
+    if SORTED_CONV is False or kvol > 32 or not 0 < rows < ORDER_MAX_ROWS:
+        return False
+    if SORTED_CONV:
+        return True
+    ppr = current_density()
+    return ppr is not None and ppr <= SORTED_MAX_PAIRS_PER_ROW
+
+
+def row_order(rb, table, rows, rowrec=None):
+    """(rec, hdr) of a sub-manifold gather table -- per slot {row, offset mask, table entries at its two lowest neighbour
+    offsets} and the tile plan: built on first use, kept with the rulebook (every layer and direction that reads the
+    table shares it).  ``rowrec``: the per-row records, if the kernel that wrote the table left them."""
+    hit = rb.orders.get(table.data_ptr())
+    if hit is None:
+        dev = table.device
+        kvol = table.size(0)
+        rec = torch.empty((max(rows, 1), 4), dtype=torch.int32, device=dev)
+        hdr = torch.empty((8,), dtype=torch.int32, device=dev)
+        dense_k = kvol // 2 if kvol % 2 == 1 else -1
+        if rowrec is not None:
+            L.check(L.lib.ococc_subm_row_order_place(L.ptr(rowrec), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
+                                                     L.ptr(order_counters(dev)), L.ptr(rec), L.ptr(hdr), L.stream()),
+                    'subm_row_order_place')
+        else:
+            ws = L.workspace(L.lib.ococc_subm_row_order_scratch_bytes(rows), dev)
+            L.check(L.lib.ococc_subm_row_order(L.ptr(table), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
+                                               L.ptr(order_counters(dev)), L.ptr(ws), L.ptr(rec), L.ptr(hdr), L.stream()),
+                    'subm_row_order')
+        hit = rb.orders[table.data_ptr()] = (rec, hdr, table)   # (table: keeps the key's address alive)
+    return hit[:2]
+
+
 def _fragment_major(rb, kd, ncols):
     """the tile kernel loads its weight fragments straight from L2 and wants them in fragment-major order (prepare
     mode + 4)"""
@@ -578,6 +660,13 @@ def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
                                                   L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
                                                   L.dtype_code(out_dtype), L.stream()),
                 'sparse_conv_tile')
+        return out
+    if _use_sorted_kernel(rb, kd, ncols):
+        rec, hdr = row_order(rb, table, rows)
+        L.check(L.lib.ococc_sparse_conv_sorted_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
+                                                    L.ptr(table), L.ptr(rec), L.ptr(hdr), rows,
+                                                    L.ptr(bias), L.ptr(out), L.dtype_code(out_dtype), L.stream()),
+                'sparse_conv_sorted')
         return out
     L.check(L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn),
                                                      kvol, ncols, L.ptr(table), L.ptr(mask), rows,

@@ -112,3 +112,57 @@ def test_encoder_uses_the_fused_geometry_and_matches(dev):
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', [CASES[0], CASES[1], CASES[2], CASES[4]])
+@pytest.mark.parametrize('slices', [4, 13, None])
+def test_emit_leaves_the_row_order_records(dev, case, slices):
+    """with a sparse density on record the emit kernel also writes the neighbour-pattern order's row records: the order
+    built from them is a valid one (every row once, masks and the two lowest entries as in the table, classes 3+ / 2 /
+    1 / 0 neighbours in that sequence with the same sizes as the order built from the table alone) and the counters are
+    back to zero"""
+    from objectcentricocccompletion_amd.spconv import ops
+    from objectcentricocccompletion_amd.voxel import object_grid_geometry
+    B, shape, vs = case['B'], list(case['shape']), case['vs']
+    xyz, feats, bidx = _points(B, case['per_grid'], seed=B * 5 + (slices or 0), half=case['half'], ragged=case.get('ragged', False),
+                               empty_grid=case.get('empty_grid'))
+    rng = [-case['half']] * 2 + [-shape[0] * vs / 2] + [case['half']] * 2 + [shape[0] * vs / 2]
+    xyz[:, 2] = xyz[:, 2] * (shape[0] * vs / 2) / case['half']
+    xyz, feats, bidx = xyz.to(dev), feats.to(dev), bidx.to(dev)
+    keep = ops.DEFAULT_PAIRS_PER_ROW
+    try:
+        ops.DEFAULT_PAIRS_PER_ROW = 1.8
+        got = object_grid_geometry(xyz, bidx, feats, [vs] * 3, rng, shape, B, out_dtype=torch.bfloat16, slices=slices)
+    finally:
+        ops.DEFAULT_PAIRS_PER_ROW = keep
+    pairs = got[5]
+    rb = pairs._ococc
+    table, _, rows = rb.tables[(False, 'fwd')]
+    assert len(rb.orders) == 1
+    rec, hdr = ops.row_order(rb, table, rows)
+    assert int(ops.order_counters(dev).view(torch.int32).abs().sum()) == 0
+    rec, hdr = rec.cpu().long(), hdr.cpu().tolist()
+    tab = table.cpu().long()
+    perm, smask = rec[:, 0], rec[:, 1] & 0xffffffff
+    assert torch.equal(perm.sort().values, torch.arange(rows))
+    tmask = torch.zeros(rows, dtype=torch.long)
+    for k in range(27):
+        tmask |= (tab[k] >= 0).long() << k
+    assert torch.equal(smask, tmask[perm])
+    nb = smask & ~(1 << 13)
+    low1 = nb & -nb
+    nb2 = nb & (nb - 1)
+    low2 = nb2 & -nb2
+    for col, low in ((2, low1), (3, low2)):
+        want = torch.full((rows,), -1, dtype=torch.long)
+        has = low != 0
+        kk = torch.tensor([int(v).bit_length() - 1 for v in low.tolist()])
+        want[has] = tab[kk[has], perm[has]]
+        assert torch.equal(rec[:, col], want)
+    pc = torch.tensor([bin(int(v)).count('1') for v in nb.tolist()])
+    cls = 3 - pc.clamp(max=3)
+    assert bool((cls[1:] >= cls[:-1]).all())
+    # the same header as the order built by the stand-alone counting pass
+    rb2 = ops.RulebookTables(True, 27)
+    _, hdr2 = ops.row_order(rb2, table, rows)
+    assert hdr == hdr2.cpu().tolist()

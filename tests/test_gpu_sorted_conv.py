@@ -1,0 +1,176 @@
+"""ococc_sparse_conv_sorted_bf16 / ococc_subm_row_order (sub-manifold convolution with the output rows taken in
+neighbour-pattern order) against the voxel-order output-stationary kernel, which is pinned to the oracle in
+test_gpu_spconv.py: the two must agree BIT FOR BIT (a row's products are added in ascending offset order in both).
+Reference: indiceConv / indiceConvBackward, mmdet3d/ops/spconv/include/spconv/spconv_ops.h:260-456."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _scene(dev, batch, shape, density, seed):
+    g = torch.Generator().manual_seed(seed)
+    cells = batch * shape[0] * shape[1] * shape[2]
+    n = max(int(cells * density), 1)
+    flat = torch.randperm(cells, generator=g)[:n].sort().values
+    b = flat // (shape[0] * shape[1] * shape[2])
+    r = flat % (shape[0] * shape[1] * shape[2])
+    z, y, x = r // (shape[1] * shape[2]), (r // shape[2]) % shape[1], r % shape[2]
+    return torch.stack([b, z, y, x], 1).to(torch.int32).to(dev)
+
+
+def _both(ops, fn):
+    res = {}
+    keep = ops.SORTED_CONV, ops.SPARSE_TILE_CONV
+    try:
+        ops.SPARSE_TILE_CONV = False
+        for on in (False, True):
+            ops.SORTED_CONV = on
+            res[on] = fn()
+    finally:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = keep
+    return res[False], res[True]
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (32, 128), (128, 32)])
+@pytest.mark.parametrize('density', [0.03, 0.12, 0.45])
+def test_sorted_rows_give_the_same_bits_as_voxel_order(dev, cin, cout, density):
+    from objectcentricocccompletion_amd.spconv import ops
+    shape = [20, 18, 19]
+    coors = _scene(dev, 4, shape, density, seed=cin + cout)
+    n = coors.shape[0]
+    _, pairs, num = ops.get_indice_pairs(coors, 4, shape, 3, subm=True)
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.1).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    for dt in (torch.bfloat16, torch.float32):
+        x = torch.randn(n, cin, generator=g).to(dev).to(dt)
+        dy = torch.randn(n, cout, generator=g).to(dev).to(dt)
+
+        def run():
+            y = ops.indice_conv(x, w, pairs, num, n, False, True, bias=bias)
+            dx, _ = ops.indice_conv_backward(x, w, dy, pairs, num, False, True, need_filter_grad=False)
+            return y, dx
+        (y0, dx0), (y1, dx1) = _both(ops, run)
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        assert bool(torch.isfinite(y1.float()).all()) and float(y1.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize('tiles', [(4, 8), (4, 4), (8, 16), (16, 16), (8, 4)])
+def test_tile_plan_sizes_and_padding_rows(dev, tiles):
+    """fixed-capacity padding rows (-1 coordinates: no offsets at all, not even the centre) produce the bias; every
+    tile plan gives the same bits; the row count is no multiple of anything."""
+    from objectcentricocccompletion_amd.spconv import ops
+    shape = [17, 13, 15]
+    coors = _scene(dev, 3, shape, 0.15, seed=11)
+    coors = torch.cat([coors, torch.full((77, 4), -1, dtype=torch.int32, device=dev)], 0)
+    n = coors.shape[0]
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(3, 3, 3, 64, 128, generator=g) * 0.1).to(dev)
+    bias = torch.randn(128, generator=g).to(dev)
+    x = torch.randn(n, 64, generator=g).to(dev).bfloat16()
+    keep = ops.SORTED_TILES
+    try:
+        ops.SORTED_TILES = tiles
+        _, pairs, num = ops.get_indice_pairs(coors, 3, shape, 3, subm=True)   # (a fresh rulebook: the order is cached on it)
+        y0, y1 = _both(ops, lambda: ops.indice_conv(x, w, pairs, num, n, False, True, bias=bias))
+    finally:
+        ops.SORTED_TILES = keep
+    assert torch.equal(y0, y1)
+    assert torch.equal(y1[-77:].float(), bias.bfloat16().float().expand(77, 128))
+
+
+def test_row_order_is_a_permutation_grouped_by_pattern(dev):
+    from objectcentricocccompletion_amd.spconv import ops
+    shape = [24, 24, 24]
+    coors = _scene(dev, 6, shape, 0.04, seed=3)
+    n = coors.shape[0]
+    _, pairs, num = ops.get_indice_pairs(coors, 6, shape, 3, subm=True)
+    rb, (table, mask, rows) = ops._tables_for(pairs, num, False, 'fwd', n, True)
+    rec, hdr = ops.row_order(rb, table, rows)
+    rec, hdr = rec.cpu().long(), hdr.cpu().tolist()
+    perm, smask = rec[:, 0], rec[:, 1] & 0xffffffff
+    assert torch.equal(perm.sort().values, torch.arange(n))
+    tmask = torch.zeros(n, dtype=torch.long)
+    tab = table.cpu().long()
+    for k in range(27):
+        tmask |= (tab[k] >= 0).long() << k
+    assert torch.equal(smask, tmask[perm])
+    # the record's two table entries: at the row's lowest and second lowest neighbour offsets
+    for col in (2, 3):
+        want = torch.full((n,), -1, dtype=torch.long)
+        left = (smask & ~(1 << 13)).clone()
+        for _ in range(col - 2):
+            left &= left - 1                      # drop the lowest set bit
+        has = left != 0
+        low = (left & -left)
+        kk = torch.tensor([int(v).bit_length() - 1 for v in low.tolist()])
+        want[has] = tab[kk[has], perm[has]]
+        assert torch.equal(rec[:, col], want)
+    # classes in order 3+, 2, 1, 0 neighbours besides the centre; inside a class by the two lowest offsets
+    nb = smask & ~(1 << 13)
+    pc = torch.tensor([bin(int(v)).count('1') for v in nb])
+    cls = 3 - pc.clamp(max=3)
+    assert bool((cls[1:] >= cls[:-1]).all())
+    e3, e2 = int((cls == 0).sum()), int((cls <= 1).sum())
+    b_total = (n + 15) // 16
+    assert hdr[0] == min((e3 + 15) // 16, b_total) and hdr[1] == min(max(hdr[0], (e2 + 15) // 16), b_total) and hdr[2] == b_total
+    hb, mb = ops.SORTED_TILES
+    assert hdr[3] == -(-hdr[0] // hb) - (-(hdr[1] - hdr[0]) // mb) - (-(hdr[2] - hdr[1]) // 16)
+    assert hdr[4:] == [n, hb, mb, 13]
+    # (the payoff: workgroup-offset iterations in this order against voxel order)
+    def iters(m):
+        m = torch.cat([m, torch.zeros((-len(m)) % 256, dtype=torch.long)]).view(-1, 256)
+        acc = torch.zeros(m.shape[0], dtype=torch.long)
+        for j in range(256):
+            acc |= m[:, j]
+        return sum(bin(int(v)).count('1') for v in acc)
+    assert iters(smask) * 2 < iters(tmask)
+
+
+def test_empty_and_tiny_tables(dev):
+    from objectcentricocccompletion_amd.spconv import ops
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn(3, 3, 3, 32, 64, generator=g) * 0.1).to(dev)
+    for n_vox in (1, 5, 17):
+        coors = _scene(dev, 1, [6, 6, 6], n_vox / 216.0, seed=n_vox)
+        n = coors.shape[0]
+        _, pairs, num = ops.get_indice_pairs(coors, 1, [6, 6, 6], 3, subm=True)
+        x = torch.randn(n, 32, generator=g).to(dev).bfloat16()
+        y0, y1 = _both(ops, lambda: ops.indice_conv(x, w, pairs, num, n, False, True))
+        assert torch.equal(y0, y1)
+
+
+def test_density_selects_the_order(dev):
+    """unset switch: sparse rulebooks (pairs per row known and small) take the order, built with the rulebook; dense or
+    unmeasured ones keep the voxel-order kernels"""
+    from objectcentricocccompletion_amd.spconv import ops
+    assert ops.SORTED_CONV is None and ops.SPARSE_TILE_CONV is None
+    shape = [16, 16, 16]
+    coors = _scene(dev, 2, shape, 0.05, seed=9)
+    n = coors.shape[0]
+    g = torch.Generator().manual_seed(4)
+    w = (torch.randn(3, 3, 3, 64, 128, generator=g) * 0.1).to(dev)
+    x = torch.randn(n, 64, generator=g).to(dev).bfloat16()
+    keep = ops.DEFAULT_PAIRS_PER_ROW
+    try:
+        outs = []
+        for ppr, sorted_expected in ((1.8, True), (9.0, False), (None, False)):
+            ops.DEFAULT_PAIRS_PER_ROW = ppr
+            if ppr is None:
+                ops.density.reset()
+            _, pairs, num = ops.get_indice_pairs(coors, 2, shape, 3, subm=True)
+            rb = pairs._ococc
+            assert bool(rb.orders) == sorted_expected            # built with the rulebook, or not at all
+            outs.append(ops.indice_conv(x, w, pairs, num, n, False, True))
+            assert bool(rb.orders) == sorted_expected
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        ops.DEFAULT_PAIRS_PER_ROW = keep
