@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # gather_gemm_stream_kernel<64,128>: gathers X rows (64 ch), writes Y rows (128 ch).  (Its dgrad, which
 # gathers dY[.,128] and writes dX[.,64], was the dominant one until it moved to subm_tile_conv_kernel.)
 PROBE_KD, PROBE_NC = 64, 128
-PMC_JSON = 'r02_pmc_gather_gemm_stream_64_128.json'
+PMC_JSON = {'stream': 'r02_pmc_gather_gemm_stream_64_128.json', 'sorted': 'r04_pmc_gather_gemm_sorted_64_128.json'}
 
 
 def parse():
@@ -119,11 +119,11 @@ def cpu_baseline(sample_grids, points, model):
                       'oracle/encoder_torch_cpu.py'}
 
 
-def pmc_traffic():
+def pmc_traffic(kernel='stream'):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON)."""
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON[kernel])."""
     try:
-        with open(os.path.join(ROOT, 'profiles', PMC_JSON)) as f:
+        with open(os.path.join(ROOT, 'profiles', PMC_JSON[kernel])) as f:
             return json.load(f)['traffic_bytes_per_launch']
     except Exception:
         return None
@@ -551,6 +551,24 @@ def main():
             active = int(((mask[:, None] >> torch.arange(27, device=mask.device)[None, :]) & 1).sum().item())
             over_issue = round(active * 16 / max(n_pairs, 1), 2)
         del ref_out
+
+    def sorted_kernel_in_use():
+        """does the 64 -> 128 forward of a rulebook built now run on the neighbour-pattern row order?  (and its over-issue:
+        16-row blocks of SLOTS with any neighbour at an offset)"""
+        with torch.no_grad():
+            o = model(xyz, feats, bidx, B)
+            rb2 = getattr(o.indice_dict['subm1'][2], '_ococc', None)
+            if rb2 is None or not sp_ops._use_sorted_kernel(rb2, PROBE_KD, PROBE_NC):
+                return False, None
+            table, _, rows = rb2.tables[(False, 'fwd')]
+            rec, _ = sp_ops.row_order(rb2, table, rows)
+            m = rec[:, 1].to(torch.int64) & 0xffffffff
+            m = torch.cat([m, m.new_zeros((-m.numel()) % 16)]).view(-1, 16)
+            blk = m[:, 0]
+            for j in range(1, 16):
+                blk = blk | m[:, j]
+            active = int(((blk[:, None] >> torch.arange(27, device=blk.device)[None, :]) & 1).sum().item())
+            return True, round(active * 16 / max(n_pairs, 1), 2)
     # The sub-manifold convolutions pick their kernel from the rulebook density (compact-then-multiply below ~2-3 pairs
     # per row).  Nothing is set here: spconv.ops.density measured it on the device while that first forward built its
     # rulebook (an asynchronous copy behind an event); harvest it now, before the warm-up steps and the graph capture.
@@ -722,6 +740,7 @@ def main():
     if rank == 0:
         n_vox = int(n_act)
         kern_ms = probe.mean_ms()
+        sorted_used, sorted_over_issue = sorted_kernel_in_use()
         # algorithmic (compulsory) bytes of one launch on the 64<->128 layer, SURVEY.md 8d:
         # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
         alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
@@ -748,15 +767,17 @@ def main():
                 'host_us_to_queue_one_step': round(host_us, 1),
             },
             'roofline': {
-                'kernel': 'gather_gemm_stream_kernel<64,128,true> (SubMConv3d 64->128 forward: gathers X[.,64], writes Y[.,128])',
+                'kernel': ('gather_gemm_sorted_kernel<64,128,true>' if sorted_used else 'gather_gemm_stream_kernel<64,128,true>') +
+                          ' (SubMConv3d 64->128 forward: gathers X[.,64], writes Y[.,128])',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': pmc_traffic(),
+                'traffic': pmc_traffic('sorted' if sorted_used else 'stream'),
                 'algorithmic_bytes_per_launch': alg_bytes,
-                'mfma_over_issue': over_issue,   # rows the kernel multiplies / rows that have a neighbour (16-row blocks)
+                'mfma_over_issue': sorted_over_issue if sorted_used else over_issue,   # rows the kernel multiplies / rows that have a neighbour (16-row blocks)
+                'mfma_over_issue_voxel_order': over_issue,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
                 'launches_timed': probe.count(),
                 'timed_in': 'timed region' if not use_graph else

@@ -13,10 +13,13 @@ ap.add_argument('--vox', type=int, default=2000)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--mode', default='fwd', choices=['fwd', 'bwd', 'both'])
 ap.add_argument('--tile', action='store_true', help='force the compact-then-multiply kernel (ococc_sparse_conv_tile_bf16)')
+ap.add_argument('--sorted', action='store_true', help='force the neighbour-pattern row order (ococc_sparse_conv_sorted_bf16)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 if a.tile:
     ops.SPARSE_TILE_CONV = True
+if a.sorted:
+    ops.SPARSE_TILE_CONV, ops.SORTED_CONV = False, True
 g = torch.Generator().manual_seed(3)
 B = a.grids
 cells = torch.stack([torch.randperm(64000, generator=g)[:a.vox].sort().values + b * 64000 for b in range(B)]).flatten()
