@@ -193,7 +193,7 @@ int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_featur
                                    int64_t workspace_bytes, ococc_stream_t stream);
 /* The same, also leaving the per-row records of the neighbour-pattern row order (ococc_subm_row_order below) for the
  * table it writes: order_counters as there (zero on entry), order_rowrec [capacity, 4] int32, 16-byte aligned, capacity
- * below 2^21.  Follow with ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, ...).  Both NULL: exactly the
+ * below 2^20.  Follow with ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, ...).  Both NULL: exactly the
  * call above. */
 int ococc_object_grid_geometry_order_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
                                          int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
@@ -334,7 +334,7 @@ int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, 
  * the table: build it once per rulebook, use it for every layer and direction that gathers through the table.
  *   counters ococc_subm_row_order_counter_bytes() bytes, ZERO on entry; the call leaves them zero again (one buffer,
  *            zeroed once, serves every build on a stream -- there is no memset launch per build)
- *   scratch  ococc_subm_row_order_scratch_bytes(n) bytes, 16-byte aligned (the row records: n below 2^21)
+ *   scratch  ococc_subm_row_order_scratch_bytes(n) bytes, 16-byte aligned (the row records: n below 2^20)
  *   rec      [n, 4] int32, 16-byte aligned: per slot {row, offset mask (bit k: table[k][row] >= 0), table entries at the
  *            row's lowest and second lowest neighbour offsets (-1: none)}
  *   hdr      [8] int32   tile plan read by the kernel (heavy_blocks / mid_blocks: 16-row blocks per workgroup tile

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libococc_hip.so')
+LIB_PATH = os.environ.get('OCOCC_LIB_PATH') or os.path.join(_HERE, 'libococc_hip.so')   # (the override: diagnostic builds, tools/probe)
 
 F32, BF16 = 0, 1
 REDUCE = {'sum': 0, 'mean': 1, 'avg': 1, 'max': 2}

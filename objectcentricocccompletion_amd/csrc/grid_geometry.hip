@@ -349,7 +349,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
   extern __shared__ uint32_t smem[];
   // (order_hist != null: the rows' neighbour-pattern records of ococc_subm_row_order are written here, where the row's
   // 27 table entries sit in registers anyway -- the separate counting pass re-read the whole table, 14 us)
-  __shared__ uint32_t s_oh[kOrderBuckets];
+  __shared__ uint32_t s_oh[kLocalBuckets];
   if ((int)blockIdx.x >= emit_blocks) {
     // padding rows of the fixed-capacity form: -1 coordinates, zero count and features, no neighbours
     const int64_t total = totals[27];
@@ -364,7 +364,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     for (int k = 0; k < 27; ++k) nbr_t[(int64_t)k * cap + r] = -1;
     if (order_hist) {
       // no offsets at all: the "no neighbour" bucket; the rows of a wave take consecutive places behind ONE atomic
-      const int key = order_key(0u, 13, (int)(blockIdx.x % kHotCopies));
+      const int key = order_global(order_key_local(0u, 13), (int)(blockIdx.x % kHotCopies));
       const unsigned long long m = __ballot(true);
       uint32_t first = 0u;
       if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) first = atomicAdd(&order_hist[key], (uint32_t)__popcll(m));
@@ -406,7 +406,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
   if (threadIdx.x < kCols) s_base[threadIdx.x] = bases[((int64_t)b * g.slices + sl) * kCols + threadIdx.x];
   if (threadIdx.x < 27) s_run[threadIdx.x] = 0;
   if (order_hist)
-    for (int i = threadIdx.x; i < kOrderBuckets; i += kEmitThreads) s_oh[i] = 0u;
+    for (int i = threadIdx.x; i < kLocalBuckets; i += kEmitThreads) s_oh[i] = 0u;
   // global row of this grid's first voxel: the slice-0 base of the voxel column
   const int32_t grid_base = bases[((int64_t)b * g.slices) * kCols + 27];
   __syncthreads();
@@ -495,9 +495,10 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
           if (e1 < 0) e1 = nb[k];
           else if (e2 < 0) e2 = nb[k];
         }
-      const int key = order_key(mbits, 13, (int)(blockIdx.x % kHotCopies));
+      const int key = order_key_local(mbits, 13);
       const uint32_t rank = atomicAdd(&s_oh[key], 1u);   // place inside this workgroup's share of the bucket
-      order_rowrec[row] = i32x4_t{(int)((uint32_t)key | (rank << kOrderKeyBits)), (int)mbits, e1, e2};
+      order_rowrec[row] = i32x4_t{(int)((uint32_t)order_global(key, (int)(blockIdx.x % kHotCopies)) | (rank << kOrderKeyBits)),
+                                  (int)mbits, e1, e2};
     }
     STAMP(12);
     // 16-row block masks.  Rows are consecutive along the lanes, so a block is a run of lanes: segmented OR towards
@@ -544,15 +545,18 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     LDS_BARRIER();
   }
 
+  // the workgroup's share of every bucket starts where the bucket's counter stood: the atomics are asked for here and
+  // their answers used at the very end of the kernel, behind the point phases
+  constexpr int kOrderPer = (kLocalBuckets + kEmitThreads - 1) / kEmitThreads;
+  uint32_t o_cnt[kOrderPer], o_got[kOrderPer];
   if (order_hist) {
-    // the workgroup's share of every bucket starts where the bucket's counter stood; its rows' records get the start added
     __syncthreads();
-    order_reserve<kEmitThreads>(s_oh, order_hist);
-    __syncthreads();
-    const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
-    for (int32_t r = row_lo + threadIdx.x; r < hi; r += kEmitThreads) {
-      const uint32_t x = (uint32_t)order_rowrec[r].x;
-      order_rowrec[r].x = (int)(x + (s_oh[x & ((1u << kOrderKeyBits) - 1u)] << kOrderKeyBits));
+#pragma unroll
+    for (int i = 0; i < kOrderPer; ++i) {
+      const int bk = threadIdx.x + kEmitThreads * i;
+      o_cnt[i] = bk < kLocalBuckets ? s_oh[bk] : 0u;
+      o_got[i] = 0u;
+      if (o_cnt[i]) o_got[i] = atomicAdd(&order_hist[order_global(bk, (int)(blockIdx.x % kHotCopies))], o_cnt[i]);
     }
   }
   STAMP(7);
@@ -687,6 +691,22 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     }
   }
   STAMP(10);
+  if (order_hist) {
+    // the rows' records get their bucket's start added (their first word: bucket | place inside the workgroup's share << 11)
+#pragma unroll
+    for (int i = 0; i < kOrderPer; ++i) {
+      const int bk = threadIdx.x + kEmitThreads * i;
+      if (o_cnt[i]) s_oh[bk] = o_got[i];
+    }
+    __syncthreads();
+    const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
+    for (int32_t r = row_lo + threadIdx.x; r < hi; r += kEmitThreads) {
+      const uint32_t x = (uint32_t)order_rowrec[r].x;
+      const int gk = (int)(x & ((1u << kOrderKeyBits) - 1u));   // global bucket -> this workgroup's
+      const int lk = gk < 2 * kPairKeys ? gk : 2 * kPairKeys + (gk - 2 * kPairKeys) / kHotCopies;
+      order_rowrec[r].x = (int)(x + (s_oh[lk] << kOrderKeyBits));
+    }
+  }
 }
 
 struct GeoLayout {
@@ -753,7 +773,7 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE((order_counters == nullptr) == (order_rowrec == nullptr), "order_counters and order_rowrec go together");
   OCOCC_REQUIRE(!order_rowrec || (capacity < kOrderMaxRows && ((uintptr_t)order_rowrec & 15) == 0),
-                "row records: 16-byte aligned, below 2^21 rows");
+                "row records: 16-byte aligned, below 2^20 rows");
   GeoLayout L;
   int64_t gu;
   OCOCC_REQUIRE(n >= 1 && capacity >= 1 && c >= 1 && num_point_features >= 3, "bad sizes");

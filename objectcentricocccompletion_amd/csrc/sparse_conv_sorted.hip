@@ -53,11 +53,13 @@ struct OrderHdr {
 __global__ void __launch_bounds__(256)
 order_count_kernel(const int32_t* __restrict__ table, int kvol, int dense_k, int64_t n, i32x4_t* __restrict__ rowrec,
                    uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[kOrderBuckets];
-  for (int i = threadIdx.x; i < kOrderBuckets; i += 256) h[i] = 0u;
+  __shared__ uint32_t h[kLocalBuckets];
+  for (int i = threadIdx.x; i < kLocalBuckets; i += 256) h[i] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kOrderRowsPerWg;
+  const int copy = (int)(blockIdx.x % kHotCopies);
   i32x4_t rr[kOrderRowsPerWg / 256];
+  int lkey[kOrderRowsPerWg / 256];
 #pragma unroll
   for (int u = 0; u < kOrderRowsPerWg / 256; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
@@ -78,19 +80,19 @@ order_count_kernel(const int32_t* __restrict__ table, int kvol, int dense_k, int
           }
         }
       }
-      const int key = order_key(m, dense_k, (int)(blockIdx.x % kHotCopies));
-      const uint32_t rank = atomicAdd(&h[key], 1u);   // place inside the workgroup's share of the bucket
-      rr[u] = i32x4_t{(int)((uint32_t)key | (rank << kOrderKeyBits)), (int)m, e1, e2};
+      lkey[u] = order_key_local(m, dense_k);
+      const uint32_t rank = atomicAdd(&h[lkey[u]], 1u);   // place inside the workgroup's share of the bucket
+      rr[u] = i32x4_t{(int)((uint32_t)order_global(lkey[u], copy) | (rank << kOrderKeyBits)), (int)m, e1, e2};
     }
   }
   __syncthreads();
-  order_reserve<256>(h, hist);
+  order_reserve<256>(h, hist, copy);
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < kOrderRowsPerWg / 256; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
     if (r < n) {
-      rr[u].x = (int)((uint32_t)rr[u].x + (h[(uint32_t)rr[u].x & ((1u << kOrderKeyBits) - 1u)] << kOrderKeyBits));
+      rr[u].x = (int)((uint32_t)rr[u].x + (h[lkey[u]] << kOrderKeyBits));
       rowrec[r] = rr[u];
     }
   }
@@ -550,7 +552,7 @@ int launch_order_place(const i32x4_t* rowrec, int64_t n, int heavy_blocks, int m
 int check_order_args(int32_t kvol, int32_t dense_k, int64_t n, int32_t heavy_blocks, int32_t mid_blocks, const void* counters,
                      const void* scratch, const void* rec, const void* hdr) {
   OCOCC_REQUIRE(n >= 0, "negative row count");
-  if (n >= kOrderMaxRows) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "the row records hold places below 2^21 rows");
+  if (n >= kOrderMaxRows) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "the row records hold places below 2^20 rows");
   OCOCC_REQUIRE(kvol >= 1 && kvol <= 32, "kernel volume must be 1..32");
   OCOCC_REQUIRE(dense_k >= -1 && dense_k < kvol, "dense_k out of range");
   OCOCC_REQUIRE((heavy_blocks == 4 || heavy_blocks == 8 || heavy_blocks == 16) &&

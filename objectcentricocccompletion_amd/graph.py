@@ -16,6 +16,12 @@ import os
 import torch
 
 
+def _join_side_streams():
+    """a capture must end with every stream it forked joined again: row-order builds nobody has waited for yet"""
+    from .spconv import ops as sp_ops
+    sp_ops.join_pending_orders()
+
+
 class GraphedStep(object):
     """Record ``fn()`` (no arguments; reads its inputs from fixed device tensors) after
     ``warmup`` eager runs on a side stream, then ``replay()`` it.
@@ -49,6 +55,7 @@ class GraphedStep(object):
             # thread_local: other threads (RCCL watchdog, autograd workers) may keep calling the runtime
             with torch.cuda.graph(self.graph, pool=pool, stream=self.stream, capture_error_mode='thread_local'):
                 self.out = fn()
+                _join_side_streams()
         torch.cuda.synchronize()
 
     def pool(self):

@@ -6,6 +6,7 @@ ococc_weight_prepare_bf16, ococc_sparse_conv_gather_gemm_bf16 (forward and dgrad
 ococc_sparse_conv_wgrad_bf16.  The reference's per-offset gather/GEMM/scatter loop
 (include/spconv/spconv_ops.h:260-456) does not exist here.
 """
+import contextlib
 import os
 import weakref
 
@@ -248,7 +249,7 @@ def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None,
         # the neighbour-pattern row order is part of the geometry: built here, it runs wherever the rulebook is built
         # (bench.py: on the forked stream, beside the previous batch's convolutions) and not in front of the first layer
         # (row records at hand: the counters they were counted into must be emptied by the placing pass in any case)
-        row_order(rb, nbr_t, rows, rowrec)
+        build_row_order(rb, nbr_t, rows, rowrec)
     return rb
 
 
@@ -579,9 +580,12 @@ SORTED_CONV = {'1': True, '0': False}.get(os.environ.get('OCOCC_SORTED_CONV'))
 SORTED_TILES = tuple(int(v) for v in os.environ.get('OCOCC_SORTED_TILES', '4,8').split(','))
 
 
-# rulebook pairs per output row up to which the order pays (denser: most rows need most offsets whatever the order,
-# and the small tiles only multiply the weight traffic)
-SORTED_MAX_PAIRS_PER_ROW = float(os.environ.get('OCOCC_SORTED_MAX_PAIRS_PER_ROW', '4.0'))
+# rulebook pairs per output row between which the order pays (tools/probe/sorted_density_sweep.py, 64 -> 128 forward on
+# 64 grids of 40^3 cells: 27 -> 26 us at 1.2 pairs per row, 45 -> 31 at 1.8, 72 -> 48 at 2.2, 91 -> 70 at 2.5, 138 -> 136
+# at 3.3, 188 -> 235 at 4.1; building the order costs ~15 us per rulebook).  Sparser: nothing to regroup; denser: most
+# rows need most offsets whatever the order, and the small tiles only multiply the weight traffic.
+SORTED_MIN_PAIRS_PER_ROW = float(os.environ.get('OCOCC_SORTED_MIN_PAIRS_PER_ROW', '1.5'))
+SORTED_MAX_PAIRS_PER_ROW = float(os.environ.get('OCOCC_SORTED_MAX_PAIRS_PER_ROW', '3.0'))
 
 
 def _sorted_regime(rb):
@@ -590,7 +594,7 @@ def _sorted_regime(rb):
     if rb.orders or SORTED_CONV:   # (an order that came with the rulebook is used)
         return True
     ppr = getattr(rb, 'pairs_per_row', None)
-    return ppr is not None and ppr <= SORTED_MAX_PAIRS_PER_ROW
+    return ppr is not None and SORTED_MIN_PAIRS_PER_ROW <= ppr <= SORTED_MAX_PAIRS_PER_ROW
 
 
 def _use_sorted_kernel(rb, kd, ncols):
@@ -599,7 +603,7 @@ def _use_sorted_kernel(rb, kd, ncols):
 
 
 _order_counters = {}   # device -> the zero-in / zero-out counters of ococc_subm_row_order
-ORDER_MAX_ROWS = 1 << 21   # a row record holds places below 2^21
+ORDER_MAX_ROWS = 1 << 20   # a row record holds places below 2^20
 
 
 def order_counters(dev):
@@ -619,31 +623,84 @@ def new_rulebook_wants_order(rows, kvol=27):
     if SORTED_CONV:
         return True
     ppr = current_density()
-    return ppr is not None and ppr <= SORTED_MAX_PAIRS_PER_ROW
+    return ppr is not None and SORTED_MIN_PAIRS_PER_ROW <= ppr <= SORTED_MAX_PAIRS_PER_ROW
+
+
+# The order is needed by the first layer that runs on it -- on the benchmark's encoder the third convolution -- and by
+# nothing before, so it can be built on a side stream beside the layers in front (OCOCC_ORDER_SIDE_STREAM=1).  Off by
+# default: inside a captured HIP graph the fork and join cost more than the 7 us they hide (replay span 322 us against
+# 301 us with the build in line, r04e / r04d), as every two-branch graph measured on this ROCm did.
+ORDER_SIDE_STREAM = os.environ.get('OCOCC_ORDER_SIDE_STREAM', '0') == '1'
+_order_streams = {}
+_pending_orders = []   # [event, keepalive tensors]: builds some stream may still have to wait for
+
+
+def join_pending_orders():
+    """make the current stream wait for every row-order build still running on the side stream (the end of a graph
+    capture must not leave the side stream forked: graph.GraphedStep calls this)"""
+    cur = torch.cuda.current_stream()
+    for entry in _pending_orders:
+        if entry[0] is not None:
+            cur.wait_event(entry[0])
+            entry[0] = None
+            entry[1] = None
+    del _pending_orders[:]
+
+
+def build_row_order(rb, table, rows, rowrec=None):
+    """launch the build of a sub-manifold gather table's neighbour-pattern row order (see row_order) and keep it with
+    the rulebook.  ``rowrec``: the per-row records, if the kernel that wrote the table left them."""
+    dev = table.device
+    kvol = table.size(0)
+    rec = torch.empty((max(rows, 1), 4), dtype=torch.int32, device=dev)
+    hdr = torch.empty((8,), dtype=torch.int32, device=dev)
+    dense_k = kvol // 2 if kvol % 2 == 1 else -1
+    counters = order_counters(dev)
+    ws = None if rowrec is not None else L.workspace(L.lib.ococc_subm_row_order_scratch_bytes(rows), dev)
+    side = None
+    if ORDER_SIDE_STREAM:
+        side = _order_streams.get(dev)
+        if side is None:
+            side = _order_streams[dev] = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        if rowrec is not None:
+            L.check(L.lib.ococc_subm_row_order_place(L.ptr(rowrec), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
+                                                     L.ptr(counters), L.ptr(rec), L.ptr(hdr), L.stream()),
+                    'subm_row_order_place')
+        else:
+            L.check(L.lib.ococc_subm_row_order(L.ptr(table), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
+                                               L.ptr(counters), L.ptr(ws), L.ptr(rec), L.ptr(hdr), L.stream()),
+                    'subm_row_order')
+        entry = None
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            for t in (rec, hdr, rowrec, ws, table, counters):
+                if t is not None:
+                    t.record_stream(side)
+            entry = [ev, (rowrec, ws, table)]   # (inputs stay alive until someone has waited for the build)
+            _pending_orders[:] = [e for e in _pending_orders if e[0] is not None]
+            _pending_orders.append(entry)
+    rb.orders[table.data_ptr()] = [rec, hdr, table, entry]   # (table: keeps the key's address alive)
 
 
 def row_order(rb, table, rows, rowrec=None):
     """(rec, hdr) of a sub-manifold gather table -- per slot {row, offset mask, table entries at its two lowest neighbour
-    offsets} and the tile plan: built on first use, kept with the rulebook (every layer and direction that reads the
-    table shares it).  ``rowrec``: the per-row records, if the kernel that wrote the table left them."""
+    offsets} and the tile plan: built on first use unless it came with the rulebook, kept with it (every layer and
+    direction that reads the table shares it).  The current stream waits for the build here."""
     hit = rb.orders.get(table.data_ptr())
     if hit is None:
-        dev = table.device
-        kvol = table.size(0)
-        rec = torch.empty((max(rows, 1), 4), dtype=torch.int32, device=dev)
-        hdr = torch.empty((8,), dtype=torch.int32, device=dev)
-        dense_k = kvol // 2 if kvol % 2 == 1 else -1
-        if rowrec is not None:
-            L.check(L.lib.ococc_subm_row_order_place(L.ptr(rowrec), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
-                                                     L.ptr(order_counters(dev)), L.ptr(rec), L.ptr(hdr), L.stream()),
-                    'subm_row_order_place')
-        else:
-            ws = L.workspace(L.lib.ococc_subm_row_order_scratch_bytes(rows), dev)
-            L.check(L.lib.ococc_subm_row_order(L.ptr(table), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
-                                               L.ptr(order_counters(dev)), L.ptr(ws), L.ptr(rec), L.ptr(hdr), L.stream()),
-                    'subm_row_order')
-        hit = rb.orders[table.data_ptr()] = (rec, hdr, table)   # (table: keeps the key's address alive)
-    return hit[:2]
+        build_row_order(rb, table, rows, rowrec)
+        hit = rb.orders[table.data_ptr()]
+    entry = hit[3]
+    if entry is not None:
+        if entry[0] is not None:
+            torch.cuda.current_stream().wait_event(entry[0])
+            entry[0] = None
+            entry[1] = None
+        hit[3] = None
+    return hit[0], hit[1]
 
 
 def _fragment_major(rb, kd, ncols):
