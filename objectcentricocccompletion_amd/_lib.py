@@ -344,3 +344,15 @@ class BufferPlan(object):
 def workspace(nbytes, device):
     """Caller-owned scratch buffer (the C ABI never allocates)."""
     return empty((max(int(nbytes), 1),), torch.uint8, device)
+
+
+_logged = set()
+
+
+def log_once(key, msg):
+    """one line on the package logger the first time ``key`` is seen: a fused kernel that does not cover a module's shape
+    falls back to the operator-by-operator path -- correct, several times slower, and otherwise silent"""
+    if key not in _logged:
+        _logged.add(key)
+        import logging
+        logging.getLogger('objectcentricocccompletion_amd').warning(msg)

@@ -179,6 +179,11 @@ class OccDecoder(nn.Module):
             fused = self._fused_layers()
             if fused is not None and not (self.training and any(ln.fused_dropout for _, ln in fused[0])):
                 return self._forward_fused(fused[0], fused[1], roi_features, smp_xyzs, pts_roi_inds)
+            if fused is None:
+                from .. import _lib as L
+                L.log_once(('occ-decoder', id(type(self)), tuple(m.__class__.__name__ for m in self.conv_occ)),
+                           'OccDecoder MLP is outside the fused bf16 kernels (Linear -> LayerNorm with folded GELU [-> dropout] '
+                           'blocks of width 512 / 1024 and a one-logit head): running operator by operator')
         if (self.compute_dtype == torch.bfloat16 and FUSED_MLP and FUSED_TRAIN_MLP and smp_xyzs.is_cuda
                 and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
             out = self._forward_fused_train(roi_features, smp_xyzs, pts_roi_inds)

@@ -74,7 +74,7 @@ class SSTInputLayerV2(nn.Module):
         """keep mask + drop level of every voxel from the population of its window (:128-148)."""
         # one group-rank pass gives the rank inside the window AND the window populations (the reference's bincount is a
         # second pass with a host read-back of its own); level and keep decision in one launch
-        conti, inner, counts = group_rank(batch_win_inds, self._key_bound)
+        conti, inner, counts = group_rank(batch_win_inds, getattr(self, '_key_bound', None))   # (set by forward(); direct calls: no bound)
         n = batch_win_inds.numel()
         if not batch_win_inds.is_cuda:   # (CPU stand-ins of oracle/cpu_port.py)
             num_per_voxel = counts.to(batch_win_inds.dtype)[conti.long()]
@@ -626,9 +626,19 @@ class EncoderLayer(nn.Module):
         256, LayerNorm, post-norm, no dropout, softmax attention): anything else keeps the per-operator path."""
         mha = self.win_attn.self_attn
         drop = self.training and (self.dropout.p > 0 or self.dropout1.p > 0 or self.dropout2.p > 0)
-        return (FUSED_ENCODER_LAYER and self.compute_dtype == torch.bfloat16 and self.post_norm and not self.use_bn
-                and mha.tau is None and mha.embed_dim == 128 and mha.num_heads == 8 and self.linear1.out_features == 256
-                and self._act_name in ('gelu', 'relu') and not drop)
+        wanted = FUSED_ENCODER_LAYER and self.compute_dtype == torch.bfloat16
+        ok = (wanted and self.post_norm and not self.use_bn
+              and mha.tau is None and mha.embed_dim == 128 and mha.num_heads == 8 and self.linear1.out_features == 256
+              and self._act_name in ('gelu', 'relu') and not drop)
+        if wanted and not ok:
+            from .. import _lib as L
+            L.log_once(('sst-layer', mha.embed_dim, mha.num_heads, self.linear1.out_features, self._act_name, self.post_norm,
+                        self.use_bn, mha.tau is None, bool(drop)),
+                       f'SST encoder layer (d_model {mha.embed_dim}, {mha.num_heads} heads, ffn {self.linear1.out_features}, '
+                       f'{self._act_name}, post_norm={self.post_norm}, use_bn={self.use_bn}, cosine={mha.tau is not None}, '
+                       f'dropout={bool(drop)}) is outside the fused block kernels (128 / 8 / 256, gelu|relu, post-norm '
+                       'LayerNorm, softmax, no dropout): running operator by operator')
+        return ok
 
     def _forward_fused(self, src, pos_dict, ind_dict, key_padding_mask_dict):
         from . import fused_block as fb

@@ -238,12 +238,18 @@ def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, pop
         # voxel lists of the levels are the pieces of one stable sort.  Two read-backs (group count; voxels and windows
         # per level) where the per-level loop below has two per level.
         nl = max(levels) + 1
-        lv = voxel_drop_lvl.long()
+        lv_raw = voxel_drop_lvl.long()
+        lv = lv_raw.clamp(min=0)   # (a level of -1 -- a window population in no drop range -- is reported below, from the
+        #                             same read-back; clamped here so that no rank is left unwritten in the meantime)
         conti, inner, counts = group_rank(lv * int(key_bound) + batch_win_inds.long(), nl * int(key_bound))
         order = torch.argsort(lv, stable=True)
         ids = torch.arange(nl, device=lv.device)
         glvl = torch.zeros(counts.numel(), dtype=torch.long, device=lv.device).scatter_(0, conti.long(), lv)
-        tally = torch.stack([(lv[:, None] == ids[None, :]).sum(0), (glvl[:, None] == ids[None, :]).sum(0)]).tolist()
+        tally = torch.stack([(lv_raw[:, None] == ids[None, :]).sum(0), (glvl[:, None] == ids[None, :]).sum(0)]).tolist()
+        if sum(tally[0]) != lv.numel():
+            # the reference: assert (drop_lvl_per_voxel >= 0).all() (sst_input_layer_v2.py)
+            raise ValueError(f'{lv.numel() - sum(tally[0])} voxels sit in windows whose population is in no drop range '
+                             '(drop level -1): the drop_info ranges must cover every window size')
         vo = wo = 0
         for dl in range(nl):
             nv, nw = tally[0][dl], tally[1][dl]

@@ -8,6 +8,8 @@ CPU restatement, in float64, of one SST encoder layer and of the window partitio
                                                            mmdet3d/models/sst/sst_basic_block_v2.py:41-75,105-127
                     around torch.nn.MultiheadAttention (q = k = x + pos, v = x, key padding = the window's population)
   encoder_layer_backward   the chain rule of the same layer, written out
+  window_attention_core    the attention core alone on padded windows, forward and backward (rounding=None | 'window':
+                    the store points of the per-window kernels, csrc/window_attn.hip)
 
 ``rounding`` selects where values are rounded to bf16, i.e. which product path is mirrored:
   None     nowhere: the reference's own fp32 arithmetic (pinned against tests/golden/sst.npz, generated from the
@@ -206,3 +208,36 @@ def sst_blocks(feats, coors, sd, sparse_shape, window_shape, num_blocks=2, num_h
             P = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
             out = encoder_layer(out, poss[j], wins[j][0], P, num_heads, rounding, act)
     return out
+
+
+def window_attention_core(q, k, v, key_len, num_heads, dout=None, rounding=None):
+    """softmax(q k^T / sqrt(d) + key mask) v on padded windows [nW, T, C] in float64, and -- with ``dout`` -- its
+    backward (dq, dk, dv).  Follows mmdet3d/models/backbones/sst_basic_block_v2.py:41-75 (nn.MultiheadAttention's core
+    on the padded window layout; key_padding_mask as a length).
+    rounding='window' mirrors the store points of csrc/window_attn.hip (the per-window kernels: windows of more than 64
+    tokens, the cosine variant): the normalised probabilities are rounded to bf16 before P V, the output is stored in
+    bf16; in the backward delta = sum(dO * O) uses the bf16 output, dS = P (dP - delta) scale is rounded to bf16 before
+    the dQ / dK products, P before the dV product, and dq, dk, dv are stored in bf16.  q, k, v, dout are expected to hold
+    bf16-representable values (the kernels read bf16)."""
+    rw = r16 if rounding == 'window' else (lambda t: t)
+    nW, T, C = q.shape
+    H = num_heads
+    D = C // H
+    scale = float(D) ** -0.5
+    q4, k4, v4 = (t.double().view(nW, T, H, D) for t in (q, k, v))
+    mask = torch.arange(T, device=q.device)[None, :] >= key_len.to(q.device)[:, None].long()
+    s = torch.einsum('wthd,wshd->whts', q4, k4) * scale
+    s = s.masked_fill(mask[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, -1)
+    p = torch.where(torch.isnan(p), torch.zeros_like(p), p)        # (a window without keys: zeros, as the kernel)
+    o = rw(torch.einsum('whts,wshd->wthd', rw(p), v4)).reshape(nW, T, C)
+    if dout is None:
+        return o
+    do4 = dout.double().view(nW, T, H, D)
+    delta = (do4 * o.view(nW, T, H, D)).sum(-1)                    # [nW, T, H]
+    dp = torch.einsum('wthd,wshd->whts', do4, v4)
+    ds = rw(p * (dp - delta.permute(0, 2, 1)[..., None]) * scale)
+    dq = rw(torch.einsum('whts,wshd->wthd', ds, k4)).reshape(nW, T, C)
+    dk = rw(torch.einsum('whts,wthd->wshd', ds, q4)).reshape(nW, T, C)
+    dv = rw(torch.einsum('whts,wthd->wshd', rw(p), do4)).reshape(nW, T, C)
+    return o, dq, dk, dv

@@ -68,3 +68,26 @@ def test_written_out_backward_is_the_gradient_of_the_forward(golden_dir):
         assert float((mine['dx'] - grads[0]).abs().max()) < 1e-9 * float(grads[0].abs().max())
         for n, gr in zip(names, grads[1:]):
             assert float((mine[n] - gr).abs().max()) <= 1e-9 * float(gr.abs().max()) + 1e-12, n
+
+
+def test_window_attention_core_equals_autograd_and_its_rounded_form_stays_close():
+    """the attention core of the oracle (forward and hand-written backward) against torch autograd on the same float64
+    formula; the 'window' rounding mode (bf16 at the per-window kernels' store points) moves it by a few bf16 steps"""
+    from oracle import sst_ref
+    g = torch.Generator().manual_seed(5)
+    nW, T, H, D = 6, 23, 8, 16
+    q, k, v, do = (torch.randn(nW, T, H * D, generator=g).bfloat16().double() for _ in range(4))
+    key_len = torch.tensor([23, 1, 7, 16, 22, 10])
+    o, dq, dk, dv = sst_ref.window_attention_core(q, k, v, key_len, H, dout=do)
+    qa, ka, va = (t.clone().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum('wthd,wshd->whts', qa.view(nW, T, H, D), ka.view(nW, T, H, D)) * D ** -0.5
+    mask = torch.arange(T)[None, :] >= key_len[:, None]
+    ref = torch.einsum('whts,wshd->wthd', torch.softmax(s.masked_fill(mask[:, None, None, :], float('-inf')), -1),
+                       va.view(nW, T, H, D)).reshape(nW, T, H * D)
+    ref.backward(do)
+    for got, exp in ((o, ref.detach()), (dq, qa.grad), (dk, ka.grad), (dv, va.grad)):
+        assert float((got - exp).abs().max()) < 1e-12
+    ow, dqw, dkw, dvw = sst_ref.window_attention_core(q, k, v, key_len, H, dout=do, rounding='window')
+    for got, exp in ((ow, o), (dqw, dq), (dkw, dk), (dvw, dv)):
+        rel = float((got - exp).norm() / exp.norm())
+        assert 1e-5 < rel < 6e-3, rel          # rounded, and by bf16 steps only
