@@ -718,7 +718,7 @@ def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
                                                   L.dtype_code(out_dtype), L.stream()),
                 'sparse_conv_tile')
         return out
-    if _use_sorted_kernel(rb, kd, ncols):
+    if _use_sorted_kernel(rb, kd, ncols) and 0 < rows < ORDER_MAX_ROWS:
         rec, hdr = row_order(rb, table, rows)
         L.check(L.lib.ococc_sparse_conv_sorted_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
                                                     L.ptr(table), L.ptr(rec), L.ptr(hdr), rows,
