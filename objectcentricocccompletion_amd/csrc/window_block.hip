@@ -1131,46 +1131,55 @@ __device__ __forceinline__ void wgrad_body(const WgradPack& pk, int t, int slice
   const int64_t t0 = (int64_t)slab * pk.chunk, t1 = min(pk.tokens, t0 + pk.chunk);
   const int steps = t1 > t0 ? (int)((t1 - t0 + 31) >> 5) : 0;
   const int grow = threadIdx.x >> 3, gpc = threadIdx.x & 7;
-  u32x4 gv, xv[XP];
+  // The rows of FOUR steps are in flight in registers ahead of the one being multiplied: with one step ahead every step
+  // (32 tokens, 8-16 matrix instructions per wave) waited a full trip to memory, ~1.4 us: 127 steps = the kernel's 180 us.
+  constexpr int RD = 4;
+  u32x4 gv[RD], xv[RD][XP];
   float dbacc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dbacc[j] = 0.f;
-  auto fetch = [&](int s) {
+  constexpr bool ADD = K == 128;   // (only the attention block's q | k rows add a second operand, x + pos: K = 128)
+  u32x4 av[RD][ADD ? XP : 1];   // added when the step is stashed: no arithmetic on registers in flight
+  auto fetch = [&](int st, int s) {
     const int64_t r = t0 + (int64_t)s * 32 + grow;
-    gv = u32x4{0u, 0u, 0u, 0u};
-    if (r < t1) gv = *(const u32x4*)(gp + r * ldg + gpc * 8);
+    gv[st] = u32x4{0u, 0u, 0u, 0u};
+    if (r < t1) gv[st] = *(const u32x4*)(gp + r * ldg + gpc * 8);
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
       const int i = threadIdx.x + j * kThreads, row = i / (K / 8), pc = i % (K / 8);
       const int64_t rr = t0 + (int64_t)s * 32 + row;
-      xv[j] = u32x4{0u, 0u, 0u, 0u};
+      xv[st][j] = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (ADD) av[st][j] = u32x4{0u, 0u, 0u, 0u};
       if (rr < t1) {
-        xv[j] = *(const u32x4*)(xp + rr * K + pc * 8);
-        if (ap) {
-          const u32x4 a = *(const u32x4*)(ap + rr * K + pc * 8);
-          xv[j].x = add_bf16x2(xv[j].x, a.x);
-          xv[j].y = add_bf16x2(xv[j].y, a.y);
-          xv[j].z = add_bf16x2(xv[j].z, a.z);
-          xv[j].w = add_bf16x2(xv[j].w, a.w);
+        xv[st][j] = *(const u32x4*)(xp + rr * K + pc * 8);
+        if constexpr (ADD) {
+          if (ap) av[st][j] = *(const u32x4*)(ap + rr * K + pc * 8);
         }
       }
     }
   };
-  auto stash = [&](int buf) {
-    *(u32x4*)(gs + (buf * 32 + grow) * LDG + gpc * 8) = gv;
+  auto stash = [&](int buf, int st) {
+    *(u32x4*)(gs + (buf * 32 + grow) * LDG + gpc * 8) = gv[st];
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
       const int i = threadIdx.x + j * kThreads, row = i / (K / 8), pc = i % (K / 8);
-      *(u32x4*)(xs + (buf * 32 + row) * LDK + pc * 8) = xv[j];
+      u32x4 v = xv[st][j];
+      if constexpr (ADD) if (ap) {
+        v.x = add_bf16x2(v.x, av[st][j].x);
+        v.y = add_bf16x2(v.y, av[st][j].y);
+        v.z = add_bf16x2(v.z, av[st][j].z);
+        v.w = add_bf16x2(v.w, av[st][j].w);
+      }
+      *(u32x4*)(xs + (buf * 32 + row) * LDK + pc * 8) = v;
     }
-    dbacc[0] += __uint_as_float(gv.x << 16);
-    dbacc[1] += __uint_as_float(gv.x & 0xffff0000u);
-    dbacc[2] += __uint_as_float(gv.y << 16);
-    dbacc[3] += __uint_as_float(gv.y & 0xffff0000u);
-    dbacc[4] += __uint_as_float(gv.z << 16);
-    dbacc[5] += __uint_as_float(gv.z & 0xffff0000u);
-    dbacc[6] += __uint_as_float(gv.w << 16);
-    dbacc[7] += __uint_as_float(gv.w & 0xffff0000u);
+    dbacc[0] += __uint_as_float(gv[st].x << 16);
+    dbacc[1] += __uint_as_float(gv[st].x & 0xffff0000u);
+    dbacc[2] += __uint_as_float(gv[st].y << 16);
+    dbacc[3] += __uint_as_float(gv[st].y & 0xffff0000u);
+    dbacc[4] += __uint_as_float(gv[st].z << 16);
+    dbacc[5] += __uint_as_float(gv[st].z & 0xffff0000u);
+    dbacc[6] += __uint_as_float(gv[st].w << 16);
+    dbacc[7] += __uint_as_float(gv[st].w & 0xffff0000u);
   };
   constexpr int KB = K / 64;      // 16-column blocks of X per wave
   f32x4 acc[4][KB];
@@ -1178,27 +1187,31 @@ __device__ __forceinline__ void wgrad_body(const WgradPack& pk, int t, int slice
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) acc[nb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (steps > 0) {
-    fetch(0);
-    stash(0);
-  }
+#pragma unroll
+  for (int st = 0; st < RD; ++st) fetch(st, st);   // (steps past the slab's end fetch nothing: zero rows)
+  if (steps > 0) stash(0, 0);
   __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < steps) fetch(s + 1);
-    const uint16_t* gb = gs + (buf * 32 + 4 * g + q_) * LDG + 4 * p_;
-    const uint16_t* xb = xs + (buf * 32 + 4 * g + q_) * LDK + 4 * p_ + wave * (16 * KB);
-    bf16x8 a[4], b[KB];
+  for (int s0 = 0; s0 < steps; s0 += RD) {
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) a[nb] = tr_pair(gb + 16 * nb, gb + 16 * nb + 16 * LDG);
+    for (int d = 0; d < RD; ++d) {   // ring positions are compile-time
+      const int s = s0 + d;
+      if (s >= steps) break;
+      const int buf = s & 1;
+      fetch(d, s + RD);              // the stage of step s was stashed before this step: free again
+      const uint16_t* gb = gs + (buf * 32 + 4 * g + q_) * LDG + 4 * p_;
+      const uint16_t* xb = xs + (buf * 32 + 4 * g + q_) * LDK + 4 * p_ + wave * (16 * KB);
+      bf16x8 a[4], b[KB];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) b[kb] = tr_pair(xb + 16 * kb, xb + 16 * kb + 16 * LDK);
+      for (int nb = 0; nb < 4; ++nb) a[nb] = tr_pair(gb + 16 * nb, gb + 16 * nb + 16 * LDG);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+      for (int kb = 0; kb < KB; ++kb) b[kb] = tr_pair(xb + 16 * kb, xb + 16 * kb + 16 * LDK);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
-    if (s + 1 < steps) stash(buf ^ 1);
-    __syncthreads();
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nb], b[kb], acc[nb][kb], 0, 0, 0);
+      if (s + 1 < steps) stash(buf ^ 1, (d + 1) % RD);
+      __syncthreads();
+    }
   }
   const int N = pk.n[t];
   float* dw = pk.dw[t] + ((int64_t)slab * N + n0) * K;
@@ -1483,6 +1496,7 @@ extern "C" int ococc_token_wgrad_bf16(int32_t count, const void* const* g, const
     OCOCC_REQUIRE(n[i] > 0 && n[i] % kWgSlice == 0 && (k[i] == 128 || k[i] == 256) && ldg[i] >= n[i] && ldg[i] % 8 == 0,
                   "dW rows in multiples of 64, 128 or 256 columns, 16-byte aligned gradient rows");
     OCOCC_REQUIRE(aligned16(g[i]) && aligned16(x[i]) && aligned16(xadd[i]), "operands must be 16-byte aligned");
+    OCOCC_REQUIRE(!xadd[i] || k[i] == 128, "a second x operand (xadd) only with 128 columns");
     pk.g[i] = (const uint16_t*)g[i];
     pk.x[i] = (const uint16_t*)x[i];
     pk.xadd[i] = (const uint16_t*)xadd[i];
