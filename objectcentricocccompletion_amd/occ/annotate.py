@@ -3,7 +3,6 @@ tools/occ/occ_annotate.py (point_cloud_to_range_image_idx :141-207, OccAnnotator
 as one HIP kernel (ococc_occ_visibility_f64), and the file handling around it (OccAnnotator below: tracklets from the
 GT metrics file, per-frame points and raw range images, aggregation in the box frame, voxelisation, the .npz files
 LoadAnnotationsOcc reads)."""
-import ctypes
 import math
 
 import numpy as np

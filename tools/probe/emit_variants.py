@@ -1,6 +1,6 @@
 """cost of the row-order bookkeeping inside grid_emit_kernel: time of object_grid_geometry with the library built as
 shipped and with parts of the bookkeeping compiled out (OCOCC_LIB_PATH selects the build; wrong orders, timing only)."""
-import os, sys, time
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
