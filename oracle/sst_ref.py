@@ -108,8 +108,12 @@ def _params(P, rounding, detach=True):
                 b2=f('linear2.bias'), g1=f('norm1.weight'), be1=f('norm1.bias'), g2=f('norm2.weight'), be2=f('norm2.bias'))
 
 
-def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e-5, keep=False, detach=True):
-    """x, pos [V, E]; win [V] window id of every token -> y2 [V, E] float64 (and the intermediates when keep)."""
+def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e-5, keep=False, detach=True, ops_rows=None):
+    """x, pos [V, E]; win [V] window id of every token -> y2 [V, E] float64 (and the intermediates when keep).
+    ``ops_rows`` (bool [V], with rounding='bf16'): rows whose attention block runs operator by operator in the product
+    (windows of more than 64 tokens: bf16 library GEMMs with bf16 biases, the per-window attention kernels, a bf16
+    residual sum, a stand-alone LayerNorm) -- the forward of those rows gets that path's store points: projections
+    rounded after a bf16-rounded bias, the out-projection and the residual sum rounded before the norm."""
     rq = r16 if rounding in ('core', 'bf16') else (lambda t: t)      # operands of the attention core
     ra = r16 if rounding == 'bf16' else (lambda t: t)                # everything else the fused kernels store
     p = _params(P, rounding, detach)   # detach=False: the parameters stay on the autograd tape (tests)
@@ -120,6 +124,12 @@ def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e
     q = rq(xp @ p['wqkv'][:E].t() + p['bqkv'][:E])
     k = rq(xp @ p['wqkv'][E:2 * E].t() + p['bqkv'][E:2 * E])
     v = rq(x @ p['wqkv'][2 * E:].t() + p['bqkv'][2 * E:])
+    if ops_rows is not None:
+        sel = ops_rows[:, None]
+        b16 = r16(p['bqkv'])
+        q = torch.where(sel, r16(xp @ p['wqkv'][:E].t() + b16[:E]), q)
+        k = torch.where(sel, r16(xp @ p['wqkv'][E:2 * E].t() + b16[E:2 * E]), k)
+        v = torch.where(sel, r16(x @ p['wqkv'][2 * E:].t() + b16[2 * E:]), v)
     idx = _windows(win)
     nW, T = idx.shape
     valid = idx >= 0
@@ -133,6 +143,8 @@ def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e
     o[idx[valid]] = ow[valid]
     o = rq(o)
     z1 = o @ p['wo'].t() + p['bo'] + x
+    if ops_rows is not None:
+        z1 = torch.where(ops_rows[:, None], r16(r16(o @ p['wo'].t() + r16(p['bo'])) + x), z1)
     y1f, xh1, rstd1 = _ln(z1, p['g1'], p['be1'], eps)
     y1 = ra(y1f)
     fa, fg = _act(act)

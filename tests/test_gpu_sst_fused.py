@@ -195,18 +195,25 @@ def test_windows_above_64_tokens_take_the_per_window_kernels(dev, golden_dir):
     y.backward(dy.to(dev).bfloat16())
     win, _ = S.window_ids(coors, SPARSE, WINDOW, False)
     pos = window2flat_v2(*args[:2]).bfloat16().float().cpu()
-    exp, c = S.encoder_layer(feats, pos, win, sd, rounding='bf16', keep=True)
-    grads = S.encoder_layer_backward(dy, c)
     small = torch.ones(len(feats), dtype=torch.bool)
     small[big[0].cpu()] = False
+    exp, c = S.encoder_layer(feats, pos, win, sd, rounding='bf16', keep=True, ops_rows=~small)
+    grads = S.encoder_layer_backward(dy, c)
     e_small = _norm_err(y.detach().float().cpu()[small], exp[small])
     e_big = _norm_err(y.detach().float().cpu()[~small], exp[~small])
-    print(f'rows of small windows {e_small[0]:.2e}, rows of windows above 64 tokens {e_big[0]:.2e} (other rounding points)')
-    assert e_small[0] < 1e-3 and e_small[1] <= BF16_STEP and e_big[0] < 1e-2
-    assert _norm_err(x.grad.cpu()[small], grads['dx'][small])[0] < 1e-3
-    assert _norm_err(x.grad.cpu()[~small], grads['dx'][~small])[0] < 2e-2
-    for name, p in enc.named_parameters():
-        assert _norm_err(p.grad, grads[name])[0] < 1e-2, name
+    print(f'rows of small windows {e_small[0]:.2e}, rows of windows above 64 tokens {e_big[0]:.2e} (the oracle follows the '
+          'operator-by-operator store points on those rows)')
+    assert e_small[0] < 1e-3 and e_small[1] <= BF16_STEP and e_big[0] < 1e-3
+    g_small = _norm_err(x.grad.cpu()[small], grads['dx'][small])[0]
+    g_big = _norm_err(x.grad.cpu()[~small], grads['dx'][~small])[0]
+    g_par = {name: _norm_err(p.grad, grads[name])[0] for name, p in enc.named_parameters()}
+    print(f'dx: rows of small windows {g_small:.2e}, rows of big windows {g_big:.2e}; parameter gradients: worst '
+          f'{max(g_par.values()):.2e} ({max(g_par, key=g_par.get)})')
+    # (the backward of the big windows' rows is autograd over bf16 operators: gradients rounded to bf16 at every operator
+    # boundary, which the oracle's hand-written chain -- the fused kernels' -- does not follow)
+    assert g_small < 1e-3 and g_big < 6e-3      # (measured 7.4e-4 / 3.1e-3)
+    for name, err in g_par.items():
+        assert err < 5e-3, name                  # (measured: worst 2.3e-3, in_proj_weight)
 
 
 def test_f32_block_path_vs_oracle_with_bf16_attention_core(dev, golden_dir):
