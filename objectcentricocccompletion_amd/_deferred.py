@@ -51,10 +51,12 @@ def _forget_reader(key):
     GRADS_READ_AFTER_BACKWARD = bool(_readers) and all(_readers.values())
 
 
-_pass_id = None  # graph-task id of the pass the queues belong to
 _flushers = {}   # kind -> fn(list of jobs)
-_jobs = {}       # kind -> [job, ...] of the running pass
-_grads = []      # (param, finished-at-flush buffer)
+# One queue per backward pass, keyed by the pass's graph-task id: a reentrant pass (torch.utils.checkpoint with
+# use_reentrant=True, a custom Function that calls backward()) runs INSIDE another one, has its own id and its own
+# end-of-pass callback, and must neither flush nor void what the outer pass has queued.
+_queues = {}     # graph-task id -> [jobs {kind: [job, ...]}, grads [(param, finished-at-flush buffer), ...], weak
+                 # reference to the pass's end-of-pass callback]
 
 
 _joint = {}      # (kind, kind) -> fn(jobs of the first, jobs of the second) or None when it does not apply
@@ -129,50 +131,66 @@ def deferrable(*params):
 def defer(kind, job, grads):
     """Queue `job` for the kind's flusher; `grads` = [(param, buffer the job will have written), ...].  True: the
     caller's backward must return None for these parameters.  False outside a backward pass (nothing queued)."""
-    try:  # (one callback per job: a pass that raised never ran its callbacks, so "first of the pass" is unknowable;
-        # the second and later calls of a pass find the queues empty)
-        torch.autograd.Variable._execution_engine.queue_callback(_flush)
-    except RuntimeError:  # "Final callbacks can only be installed during backward pass"
+    q = _queue_of_running_pass()
+    if q is None:
         return False
-    global _pass_id
-    task = torch._C._current_graph_task_id()
-    if task != _pass_id:   # a new pass: whatever an interrupted pass (OOM, a raising hook) left queued is void
-        if not _held and (_jobs or _grads):
-            discard()
-        _pass_id = task
-    _jobs.setdefault(kind, []).append(job)
+    q[0].setdefault(kind, []).append(job)
     for p, v in grads:
-        _grads.append((p, v.detach()))
+        q[1].append((p, v.detach()))
     return True
 
 
 def defer_many(kind, jobs, grads):
     """``defer`` for several jobs of one kind at once (a whole SIR layer's LayerNorm and weight sums); ``grads`` buffers
     must be plain tensors outside any graph (they are stored as they are)."""
-    try:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush)
-    except RuntimeError:
+    q = _queue_of_running_pass()
+    if q is None:
         return False
-    global _pass_id
-    task = torch._C._current_graph_task_id()
-    if task != _pass_id:
-        if not _held and (_jobs or _grads):
-            discard()
-        _pass_id = task
-    _jobs.setdefault(kind, []).extend(jobs)
-    _grads.extend(grads)
+    q[0].setdefault(kind, []).extend(jobs)
+    q[1].extend(grads)
     return True
 
 
+class _PassEnd(object):
+    """The end-of-pass callback of ONE backward pass.  The engine owns it for as long as the pass exists -- it is released
+    when the pass ends, normally or by an exception -- so a dead weak reference to it says "that pass is gone"."""
+    __slots__ = ('task', '__weakref__')
+
+    def __init__(self, task):
+        self.task = task
+
+    def __call__(self):
+        _flush(self.task)
+
+
+def _queue_of_running_pass():
+    task = torch._C._current_graph_task_id()
+    q = _queues.get(task)
+    if q is None:
+        end = _PassEnd(task)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(end)
+        except RuntimeError:  # "Final callbacks can only be installed during backward pass"
+            return None
+        # First job of this pass.  A backward pass that raised (OOM, a raising hook) never ran its end-of-pass callback:
+        # what it queued is void -- its buffers mean nothing any more.  A pass that is still in flight (this one is a
+        # reentrant pass inside it) keeps its queue.
+        if not _held:
+            for t in [t for t, other in _queues.items() if other[2]() is None]:
+                del _queues[t]
+        import weakref
+        q = _queues[task] = [{}, [], weakref.ref(end)]
+    return q
+
+
 def pending():
-    return sum(len(v) for v in _jobs.values())
+    return sum(len(v) for q in _queues.values() for v in q[0].values())
 
 
 def discard():
-    """Drop what is queued (a backward pass that raised never runs its end-of-pass callback: its jobs would otherwise
-    be finished by the NEXT pass, against buffers that no longer mean anything)."""
-    global _jobs, _grads
-    _jobs, _grads = {}, []
+    """Drop what is queued (a backward pass that raised never runs its end-of-pass callback: its jobs must not be
+    finished by a later pass, against buffers that no longer mean anything)."""
+    _queues.clear()
 
 
 _held = False
@@ -201,17 +219,20 @@ def flush():
     global _held
     was, _held = _held, False
     try:
-        _flush()
+        for task in sorted(_queues, reverse=True):   # (inner passes first: the order their callbacks would have run in)
+            _flush(task)
     finally:
         _held = was
 
 
-def _flush():
-    global _jobs, _grads
+def _flush(task=None):
+    """End-of-pass callback of the running pass (``task`` None), or one held queue by its id."""
     if _held:
         return
-    jobs, grads = _jobs, _grads
-    _jobs, _grads = {}, []
+    q = _queues.pop(torch._C._current_graph_task_id() if task is None else task, None)
+    if q is None:
+        return
+    jobs, grads = q[0], q[1]
     for (a, b), fn in _joint.items():
         if jobs.get(a) and jobs.get(b) and fn(jobs[a], jobs[b]):
             jobs[a], jobs[b] = [], []

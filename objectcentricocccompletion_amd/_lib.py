@@ -349,10 +349,10 @@ def workspace(nbytes, device):
 _logged = set()
 
 
-def log_once(key, msg):
+def log_once(key, msg, level='warning'):
     """one line on the package logger the first time ``key`` is seen: a fused kernel that does not cover a module's shape
     falls back to the operator-by-operator path -- correct, several times slower, and otherwise silent"""
     if key not in _logged:
         _logged.add(key)
         import logging
-        logging.getLogger('objectcentricocccompletion_amd').warning(msg)
+        getattr(logging.getLogger('objectcentricocccompletion_amd'), level)(msg)

@@ -122,6 +122,13 @@ class GradBuckets(object):
             return
         task = torch._C._current_graph_task_id()
         if task != self._pass_id:   # first gradient of a pass: forget whatever an interrupted pass left behind
+            if self._pass_id is not None and task < self._pass_id:
+                # graph-task ids only grow: a LOWER one is an outer pass going on after a reentrant pass inside it
+                # (torch.utils.checkpoint(use_reentrant=True), a Function that calls backward()), whose gradients
+                # were taken for a new step
+                raise RuntimeError('GradBuckets(overlap=True) saw gradients of a backward pass nested in another one; '
+                                   'reentrant passes are not supported in overlap mode: use non-reentrant checkpointing '
+                                   'or GradBuckets without overlap (pack / all_reduce after backward())')
             self._reset_pass()
             self._pass_id = task
         bi, off, n = self._where[id(p)]

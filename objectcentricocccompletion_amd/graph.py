@@ -62,6 +62,8 @@ class GraphedStep(object):
         return self.graph.pool()
 
     def replay(self):
+        from .spconv import ops as sp_ops
+        sp_ops.refresh_graph_operands()   # (weight operands the graph reads without preparing them: see there)
         self.graph.replay()
         return self.out
 

@@ -183,10 +183,18 @@ class DensityTracker(object):
     NEXT build (or ``poll()``) harvests it once the event has passed.  The estimate therefore lags the data by one
     build; a rulebook built before the first harvest carries no hint and runs on the output-stationary kernels (every
     kernel is correct for every table: a stale or missing estimate costs time, never results).  A captured HIP graph
-    bakes in the choice made at capture time; ``regime(shape)`` tells a training loop when a re-capture would pay."""
+    bakes in the choice made at capture time; ``regime(shape)`` tells a training loop when a re-capture would pay.
+
+    The kernel choices key on ``stable``, not on the running average: it follows ``value`` only when that has moved by more
+    than ``HYSTERESIS`` (relative) from the last committed number, so batches that jitter around a threshold of
+    ``_TILE_SHAPES`` / ``SORTED_*_PAIRS_PER_ROW`` do not flip the kernel family (and with it the summation order and the
+    prepared weight layouts) from step to step, whenever the copy happens to land.  One tracker per process:
+    ``OCOCC_AUTO_DENSITY=0`` or ``DEFAULT_PAIRS_PER_ROW`` pin the regime for runs that must be bit-reproducible."""
+    HYSTERESIS = 0.10
 
     def __init__(self):
         self.value = None       # pairs per row, exponentially averaged over the observed builds
+        self.stable = None      # what the kernel choices see
         self.samples = 0
         self._host = None
         self._pending = None
@@ -216,10 +224,16 @@ class DensityTracker(object):
             self.value = v if self.value is None else 0.5 * self.value + 0.5 * v
             self.samples += 1
             self._pending = None
+            if self.stable is None or abs(self.value - self.stable) > self.HYSTERESIS * self.stable:
+                if self.stable is not None:
+                    L.log_once(('density', round(self.stable, 1), round(self.value, 1)),
+                               'rulebook density estimate moved from %.2f to %.2f pairs per row: kernel choices follow'
+                               % (self.stable, self.value), level='info')
+                self.stable = self.value
         return self.value
 
     def reset(self):
-        self.value, self.samples, self._pending = None, 0, None
+        self.value, self.stable, self.samples, self._pending = None, None, 0, None
 
 
 density = DensityTracker()
@@ -228,7 +242,7 @@ density = DensityTracker()
 def current_density():
     """the density new rulebooks are assumed to have: an explicit DEFAULT_PAIRS_PER_ROW wins, else the device-measured
     estimate (None until the first observation has landed)"""
-    return float(DEFAULT_PAIRS_PER_ROW) if DEFAULT_PAIRS_PER_ROW is not None else density.value
+    return float(DEFAULT_PAIRS_PER_ROW) if DEFAULT_PAIRS_PER_ROW is not None else density.stable
 
 
 def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None, rowrec=None):
@@ -430,6 +444,12 @@ class overlap_wgrad(object):
 _overlap = None
 _weight_cache = None  # {(data_ptr, mode, kd, nc): wn} filled by prepare_weights() for ONE forward+backward
 _graph_operands = []  # operand buffers captured HIP graphs refer to (kept alive for the life of the process)
+# ... and what they hold: {(data_ptr, mode, kd, nc): (wn, parameter version, weak reference to the parameter)}.  A graph
+# captured on a cache hit records NO preparation launch: it relies on somebody rewriting these very buffers whenever the
+# parameter changes.  They therefore stay refresh targets of the optimizer whatever later prepare_weights() calls were
+# given (an evaluation forward, a second model), and graph.GraphedStep.replay re-prepares the ones a parameter write
+# outside the optimizer (load_state_dict, an EMA copy) has left behind (refresh_graph_operands).
+_graph_entries = {}
 
 
 def prepare_weights(items):
@@ -456,11 +476,12 @@ def prepare_weights(items):
                 mode += 4
         kvol = filters.numel() // (cin * cout)
         key = (filters.data_ptr(), mode, kd, nc)
-        hit = previous.get(key)
+        hit = previous.get(key) or _graph_entries.get(key)
         if hit is not None and hit[2]() is filters and hit[1] == filters._version:
             _weight_cache[key] = hit    # still current: the optimizer refreshed it with the update (refresh_targets)
             if torch.cuda.is_current_stream_capturing():
                 _graph_operands.append(hit[0])   # a captured graph reads and rewrites this buffer: it must outlive the cache
+                _graph_entries[key] = hit
             continue
         wn = torch.empty((kvol, nc, kd), dtype=torch.bfloat16, device=filters.device)
         todo.append((filters, mode, kvol, cin, cout, wn))
@@ -480,21 +501,49 @@ def refresh_targets(param):
     rewrites them together with the parameter (optim.AdamW -> ococc_adamw_operands_f32) calls operands_refreshed() behind
     its launch, and the next prepare_weights() finds them current: no preparation launch in steady state."""
     out = []
-    if not _weight_cache or param.dim() < 3 or param.dtype != torch.float32 or not param.is_contiguous():
+    if not (_weight_cache or _graph_entries) or param.dim() < 3 or param.dtype != torch.float32 or not param.is_contiguous():
         return out
     cin, cout = param.shape[-2], param.shape[-1]
     kvol = param.numel() // (cin * cout)
-    for (ptr, mode, kd, nc), (wn, _, ref) in _weight_cache.items():
-        if ptr == param.data_ptr() and ref() is param and (kd, nc) == ((cin, cout) if (mode & 3) == 0 else (cout, cin)):
-            out.append((mode, kvol, cin, cout, wn))
+    seen = set()
+    for table in (_weight_cache or {}, _graph_entries):
+        for (ptr, mode, kd, nc), (wn, _, ref) in table.items():
+            if (ptr == param.data_ptr() and ref() is param and wn.data_ptr() not in seen
+                    and (kd, nc) == ((cin, cout) if (mode & 3) == 0 else (cout, cin))):
+                seen.add(wn.data_ptr())
+                out.append((mode, kvol, cin, cout, wn))
     return out
 
 
 def operands_refreshed(param):
     """the cached operand layouts of ``param`` hold its CURRENT values (call after the version counter was bumped)"""
-    for key, (wn, _, ref) in list((_weight_cache or {}).items()):
-        if key[0] == param.data_ptr() and ref() is param:
-            _weight_cache[key] = (wn, param._version, ref)
+    for table in (_weight_cache or {}, _graph_entries):
+        for key, (wn, _, ref) in list(table.items()):
+            if key[0] == param.data_ptr() and ref() is param:
+                table[key] = (wn, param._version, ref)
+
+
+def refresh_graph_operands():
+    """Re-prepare, eagerly and in place, every operand buffer a captured graph reads whose parameter was written since
+    (host check of a few version counters per replay; a launch only when something is stale)."""
+    import ctypes
+    stale = []
+    for key, (wn, ver, ref) in list(_graph_entries.items()):
+        p = ref()
+        if p is None:
+            del _graph_entries[key]
+        elif p._version != ver:
+            stale.append((key, p, wn))
+    for key, p, wn in stale:
+        cin, cout = p.shape[-2], p.shape[-1]
+        vp, i32 = ctypes.c_void_p * 1, ctypes.c_int32 * 1
+        L.check(L.lib.ococc_weight_prepare_multi_bf16(1, vp(p.data_ptr()), i32(p.numel() // (cin * cout)), i32(cin), i32(cout),
+                                                      i32(key[1]), vp(wn.data_ptr()), L.stream()), 'weight_prepare_multi')
+        entry = (wn, p._version, weakref.ref(p))
+        _graph_entries[key] = entry
+        if _weight_cache is not None and key in _weight_cache and _weight_cache[key][0] is wn:
+            _weight_cache[key] = entry
+    return len(stale)
 
 
 def _prep_weights(filters, mode, kd_pad, nc_pad):

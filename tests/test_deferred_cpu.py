@@ -140,3 +140,57 @@ def test_multi_rank_needs_the_gradient_exchange_to_opt_in(monkeypatch):
     w.grad = None
     _Mul.apply(x, w).sum().backward()
     assert _LOG == [1] and torch.equal(w.grad, x.sum(0).detach())
+
+
+class _Nested(torch.autograd.Function):
+    """identity whose backward runs a whole backward pass of its own (what torch.utils.checkpoint(use_reentrant=True)
+    does): a reentrant pass inside the running one, with its own queued reduction"""
+
+    @staticmethod
+    def forward(ctx, x, w_inner, x_inner):
+        ctx.w_inner, ctx.x_inner = w_inner, x_inner
+        return x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.enable_grad():
+            _Mul.apply(ctx.x_inner, ctx.w_inner).sum().backward()
+        return g, None, None
+
+
+def test_reentrant_pass_inside_a_pass_keeps_both_queues():
+    """the inner pass has its own graph-task id; it must flush ITS queue at its end and leave the outer pass's
+    queued sums alone (they used to be discarded as 'left by an interrupted pass': gradients silently lost)."""
+    w, x = _setup()
+    w_in = torch.nn.Parameter(torch.randn(4))
+    x_in = torch.randn(5, 4)
+    w_last = torch.nn.Parameter(torch.randn(4))
+    # backward order: w_last (outer queue) -> nested pass (w_in: inner queue, flushed there) -> w (outer queue)
+    y = _Mul.apply(_Nested.apply(_Mul.apply(x, w), w_in, x_in), w_last)
+    y.sum().backward()
+    assert _LOG == [1, 2] and D.pending() == 0, _LOG
+    assert torch.equal(w_in.grad, x_in.sum(0))
+    assert torch.equal(w_last.grad, (x * w).sum(0).detach())
+    assert torch.equal(w.grad, (w_last * x).sum(0).detach())
+
+
+def test_queue_of_a_pass_that_raised_is_never_run():
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise ValueError('boom')
+
+    w, x = _setup()
+    try:   # backward order: _Mul (queues w's sum), then _Boom raises: the pass never reaches its end-of-pass callback
+        _Mul.apply(_Boom.apply(x), w).sum().backward()
+    except ValueError:
+        pass
+    assert D.pending() == 1 and w.grad is None and _LOG == []
+    w3, x3 = _setup()
+    _Mul.apply(x3, w3).sum().backward()
+    assert D.pending() == 0 and _LOG == [1]       # only its own job ran; what the raised pass left is gone
+    assert torch.equal(w3.grad, x3.sum(0)) and w.grad is None

@@ -224,3 +224,44 @@ def test_adamw_refreshes_the_cached_conv_operands(dev):
     assert sum(results[True][1]) < sum(results[False][1]) and len(results[True][1]) <= 2 and len(results[False][1]) == 3
     for a, b in zip(results[True][0], results[False][0]):
         assert torch.equal(a, b)
+
+
+def test_graph_on_cached_operands_follows_parameter_writes(dev):
+    """a graph captured while the bf16 weight operands were cache hits records no preparation launch and reads
+    those buffers on every replay.  A parameter write outside the optimizer (load_state_dict, EMA) and an evaluation
+    forward in between (whose prepare_weights() call names the forward operands only) must not leave the replay on stale
+    operands: GraphedStep.replay re-prepares what a version counter says is behind."""
+    from objectcentricocccompletion_amd.graph import GraphedStep
+    from objectcentricocccompletion_amd.spconv import ops
+    model, xyz, feats, bidx, B = _setup(dev)
+    with torch.no_grad():
+        n = model(xyz, feats, bidx, B).features.shape[0]
+    d_s = torch.zeros(xyz.shape[0], 128, dtype=torch.bfloat16, device=dev)
+    d_s[:n] = (torch.randn(n, 128, device=dev) / n).to(torch.bfloat16)
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        out = model(xyz, feats, bidx, B, static=True)
+        out.features.backward(d_s)
+        return out
+
+    g = GraphedStep(fwd_bwd, warmup=2)
+    assert len(ops._graph_entries) >= 5          # captured on hits: 3 forward + 2 input-gradient operands
+    g.replay()
+    before = g.out.features.clone()
+    with torch.no_grad():
+        for layer in model.conv_layers:
+            layer[0].weight.mul_(1.25)
+        model(xyz, feats, bidx, B)               # evaluation forward: forward operands only
+    out_g = g.replay()
+    torch.cuda.synchronize()
+    feat_g = out_g.features.clone()
+    g_g = [p.grad.clone() for p in model.parameters()]
+    assert not torch.equal(feat_g, before)
+    ops._weight_cache = None                     # eager pass on freshly prepared operands
+    out_e = fwd_bwd()
+    torch.cuda.synchronize()
+    assert torch.equal(feat_g, out_e.features)
+    for a, p in zip(g_g, model.parameters()):
+        assert torch.equal(p.grad, a)
+    assert ops.refresh_graph_operands() == 0
