@@ -191,10 +191,15 @@ int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_featur
                                    uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status, int32_t* nbr_t,
                                    uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
                                    int64_t workspace_bytes, ococc_stream_t stream);
-/* The same, also leaving the per-row records of the neighbour-pattern row order (ococc_subm_row_order below) for the
- * table it writes: order_counters as there (zero on entry), order_rowrec [capacity, 4] int32, 16-byte aligned, capacity
- * below 2^20.  Follow with ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, ...).  Both NULL: exactly the
- * call above. */
+/* The same, also building the neighbour-pattern row order (ococc_subm_row_order below) of the table it writes, where
+ * the rows' 27 table entries sit in registers anyway: order_counters as there, order_rowrec [capacity, 4] int32, 16-byte
+ * aligned (scratch: the per-row records), capacity below 2^20.
+ *   order_rec [capacity, 4] int32 + order_hdr [8] int32 given: the finished order, as ococc_subm_row_order leaves it
+ *     (heavy_blocks / mid_blocks as there).  When every workgroup of the last kernel fits the chip at once the slots are
+ *     assigned inside it, behind a barrier over its grid; otherwise ococc_subm_row_order_place runs behind it.
+ *   order_rec / order_hdr NULL: only the row records; follow with ococc_subm_row_order_place(order_rowrec, 27, 13,
+ *     capacity, ...).
+ * order_counters and order_rowrec NULL: exactly the call above. */
 int ococc_object_grid_geometry_order_f32(const float* points, int32_t num_point_features, const int32_t* batch_idx,
                                          int64_t n, const float* feats, int32_t c, const float host_voxel_size[3],
                                          const float host_coors_range[6], int32_t batch_size,
@@ -203,6 +208,7 @@ int ococc_object_grid_geometry_order_f32(const float* points, int32_t num_point_
                                          uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status, int32_t* nbr_t,
                                          uint32_t* blockmask, int32_t* indice_pairs, int32_t* indice_num, void* workspace,
                                          int64_t workspace_bytes, void* order_counters, int32_t* order_rowrec,
+                                         int32_t* order_rec, int32_t* order_hdr, int32_t heavy_blocks, int32_t mid_blocks,
                                          ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
@@ -332,8 +338,8 @@ int ococc_sparse_conv_tile_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, 
  * 2, 1, 0; lowest two neighbour offsets) -- rows that share their offsets become neighbours in the order, so a
  * workgroup walks only the offsets its rows have and 16-row MFMA blocks are nearly full.  The order is a property of
  * the table: build it once per rulebook, use it for every layer and direction that gathers through the table.
- *   counters ococc_subm_row_order_counter_bytes() bytes, ZERO on entry; the call leaves them zero again (one buffer,
- *            zeroed once, serves every build on a stream -- there is no memset launch per build)
+ *   counters ococc_subm_row_order_counter_bytes() bytes of scratch: cleared by every build before it counts (a memset node
+ *            here; inside the first geometry kernel in ococc_object_grid_geometry_order_f32), contents undefined after
  *   scratch  ococc_subm_row_order_scratch_bytes(n) bytes, 16-byte aligned (the row records: n below 2^20)
  *   rec      [n, 4] int32, 16-byte aligned: per slot {row, offset mask (bit k: table[k][row] >= 0), table entries at the
  *            row's lowest and second lowest neighbour offsets (-1: none)}
@@ -350,7 +356,8 @@ int ococc_subm_row_order(const int32_t* table, int32_t kvol, int32_t dense_k, in
                          int32_t mid_blocks, void* counters, void* scratch, int32_t* rec, int32_t* hdr,
                          ococc_stream_t stream);
 /* The second half of ococc_subm_row_order alone, for row records some other kernel left while it wrote the table
- * (ococc_object_grid_geometry_order_f32): records -> slots, header, counters back to zero. */
+ * (ococc_object_grid_geometry_order_f32 without order_rec, which also counted them into ``counters``): records ->
+ * slots, header. */
 int ococc_subm_row_order_place(const int32_t* rowrec, int32_t kvol, int32_t dense_k, int64_t n, int32_t heavy_blocks,
                                int32_t mid_blocks, void* counters, int32_t* rec, int32_t* hdr, ococc_stream_t stream);
 int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,

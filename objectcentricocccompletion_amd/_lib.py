@@ -41,7 +41,7 @@ SIGNATURES = {
                                                c_vp, c_i64, c_vp]),
     'ococc_object_grid_geometry_order_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3, c_i32,
                                                      c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                                     c_vp, c_i64, c_vp, c_vp, c_vp]),
+                                                     c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     'ococc_voxelize_scatter_mean_f32': (c_i32, [c_vp, c_i32, c_vp, c_i64, c_vp, c_i32, _F3, _F6, c_i32, _I3,
                                                 c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ococc_occ_visibility_f64': (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,

@@ -43,10 +43,14 @@ __device__ long long* g_stamps = nullptr;
 #define STAMP(slot) do { } while (0)
 #endif
 
+#ifndef OCOCC_GEO_INLINE_PLACE
+#define OCOCC_GEO_INLINE_PLACE 1   // (0: diagnostic builds that time the two-launch form)
+#endif
 constexpr int kThreads = 1024;       // kernel A: one workgroup per grid
 constexpr int kWaves = kThreads / 64;
 constexpr int kEmitThreads = 256;    // kernel B: one workgroup per (grid, row slice), several per CU
 constexpr int kEmitWaves = kEmitThreads / 64;
+constexpr int kPadBlocks = 64;       // workgroups of kernel B that write the padding rows of the fixed-capacity form
 constexpr int kCols = 28;            // 27 kernel offsets + the voxel count
 constexpr int kMaxSlices = 16;
 constexpr int kCodesPerThread = 8;   // point codes a thread of kernel B fetches in one round
@@ -141,7 +145,7 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
                        GeoParams g, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ local_prefix,
                        int32_t* __restrict__ code_of, int32_t* __restrict__ table, int64_t* __restrict__ seg,
                        uint32_t* __restrict__ blockmask, int64_t mask_words, int32_t* __restrict__ inv,
-                       int32_t* __restrict__ bad_flags) {
+                       int32_t* __restrict__ bad_flags, uint32_t* __restrict__ order_hist) {
   extern __shared__ uint32_t smem[];
   uint32_t* bm = smem;             // [words]
   uint32_t* pf = smem + g.words;   // [words]
@@ -159,6 +163,9 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
   if (threadIdx.x == 0) s_bad = 0;
   // the block masks are OR-ed by kernel B: cleared here, one slice per workgroup
   for (int64_t w = (int64_t)blockIdx.x * kThreads + threadIdx.x; w < mask_words; w += (int64_t)gridDim.x * kThreads) blockmask[w] = 0u;
+  // ... and so are the bucket counters of the row order kernel B counts into
+  if (order_hist && blockIdx.x == 0)
+    for (int w = threadIdx.x; w < kOrderCounterWords; w += kThreads) order_hist[w] = 0u;
   int64_t lo, hi;
   segment_bounds(batch_idx, n, b, s_two, &lo, &hi);
   if (threadIdx.x == 0 && my_sl == 0) {
@@ -337,6 +344,52 @@ __device__ __forceinline__ void put_feat_row(const float* __restrict__ src, floa
   }
 }
 
+// ---- slots of the neighbour-pattern order at the end of kernel B ------------------------------------------------------
+// Every workgroup that counted rows into the bucket counters arrives at a barrier over the whole grid (one atomic and a
+// polling loop; the host launches this form only when all workgroups of the launch fit the chip at once), then scans
+// the counters for itself and moves the records of its OWN rows -- still hot in its L2 -- to their slots: no second
+// launch (ococc_subm_row_order_place: 6.6 us + the gap in front of it) and no patching pass over the records.
+// ``local_base`` (LDS): where this workgroup's share of each of ITS buckets starts inside the bucket; null when the
+// records already hold places counted from the bucket's start (padding rows).
+__device__ __forceinline__ void order_place_tail(uint32_t* __restrict__ hist, const i32x4_t* __restrict__ rowrec,
+                                                 i32x4_t* __restrict__ rec, OrderHdr* __restrict__ hdr, int64_t lo, int64_t hi,
+                                                 int64_t turn, const uint32_t* local_base, uint32_t* lds, int emit_blocks, int64_t total,
+                                                 int64_t cap, int heavy_blocks, int mid_blocks) {
+  uint32_t* start = lds;                         // [kOrderBuckets + 1]
+  uint32_t* part = lds + kOrderBuckets + 1;      // [kEmitWaves]
+  const int64_t r_first = lo + threadIdx.x;
+  i32x4_t mine = i32x4_t{0, 0, 0, 0};
+  if (r_first < hi) mine = rowrec[r_first];      // (in flight across the barrier)
+  // workgroups that take part: the (grid, slice) ones and the padding ones that have rows
+  const int64_t pad_rows = total < cap ? (cap - total + kEmitThreads - 1) / kEmitThreads : 0;
+  const int64_t pad_wgs = (int64_t)gridDim.x - emit_blocks;
+  const uint32_t target = (uint32_t)emit_blocks + (uint32_t)(pad_rows < pad_wgs ? pad_rows : pad_wgs);
+  uint32_t* arrived = hist + kOrderBuckets;
+  __syncthreads();                               // every atomic of this workgroup has come back (its results were used)
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int polls = 0;
+    while (__hip_atomic_load(arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++polls > (1 << 24)) {                 // ~1 s: cannot happen on a grid that fits the chip; never hang the device
+        hist[kOrderBuckets + 1] = 0xdeadu;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  order_scan_starts<kEmitThreads>([&](int b) { return __hip_atomic_load(hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+                                  start, part);
+  if (blockIdx.x == 0 && threadIdx.x == 0) order_write_hdr(start, cap, heavy_blocks, mid_blocks, 13, hdr);
+  for (int64_t r = r_first; r < hi; r += turn) {   // (rows lo + k * turn .. + 255, k = 0, 1, ...)
+    const i32x4_t rr = r == r_first ? mine : rowrec[r];
+    const uint32_t x = (uint32_t)rr.x;
+    const int gk = (int)(x & ((1u << kOrderKeyBits) - 1u));
+    const uint32_t slot = start[gk] + (x >> kOrderKeyBits) + (local_base ? local_base[order_local(gk)] : 0u);
+    if (slot < (uint32_t)cap) rec[slot] = i32x4_t{(int)r, rr.y, rr.z, rr.w};
+  }
+}
+
 // ---- B: one workgroup per (grid, row slice); the workgroups behind them write the padding rows -------------------
 __global__ void __launch_bounds__(kEmitThreads)
 grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g, const uint32_t* __restrict__ bitmap,
@@ -345,33 +398,47 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
                  const int32_t* __restrict__ totals, int32_t* __restrict__ inv, int32_t* __restrict__ out_coors,
                  int32_t* __restrict__ counts, float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int64_t cap,
                  int32_t* __restrict__ nbr_t, uint32_t* __restrict__ blockmask, int32_t* __restrict__ pairs,
-                 int emit_blocks, uint32_t* __restrict__ order_hist, i32x4_t* __restrict__ order_rowrec) {
+                 int emit_blocks, uint32_t* __restrict__ order_hist, i32x4_t* __restrict__ order_rowrec,
+                 i32x4_t* __restrict__ order_rec, OrderHdr* __restrict__ order_hdr, int heavy_blocks, int mid_blocks) {
   extern __shared__ uint32_t smem[];
   // (order_hist != null: the rows' neighbour-pattern records of ococc_subm_row_order are written here, where the row's
   // 27 table entries sit in registers anyway -- the separate counting pass re-read the whole table, 14 us)
   __shared__ uint32_t s_oh[kLocalBuckets];
   if ((int)blockIdx.x >= emit_blocks) {
-    // padding rows of the fixed-capacity form: -1 coordinates, zero count and features, no neighbours
+    // padding rows of the fixed-capacity form: -1 coordinates, zero count and features, no neighbours; the padding
+    // workgroups take them in turns of 256
     const int64_t total = totals[27];
-    const int64_t r = total + (int64_t)(blockIdx.x - emit_blocks) * kEmitThreads + threadIdx.x;
-    if (r >= cap) return;
-    *(int4*)(out_coors + r * 4) = make_int4(-1, -1, -1, -1);
-    counts[r] = 0;
-    for (int ch = 0; ch < c; ++ch) {
-      out_f32[r * c + ch] = 0.f;
-      if (out_bf16) out_bf16[r * c + ch] = 0;
+    const int64_t turn = (int64_t)(gridDim.x - emit_blocks) * kEmitThreads;
+    const int64_t r0 = total + (int64_t)(blockIdx.x - emit_blocks) * kEmitThreads;
+    if (r0 >= cap) return;
+    for (int64_t r = r0 + threadIdx.x; r - threadIdx.x < cap; r += turn) {
+      const bool have = r < cap;
+      if (have) {
+        *(int4*)(out_coors + r * 4) = make_int4(-1, -1, -1, -1);
+        counts[r] = 0;
+        for (int ch = 0; ch < c; ++ch) {
+          out_f32[r * c + ch] = 0.f;
+          if (out_bf16) out_bf16[r * c + ch] = 0;
+        }
+        for (int k = 0; k < 27; ++k) nbr_t[(int64_t)k * cap + r] = -1;
+      }
+      if (order_hist) {
+        // no offsets at all: the "no neighbour" bucket; the rows of a wave take consecutive places behind ONE atomic
+        const int key = order_global(order_key_local(0u, 13), (int)blockIdx.x);
+        const unsigned long long m = __ballot(have);
+        if (m) {
+          const int leader = __ffsll((long long)m) - 1;
+          uint32_t first = 0u;
+          if ((int)(threadIdx.x & 63) == leader) first = atomicAdd(&order_hist[key], (uint32_t)__popcll(m));
+          first = __shfl(first, leader, 64);
+          const uint32_t place = first + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (have) order_rowrec[r] = i32x4_t{(int)((uint32_t)key | (place << kOrderKeyBits)), 0, -1, -1};
+        }
+      }
     }
-    for (int k = 0; k < 27; ++k) nbr_t[(int64_t)k * cap + r] = -1;
-    if (order_hist) {
-      // no offsets at all: the "no neighbour" bucket; the rows of a wave take consecutive places behind ONE atomic
-      const int key = order_global(order_key_local(0u, 13), (int)(blockIdx.x % kHotCopies));
-      const unsigned long long m = __ballot(true);
-      uint32_t first = 0u;
-      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) first = atomicAdd(&order_hist[key], (uint32_t)__popcll(m));
-      first = __shfl(first, __ffsll((long long)m) - 1, 64);
-      const uint32_t place = first + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      order_rowrec[r] = i32x4_t{(int)((uint32_t)key | (place << kOrderKeyBits)), 0, -1, -1};
-    }
+    if (order_hist && order_rec)
+      order_place_tail(order_hist, order_rowrec, order_rec, order_hdr, r0, cap, turn, nullptr, smem, emit_blocks, total, cap,
+                       heavy_blocks, mid_blocks);
     return;
   }
   uint32_t* bm = smem;            // [words]
@@ -497,7 +564,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
         }
       const int key = order_key_local(mbits, 13);
       const uint32_t rank = atomicAdd(&s_oh[key], 1u);   // place inside this workgroup's share of the bucket
-      order_rowrec[row] = i32x4_t{(int)((uint32_t)order_global(key, (int)(blockIdx.x % kHotCopies)) | (rank << kOrderKeyBits)),
+      order_rowrec[row] = i32x4_t{(int)((uint32_t)order_global(key, (int)blockIdx.x) | (rank << kOrderKeyBits)),
                                   (int)mbits, e1, e2};
     }
     STAMP(12);
@@ -556,7 +623,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
       const int bk = threadIdx.x + kEmitThreads * i;
       o_cnt[i] = bk < kLocalBuckets ? s_oh[bk] : 0u;
       o_got[i] = 0u;
-      if (o_cnt[i]) o_got[i] = atomicAdd(&order_hist[order_global(bk, (int)(blockIdx.x % kHotCopies))], o_cnt[i]);
+      if (o_cnt[i]) o_got[i] = atomicAdd(&order_hist[order_global(bk, (int)blockIdx.x)], o_cnt[i]);
     }
   }
   STAMP(7);
@@ -692,7 +759,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
   }
   STAMP(10);
   if (order_hist) {
-    // the rows' records get their bucket's start added (their first word: bucket | place inside the workgroup's share << 11)
+    // this workgroup's share of every bucket starts where the counter stood when its atomic arrived
 #pragma unroll
     for (int i = 0; i < kOrderPer; ++i) {
       const int bk = threadIdx.x + kEmitThreads * i;
@@ -700,10 +767,16 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     }
     __syncthreads();
     const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
+    if (order_rec) {   // slots right here, behind a barrier over the whole grid (the host checked that it fits the chip)
+      order_place_tail(order_hist, order_rowrec, order_rec, order_hdr, row_lo, hi, kEmitThreads, s_oh, smem, emit_blocks,
+                       totals[27], cap, heavy_blocks, mid_blocks);
+      return;
+    }
+    // else: the records' first word (bucket | place inside the workgroup's share << 12) gets that start added, and
+    // ococc_subm_row_order_place moves them to their slots
     for (int32_t r = row_lo + threadIdx.x; r < hi; r += kEmitThreads) {
       const uint32_t x = (uint32_t)order_rowrec[r].x;
-      const int gk = (int)(x & ((1u << kOrderKeyBits) - 1u));   // global bucket -> this workgroup's
-      const int lk = gk < 2 * kPairKeys ? gk : 2 * kPairKeys + (gk - 2 * kPairKeys) / kHotCopies;
+      const int lk = order_local((int)(x & ((1u << kOrderKeyBits) - 1u)));   // global bucket -> this workgroup's
       order_rowrec[r].x = (int)(x + (s_oh[lk] << kOrderKeyBits));
     }
   }
@@ -769,9 +842,16 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
                                                     uint16_t* voxel_feats_bf16, int32_t* num_voxels, int32_t* status,
                                                     int32_t* nbr_t, uint32_t* blockmask, int32_t* indice_pairs,
                                                     int32_t* indice_num, void* workspace, int64_t workspace_bytes,
-                                                    void* order_counters, int32_t* order_rowrec, ococc_stream_t stream_) {
+                                                    void* order_counters, int32_t* order_rowrec, int32_t* order_rec,
+                                                    int32_t* order_hdr, int32_t heavy_blocks, int32_t mid_blocks,
+                                                    ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OCOCC_REQUIRE((order_counters == nullptr) == (order_rowrec == nullptr), "order_counters and order_rowrec go together");
+  OCOCC_REQUIRE((order_rec == nullptr) == (order_hdr == nullptr) && (!order_rec || order_rowrec),
+                "order_rec and order_hdr go together, with order_counters and order_rowrec");
+  OCOCC_REQUIRE(!order_rec || ((heavy_blocks == 4 || heavy_blocks == 8 || heavy_blocks == 16) &&
+                               (mid_blocks == 4 || mid_blocks == 8 || mid_blocks == 16) && ((uintptr_t)order_rec & 15) == 0),
+                "tile sizes must be 4, 8 or 16 blocks; order_rec 16-byte aligned");
   OCOCC_REQUIRE(!order_rowrec || (capacity < kOrderMaxRows && ((uintptr_t)order_rowrec & 15) == 0),
                 "row records: 16-byte aligned, below 2^20 rows");
   GeoLayout L;
@@ -817,20 +897,42 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
   }
   hipLaunchKernelGGL(grid_mark_count_kernel, dim3(batch_size * g.asplit), dim3(kThreads), lds, stream, points,
                      (int)num_point_features, batch_idx, n, g, bitmap, lpre, code_of, table, seg, blockmask, mask_words,
-                     inv, bad_flags);
+                     inv, bad_flags, (uint32_t*)order_counters);
   OCOCC_CHECK_LAUNCH();
   const int64_t entries = (int64_t)batch_size * slices;
   hipLaunchKernelGGL(geometry_bases_kernel, dim3(kCols), dim3(64), 0, stream, table, entries, bases, totals,
                      indice_num, num_voxels, capacity, bad_flags, (int)(batch_size * g.asplit), status);
   OCOCC_CHECK_LAUNCH();
   const int emit_blocks = (int)entries;
-  // worst case every row is padding; the padding workgroups index rows from the device-side total
-  const int pad_blocks = (int)ococc_cdiv(capacity, kEmitThreads);
+  // the padding workgroups index rows from the device-side total and take them in turns (worst case every row is
+  // padding: an empty batch)
+  const int64_t pad_need = ococc_cdiv(capacity, kEmitThreads);
+  const int pad_blocks = (int)(pad_need < kPadBlocks ? pad_need : kPadBlocks);
+  // The slots of the row order inside kernel B need a barrier over its whole grid: only when every workgroup of the
+  // launch fits the chip at once (and the scan's LDS fits the bitmap's); otherwise the placing pass runs behind it.
+  bool inline_place = false;
+  if (order_rec && lds >= (size_t)(kOrderBuckets + 1 + kEmitWaves) * 4) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      OCOCC_HIP(hipGetDevice(&dev));
+      OCOCC_HIP(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    OCOCC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grid_emit_kernel, kEmitThreads, lds));
+    inline_place = OCOCC_GEO_INLINE_PLACE && (int64_t)emit_blocks + pad_blocks <= (int64_t)per_cu * cus;
+  }
   hipLaunchKernelGGL(grid_emit_kernel, dim3(emit_blocks + pad_blocks), dim3(kEmitThreads), lds, stream, feats, (int)c, n, g,
                      bitmap, lpre, prefix, code_of, seg, bases, totals, inv, voxel_coors, counts, voxel_feats,
                      voxel_feats_bf16, capacity, nbr_t, blockmask, indice_pairs, emit_blocks, (uint32_t*)order_counters,
-                     (i32x4_t*)order_rowrec);
+                     (i32x4_t*)order_rowrec, inline_place ? (i32x4_t*)order_rec : nullptr, (OrderHdr*)order_hdr,
+                     (int)heavy_blocks, (int)mid_blocks);
   OCOCC_CHECK_LAUNCH();
+  if (order_rec && !inline_place)
+    return ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, heavy_blocks, mid_blocks, order_counters, order_rec,
+                                      order_hdr, stream_);
   return OCOCC_OK;
 }
 
@@ -846,5 +948,6 @@ extern "C" int ococc_object_grid_geometry_f32(const float* points, int32_t num_p
   return ococc_object_grid_geometry_order_f32(points, num_point_features, batch_idx, n, feats, c, host_voxel_size,
                                               host_coors_range, batch_size, host_grid_zyx, slices, voxel_coors, capacity, inv,
                                               counts, voxel_feats, voxel_feats_bf16, num_voxels, status, nbr_t, blockmask,
-                                              indice_pairs, indice_num, workspace, workspace_bytes, nullptr, nullptr, stream_);
+                                              indice_pairs, indice_num, workspace, workspace_bytes, nullptr, nullptr, nullptr,
+                                              nullptr, 0, 0, stream_);
 }

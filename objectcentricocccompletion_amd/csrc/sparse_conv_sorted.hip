@@ -42,12 +42,6 @@ __device__ long long* s_stamps = nullptr;
 constexpr int kSortThreads = 256;
 constexpr int kOrderRowsPerWg = 512;
 
-// header the order carries (int32[8]): blocks of 16 slots up to which tiles have heavy_blocks / mid_blocks blocks (16
-// after), total blocks, tiles
-struct OrderHdr {
-  int b_heavy, b_mid, b_total, tiles, n, heavy_blocks, mid_blocks, dense_k;
-};
-
 // rowrec[r] = {bucket | place in the bucket << 11, offset mask, table entry at the lowest neighbour offset, at the
 // second lowest}.  (For the benchmark's grids grid_emit_kernel writes these records while it writes the table.)
 __global__ void __launch_bounds__(256)
@@ -57,7 +51,7 @@ order_count_kernel(const int32_t* __restrict__ table, int kvol, int dense_k, int
   for (int i = threadIdx.x; i < kLocalBuckets; i += 256) h[i] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kOrderRowsPerWg;
-  const int copy = (int)(blockIdx.x % kHotCopies);
+  const int copy = (int)blockIdx.x;   // (which of a bucket's counter copies: order_global takes it modulo)
   i32x4_t rr[kOrderRowsPerWg / 256];
   int lkey[kOrderRowsPerWg / 256];
 #pragma unroll
@@ -101,14 +95,13 @@ order_count_kernel(const int32_t* __restrict__ table, int kvol, int dense_k, int
 // Slots.  Every workgroup scans the (small) bucket histogram itself -- no scan launch in between -- and moves its rows'
 // records to first slot of the bucket + the row's place in the bucket, which the counting pass left in the record (a
 // second round of atomics here, one per workgroup and bucket, took 12 of this kernel's 18 us; per-row atomics on the
-// cursors of the few big buckets 666 us).  Workgroup 0 writes the header; the last one to finish zeroes the counters.
+// cursors of the few big buckets 666 us).  Workgroup 0 writes the header.  The counters are left as they are: every
+// build clears them before it counts (no "who is last" atomic at the end of this kernel).
 __global__ void __launch_bounds__(256)
-order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, uint32_t* __restrict__ hist, uint32_t* __restrict__ done,
+order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, const uint32_t* __restrict__ hist,
                    int heavy_blocks, int mid_blocks, int dense_k, i32x4_t* __restrict__ rec, OrderHdr* __restrict__ hdr) {
-  constexpr int PER = (kOrderBuckets + 255) / 256;
   __shared__ uint32_t start[kOrderBuckets + 1];   // first slot of the bucket
   __shared__ uint32_t part[4];
-  __shared__ uint32_t last;
   const int64_t base = (int64_t)blockIdx.x * kOrderRowsPerWg;
   i32x4_t rr[kOrderRowsPerWg / 256];
 #pragma unroll
@@ -116,45 +109,8 @@ order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, uint32_t* __re
     const int64_t r = base + u * 256 + threadIdx.x;
     rr[u] = r < n ? rowrec[r] : i32x4_t{0, 0, 0, 0};
   }
-  uint32_t v[PER], s = 0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int b = threadIdx.x * PER + i;
-    v[i] = b < kOrderBuckets ? hist[b] : 0u;
-    s += v[i];
-  }
-  // exclusive prefix over the 256 threads: inside the wave with shuffles, across the four waves through LDS
-  uint32_t inc = s;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = __shfl_up(inc, d, 64);
-    if ((threadIdx.x & 63) >= d) inc += t;
-  }
-  if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  uint32_t run = inc - s;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += part[w];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int b = threadIdx.x * PER + i;
-    if (b <= kOrderBuckets) start[b] = run;
-    run += v[i];
-  }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const int e3 = (int)start[kPairKeys], e2 = (int)start[2 * kPairKeys];   // ends of the 3+ and of the 2 neighbour class
-    OrderHdr o;
-    o.b_total = (int)((n + 15) >> 4);
-    o.b_heavy = min((e3 + 15) >> 4, o.b_total);
-    o.b_mid = min(max(o.b_heavy, (e2 + 15) >> 4), o.b_total);
-    o.tiles = (o.b_heavy + heavy_blocks - 1) / heavy_blocks + (o.b_mid - o.b_heavy + mid_blocks - 1) / mid_blocks +
-              (o.b_total - o.b_mid + 15) / 16;
-    o.n = (int)n;
-    o.heavy_blocks = heavy_blocks;
-    o.mid_blocks = mid_blocks;
-    o.dense_k = dense_k;
-    *hdr = o;
-  }
+  order_scan_starts<256>([&](int b) { return hist[b]; }, start, part);
+  if (blockIdx.x == 0 && threadIdx.x == 0) order_write_hdr(start, n, heavy_blocks, mid_blocks, dense_k, hdr);
 #pragma unroll
   for (int u = 0; u < kOrderRowsPerWg / 256; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
@@ -162,14 +118,6 @@ order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, uint32_t* __re
       const uint32_t x = (uint32_t)rr[u].x;
       rec[start[x & ((1u << kOrderKeyBits) - 1u)] + (x >> kOrderKeyBits)] = i32x4_t{(int)r, rr[u].y, rr[u].z, rr[u].w};
     }
-  }
-  // the last workgroup to get here leaves the counters zeroed for the next build (they were zero on entry: no
-  // memset launch per build)
-  if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (last) {
-    for (int i = threadIdx.x; i < kOrderBuckets; i += 256) hist[i] = 0u;
-    if (threadIdx.x == 0) *done = 0u;
   }
 }
 
@@ -538,13 +486,13 @@ int dispatch_sorted(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int 
   return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd x ncols must be one of {32,64,128} x {32,64,128} below 128 x 128");
 }
 
-constexpr int kOrderCounterBytes = ((kOrderBuckets + 1) * 4 + 15) / 16 * 16;   // bucket counts | finished workgroups
+constexpr int kOrderCounterBytes = (kOrderCounterWords * 4 + 15) / 16 * 16;
 
 int launch_order_place(const i32x4_t* rowrec, int64_t n, int heavy_blocks, int mid_blocks, int dense_k, uint32_t* hist,
                        int32_t* rec, int32_t* hdr, hipStream_t stream) {
   const unsigned wgs = (unsigned)ococc_cdiv(n, kOrderRowsPerWg);
-  hipLaunchKernelGGL(order_place_kernel, dim3(wgs > 0 ? wgs : 1), dim3(256), 0, stream, rowrec, n, hist,
-                     hist + kOrderBuckets, heavy_blocks, mid_blocks, dense_k, (i32x4_t*)rec, (OrderHdr*)hdr);
+  hipLaunchKernelGGL(order_place_kernel, dim3(wgs > 0 ? wgs : 1), dim3(256), 0, stream, rowrec, n, (const uint32_t*)hist,
+                     heavy_blocks, mid_blocks, dense_k, (i32x4_t*)rec, (OrderHdr*)hdr);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
@@ -576,6 +524,7 @@ extern "C" int ococc_subm_row_order(const int32_t* table, int32_t kvol, int32_t 
   const int rc = check_order_args(kvol, dense_k, n, heavy_blocks, mid_blocks, counters, scratch, rec, hdr);
   if (rc != OCOCC_OK) return rc;
   OCOCC_REQUIRE(n == 0 || table, "null pointer");
+  OCOCC_HIP(hipMemsetAsync(counters, 0, kOrderCounterBytes, stream));
   if (n > 0) {
     hipLaunchKernelGGL(order_count_kernel, dim3((unsigned)ococc_cdiv(n, kOrderRowsPerWg)), dim3(256), 0, stream, table,
                        (int)kvol, (int)dense_k, n, (i32x4_t*)scratch, (uint32_t*)counters);

@@ -245,11 +245,11 @@ def current_density():
     return float(DEFAULT_PAIRS_PER_ROW) if DEFAULT_PAIRS_PER_ROW is not None else density.stable
 
 
-def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None, rowrec=None):
+def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None, rowrec=None, order=None):
     """Hang the device-side companions of a sub-manifold rulebook (offset-major gather table, 16-row block masks) on
     its indice_pairs tensor, where indice_conv / indice_conv_backward look for them.  ``num``: the per-offset pair counts
     (device), observed by the density tracker.  ``rowrec``: row records of the neighbour-pattern order, if the kernel
-    that wrote the table left them (new_rulebook_wants_order)."""
+    that wrote the table left them (new_rulebook_wants_order); ``order``: (rec, hdr), if it left the finished order."""
     rb = RulebookTables(symmetric, kvol)
     if AUTO_DENSITY and DEFAULT_PAIRS_PER_ROW is None:
         density.observe(num, rows)
@@ -259,7 +259,9 @@ def attach_subm_tables(pairs, nbr_t, mask, rows, kvol, symmetric=True, num=None,
     if symmetric:
         rb.tables[(False, 'bwd')] = (nbr_t, mask, rows)  # symmetric: same table, offset-flipped weights
     pairs._ococc = rb
-    if rowrec is not None or (_sorted_regime(rb) and 0 < rows < ORDER_MAX_ROWS):
+    if order is not None:
+        rb.orders[nbr_t.data_ptr()] = [order[0], order[1], nbr_t, None]   # (nbr_t: keeps the key's address alive)
+    elif rowrec is not None or (_sorted_regime(rb) and 0 < rows < ORDER_MAX_ROWS):
         # the neighbour-pattern row order is part of the geometry: built here, it runs wherever the rulebook is built
         # (bench.py: on the forked stream, beside the previous batch's convolutions) and not in front of the first layer
         # (row records at hand: the counters they were counted into must be emptied by the placing pass in any case)

@@ -289,19 +289,25 @@ def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid
     mask = L.empty(((cap + 15) // 16,), torch.int32, dev)
     pairs = L.empty((27, 2, cap), torch.int32, dev)
     num = L.empty((27,), torch.int32, dev)
-    # (sparse rulebooks: the emit kernel also leaves the row records of the neighbour-pattern row order, spconv.ops.row_order)
+    # (sparse rulebooks: the emit kernel also builds the neighbour-pattern row order, spconv.ops.row_order -- the finished
+    # order unless its placing pass is wanted on a side stream, then the row records only)
     rowrec = L.empty((cap, 4), torch.int32, dev) if sp_ops.new_rulebook_wants_order(cap) else None
+    order = None
+    if rowrec is not None and not sp_ops.ORDER_SIDE_STREAM:
+        order = (L.empty((cap, 4), torch.int32, dev), L.empty((8,), torch.int32, dev))
     L.check(L.lib.ococc_object_grid_geometry_order_f32(
         L.ptr(pts), pts.size(1), L.ptr(bidx), n, L.ptr(fts), c, L.f3(voxel_size), L.f6(coors_range), int(batch_size),
         L.i3(grid_zyx), int(slices), L.ptr(coors), cap, L.ptr(inv), L.ptr(counts), L.ptr(out), L.ptr(out16),
         meta.data_ptr(), meta.data_ptr() + 4, L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num), L.ptr(ws), ws.numel(),
-        L.ptr(sp_ops.order_counters(dev)) if rowrec is not None else None, L.ptr(rowrec), L.stream()), 'object_grid_geometry')
+        L.ptr(sp_ops.order_counters(dev)) if rowrec is not None else None, L.ptr(rowrec),
+        L.ptr(order[0]) if order else None, L.ptr(order[1]) if order else None, sp_ops.SORTED_TILES[0], sp_ops.SORTED_TILES[1],
+        L.stream()), 'object_grid_geometry')
     vfeats = out16 if want16 else out
     bo, po = L.c_i64(), L.c_i64()
     L.check(L.lib.ococc_grid_unique_workspace_layout(4, L.i4(dims), bo, po), 'grid_unique_layout')
     coors._ococc_grid = (ws, int(bo.value), int(po.value), tuple(dims), True)
     inv._ococc_counts = counts
-    sp_ops.attach_subm_tables(pairs, nbr_t, mask, cap, 27, num=num, rowrec=rowrec)   # (num: observed by the density tracker)
+    sp_ops.attach_subm_tables(pairs, nbr_t, mask, cap, 27, num=num, rowrec=rowrec, order=order)   # (num: observed by the density tracker)
     pairs._ococc_keepalive = ws
     return vfeats, coors, inv, counts, meta, pairs, num
 

@@ -120,13 +120,15 @@ def test_encoder_uses_the_fused_geometry_and_matches(dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('case', [CASES[0], CASES[1], CASES[2], CASES[4]])
+@pytest.mark.parametrize('case', [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4]])
 @pytest.mark.parametrize('slices', [4, 13, None])
 def test_emit_leaves_the_row_order_records(dev, case, slices):
     """with a sparse density on record the emit kernel also writes the neighbour-pattern order's row records: the order
     built from them is a valid one (every row once, masks and the two lowest entries as in the table, classes 3+ / 2 /
-    1 / 0 neighbours in that sequence with the same sizes as the order built from the table alone) and the counters are
-    back to zero"""
+    1 / 0 neighbours in that sequence with the same sizes as the order built from the table alone).  Three ways to the
+    slots: inside the emit kernel behind a barrier over its grid (grids whose bitmap leaves the scan enough LDS), the
+    placing pass launched by the same call (small grids), the placing pass launched by the caller from the row records
+    (ORDER_SIDE_STREAM)."""
     from objectcentricocccompletion_amd.spconv import ops
     from objectcentricocccompletion_amd.voxel import object_grid_geometry
     B, shape, vs = case['B'], list(case['shape']), case['vs']
@@ -135,18 +137,25 @@ def test_emit_leaves_the_row_order_records(dev, case, slices):
     rng = [-case['half']] * 2 + [-shape[0] * vs / 2] + [case['half']] * 2 + [shape[0] * vs / 2]
     xyz[:, 2] = xyz[:, 2] * (shape[0] * vs / 2) / case['half']
     xyz, feats, bidx = xyz.to(dev), feats.to(dev), bidx.to(dev)
-    keep = ops.DEFAULT_PAIRS_PER_ROW
-    try:
-        ops.DEFAULT_PAIRS_PER_ROW = 1.8
-        got = object_grid_geometry(xyz, bidx, feats, [vs] * 3, rng, shape, B, out_dtype=torch.bfloat16, slices=slices)
-    finally:
-        ops.DEFAULT_PAIRS_PER_ROW = keep
-    pairs = got[5]
-    rb = pairs._ococc
-    table, _, rows = rb.tables[(False, 'fwd')]
-    assert len(rb.orders) == 1
-    rec, hdr = ops.row_order(rb, table, rows)
-    assert int(ops.order_counters(dev).view(torch.int32).abs().sum()) == 0
+    for side in (False, True):
+        keep = ops.DEFAULT_PAIRS_PER_ROW, ops.ORDER_SIDE_STREAM
+        try:
+            ops.DEFAULT_PAIRS_PER_ROW, ops.ORDER_SIDE_STREAM = 1.8, side
+            got = object_grid_geometry(xyz, bidx, feats, [vs] * 3, rng, shape, B, out_dtype=torch.bfloat16, slices=slices)
+        finally:
+            ops.DEFAULT_PAIRS_PER_ROW, ops.ORDER_SIDE_STREAM = keep
+        pairs = got[5]
+        rb = pairs._ococc
+        table, _, rows = rb.tables[(False, 'fwd')]
+        assert len(rb.orders) == 1
+        rec, hdr = ops.row_order(rb, table, rows)
+        torch.cuda.synchronize()
+        assert int(ops.order_counters(dev).view(torch.int32)[3073]) == 0    # (the grid barrier's "gave up" flag)
+        _check_order(rec, hdr, table, rows)
+
+
+def _check_order(rec, hdr, table, rows):
+    from objectcentricocccompletion_amd.spconv import ops
     rec, hdr = rec.cpu().long(), hdr.cpu().tolist()
     tab = table.cpu().long()
     perm, smask = rec[:, 0], rec[:, 1] & 0xffffffff
