@@ -50,6 +50,10 @@ constexpr int kThreads = 1024;       // kernel A: one workgroup per grid
 constexpr int kWaves = kThreads / 64;
 constexpr int kEmitThreads = 256;    // kernel B: one workgroup per (grid, row slice), several per CU
 constexpr int kEmitWaves = kEmitThreads / 64;
+constexpr int kFusedBasesMaxEntries = 256;   // kernel-A workgroups up to which kernel B sums their count rows itself
+#ifndef OCOCC_GEO_FUSED_BASES
+#define OCOCC_GEO_FUSED_BASES 1
+#endif
 constexpr int kPadBlocks = 64;       // workgroups of kernel B that write the padding rows of the fixed-capacity form
 constexpr int kCols = 28;            // 27 kernel offsets + the voxel count
 constexpr int kMaxSlices = 16;
@@ -145,7 +149,7 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
                        GeoParams g, uint32_t* __restrict__ bitmap, uint32_t* __restrict__ local_prefix,
                        int32_t* __restrict__ code_of, int32_t* __restrict__ table, int64_t* __restrict__ seg,
                        uint32_t* __restrict__ blockmask, int64_t mask_words, int32_t* __restrict__ inv,
-                       int32_t* __restrict__ bad_flags, uint32_t* __restrict__ order_hist) {
+                       int32_t* __restrict__ bad_flags, uint32_t* __restrict__ order_hist, int32_t* __restrict__ part_sums) {
   extern __shared__ uint32_t smem[];
   uint32_t* bm = smem;             // [words]
   uint32_t* pf = smem + g.words;   // [words]
@@ -271,6 +275,13 @@ grid_mark_count_kernel(const float* __restrict__ points, int nfeat, const int32_
 #pragma unroll
     for (int j = 0; j < 16; ++j) tot += s_cnt[ls][k][j];
     table[((int64_t)b * g.slices + sl) * kCols + k] = tot;
+  }
+  if (part_sums && threadIdx.x < kCols) {   // this workgroup's slices together: what kernel B sums instead of single slices
+    int32_t tot = 0;
+    for (int ls = 0; ls < g.spa && my_sl * g.spa + ls < g.slices; ++ls)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tot += s_cnt[ls][threadIdx.x][j];
+    part_sums[(int64_t)blockIdx.x * kCols + threadIdx.x] = tot;
   }
   if (threadIdx.x == 0) bad_flags[blockIdx.x] = s_bad;  // (gathered into *status by the next launch: no memset)
   STAMP(4);
@@ -399,15 +410,34 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
                  int32_t* __restrict__ counts, float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int64_t cap,
                  int32_t* __restrict__ nbr_t, uint32_t* __restrict__ blockmask, int32_t* __restrict__ pairs,
                  int emit_blocks, uint32_t* __restrict__ order_hist, i32x4_t* __restrict__ order_rowrec,
-                 i32x4_t* __restrict__ order_rec, OrderHdr* __restrict__ order_hdr, int heavy_blocks, int mid_blocks) {
+                 i32x4_t* __restrict__ order_rec, OrderHdr* __restrict__ order_hdr, int heavy_blocks, int mid_blocks,
+                 const int32_t* __restrict__ count_table, const int32_t* __restrict__ part_sums, int32_t* __restrict__ indice_num,
+                 int32_t* __restrict__ num_voxels,
+                 const int32_t* __restrict__ bad_flags, int nflags, int32_t* __restrict__ status) {
   extern __shared__ uint32_t smem[];
+  // (part_sums != null: no geometry_bases_kernel ran -- few enough kernel-A workgroups that every workgroup here sums
+  // their count rows in front of its own, plus the single slices of its own part, and workgroup 0 writes what that
+  // kernel's lane 0s did)
+  __shared__ int32_t s_part[3][kEmitWaves][32];
   // (order_hist != null: the rows' neighbour-pattern records of ococc_subm_row_order are written here, where the row's
   // 27 table entries sit in registers anyway -- the separate counting pass re-read the whole table, 14 us)
   __shared__ uint32_t s_oh[kLocalBuckets];
   if ((int)blockIdx.x >= emit_blocks) {
     // padding rows of the fixed-capacity form: -1 coordinates, zero count and features, no neighbours; the padding
     // workgroups take them in turns of 256
-    const int64_t total = totals[27];
+    int64_t total;
+    if (part_sums) {   // rows of all grids: the voxel column of the part sums
+      int32_t v = 0;
+      for (int e = threadIdx.x; e < g.batch * g.asplit; e += kEmitThreads) v += part_sums[(int64_t)e * kCols + 27];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if ((threadIdx.x & 63) == 0) s_part[0][threadIdx.x >> 6][0] = v;
+      __syncthreads();
+      total = 0;
+      for (int w = 0; w < kEmitWaves; ++w) total += s_part[0][w][0];
+    } else {
+      total = totals[27];
+    }
     const int64_t turn = (int64_t)(gridDim.x - emit_blocks) * kEmitThreads;
     const int64_t r0 = total + (int64_t)(blockIdx.x - emit_blocks) * kEmitThreads;
     if (r0 >= cap) return;
@@ -466,17 +496,82 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
 #pragma unroll
     for (int j = 0; j < kCodesPerThread; ++j) s_code[j * kEmitThreads + threadIdx.x] = codes[j];  // (own slots: read back by this thread)
   }
+  // (part sums: column c of kernel A's count rows, lane -> column, 8 interleaved parts; asked for HERE, in front of the
+  // bitmap, and summed behind it -- the vector-memory counter retires in order, so consumed here they would hold the
+  // bitmap's loads back by a trip)
+  constexpr int kPartLoads = kFusedBasesMaxEntries / (2 * kEmitWaves);
+  int32_t pv[kPartLoads], pown = 0;
+  const int pcol = threadIdx.x & 31, ppart = threadIdx.x >> 5;
+  if (part_sums) {
+#pragma unroll
+    for (int u = 0; u < kPartLoads; ++u) {
+      const int e = ppart + u * 2 * kEmitWaves;
+      pv[u] = (pcol < kCols && e < g.batch * g.asplit) ? part_sums[(int64_t)e * kCols + pcol] : 0;
+    }
+    if (pcol < kCols && ppart == 0)   // the slices of the own part in front of this one
+      for (int s2 = (sl / g.spa) * g.spa; s2 < sl; ++s2) pown += count_table[((int64_t)b * g.slices + s2) * kCols + pcol];
+  }
   for (int w = threadIdx.x; w < g.words; w += kEmitThreads) {
     bm[w] = bitmap[(int64_t)b * g.words + w];
     pf[w] = local_prefix[(int64_t)b * g.words + w];
   }
-  if (threadIdx.x < kCols) s_base[threadIdx.x] = bases[((int64_t)b * g.slices + sl) * kCols + threadIdx.x];
+  if (part_sums) {
+    // ... summed over what lies in front of this workgroup's slice (-> its bases), in front of its grid (-> the grid's
+    // first row) and over everything (-> totals)
+    const int mine = b * g.asplit + sl / g.spa, first = b * g.asplit;
+    int32_t a_me = pown, a_grid = 0, a_all = 0;
+#pragma unroll
+    for (int u = 0; u < kPartLoads; ++u) {
+      const int e = ppart + u * 2 * kEmitWaves;
+      a_me += e < mine ? pv[u] : 0;
+      a_grid += e < first ? pv[u] : 0;
+      a_all += pv[u];
+    }
+    a_me += __shfl_xor(a_me, 32, 64);
+    a_grid += __shfl_xor(a_grid, 32, 64);
+    a_all += __shfl_xor(a_all, 32, 64);
+    if (lane < 32) {
+      s_part[0][wave][lane] = a_me;
+      s_part[1][wave][lane] = a_grid;
+      s_part[2][wave][lane] = a_all;
+    }
+  } else if (threadIdx.x < kCols) {
+    s_base[threadIdx.x] = bases[((int64_t)b * g.slices + sl) * kCols + threadIdx.x];
+  }
   if (threadIdx.x < 27) s_run[threadIdx.x] = 0;
   if (order_hist)
     for (int i = threadIdx.x; i < kLocalBuckets; i += kEmitThreads) s_oh[i] = 0u;
   // global row of this grid's first voxel: the slice-0 base of the voxel column
-  const int32_t grid_base = bases[((int64_t)b * g.slices) * kCols + 27];
+  int32_t grid_base = part_sums ? 0 : bases[((int64_t)b * g.slices) * kCols + 27];
+  int64_t total_rows = part_sums ? 0 : (int64_t)totals[27];
   __syncthreads();
+  if (part_sums) {
+#pragma unroll
+    for (int w = 0; w < kEmitWaves; ++w) {
+      grid_base += s_part[1][w][27];
+      total_rows += s_part[2][w][27];
+    }
+    if (threadIdx.x < kCols) {   // (s_base is first read behind the row loop's barriers)
+      int32_t me = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < kEmitWaves; ++w) {
+        me += s_part[0][w][threadIdx.x];
+        all += s_part[2][w][threadIdx.x];
+      }
+      s_base[threadIdx.x] = me;
+      if (blockIdx.x == 0) {
+        // indice_num[k] = pairs of offset k = entries of table column 26 - k (= column k, by symmetry); geometry.h order
+        if (threadIdx.x < 27) indice_num[26 - threadIdx.x] = all;
+        else *num_voxels = (int32_t)(all < cap ? all : cap);
+      }
+    }
+    if (blockIdx.x == 0 && wave == 1) {   // status = any workgroup of the first launch saw a point outside its grid's segment
+      int bad = 0;
+      for (int i = lane; i < nflags; i += 64) bad |= bad_flags[i];
+      const unsigned long long m = __ballot(bad != 0);
+      if (lane == 0) *status = m ? 1 : 0;
+    }
+  }
   const int w_lo = sl * g.wps < g.words ? sl * g.wps : g.words, w_hi = (w_lo + g.wps < g.words) ? w_lo + g.wps : g.words;
   const int32_t grid_rows = (int32_t)(pf[g.words - 1] + __popc(bm[g.words - 1]));
   const int32_t row_lo = grid_base + (w_lo < g.words ? (int32_t)pf[w_lo] : grid_rows);
@@ -769,7 +864,7 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
     if (order_rec) {   // slots right here, behind a barrier over the whole grid (the host checked that it fits the chip)
       order_place_tail(order_hist, order_rowrec, order_rec, order_hdr, row_lo, hi, kEmitThreads, s_oh, smem, emit_blocks,
-                       totals[27], cap, heavy_blocks, mid_blocks);
+                       total_rows, cap, heavy_blocks, mid_blocks);
       return;
     }
     // else: the records' first word (bucket | place inside the workgroup's share << 12) gets that start added, and
@@ -895,14 +990,21 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
     OCOCC_HIP(hipFuncSetAttribute((const void*)grid_mark_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     OCOCC_HIP(hipFuncSetAttribute((const void*)grid_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  // the prefix of the count table: inside kernel B for small batches (kernel A also leaves the sums of each of its
+  // workgroups' slices; every workgroup of B reads those in front of its own: quadratic in the batch, one trip to L2),
+  // a launch of its own for large ones
+  const bool fused_bases = OCOCC_GEO_FUSED_BASES && (int64_t)batch_size * g.asplit <= kFusedBasesMaxEntries;
+  int32_t* part_sums = fused_bases ? bases : nullptr;   // (the bases' own space: nobody writes them in this form)
   hipLaunchKernelGGL(grid_mark_count_kernel, dim3(batch_size * g.asplit), dim3(kThreads), lds, stream, points,
                      (int)num_point_features, batch_idx, n, g, bitmap, lpre, code_of, table, seg, blockmask, mask_words,
-                     inv, bad_flags, (uint32_t*)order_counters);
+                     inv, bad_flags, (uint32_t*)order_counters, part_sums);
   OCOCC_CHECK_LAUNCH();
   const int64_t entries = (int64_t)batch_size * slices;
-  hipLaunchKernelGGL(geometry_bases_kernel, dim3(kCols), dim3(64), 0, stream, table, entries, bases, totals,
-                     indice_num, num_voxels, capacity, bad_flags, (int)(batch_size * g.asplit), status);
-  OCOCC_CHECK_LAUNCH();
+  if (!fused_bases) {
+    hipLaunchKernelGGL(geometry_bases_kernel, dim3(kCols), dim3(64), 0, stream, table, entries, bases, totals,
+                       indice_num, num_voxels, capacity, bad_flags, (int)(batch_size * g.asplit), status);
+    OCOCC_CHECK_LAUNCH();
+  }
   const int emit_blocks = (int)entries;
   // the padding workgroups index rows from the device-side total and take them in turns (worst case every row is
   // padding: an empty batch)
@@ -928,7 +1030,8 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
                      bitmap, lpre, prefix, code_of, seg, bases, totals, inv, voxel_coors, counts, voxel_feats,
                      voxel_feats_bf16, capacity, nbr_t, blockmask, indice_pairs, emit_blocks, (uint32_t*)order_counters,
                      (i32x4_t*)order_rowrec, inline_place ? (i32x4_t*)order_rec : nullptr, (OrderHdr*)order_hdr,
-                     (int)heavy_blocks, (int)mid_blocks);
+                     (int)heavy_blocks, (int)mid_blocks, (const int32_t*)table, (const int32_t*)part_sums, indice_num, num_voxels,
+                     (const int32_t*)bad_flags, (int)(batch_size * g.asplit), status);
   OCOCC_CHECK_LAUNCH();
   if (order_rec && !inline_place)
     return ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, heavy_blocks, mid_blocks, order_counters, order_rec,
