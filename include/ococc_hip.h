@@ -195,8 +195,7 @@ int ococc_object_grid_geometry_f32(const float* points, int32_t num_point_featur
  * the rows' 27 table entries sit in registers anyway: order_counters as there, order_rowrec [capacity, 4] int32, 16-byte
  * aligned (scratch: the per-row records), capacity below 2^20.
  *   order_rec [capacity, 4] int32 + order_hdr [8] int32 given: the finished order, as ococc_subm_row_order leaves it
- *     (heavy_blocks / mid_blocks as there).  When every workgroup of the last kernel fits the chip at once the slots are
- *     assigned inside it, behind a barrier over its grid; otherwise ococc_subm_row_order_place runs behind it.
+ *     (heavy_blocks / mid_blocks as there): ococc_subm_row_order_place runs behind the last kernel.
  *   order_rec / order_hdr NULL: only the row records; follow with ococc_subm_row_order_place(order_rowrec, 27, 13,
  *     capacity, ...).
  * order_counters and order_rowrec NULL: exactly the call above. */

@@ -43,9 +43,6 @@ __device__ long long* g_stamps = nullptr;
 #define STAMP(slot) do { } while (0)
 #endif
 
-#ifndef OCOCC_GEO_INLINE_PLACE
-#define OCOCC_GEO_INLINE_PLACE 1   // (0: diagnostic builds that time the two-launch form)
-#endif
 constexpr int kThreads = 1024;       // kernel A: one workgroup per grid
 constexpr int kWaves = kThreads / 64;
 constexpr int kEmitThreads = 256;    // kernel B: one workgroup per (grid, row slice), several per CU
@@ -355,52 +352,6 @@ __device__ __forceinline__ void put_feat_row(const float* __restrict__ src, floa
   }
 }
 
-// ---- slots of the neighbour-pattern order at the end of kernel B ------------------------------------------------------
-// Every workgroup that counted rows into the bucket counters arrives at a barrier over the whole grid (one atomic and a
-// polling loop; the host launches this form only when all workgroups of the launch fit the chip at once), then scans
-// the counters for itself and moves the records of its OWN rows -- still hot in its L2 -- to their slots: no second
-// launch (ococc_subm_row_order_place: 6.6 us + the gap in front of it) and no patching pass over the records.
-// ``local_base`` (LDS): where this workgroup's share of each of ITS buckets starts inside the bucket; null when the
-// records already hold places counted from the bucket's start (padding rows).
-__device__ __forceinline__ void order_place_tail(uint32_t* __restrict__ hist, const i32x4_t* __restrict__ rowrec,
-                                                 i32x4_t* __restrict__ rec, OrderHdr* __restrict__ hdr, int64_t lo, int64_t hi,
-                                                 int64_t turn, const uint32_t* local_base, uint32_t* lds, int emit_blocks, int64_t total,
-                                                 int64_t cap, int heavy_blocks, int mid_blocks) {
-  uint32_t* start = lds;                         // [kOrderBuckets + 1]
-  uint32_t* part = lds + kOrderBuckets + 1;      // [kEmitWaves]
-  const int64_t r_first = lo + threadIdx.x;
-  i32x4_t mine = i32x4_t{0, 0, 0, 0};
-  if (r_first < hi) mine = rowrec[r_first];      // (in flight across the barrier)
-  // workgroups that take part: the (grid, slice) ones and the padding ones that have rows
-  const int64_t pad_rows = total < cap ? (cap - total + kEmitThreads - 1) / kEmitThreads : 0;
-  const int64_t pad_wgs = (int64_t)gridDim.x - emit_blocks;
-  const uint32_t target = (uint32_t)emit_blocks + (uint32_t)(pad_rows < pad_wgs ? pad_rows : pad_wgs);
-  uint32_t* arrived = hist + kOrderBuckets;
-  __syncthreads();                               // every atomic of this workgroup has come back (its results were used)
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    int polls = 0;
-    while (__hip_atomic_load(arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++polls > (1 << 24)) {                 // ~1 s: cannot happen on a grid that fits the chip; never hang the device
-        hist[kOrderBuckets + 1] = 0xdeadu;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-  order_scan_starts<kEmitThreads>([&](int b) { return __hip_atomic_load(hist + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
-                                  start, part);
-  if (blockIdx.x == 0 && threadIdx.x == 0) order_write_hdr(start, cap, heavy_blocks, mid_blocks, 13, hdr);
-  for (int64_t r = r_first; r < hi; r += turn) {   // (rows lo + k * turn .. + 255, k = 0, 1, ...)
-    const i32x4_t rr = r == r_first ? mine : rowrec[r];
-    const uint32_t x = (uint32_t)rr.x;
-    const int gk = (int)(x & ((1u << kOrderKeyBits) - 1u));
-    const uint32_t slot = start[gk] + (x >> kOrderKeyBits) + (local_base ? local_base[order_local(gk)] : 0u);
-    if (slot < (uint32_t)cap) rec[slot] = i32x4_t{(int)r, rr.y, rr.z, rr.w};
-  }
-}
-
 // ---- B: one workgroup per (grid, row slice); the workgroups behind them write the padding rows -------------------
 __global__ void __launch_bounds__(kEmitThreads)
 grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g, const uint32_t* __restrict__ bitmap,
@@ -410,7 +361,6 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
                  int32_t* __restrict__ counts, float* __restrict__ out_f32, uint16_t* __restrict__ out_bf16, int64_t cap,
                  int32_t* __restrict__ nbr_t, uint32_t* __restrict__ blockmask, int32_t* __restrict__ pairs,
                  int emit_blocks, uint32_t* __restrict__ order_hist, i32x4_t* __restrict__ order_rowrec,
-                 i32x4_t* __restrict__ order_rec, OrderHdr* __restrict__ order_hdr, int heavy_blocks, int mid_blocks,
                  const int32_t* __restrict__ count_table, const int32_t* __restrict__ part_sums, int32_t* __restrict__ indice_num,
                  int32_t* __restrict__ num_voxels,
                  const int32_t* __restrict__ bad_flags, int nflags, int32_t* __restrict__ status) {
@@ -466,9 +416,6 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
         }
       }
     }
-    if (order_hist && order_rec)
-      order_place_tail(order_hist, order_rowrec, order_rec, order_hdr, r0, cap, turn, nullptr, smem, emit_blocks, total, cap,
-                       heavy_blocks, mid_blocks);
     return;
   }
   uint32_t* bm = smem;            // [words]
@@ -543,13 +490,11 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     for (int i = threadIdx.x; i < kLocalBuckets; i += kEmitThreads) s_oh[i] = 0u;
   // global row of this grid's first voxel: the slice-0 base of the voxel column
   int32_t grid_base = part_sums ? 0 : bases[((int64_t)b * g.slices) * kCols + 27];
-  int64_t total_rows = part_sums ? 0 : (int64_t)totals[27];
   __syncthreads();
   if (part_sums) {
 #pragma unroll
     for (int w = 0; w < kEmitWaves; ++w) {
       grid_base += s_part[1][w][27];
-      total_rows += s_part[2][w][27];
     }
     if (threadIdx.x < kCols) {   // (s_base is first read behind the row loop's barriers)
       int32_t me = 0, all = 0;
@@ -862,13 +807,9 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     }
     __syncthreads();
     const int32_t hi = row_hi < cap ? row_hi : (int32_t)cap;
-    if (order_rec) {   // slots right here, behind a barrier over the whole grid (the host checked that it fits the chip)
-      order_place_tail(order_hist, order_rowrec, order_rec, order_hdr, row_lo, hi, kEmitThreads, s_oh, smem, emit_blocks,
-                       total_rows, cap, heavy_blocks, mid_blocks);
-      return;
-    }
-    // else: the records' first word (bucket | place inside the workgroup's share << 12) gets that start added, and
-    // ococc_subm_row_order_place moves them to their slots
+    // the records' first word (bucket | place inside the workgroup's share << 12) gets that start added;
+    // ococc_subm_row_order_place moves them to their slots.  (Assigning the slots HERE, behind a barrier over the whole
+    // grid, was built and measured: EXPERIMENTS.md (i) -- 81-136 us per geometry against 55.5 with the second launch.)
     for (int32_t r = row_lo + threadIdx.x; r < hi; r += kEmitThreads) {
       const uint32_t x = (uint32_t)order_rowrec[r].x;
       const int lk = order_local((int)(x & ((1u << kOrderKeyBits) - 1u)));   // global bucket -> this workgroup's
@@ -1010,30 +951,13 @@ extern "C" int ococc_object_grid_geometry_order_f32(const float* points, int32_t
   // padding: an empty batch)
   const int64_t pad_need = ococc_cdiv(capacity, kEmitThreads);
   const int pad_blocks = (int)(pad_need < kPadBlocks ? pad_need : kPadBlocks);
-  // The slots of the row order inside kernel B need a barrier over its whole grid: only when every workgroup of the
-  // launch fits the chip at once (and the scan's LDS fits the bitmap's); otherwise the placing pass runs behind it.
-  bool inline_place = false;
-  if (order_rec && lds >= (size_t)(kOrderBuckets + 1 + kEmitWaves) * 4) {
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      OCOCC_HIP(hipGetDevice(&dev));
-      OCOCC_HIP(hipGetDeviceProperties(&prop, dev));
-      cus = prop.multiProcessorCount;
-    }
-    int per_cu = 0;
-    OCOCC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, grid_emit_kernel, kEmitThreads, lds));
-    inline_place = OCOCC_GEO_INLINE_PLACE && (int64_t)emit_blocks + pad_blocks <= (int64_t)per_cu * cus;
-  }
   hipLaunchKernelGGL(grid_emit_kernel, dim3(emit_blocks + pad_blocks), dim3(kEmitThreads), lds, stream, feats, (int)c, n, g,
                      bitmap, lpre, prefix, code_of, seg, bases, totals, inv, voxel_coors, counts, voxel_feats,
                      voxel_feats_bf16, capacity, nbr_t, blockmask, indice_pairs, emit_blocks, (uint32_t*)order_counters,
-                     (i32x4_t*)order_rowrec, inline_place ? (i32x4_t*)order_rec : nullptr, (OrderHdr*)order_hdr,
-                     (int)heavy_blocks, (int)mid_blocks, (const int32_t*)table, (const int32_t*)part_sums, indice_num, num_voxels,
+                     (i32x4_t*)order_rowrec, (const int32_t*)table, (const int32_t*)part_sums, indice_num, num_voxels,
                      (const int32_t*)bad_flags, (int)(batch_size * g.asplit), status);
   OCOCC_CHECK_LAUNCH();
-  if (order_rec && !inline_place)
+  if (order_rec)   // the slots: a launch of its own
     return ococc_subm_row_order_place(order_rowrec, 27, 13, capacity, heavy_blocks, mid_blocks, order_counters, order_rec,
                                       order_hdr, stream_);
   return OCOCC_OK;

@@ -27,7 +27,7 @@ constexpr int kOrderKeyBits = 12;                                // a row record
 constexpr int64_t kOrderMaxRows = 1ll << (32 - kOrderKeyBits);
 static_assert(kOrderBuckets <= (1 << kOrderKeyBits), "bucket index must fit the key bits");
 
-constexpr int kOrderCounterWords = kOrderBuckets + 2;             // bucket counts | workgroups that have counted | trouble flag
+constexpr int kOrderCounterWords = kOrderBuckets;
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 

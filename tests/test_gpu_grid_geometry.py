@@ -125,10 +125,8 @@ def test_encoder_uses_the_fused_geometry_and_matches(dev):
 def test_emit_leaves_the_row_order_records(dev, case, slices):
     """with a sparse density on record the emit kernel also writes the neighbour-pattern order's row records: the order
     built from them is a valid one (every row once, masks and the two lowest entries as in the table, classes 3+ / 2 /
-    1 / 0 neighbours in that sequence with the same sizes as the order built from the table alone).  Three ways to the
-    slots: inside the emit kernel behind a barrier over its grid (grids whose bitmap leaves the scan enough LDS), the
-    placing pass launched by the same call (small grids), the placing pass launched by the caller from the row records
-    (ORDER_SIDE_STREAM)."""
+    1 / 0 neighbours in that sequence with the same sizes as the order built from the table alone).  Two ways to the
+    slots: the placing pass launched by the same call, or by the caller from the row records (ORDER_SIDE_STREAM)."""
     from objectcentricocccompletion_amd.spconv import ops
     from objectcentricocccompletion_amd.voxel import object_grid_geometry
     B, shape, vs = case['B'], list(case['shape']), case['vs']
@@ -149,8 +147,6 @@ def test_emit_leaves_the_row_order_records(dev, case, slices):
         table, _, rows = rb.tables[(False, 'fwd')]
         assert len(rb.orders) == 1
         rec, hdr = ops.row_order(rb, table, rows)
-        torch.cuda.synchronize()
-        assert int(ops.order_counters(dev).view(torch.int32)[3073]) == 0    # (the grid barrier's "gave up" flag)
         _check_order(rec, hdr, table, rows)
 
 
