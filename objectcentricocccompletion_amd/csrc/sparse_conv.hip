@@ -880,10 +880,9 @@ __device__ __forceinline__ void wg_span(const int32_t* __restrict__ num, int k, 
 }
 
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(kWgThreads)
-wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
-             int64_t cap, float* __restrict__ slabs) {
+__device__ __forceinline__ void wgrad_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                           const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
+                                           int64_t cap, float* __restrict__ slabs, int first_item, int item_stride) {
   constexpr int MB = CIN / 16, NB = COUT / 16;
   constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
   constexpr int WM = 4 / WN;            // waves along the cin blocks
@@ -897,10 +896,10 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
   // Work items (slabs) are dealt round-robin to a grid that no longer has to cover the worst case
   // kvol * cap / 256 of them: on sparse grids most of those workgroups only found out that there was
   // nothing for them (13.5 k launches for 0.9 k items, ~10 us per call).
-  for (int item = blockIdx.x;; item += gridDim.x) {
+  for (int item = first_item;; item += item_stride) {
   int k, part, base;
   if (!wg_locate(num, kvol, item, &k, &part, &base)) return;
-  if (item != (int)blockIdx.x) __syncthreads();  // the step buffers of the previous item are free
+  if (item != first_item) __syncthreads();  // the step buffers of the previous item are free
   const int nk = num[k];
   const int ksteps = (nk + 31) >> 5;
   const int first = part * kWgSteps;
@@ -1029,6 +1028,38 @@ wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
     }
   }
   }  // next item
+}
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(kWgThreads)
+wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+             const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
+             int64_t cap, float* __restrict__ slabs) {
+  wgrad_body<CIN, COUT>(x, dy, pairs, num, kvol, cap, slabs, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The weight gradients of TWO small layers in one launch (ococc_sparse_conv_wgrad_pair_bf16): the 16 -> 32 and 32 -> 64
+// layers of the encoder are a few hundred latency-bound work items each, 10 + 13 us one after the other on a chip they
+// fill to a fifth; queued to the end of the backward pass (spconv/ops.py) they run side by side.  (All three shapes in
+// one launch was tried in round 3: the 64 x 128 body pushes the joint register allocation to 210.)
+struct WgradJob {
+  const uint16_t* x;
+  const uint16_t* dy;
+  const int32_t* pairs;
+  const int32_t* num;
+  float* slabs;
+  int64_t cap;
+  int32_t kvol, shape, first_block, blocks;
+};
+struct WgradPairPack {
+  WgradJob job[2];
+};
+__global__ void __launch_bounds__(kWgThreads) wgrad_pair_kernel(WgradPairPack pk) {
+  const int j = (int)blockIdx.x >= pk.job[1].first_block ? 1 : 0;
+  const WgradJob& w = pk.job[j];
+  const int local = (int)blockIdx.x - w.first_block;
+  if (w.shape == 0) wgrad_body<16, 32>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks);
+  else wgrad_body<32, 64>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks);
 }
 
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
@@ -1365,6 +1396,35 @@ extern "C" int ococc_backward_param_reduce_multi(int32_t wcount, const void* con
   lp.first[lcount] = lblocks;
   hipLaunchKernelGGL(backward_reduce_multi_kernel, dim3(wgrad_grid + lblocks), dim3(256), 0, stream, pk, lp, (int)lcount,
                      wgrad_grid);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_sparse_conv_wgrad_pair_bf16(const uint16_t* const* x, const uint16_t* const* dy, const int32_t* cin,
+                                                 const int32_t* cout, const int32_t* const* indice_pairs,
+                                                 const int32_t* const* indice_num, const int32_t* kvol,
+                                                 const int64_t* pair_capacity, void* const* workspaces,
+                                                 const int64_t* workspace_bytes, ococc_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(x && dy && cin && cout && indice_pairs && indice_num && kvol && pair_capacity && workspaces && workspace_bytes,
+                "null pointer table");
+  WgradPairPack pk;
+  int blocks = 0;
+  for (int j = 0; j < 2; ++j) {
+    const int shape = (cin[j] == 16 && cout[j] == 32) ? 0 : (cin[j] == 32 && cout[j] == 64) ? 1 : -1;
+    if (shape < 0) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "shapes served in pairs: 16x32 and 32x64");
+    OCOCC_REQUIRE(kvol[j] >= 1 && pair_capacity[j] >= 1, "bad sizes");
+    OCOCC_REQUIRE(x[j] && dy[j] && indice_pairs[j] && indice_num[j] && workspaces[j], "null pointer");
+    OCOCC_REQUIRE(workspace_bytes[j] >= ococc_sparse_conv_wgrad_workspace_bytes(kvol[j], pair_capacity[j], cin[j], cout[j]),
+                  "workspace too small");
+    const int64_t maxg = wgrad_max_groups(kvol[j], pair_capacity[j]);
+    WgradJob& w = pk.job[j];
+    w.x = x[j]; w.dy = dy[j]; w.pairs = indice_pairs[j]; w.num = indice_num[j]; w.slabs = (float*)workspaces[j];
+    w.cap = pair_capacity[j]; w.kvol = kvol[j]; w.shape = shape; w.first_block = blocks;
+    w.blocks = (int)(maxg < kWgGrid / 2 ? maxg : kWgGrid / 2);
+    blocks += w.blocks;
+  }
+  hipLaunchKernelGGL(wgrad_pair_kernel, dim3(blocks), dim3(kWgThreads), 0, stream, pk);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
