@@ -423,14 +423,15 @@ int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, c
                                  const int32_t* indice_num, int32_t kvol, int64_t pair_capacity,
                                  float* dw, void* workspace, int64_t workspace_bytes,
                                  ococc_stream_t stream);
-/* The slab pass of ococc_sparse_conv_wgrad_bf16 (dw == NULL form) for TWO small layers in one launch: arrays of two,
- * shapes 16 x 32 and 32 x 64 (OCOCC_EUNSUPPORTED otherwise).  Each is a few hundred latency-bound work items that fill
- * a fifth of the chip: side by side they take the time of the longer one.  Same slabs as two separate calls, bit for
- * bit; finish them with ococc_sparse_conv_wgrad_reduce_multi / ococc_backward_param_reduce_multi. */
-int ococc_sparse_conv_wgrad_pair_bf16(const uint16_t* const* x, const uint16_t* const* dy, const int32_t* cin,
-                                      const int32_t* cout, const int32_t* const* indice_pairs,
-                                      const int32_t* const* indice_num, const int32_t* kvol, const int64_t* pair_capacity,
-                                      void* const* workspaces, const int64_t* workspace_bytes, ococc_stream_t stream);
+/* The slab pass of ococc_sparse_conv_wgrad_bf16 (dw == NULL form) for TWO or THREE layers in one launch: arrays of
+ * ``count``, shapes 16 x 32, 32 x 64 and 64 x 128 (OCOCC_EUNSUPPORTED otherwise; put the longest first).  Each is a few
+ * hundred latency-bound work items that fill a fifth of the chip: side by side they take little more than the longest.
+ * Same slabs as separate calls, bit for bit; finish them with ococc_sparse_conv_wgrad_reduce_multi /
+ * ococc_backward_param_reduce_multi. */
+int ococc_sparse_conv_wgrad_multi_bf16(int32_t count, const uint16_t* const* x, const uint16_t* const* dy, const int32_t* cin,
+                                       const int32_t* cout, const int32_t* const* indice_pairs,
+                                       const int32_t* const* indice_num, const int32_t* kvol, const int64_t* pair_capacity,
+                                       void* const* workspaces, const int64_t* workspace_bytes, ococc_stream_t stream);
 /* Both kinds of end-of-backward parameter-gradient sums in ONE launch: the weight-gradient slab sums of
  * ococc_sparse_conv_wgrad_reduce_multi (first five tables) and the LayerNorm d gamma / d beta column sums of
  * ococc_layernorm_param_reduce_multi (last five); same results as the two calls, bit for bit.  (No reference

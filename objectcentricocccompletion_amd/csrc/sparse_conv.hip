@@ -882,7 +882,8 @@ __device__ __forceinline__ void wg_span(const int32_t* __restrict__ num, int k, 
 template <int CIN, int COUT>
 __device__ __forceinline__ void wgrad_body(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                            const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
-                                           int64_t cap, float* __restrict__ slabs, int first_item, int item_stride) {
+                                           int64_t cap, float* __restrict__ slabs, int first_item, int item_stride,
+                                           uint16_t* lds_base, int32_t* sidx_base) {
   constexpr int MB = CIN / 16, NB = COUT / 16;
   constexpr int WN = NB >= 4 ? 4 : NB;  // waves along the cout blocks
   constexpr int WM = 4 / WN;            // waves along the cin blocks
@@ -890,8 +891,9 @@ __device__ __forceinline__ void wgrad_body(const uint16_t* __restrict__ x, const
   constexpr int LDX = CIN + 8, LDY = COUT + 8;  // LDS row strides (elements)
   constexpr int PX = 32 * CIN / 8, PY = 32 * COUT / 8;  // 16-byte pieces per step
   constexpr int PT = (PX + PY + kWgThreads - 1) / kWgThreads;
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2][32 * LDX + 32 * LDY];
-  __shared__ int32_t sidx[2][kWgSteps * 32];  // the item's pair list: input rows, output rows
+  // (LDS handed in by the kernel: several bodies in one launch share the space of the largest)
+  uint16_t (*lds)[32 * LDX + 32 * LDY] = (uint16_t (*)[32 * LDX + 32 * LDY])lds_base;   // [2]: the step buffers
+  int32_t (*sidx)[kWgSteps * 32] = (int32_t (*)[kWgSteps * 32])sidx_base;               // [2]: the item's pair list: input rows, output rows
 
   // Work items (slabs) are dealt round-robin to a grid that no longer has to cover the worst case
   // kvol * cap / 256 of them: on sparse grids most of those workgroups only found out that there was
@@ -1035,7 +1037,9 @@ __global__ void __launch_bounds__(kWgThreads)
 wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
              const int32_t* __restrict__ pairs, const int32_t* __restrict__ num, int kvol,
              int64_t cap, float* __restrict__ slabs) {
-  wgrad_body<CIN, COUT>(x, dy, pairs, num, kvol, cap, slabs, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * (32 * (CIN + 8) + 32 * (COUT + 8))];
+  __shared__ int32_t sidx[2 * kWgSteps * 32];
+  wgrad_body<CIN, COUT>(x, dy, pairs, num, kvol, cap, slabs, (int)blockIdx.x, (int)gridDim.x, lds, sidx);
 }
 
 // The weight gradients of TWO small layers in one launch (ococc_sparse_conv_wgrad_pair_bf16): the 16 -> 32 and 32 -> 64
@@ -1051,15 +1055,23 @@ struct WgradJob {
   int64_t cap;
   int32_t kvol, shape, first_block, blocks;
 };
+constexpr int kWgradMulti = 3;
 struct WgradPairPack {
-  WgradJob job[2];
+  WgradJob job[kWgradMulti];
+  int32_t count;
 };
+template <bool BIG>
 __global__ void __launch_bounds__(kWgThreads) wgrad_pair_kernel(WgradPairPack pk) {
-  const int j = (int)blockIdx.x >= pk.job[1].first_block ? 1 : 0;
+  constexpr int CI = BIG ? 64 : 32, CO = BIG ? 128 : 64;   // the largest body of the launch sizes the shared LDS
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * (32 * (CI + 8) + 32 * (CO + 8))];
+  __shared__ int32_t sidx[2 * kWgSteps * 32];
+  int j = 0;
+  while (j + 1 < pk.count && (int)blockIdx.x >= pk.job[j + 1].first_block) ++j;
   const WgradJob& w = pk.job[j];
   const int local = (int)blockIdx.x - w.first_block;
-  if (w.shape == 0) wgrad_body<16, 32>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks);
-  else wgrad_body<32, 64>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks);
+  if (w.shape == 0) wgrad_body<16, 32>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks, lds, sidx);
+  else if (w.shape == 1 || !BIG) wgrad_body<32, 64>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks, lds, sidx);
+  else wgrad_body<64, 128>(w.x, w.dy, w.pairs, w.num, w.kvol, w.cap, w.slabs, local, w.blocks, lds, sidx);
 }
 
 // dw[k][i] = sum of the slabs of offset k, fixed order: 16 elements x 16 slab lanes per
@@ -1400,19 +1412,24 @@ extern "C" int ococc_backward_param_reduce_multi(int32_t wcount, const void* con
   return OCOCC_OK;
 }
 
-extern "C" int ococc_sparse_conv_wgrad_pair_bf16(const uint16_t* const* x, const uint16_t* const* dy, const int32_t* cin,
-                                                 const int32_t* cout, const int32_t* const* indice_pairs,
-                                                 const int32_t* const* indice_num, const int32_t* kvol,
-                                                 const int64_t* pair_capacity, void* const* workspaces,
-                                                 const int64_t* workspace_bytes, ococc_stream_t stream_) {
+extern "C" int ococc_sparse_conv_wgrad_multi_bf16(int32_t count, const uint16_t* const* x, const uint16_t* const* dy,
+                                                  const int32_t* cin, const int32_t* cout,
+                                                  const int32_t* const* indice_pairs, const int32_t* const* indice_num,
+                                                  const int32_t* kvol, const int64_t* pair_capacity,
+                                                  void* const* workspaces, const int64_t* workspace_bytes,
+                                                  ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  OCOCC_REQUIRE(count >= 2 && count <= kWgradMulti, "2 or 3 layers per call");
   OCOCC_REQUIRE(x && dy && cin && cout && indice_pairs && indice_num && kvol && pair_capacity && workspaces && workspace_bytes,
                 "null pointer table");
   WgradPairPack pk;
   int blocks = 0;
-  for (int j = 0; j < 2; ++j) {
-    const int shape = (cin[j] == 16 && cout[j] == 32) ? 0 : (cin[j] == 32 && cout[j] == 64) ? 1 : -1;
-    if (shape < 0) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "shapes served in pairs: 16x32 and 32x64");
+  bool big = false;
+  for (int j = 0; j < count; ++j) {
+    const int shape = (cin[j] == 16 && cout[j] == 32) ? 0 : (cin[j] == 32 && cout[j] == 64) ? 1
+                      : (cin[j] == 64 && cout[j] == 128) ? 2 : -1;
+    if (shape < 0) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "shapes served together: 16x32, 32x64, 64x128");
+    big = big || shape == 2;
     OCOCC_REQUIRE(kvol[j] >= 1 && pair_capacity[j] >= 1, "bad sizes");
     OCOCC_REQUIRE(x[j] && dy[j] && indice_pairs[j] && indice_num[j] && workspaces[j], "null pointer");
     OCOCC_REQUIRE(workspace_bytes[j] >= ococc_sparse_conv_wgrad_workspace_bytes(kvol[j], pair_capacity[j], cin[j], cout[j]),
@@ -1421,10 +1438,13 @@ extern "C" int ococc_sparse_conv_wgrad_pair_bf16(const uint16_t* const* x, const
     WgradJob& w = pk.job[j];
     w.x = x[j]; w.dy = dy[j]; w.pairs = indice_pairs[j]; w.num = indice_num[j]; w.slabs = (float*)workspaces[j];
     w.cap = pair_capacity[j]; w.kvol = kvol[j]; w.shape = shape; w.first_block = blocks;
-    w.blocks = (int)(maxg < kWgGrid / 2 ? maxg : kWgGrid / 2);
+    // (a workgroup without an item still costs its slot ~2 us to find that out: the benchmark's layers have ~460 items each)
+    w.blocks = (int)(maxg < kWgGrid / 4 ? maxg : kWgGrid / 4);
     blocks += w.blocks;
   }
-  hipLaunchKernelGGL(wgrad_pair_kernel, dim3(blocks), dim3(kWgThreads), 0, stream, pk);
+  pk.count = count;
+  if (big) hipLaunchKernelGGL(wgrad_pair_kernel<true>, dim3(blocks), dim3(kWgThreads), 0, stream, pk);
+  else hipLaunchKernelGGL(wgrad_pair_kernel<false>, dim3(blocks), dim3(kWgThreads), 0, stream, pk);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

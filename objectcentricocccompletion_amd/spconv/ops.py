@@ -356,32 +356,41 @@ def _to_bf16_padded(t, cols):
 # the join 11 us before the reduction does, more than the 18 us the overlap saves.  (One merged kernel was tried as
 # well: the shapes' bodies inlined into one launch need 210 registers -- two workgroups per CU -- and 248 out of line.)
 WGRAD_AT_END = os.environ.get('OCOCC_WGRAD_AT_END', '0') == '1'
-# What does pay (round 4): the two SMALL shapes of the encoder (16 -> 32 and 32 -> 64: 10 + 13 us, a few hundred work
-# items each) queued to the end of the pass and run as ONE launch, ococc_sparse_conv_wgrad_pair_bf16 (92 registers for
-# the two bodies; with the 64 x 128 body in the same kernel it was 169-210).
-WGRAD_PAIR = os.environ.get('OCOCC_WGRAD_PAIR', '1') == '1'
-_PAIR_SHAPES = ((16, 32), (32, 64))
+# What does pay (round 4): the weight gradients of the encoder's layers (16 -> 32, 32 -> 64, 64 -> 128: 10 + 13 + 19 us, a
+# few hundred work items each) queued to the end of the pass and run as ONE launch, ococc_sparse_conv_wgrad_multi_bf16.
+# OCOCC_WGRAD_TOGETHER: 0 = each in its layer's backward, 2 = the two small shapes together (92 registers for the two
+# bodies), 3 = all three (169 registers).
+WGRAD_TOGETHER = int(os.environ.get('OCOCC_WGRAD_TOGETHER', '2'))
+_TOGETHER_SHAPES = ((64, 128), (32, 64), (16, 32))   # (longest first)
 _wgrad_streams = {}
+
+
+def _wgrad_waits(kd_in, kd_out):
+    return (kd_in, kd_out) in _TOGETHER_SHAPES[3 - WGRAD_TOGETHER:] if WGRAD_TOGETHER >= 2 else False
 
 
 def _run_queued_wgrads(todo):
     late = [j for j in todo if len(j) > 5 and j[5] is not None]
     if not late:
         return
-    if WGRAD_PAIR and not WGRAD_AT_END:
+    if WGRAD_TOGETHER >= 2 and not WGRAD_AT_END:
         import ctypes
-        small = [j for j in late if (j[5][2], j[5][5]) in _PAIR_SHAPES]
-        rest = [j for j in late if (j[5][2], j[5][5]) not in _PAIR_SHAPES]
-        vp2, i32x2, i64x2 = ctypes.c_void_p * 2, ctypes.c_int32 * 2, ctypes.c_int64 * 2
-        while len(small) >= 2:
-            a, b = small.pop(0), small.pop(0)
-            ca, cb = a[5], b[5]     # (x, n_in, kd_in, dy, n_out, kd_out, pairs, num, kvol, cap)
-            L.check(L.lib.ococc_sparse_conv_wgrad_pair_bf16(
-                vp2(ca[0].data_ptr(), cb[0].data_ptr()), vp2(ca[3].data_ptr(), cb[3].data_ptr()), i32x2(ca[2], cb[2]),
-                i32x2(ca[5], cb[5]), vp2(ca[6].data_ptr(), cb[6].data_ptr()), vp2(ca[7].data_ptr(), cb[7].data_ptr()),
-                i32x2(ca[8], cb[8]), i64x2(ca[9], cb[9]), vp2(a[0].data_ptr(), b[0].data_ptr()),
-                i64x2(a[0].numel(), b[0].numel()), L.stream()), 'sparse_conv_wgrad_pair')
-        for job in small + rest:
+        shape = lambda j: (j[5][2], j[5][5])
+        mine = sorted([j for j in late if _wgrad_waits(*shape(j))], key=lambda j: _TOGETHER_SHAPES.index(shape(j)))
+        rest = [j for j in late if not _wgrad_waits(*shape(j))]
+        while len(mine) >= 2:
+            ch, mine = mine[:3], mine[3:]
+            if len(mine) == 1:           # (never leave one behind)
+                ch, mine = ch[:2], ch[2:] + mine
+            n = len(ch)
+            vp, i32, i64 = ctypes.c_void_p * n, ctypes.c_int32 * n, ctypes.c_int64 * n
+            c = [j[5] for j in ch]       # (x, n_in, kd_in, dy, n_out, kd_out, pairs, num, kvol, cap)
+            L.check(L.lib.ococc_sparse_conv_wgrad_multi_bf16(
+                n, vp(*[q[0].data_ptr() for q in c]), vp(*[q[3].data_ptr() for q in c]), i32(*[q[2] for q in c]),
+                i32(*[q[5] for q in c]), vp(*[q[6].data_ptr() for q in c]), vp(*[q[7].data_ptr() for q in c]),
+                i32(*[q[8] for q in c]), i64(*[q[9] for q in c]), vp(*[j[0].data_ptr() for j in ch]),
+                i64(*[j[0].numel() for j in ch]), L.stream()), 'sparse_conv_wgrad_multi')
+        for job in mine + rest:
             ws, _, _, _, _, (x, n_in, kd_in, dy, n_out, kd_out, pairs, num, kvol, cap) = job
             L.check(L.lib.ococc_sparse_conv_wgrad_bf16(L.ptr(x), n_in, kd_in, L.ptr(dy), n_out, kd_out, L.ptr(pairs), L.ptr(num),
                                                        kvol, cap, None, L.ptr(ws), ws.numel(), L.stream()), 'sparse_conv_wgrad')
@@ -985,7 +994,7 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             # go into ONE launch queued to the end of the pass (_deferred): dW feeds nothing before that.
             # the slabs themselves wait for the end of the pass as well: all layers (WGRAD_AT_END), or the small shapes
             # that then share one launch
-            late = _autograd and (WGRAD_AT_END or (WGRAD_PAIR and (kd_in, kd_out) in _PAIR_SHAPES))
+            late = _autograd and (WGRAD_AT_END or _wgrad_waits(kd_in, kd_out))
             compute = (x, n_in, kd_in, dy, n_out, kd_out, pairs, indice_pair_num, kvol, cap) if late else None
             defer = (_autograd and _overlap is None and cap > 0 and n_in > 0 and n_out > 0 and cin == kd_in
                      and cout == kd_out and _deferred.deferrable(filters)

@@ -196,30 +196,31 @@ def test_param_reduce_multi_c_abi(dev):
 
 
 def test_small_weight_gradients_share_one_launch(dev):
-    """the 16 -> 32 and 32 -> 64 layers' slab passes wait for the end of the backward pass and run as ONE launch
-    (ococc_sparse_conv_wgrad_pair_bf16); the gradients equal those of the per-layer launches bit for bit"""
+    """the small layers' slab passes (or all three) wait for the end of the backward pass and run as ONE launch
+    (ococc_sparse_conv_wgrad_multi_bf16); the gradients equal those of the per-layer launches bit for bit"""
     from objectcentricocccompletion_amd import _lib as L
     from objectcentricocccompletion_amd.spconv import ops
     blocks = _stack(dev, (16, 32, 64, 128), True)
     idx, feats, dout = _inputs(dev, 16, 128)
     calls = []
-    orig = L.lib.ococc_sparse_conv_wgrad_pair_bf16
+    orig = L.lib.ococc_sparse_conv_wgrad_multi_bf16
 
     class Spy(object):
         def __call__(self, *a):
             calls.append(1)
             return orig(*a)
-    keep = ops.WGRAD_PAIR
+    keep = ops.WGRAD_TOGETHER
     try:
-        L.lib.ococc_sparse_conv_wgrad_pair_bf16 = Spy()
-        ops.WGRAD_PAIR = True
-        paired = _run(blocks, idx, feats, dout)
-        assert len(calls) == 1
-        ops.WGRAD_PAIR = False
-        single = _run(blocks, idx, feats, dout)
-        assert len(calls) == 1
+        L.lib.ococc_sparse_conv_wgrad_multi_bf16 = Spy()
+        got = {}
+        for mode in (2, 3, 0):
+            ops.WGRAD_TOGETHER = mode
+            del calls[:]
+            got[mode] = _run(blocks, idx, feats, dout)
+            assert len(calls) == (1 if mode else 0)
     finally:
-        L.lib.ococc_sparse_conv_wgrad_pair_bf16 = orig
-        ops.WGRAD_PAIR = keep
-    for a, b in zip(paired, single):
-        assert torch.equal(a, b)
+        L.lib.ococc_sparse_conv_wgrad_multi_bf16 = orig
+        ops.WGRAD_TOGETHER = keep
+    for mode in (2, 3):
+        for a, b in zip(got[mode], got[0]):
+            assert torch.equal(a, b)
