@@ -30,7 +30,9 @@ CASES = [dict(B=64, per_grid=2000, shape=(40, 40, 40), vs=0.2, half=4.0),       
          dict(B=4, per_grid=900, shape=(40, 40, 40), vs=0.2, half=4.0, empty_grid=2),
          dict(B=3, per_grid=5000, shape=(16, 16, 16), vs=0.5, half=4.0),                # dense: many points per cell
          dict(B=2, per_grid=6000, shape=(64, 80, 80), vs=0.1, half=4.0),                # configs[4] cell size (z cut)
-         dict(B=1, per_grid=1, shape=(40, 40, 40), vs=0.2, half=4.0)]
+         dict(B=1, per_grid=1, shape=(40, 40, 40), vs=0.2, half=4.0),
+         dict(B=70, per_grid=150, shape=(40, 40, 40), vs=0.2, half=4.0),               # > 256 count workgroups: the prefix launch
+         dict(B=2, per_grid=30000, shape=(16, 16, 16), vs=0.5, half=4.0)]              # 52 k padding rows: several turns of the padding workgroups
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -120,7 +122,7 @@ def test_encoder_uses_the_fused_geometry_and_matches(dev):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('case', [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4]])
+@pytest.mark.parametrize('case', [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[6], CASES[7]])
 @pytest.mark.parametrize('slices', [4, 13, None])
 def test_emit_leaves_the_row_order_records(dev, case, slices):
     """with a sparse density on record the emit kernel also writes the neighbour-pattern order's row records: the order
