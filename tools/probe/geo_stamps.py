@@ -15,6 +15,7 @@ csrc = os.path.join(ROOT, 'objectcentricocccompletion_amd', 'csrc')
 so = '/tmp/libgeo_stamps.so'
 subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-DOCOCC_GEO_STAMPS',
                 os.path.join(csrc, 'grid_geometry.hip'), os.path.join(csrc, 'grid_unique.hip'), os.path.join(csrc, 'capi.hip'),
+                os.path.join(csrc, 'sparse_conv_sorted.hip'),   # (the geometry call launches the order's placing pass)
                 '-o', so], check=True)
 lib = ctypes.CDLL(so)
 from objectcentricocccompletion_amd import _lib as L  # noqa: E402  (argument helpers only)
