@@ -67,6 +67,15 @@ struct PosArgs {
   float norm[3];            // normalize_pos: 2 * 3.1415 / win (x, y, z), else 0
   int32_t ndim, pos_length, feat_dim, out_bf16;
 };
+// value of channel j of an axis at in-window coordinate ``coord``
+__device__ __forceinline__ float pos_value(const PosArgs& a, int axis, float coord, int j) {
+  float p = coord - a.half[axis];
+  if (a.norm[axis] != 0.f) p = p / (float)(2.f * a.half[axis]) * 2.f * 3.1415f;
+  const float e = p / a.inv_freq[j];
+  // stack([e[:, ::2].sin(), e[:, 1::2].cos()], -1).flatten(1): column 2 m is sin(e[2 m]), column 2 m + 1 cos(e[2 m + 1])
+  return (j & 1) ? cosf(e) : sinf(e);
+}
+
 __global__ void __launch_bounds__(256)
 sst_pos_embed_kernel(PosArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -78,16 +87,70 @@ sst_pos_embed_kernel(PosArgs a) {
   if (axis < a.ndim) {
     const int j = c - axis * a.pos_length;
     // in_win columns are (z, y, x)
-    float p = (float)a.in_win[row * 3 + (2 - axis)] - a.half[axis];
-    if (a.norm[axis] != 0.f) p = p / (float)(2.f * a.half[axis]) * 2.f * 3.1415f;
-    const float e = p / a.inv_freq[j];
-    // stack([e[:, ::2].sin(), e[:, 1::2].cos()], -1).flatten(1): column 2 m is sin(e[2 m]), column 2 m + 1 cos(e[2 m + 1])
-    v = (j & 1) ? cosf(e) : sinf(e);
+    v = pos_value(a, axis, (float)a.in_win[row * 3 + (2 - axis)], j);
   }
   if (a.out_bf16)
     ((uint16_t*)a.out)[i] = ococc_f32_to_bf16(v);
   else
     ((float*)a.out)[i] = v;
+}
+
+// The same values from a table: an in-window coordinate takes ``extent`` values per axis, so the embedding has
+// ndim x extent x pos_length distinct numbers (1 008 for 8 x 8 x 8 windows and 128 channels) -- every workgroup works
+// them out once (the same expression: same bits) and then only copies; one full-precision sine or cosine per OUTPUT
+// element made this launch 110 us for 33 M elements (0.6 TB/s of stores).
+constexpr int kPosRows = 256;   // rows per workgroup
+constexpr int kPosMaxFeat = 512;
+__global__ void __launch_bounds__(256)
+sst_pos_embed_table_kernel(PosArgs a, int extent) {
+  extern __shared__ float pos_tab[];   // [ndim][extent][pos_length]
+  __shared__ int16_t chan_base[kPosMaxFeat];   // channel -> index of its (axis, j) at coordinate 0, -1 for the zero tail
+  const int per_axis = extent * a.pos_length;
+  for (int t = threadIdx.x; t < a.ndim * per_axis; t += 256) {
+    const int axis = t / per_axis, r = t - axis * per_axis, coord = r / a.pos_length;
+    pos_tab[t] = pos_value(a, axis, (float)coord, r - coord * a.pos_length);
+  }
+  for (int c = threadIdx.x; c < a.feat_dim; c += 256) {
+    const int axis = c / a.pos_length;
+    chan_base[c] = axis < a.ndim ? (int16_t)(axis * per_axis + (c - axis * a.pos_length)) : (int16_t)-1;
+  }
+  __syncthreads();
+  // one item = 8 consecutive channels of a row: three coordinate loads, eight table reads, one 16-byte (bf16) store
+  const int chunks = a.feat_dim / 8;
+  const int64_t row0 = (int64_t)blockIdx.x * kPosRows;
+  // (1 024 rows per workgroup: 106 us, too few loads in flight; the coordinates of four items asked for together: 72 us)
+  for (int it = threadIdx.x; it < kPosRows * chunks; it += 256) {
+    const int lr = it / chunks, c0 = (it - lr * chunks) * 8;
+    const int64_t row = row0 + lr;
+    if (row >= a.n) break;
+    int64_t co[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) co[d] = a.in_win[row * 3 + d];   // (z, y, x)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int base = chan_base[c0 + u];
+      v[u] = 0.f;
+      if (base >= 0) {
+        const int axis = base / per_axis;
+        const int64_t coord = co[2 - axis];
+        v[u] = (uint64_t)coord < (uint64_t)extent ? pos_tab[base + (int)coord * a.pos_length]
+                                                  : pos_value(a, axis, (float)coord, base - axis * per_axis);
+      }
+    }
+    const int64_t i = row * a.feat_dim + c0;
+    if (a.out_bf16) {
+      uint4 q;
+      q.x = (uint32_t)ococc_f32_to_bf16(v[0]) | ((uint32_t)ococc_f32_to_bf16(v[1]) << 16);
+      q.y = (uint32_t)ococc_f32_to_bf16(v[2]) | ((uint32_t)ococc_f32_to_bf16(v[3]) << 16);
+      q.z = (uint32_t)ococc_f32_to_bf16(v[4]) | ((uint32_t)ococc_f32_to_bf16(v[5]) << 16);
+      q.w = (uint32_t)ococc_f32_to_bf16(v[6]) | ((uint32_t)ococc_f32_to_bf16(v[7]) << 16);
+      *(uint4*)((uint16_t*)a.out + i) = q;
+    } else {
+      *(float4*)((float*)a.out + i) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)((float*)a.out + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
 }
 
 }  // namespace
@@ -156,8 +219,16 @@ extern "C" int ococc_sst_pos_embed(const int64_t* coors_in_win, int64_t n, const
   a.pos_length = pos_length;
   a.feat_dim = feat_dim;
   a.out_bf16 = out_dtype == OCOCC_BF16;
-  hipLaunchKernelGGL(sst_pos_embed_kernel, dim3((unsigned)ococc_cdiv(n * feat_dim, 256)), dim3(256), 0, (hipStream_t)stream,
-                     a);
+  int extent = 1;
+  for (int d = 0; d < ndim; ++d) extent = window_shape_xyz[d] > extent ? window_shape_xyz[d] : extent;
+  const int64_t tab_bytes = (int64_t)ndim * extent * pos_length * 4;
+  if (tab_bytes <= 32 * 1024 && n >= kPosRows && feat_dim % 8 == 0 && feat_dim <= kPosMaxFeat && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL(sst_pos_embed_table_kernel, dim3((unsigned)ococc_cdiv(n, kPosRows)), dim3(256), (size_t)tab_bytes,
+                       (hipStream_t)stream, a, extent);
+  } else {
+    hipLaunchKernelGGL(sst_pos_embed_kernel, dim3((unsigned)ococc_cdiv(n * feat_dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                       a);
+  }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
