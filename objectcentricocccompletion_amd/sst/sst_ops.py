@@ -242,10 +242,19 @@ def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True, pop
         lv = lv_raw.clamp(min=0)   # (a level of -1 -- a window population in no drop range -- is reported below, from the
         #                             same read-back; clamped here so that no rank is left unwritten in the meantime)
         conti, inner, counts = group_rank(lv * int(key_bound) + batch_win_inds.long(), nl * int(key_bound))
-        order = torch.argsort(lv, stable=True)
+        # voxels by level: ONE stable sort of 8-bit keys (a level of -1 wraps to 255 and sorts last); the sorted keys
+        # also give the voxels per level (binary searches for the level boundaries) -- an int64 sort plus an [n, levels]
+        # comparison summed over n cost 0.2 ms per call
+        if nl < 255:
+            vals, order = torch.sort(lv_raw.to(torch.uint8), stable=True)
+            bounds = torch.searchsorted(vals, torch.arange(nl + 1, device=lv.device, dtype=torch.uint8))
+            per_level = bounds[1:] - bounds[:-1]
+        else:
+            order = torch.argsort(lv, stable=True)
+            per_level = (lv_raw[:, None] == torch.arange(nl, device=lv.device)[None, :]).sum(0)
         ids = torch.arange(nl, device=lv.device)
         glvl = torch.zeros(counts.numel(), dtype=torch.long, device=lv.device).scatter_(0, conti.long(), lv)
-        tally = torch.stack([(lv_raw[:, None] == ids[None, :]).sum(0), (glvl[:, None] == ids[None, :]).sum(0)]).tolist()
+        tally = torch.stack([per_level.long(), (glvl[:, None] == ids[None, :]).sum(0)]).tolist()
         if sum(tally[0]) != lv.numel():
             # the reference: assert (drop_lvl_per_voxel >= 0).all() (sst_input_layer_v2.py)
             raise ValueError(f'{lv.numel() - sum(tally[0])} voxels sit in windows whose population is in no drop range '
