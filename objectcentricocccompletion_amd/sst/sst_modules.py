@@ -105,14 +105,22 @@ class SSTInputLayerV2(nn.Module):
         keep_inds = torch.arange(n_all, device=win0.device, dtype=torch.long)
         keep0, lvl0 = self.drop_single_shift(win0)
         keep0 = torch.where(keep0)[0]          # (index lists: ONE read-back per mask instead of one per masked tensor)
-        lvl0, keep_inds, win0 = lvl0[keep0], keep_inds[keep0], win0[keep0]
-        win1 = info['batch_win_inds_shift1'][keep0]
+        # (the list's length is on the host with it: a shift that drops nothing -- every window below its level's
+        # max_tokens, the usual case for object grids -- selects every row, and the selections are skipped: for 260 k
+        # voxels the feature gather, its index_add backward and a dozen index gathers, ~0.3 ms per step)
+        win1 = info['batch_win_inds_shift1']
+        if keep0.numel() != n_all:
+            lvl0, keep_inds, win0, win1 = lvl0[keep0], keep_inds[keep0], win0[keep0], win1[keep0]
         keep1, lvl1 = self.drop_single_shift(win1)
         keep1 = torch.where(keep1)[0]
-        info['voxel_keep_inds'] = keep_inds[keep1]
-        info['voxel_drop_level_shift0'], info['batch_win_inds_shift0'] = lvl0[keep1], win0[keep1]
-        info['voxel_drop_level_shift1'], info['batch_win_inds_shift1'] = lvl1[keep1], win1[keep1]
+        if keep1.numel() != win1.shape[0]:
+            keep_inds, lvl0, win0, lvl1, win1 = keep_inds[keep1], lvl0[keep1], win0[keep1], lvl1[keep1], win1[keep1]
+        info['voxel_keep_inds'] = keep_inds
+        info['voxel_drop_level_shift0'], info['batch_win_inds_shift0'] = lvl0, win0
+        info['voxel_drop_level_shift1'], info['batch_win_inds_shift1'] = lvl1, win1
         keep = info['voxel_keep_inds']
+        if keep.numel() == n_all:
+            return info
         for k, v in list(info.items()):
             if isinstance(v, torch.Tensor) and len(v) == n_all and k not in (
                     'voxel_keep_inds', 'voxel_drop_level_shift0', 'batch_win_inds_shift0',
