@@ -90,9 +90,10 @@ class TilePlan(object):
         self.rows, self.span = self.rows[:self.num_tiles * TILE], self.span[:self.num_tiles * TILE]
 
 
-def _wgrad(items, num_tokens, device):
+def _wgrad(items, num_tokens, device, ln_partial=None, ln_tiles=0):
     """items: [(G [V, ldg] bf16 view whose first n columns are used, n, X [V, k] bf16, xadd or None, add_rows)] ->
-    [(dW [n, k] f32, db [n] f32)] through one wgrad launch and one row-sum launch."""
+    [(dW [n, k] f32, db [n] f32)] through one wgrad launch and one row-sum launch.  ``ln_partial`` [ln_tiles, 2, 128] f32:
+    the block's LayerNorm partial rows ride on the same row-sum launch; (d gamma, d beta) is appended to the result."""
     slabs = int(L.lib.ococc_token_wgrad_slabs(num_tokens))
     dwp = [torch.empty((slabs, n, x.shape[1]), dtype=torch.float32, device=device) for _, n, x, _, _ in items]
     dbp = [torch.empty((slabs, n), dtype=torch.float32, device=device) for _, n, _, _, _ in items]
@@ -104,22 +105,20 @@ def _wgrad(items, num_tokens, device):
         _vp([t.data_ptr() for t in dbp]), L.stream()), 'token_wgrad')
     dw = [torch.empty(t.shape[1:], dtype=torch.float32, device=device) for t in dwp]
     db = [torch.empty(t.shape[1:], dtype=torch.float32, device=device) for t in dbp]
-    src, dst = dwp + dbp, dw + db
-    L.check(L.lib.ococc_partial_rows_sum_f32(len(src), _vp([t.data_ptr() for t in src]), _i64([slabs] * len(src)),
+    src, dst, rows = dwp + dbp, dw + db, [slabs] * (len(dwp) + len(dbp))
+    ln_out = None
+    if ln_partial is not None and ln_tiles > 0:
+        ln_out = torch.empty((2, 128), dtype=torch.float32, device=device)
+        src, dst, rows = src + [ln_partial], dst + [ln_out], rows + [ln_tiles]
+    L.check(L.lib.ococc_partial_rows_sum_f32(len(src), _vp([t.data_ptr() for t in src]), _i64(rows),
                                              _i64([t[0].numel() for t in src]), _vp([t.data_ptr() for t in dst]),
                                              L.stream()), 'partial_rows_sum')
-    return list(zip(dw, db))
-
-
-def _ln_param_sums(partial, tiles):
-    """[tiles, 2, 128] f32 partial rows -> (dgamma, dbeta)"""
-    if tiles == 0:
-        z = torch.zeros((2, 128), dtype=torch.float32, device=partial.device)
-        return z[0], z[1]
-    out = torch.empty((2, 128), dtype=torch.float32, device=partial.device)
-    L.check(L.lib.ococc_partial_rows_sum_f32(1, _vp([partial.data_ptr()]), _i64([tiles]), _i64([256]),
-                                             _vp([out.data_ptr()]), L.stream()), 'partial_rows_sum')
-    return out[0], out[1]
+    out = list(zip(dw, db))
+    if ln_partial is not None:
+        if ln_out is None:
+            ln_out = torch.zeros((2, 128), dtype=torch.float32, device=device)
+        out.append((ln_out[0], ln_out[1]))
+    return out
 
 
 class AttnBlock(torch.autograd.Function):
@@ -162,8 +161,7 @@ class AttnBlock(torch.autograd.Function):
             L.ptr(bq), L.ptr(wo), L.ptr(bo), L.ptr(g1), eps, L.ptr(wot), L.ptr(wqkvt), L.ptr(dx), L.ptr(dqkv), L.ptr(dz),
             L.ptr(o), L.ptr(lnp), L.stream()), 'window_attn_block_bwd')
         # rows outside the plan hold zeros in dqkv / dz: they add nothing to the sums below
-        (dwqkv, dbqkv), (dwo, dbo) = _wgrad([(dqkv, 3 * E, x, pos, 2 * E), (dz, E, o, None, 0)], V, x.device)
-        dg, db = _ln_param_sums(lnp, prow)
+        (dwqkv, dbqkv), (dwo, dbo), (dg, db) = _wgrad([(dqkv, 3 * E, x, pos, 2 * E), (dz, E, o, None, 0)], V, x.device, lnp, prow)
         return (dx, None, None, dwqkv.to(in_w.dtype), dbqkv.to(in_b.dtype), dwo.to(out_w.dtype), dbo.to(out_b.dtype),
                 dg.to(ln_w.dtype), db.to(ln_w.dtype), None, None, None)
 
@@ -205,7 +203,6 @@ class FfnBlock(torch.autograd.Function):
         L.check(L.lib.ococc_token_ffn_block_bwd_bf16(
             L.ptr(x), L.ptr(dy), V, E, F, L.ptr(f1), L.ptr(c1), L.ptr(f2), L.ptr(c2), L.ptr(g), eps, ACT[act], L.ptr(f2t),
             L.ptr(f1t), L.ptr(dx), L.ptr(a), L.ptr(dh), L.ptr(dz), L.ptr(lnp), L.stream()), 'token_ffn_block_bwd')
-        (dw1, db1), (dw2, db2) = _wgrad([(dh, F, x, None, 0), (dz, E, a, None, 0)], V, dev)
-        dg, db = _ln_param_sums(lnp, prow)
+        (dw1, db1), (dw2, db2), (dg, db) = _wgrad([(dh, F, x, None, 0), (dz, E, a, None, 0)], V, dev, lnp, prow)
         return (dx, dw1.to(w1.dtype), db1.to(b1.dtype), dw2.to(w2.dtype), db2.to(b2.dtype), dg.to(ln_w.dtype),
                 db.to(ln_w.dtype), None, None)
