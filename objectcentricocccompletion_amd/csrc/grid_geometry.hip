@@ -431,6 +431,25 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   STAMP(5);
+  // (part sums: column c of kernel A's count rows, lane -> column, 8 interleaved parts; asked for FIRST -- they depend
+  // on nothing, the point codes below wait for their segment's bounds -- and only summed behind the bitmap: the
+  // vector-memory counter retires in order, so consumed here they would hold everything behind them back by a trip)
+  constexpr int kPartLoads = kFusedBasesMaxEntries / (2 * kEmitWaves);
+  constexpr int kOwnLoads = kMaxSlices / 4;   // slices of the own part in front of this one: at most spa - 1 < 4
+  int32_t pv[kPartLoads], pw[kOwnLoads];
+  const int pcol = threadIdx.x & 31, ppart = threadIdx.x >> 5;
+  if (part_sums) {
+#pragma unroll
+    for (int u = 0; u < kPartLoads; ++u) {
+      const int e = ppart + u * 2 * kEmitWaves;
+      pv[u] = (pcol < kCols && e < g.batch * g.asplit) ? part_sums[(int64_t)e * kCols + pcol] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kOwnLoads; ++u) {   // the slices of the own part in front of this one
+      const int s2 = (sl / g.spa) * g.spa + u;
+      pw[u] = (pcol < kCols && ppart == 0 && s2 < sl) ? count_table[((int64_t)b * g.slices + s2) * kCols + pcol] : 0;
+    }
+  }
   // the point codes of the first round are requested before anything else: their latency hides behind the row loop
   const int64_t p_lo = seg[2 * b], p_hi = seg[2 * b + 1];
   {
@@ -443,21 +462,6 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
 #pragma unroll
     for (int j = 0; j < kCodesPerThread; ++j) s_code[j * kEmitThreads + threadIdx.x] = codes[j];  // (own slots: read back by this thread)
   }
-  // (part sums: column c of kernel A's count rows, lane -> column, 8 interleaved parts; asked for HERE, in front of the
-  // bitmap, and summed behind it -- the vector-memory counter retires in order, so consumed here they would hold the
-  // bitmap's loads back by a trip)
-  constexpr int kPartLoads = kFusedBasesMaxEntries / (2 * kEmitWaves);
-  int32_t pv[kPartLoads], pown = 0;
-  const int pcol = threadIdx.x & 31, ppart = threadIdx.x >> 5;
-  if (part_sums) {
-#pragma unroll
-    for (int u = 0; u < kPartLoads; ++u) {
-      const int e = ppart + u * 2 * kEmitWaves;
-      pv[u] = (pcol < kCols && e < g.batch * g.asplit) ? part_sums[(int64_t)e * kCols + pcol] : 0;
-    }
-    if (pcol < kCols && ppart == 0)   // the slices of the own part in front of this one
-      for (int s2 = (sl / g.spa) * g.spa; s2 < sl; ++s2) pown += count_table[((int64_t)b * g.slices + s2) * kCols + pcol];
-  }
   for (int w = threadIdx.x; w < g.words; w += kEmitThreads) {
     bm[w] = bitmap[(int64_t)b * g.words + w];
     pf[w] = local_prefix[(int64_t)b * g.words + w];
@@ -466,7 +470,9 @@ grid_emit_kernel(const float* __restrict__ feats, int c, int64_t n, GeoParams g,
     // ... summed over what lies in front of this workgroup's slice (-> its bases), in front of its grid (-> the grid's
     // first row) and over everything (-> totals)
     const int mine = b * g.asplit + sl / g.spa, first = b * g.asplit;
-    int32_t a_me = pown, a_grid = 0, a_all = 0;
+    int32_t a_me = 0, a_grid = 0, a_all = 0;
+#pragma unroll
+    for (int u = 0; u < kOwnLoads; ++u) a_me += pw[u];
 #pragma unroll
     for (int u = 0; u < kPartLoads; ++u) {
       const int e = ppart + u * 2 * kEmitWaves;
