@@ -645,7 +645,7 @@ FUSE_LN_BACKWARD = os.environ.get('OCOCC_FUSE_LN_BACKWARD', '1') == '1'
 
 
 def _use_tile_kernel(rb, kd, ncols):
-    if (rb is None or not rb.subm or rb.kvol % 2 == 0 or kd not in (32, 64, 128) or ncols not in (32, 64, 128)
+    if (rb is None or not rb.subm or rb.kvol % 2 == 0 or rb.kvol > 27 or kd not in (32, 64, 128) or ncols not in (32, 64, 128)
             or kd * ncols >= 128 * 128):
         return False
     if SPARSE_TILE_CONV is not None:
@@ -794,6 +794,21 @@ def _fragment_major(rb, kd, ncols):
 
 def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
     kvol, ncols, kd = wn.shape
+    if kvol > 32:
+        # Kernel volumes above 32 offsets (5 x 5 x 5, 1 x 7 x 7, ...: the reference's indiceConv loops over any number,
+        # spconv_ops.h:300-354; its configs use 3 x 3 x 3): the kernels walk at most 32 offsets -- one mask word per
+        # 16-row block -- so the offsets go through in slices of 32 whose f32 partial outputs are summed.  No block
+        # masks (every block of a slice is multiplied): correct, not fast.
+        acc = None
+        for k0 in range(0, kvol, 32):
+            part = torch.empty((rows, ncols), dtype=torch.float32, device=x_bf16.device)
+            L.check(L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn[k0:k0 + 32]),
+                                                             min(32, kvol - k0), ncols, L.ptr(table[k0:k0 + 32]), None, rows,
+                                                             L.ptr(bias) if k0 == 0 else None, L.ptr(part),
+                                                             L.dtype_code(torch.float32), L.stream()),
+                    'sparse_conv_gather_gemm')
+            acc = part if acc is None else acc.add_(part)
+        return acc if out_dtype == torch.float32 else acc.to(out_dtype)
     out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
     if _use_tile_kernel(rb, kd, ncols):  # (the caller prepared wn in fragment-major order under the same test)
         L.check(L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,

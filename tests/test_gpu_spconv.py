@@ -539,3 +539,30 @@ def test_wide_channels_run_as_panels_vs_oracle(dev, cin, cout):
     assert np.allclose(out.detach().cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert np.allclose(xin.grad.cpu().numpy(), din.cpu().numpy(), rtol=1e-5, atol=1e-5)
     assert np.allclose(conv.weight.grad.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('ksize', [(5, 5, 5), (1, 7, 7), (3, 3, 5)])
+def test_kernel_volumes_above_32_offsets_vs_oracle(dev, ksize):
+    """125, 49 and 45 offsets: the kernels walk at most 32 per launch (one mask word per 16-row block), so the offsets go
+    through in slices whose f32 partial outputs are summed (spconv/ops.py:_gather_gemm); rulebook, forward, input and
+    weight gradients against the oracle.  (The reference's indiceConv takes any kernel size, spconv_ops.h:300-354.)"""
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(sum(ksize))
+    B, shape, cin, cout = 2, (12, 13, 14), 16, 32
+    idx = _voxels(rng, B, shape, 0.2, True)
+    n = len(idx)
+    x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+    w = O.bf16_round(rng.standard_normal(ksize + (cin, cout)).astype(np.float32) * 0.2)
+    dy = O.bf16_round(rng.standard_normal((n, cout)).astype(np.float32))
+    _, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), list(ksize), subm=True)
+    ep, en = O.subm_rulebook(idx, B, shape, ksize=ksize)
+    assert np.array_equal(num.cpu().numpy(), en)
+    xt, wt, dyt = (torch.from_numpy(a).to(dev) for a in (x, w, dy))
+    y = ops.indice_conv(xt, wt, pairs, num, n, False, True)
+    assert np.allclose(y.cpu().numpy(), O.indice_conv(x, w, ep, en, n, subm=True), **TOL)
+    yb = ops.indice_conv(xt.bfloat16(), wt.bfloat16(), pairs, num, n, False, True)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, y.bfloat16())
+    din, dw = ops.indice_conv_backward(xt, wt, dyt, pairs, num, False, True)
+    edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
+    assert np.allclose(din.cpu().numpy(), edin, **TOL)
+    assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * max(1.0, float(np.abs(edw).max())))
