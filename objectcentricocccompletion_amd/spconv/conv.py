@@ -172,6 +172,35 @@ class SparseConv3d(SparseConvolution):
 
 
 @CONV_LAYERS.register_module()
+class SparseConvTranspose2d(SparseConvolution):
+    """conv.py:286-310 of the reference: output sites by the transposed rule (get_deconv_output_size)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, transposed=True, indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SparseConvTranspose3d(SparseConvolution):
+    """conv.py:313-337"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, transposed=True, indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SparseInverseConv2d(SparseConvolution):
+    """conv.py:340-356"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(2, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                         indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
 class SparseInverseConv3d(SparseConvolution):
 
     def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):

@@ -566,3 +566,58 @@ def test_kernel_volumes_above_32_offsets_vs_oracle(dev, ksize):
     edin, edw = O.indice_conv_backward(x, w, dy, ep, en, subm=True)
     assert np.allclose(din.cpu().numpy(), edin, **TOL)
     assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * max(1.0, float(np.abs(edw).max())))
+
+
+def test_transposed_and_2d_modules_vs_dense(dev):
+    """SparseConvTranspose3d / SparseConvTranspose2d (conv.py:286-337 of the reference) against torch's dense transposed
+    convolution on the scattered volume (every output site the dense result is non-zero at is an output row; equal
+    values there), SparseConv2d + SparseInverseConv2d (conv.py:340-356) returning to the input sites; gradients exist."""
+    from objectcentricocccompletion_amd.spconv import (SparseConv2d, SparseConvTensor, SparseConvTranspose2d,
+                                                       SparseConvTranspose3d, SparseInverseConv2d)
+    rng = np.random.default_rng(31)
+    torch.manual_seed(2)
+    for ndim, shape, cls in ((3, (5, 6, 7), SparseConvTranspose3d), (2, (9, 11), SparseConvTranspose2d)):
+        B, cin, cout = 2, 16, 32
+        idx = _voxels(rng, B, shape, 0.25, True)
+        n = len(idx)
+        layer = cls(cin, cout, 3, stride=2, padding=1, bias=False).to(dev)
+        x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+        xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+        out = layer(SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B))
+        w = torch.from_numpy(O.bf16_round(layer.weight.detach().cpu().numpy()))
+        dense = torch.zeros((B,) + shape + (cin,))
+        dense[tuple(idx[:, i] for i in range(ndim + 1))] = torch.from_numpy(x)
+        if ndim == 3:
+            # weight [kD,kH,kW,Cin,Cout] -> conv_transpose3d's [Cin, Cout, kD, kH, kW]
+            yd = torch.nn.functional.conv_transpose3d(dense.permute(0, 4, 1, 2, 3), w.permute(3, 4, 0, 1, 2), stride=2,
+                                                      padding=1).permute(0, 2, 3, 4, 1)
+        else:
+            yd = torch.nn.functional.conv_transpose2d(dense.permute(0, 3, 1, 2), w.permute(2, 3, 0, 1), stride=2,
+                                                      padding=1).permute(0, 2, 3, 1)
+        assert list(out.spatial_shape) == list(yd.shape[1:-1])
+        oi = out.indices.cpu().numpy()
+        got = out.features.detach().float().cpu().numpy()
+        assert np.allclose(got, yd[tuple(oi[:, i] for i in range(ndim + 1))].numpy(), rtol=1e-3, atol=2e-3)
+        covered = torch.zeros(yd.shape[:-1], dtype=torch.bool)
+        covered[tuple(oi[:, i] for i in range(ndim + 1))] = True
+        assert float(yd[~covered].abs().max()) == 0.0 if bool((~covered).any()) else True
+        out.features.float().pow(2).sum().backward()
+        assert bool(torch.isfinite(xt.grad).all()) and float(xt.grad.abs().sum()) > 0 and layer.weight.grad is not None
+    # 2-D strided conv and its inverse partner
+    B, shape, cin, cmid = 2, (12, 14), 16, 32
+    idx = _voxels(rng, B, shape, 0.3, True)
+    n = len(idx)
+    down = SparseConv2d(cin, cmid, 3, stride=2, padding=1, bias=False, indice_key='p').to(dev)
+    up = SparseInverseConv2d(cmid, cin, 3, indice_key='p', bias=False).to(dev)
+    xt = torch.from_numpy(O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))).to(dev).requires_grad_(True)
+    mid = down(SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B))
+    out = up(mid)
+    assert out.features.shape == (n, cin) and torch.equal(out.indices.cpu(), torch.from_numpy(idx))
+    dense = torch.zeros((B,) + shape + (cin,))
+    dense[idx[:, 0], idx[:, 1], idx[:, 2]] = xt.detach().cpu()
+    w1 = torch.from_numpy(O.bf16_round(down.weight.detach().cpu().numpy()))
+    yd = torch.nn.functional.conv2d(dense.permute(0, 3, 1, 2), w1.permute(3, 2, 0, 1), padding=1, stride=2).permute(0, 2, 3, 1)
+    oi = mid.indices.cpu().numpy()
+    assert np.allclose(mid.features.detach().float().cpu().numpy(), yd[oi[:, 0], oi[:, 1], oi[:, 2]].numpy(), rtol=1e-3, atol=2e-3)
+    out.features.float().pow(2).sum().backward()
+    assert bool(torch.isfinite(xt.grad).all()) and up.weight.grad is not None and down.weight.grad is not None
