@@ -102,3 +102,44 @@ class SparseBasicBlock(SparseModule):
         out = replace_feature(out, out.features + identity)
         out = replace_feature(out, self.relu(out.features))
         return out
+
+
+class SparseBottleneck(SparseModule):
+    """Bottleneck block of sub-manifold convs (sparse_block.py:22-78; the reference inherits the constructor and the
+    layer names conv1 / bn1 / conv2 / bn2 / conv3 / bn3 / relu / downsample from mmdet's ResNet Bottleneck, 'pytorch'
+    style: 1 x 1 -> 3 x 3 (the stride sits here) -> 1 x 1 onto ``planes * 4`` channels).  Not used by ococcnet.py."""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        assert conv_cfg is not None and norm_cfg is not None
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.norm3_name, norm3 = build_norm_layer(norm_cfg, planes * self.expansion, postfix=3)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 1, stride=1, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.conv3 = build_conv_layer(conv_cfg, planes, planes * self.expansion, 1, bias=False)
+        self.add_module(self.norm3_name, norm3)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.inplanes, self.planes, self.stride = inplanes, planes, stride
+
+    norm1 = property(lambda self: getattr(self, self.norm1_name))
+    norm2 = property(lambda self: getattr(self, self.norm2_name))
+    norm3 = property(lambda self: getattr(self, self.norm3_name))
+
+    def forward(self, x):
+        identity = x.features
+        out = self.conv1(x)
+        out = replace_feature(out, self.relu(self.norm1(out.features)))
+        out = self.conv2(out)
+        out = replace_feature(out, self.relu(self.norm2(out.features)))
+        out = self.conv3(out)
+        out = replace_feature(out, self.norm3(out.features))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = replace_feature(out, out.features + identity)
+        return replace_feature(out, self.relu(out.features))

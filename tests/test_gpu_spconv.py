@@ -621,3 +621,33 @@ def test_transposed_and_2d_modules_vs_dense(dev):
     assert np.allclose(mid.features.detach().float().cpu().numpy(), yd[oi[:, 0], oi[:, 1], oi[:, 2]].numpy(), rtol=1e-3, atol=2e-3)
     out.features.float().pow(2).sum().backward()
     assert bool(torch.isfinite(xt.grad).all()) and up.weight.grad is not None and down.weight.grad is not None
+
+
+def test_sparse_bottleneck_block_vs_dense_math(dev):
+    """SparseBottleneck (sparse_block.py:22-78): 1x1 -> BN -> ReLU -> 3x3 sub-manifold -> BN -> ReLU -> 1x1 -> BN, + identity,
+    ReLU -- against the same chain written with the oracle's sub-manifold convolution and torch's batch norm (eval)."""
+    from objectcentricocccompletion_amd.sparse_block import SparseBottleneck
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor
+    rng = np.random.default_rng(41)
+    torch.manual_seed(4)
+    B, shape, planes = 2, (9, 10, 11), 16
+    idx = _voxels(rng, B, shape, 0.25, True)
+    n = len(idx)
+    blk = SparseBottleneck(planes * 4, planes, conv_cfg=dict(type='SubMConv3d', indice_key='b'), norm_cfg=dict(type='BN1d')).to(dev).eval()
+    with torch.no_grad():
+        for bn in (blk.norm1, blk.norm2, blk.norm3):
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.1)
+    x = rng.standard_normal((n, planes * 4)).astype(np.float32)
+    out = blk(SparseConvTensor(torch.from_numpy(x).to(dev), torch.from_numpy(idx).to(dev), list(shape), B))
+    ep, en = O.subm_rulebook(idx, B, shape)
+    bnf = lambda bn, v: torch.nn.functional.batch_norm(torch.from_numpy(v), bn.running_mean.cpu(), bn.running_var.cpu(),
+                                                       bn.weight.detach().cpu(), bn.bias.detach().cpu(), False, 0.0, bn.eps).numpy()
+    w1, w2, w3 = (c.weight.detach().cpu().numpy() for c in (blk.conv1, blk.conv2, blk.conv3))
+    h = np.maximum(bnf(blk.norm1, x @ w1.reshape(planes * 4, planes)), 0)
+    h = np.maximum(bnf(blk.norm2, O.indice_conv(O.bf16_round(h), O.bf16_round(w2), ep, en, n, subm=True)), 0)
+    want = np.maximum(bnf(blk.norm3, h @ w3.reshape(planes, planes * 4)) + x, 0)
+    got = out.features.detach().float().cpu().numpy()
+    assert got.shape == want.shape and float(np.abs(got - want).max()) < 2e-2 * max(1.0, float(np.abs(want).max()))
