@@ -1,6 +1,7 @@
 from . import occ_ops
-from .layers import PositionalEncoding, SimpleEncoderLayer, TransformerEncoder
+from .layers import (PositionalEncoding, SimpleDecoderLayer, SimpleEncoderLayer, TransformerDecoder,
+                     TransformerEncoder)
 from .occ_base import OccDecoder, PosEncode
 
 __all__ = ['occ_ops', 'PosEncode', 'OccDecoder', 'PositionalEncoding', 'SimpleEncoderLayer',
-           'TransformerEncoder']
+           'TransformerEncoder', 'SimpleDecoderLayer', 'TransformerDecoder']
