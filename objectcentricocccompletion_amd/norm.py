@@ -217,3 +217,16 @@ class NaiveSyncBatchNorm2d(nn.BatchNorm2d, _NaiveSyncBNMixin):
         if not self._synced() or not self.training:
             return super().forward(input)
         return self._sync_forward(input, [0, 2, 3], (1, -1, 1, 1))
+
+
+@NORM_LAYERS.register_module('naiveSyncBN3d')
+class NaiveSyncBatchNorm3d(nn.BatchNorm3d, _NaiveSyncBNMixin):
+    """mmdet3d/ops/norm.py:145-198 (5-D tensors)"""
+
+    def forward(self, input):
+        if not self._synced() or not self.training:
+            return super().forward(input)
+        return self._sync_forward(input, [0, 2, 3, 4], (1, -1, 1, 1, 1))
+
+
+AllReduce = _AllGatherSum   # the reference's name (mmdet3d/ops/norm.py:9-24; imported by models/occ/occ_base.py)

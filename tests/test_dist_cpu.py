@@ -67,11 +67,15 @@ def _worker(rank, world, port, q):
     xh = xb[rank * 5:(rank + 1) * 5].clone().requires_grad_(True)
     yb = bn(xh)
     (yb * torch.arange(5.)).sum().backward()
+    # NaiveSyncBatchNorm3d (norm.py:145-198): the same over 5-D tensors
+    from objectcentricocccompletion_amd.norm import NaiveSyncBatchNorm3d
+    x5 = torch.randn(4, 5, 2, 3, 2)
+    y3 = NaiveSyncBatchNorm3d(5).train()(x5[rank * 2:(rank + 1) * 2].clone())
     # plain numpy payloads: torch tensors travel through shared-memory handles that die with the sender
     q.put((rank, [p.grad.numpy().copy() for p in model.parameters()],
            [p.detach().numpy().copy() for p in model.parameters()], float(avg), (lo, hi),
            yb.detach().numpy().copy(), xh.grad.numpy().copy(), bn.running_mean.numpy().copy(), bool(overlap_ok),
-           bool(bf16_ok)))
+           bool(bf16_ok), y3.detach().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,7 +91,13 @@ def test_world_size_2_bucketed_allreduce_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, g0, w0, a0, s0, y0, gx0, rm0, ov0, bf0), (_, g1, w1, a1, s1, y1, gx1, rm1, ov1, bf1) = out
+    (_, g0, w0, a0, s0, y0, gx0, rm0, ov0, bf0, y30), (_, g1, w1, a1, s1, y1, gx1, rm1, ov1, bf1, y31) = out
+    torch.manual_seed(7)
+    torch.randn(10, 5)                                # (the worker's generator state: xb first, then x5)
+    x5 = torch.randn(4, 5, 2, 3, 2)
+    want3 = torch.nn.BatchNorm3d(5).train()(x5).detach().numpy()
+    import numpy as _np
+    assert _np.allclose(_np.concatenate([y30, y31], 0), want3, atol=1e-5)
     assert ov0 and ov1, 'overlap-mode gradients differ from the after-the-pass exchange'
     assert bf0 and bf1, 'bf16 wire buckets'
     g0, w0, g1, w1 = ([torch.from_numpy(a) for a in t] for t in (g0, w0, g1, w1))
