@@ -423,6 +423,18 @@ int ococc_sparse_conv_wgrad_bf16(const uint16_t* x, int64_t n_in, int32_t cin, c
                                  const int32_t* indice_num, int32_t kvol, int64_t pair_capacity,
                                  float* dw, void* workspace, int64_t workspace_bytes,
                                  ococc_stream_t stream);
+/* Sparse max pooling over a rulebook -- replaces indice_maxpool_fp32/half and indice_maxpool_backward_fp32/half
+ * (mmdet3d/ops/spconv/ops.py:162-184, src/maxpool.cc:9-55).  The reference's semantics: the output starts at ZERO and
+ * takes an input only where that is larger (an output whose inputs are all negative holds 0); the backward pass gives
+ * an output's gradient to every input equal to it.  table [kvol, n_out]: input row of (offset, output row) or -1
+ * (ococc_rulebook_pairs_to_table, side of the forward direction); table_bwd [kvol, n_in]: output row of (offset, input
+ * row) or -1.  dtype OCOCC_F32 / OCOCC_BF16 for features, out, out_bp and input_bp alike.  Sums in ascending offset
+ * order, as the reference's CPU functor: f32 results bit for bit. */
+int ococc_indice_maxpool(const void* features, int32_t dtype, int64_t n_in, int32_t channels, const int32_t* table,
+                         int32_t kvol, int64_t n_out, void* out, ococc_stream_t stream);
+int ococc_indice_maxpool_backward(const void* features, const void* out_features, const void* out_bp, int32_t dtype,
+                                  int64_t n_in, int32_t channels, const int32_t* table_bwd, int32_t kvol, int64_t n_out,
+                                  void* input_bp, ococc_stream_t stream);
 /* The slab pass of ococc_sparse_conv_wgrad_bf16 (dw == NULL form) for TWO or THREE layers in one launch: arrays of
  * ``count``, shapes 16 x 32, 32 x 64 and 64 x 128 (OCOCC_EUNSUPPORTED otherwise; put the longest first).  Each is a few
  * hundred latency-bound work items that fill a fifth of the chip: side by side they take little more than the longest.

@@ -62,6 +62,8 @@ SIGNATURES = {
     'ococc_rulebook_pairs_to_table': (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp,
                                               c_vp]),
     'ococc_sparse_conv_wgrad_reduce_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_indice_maxpool': (c_i32, [c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
+    'ococc_indice_maxpool_backward': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
     'ococc_sparse_conv_wgrad_multi_bf16': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_backward_param_reduce_multi': (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_tile_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp,

@@ -173,6 +173,24 @@ def torch_is_grad_enabled():
     return torch.is_grad_enabled()
 
 
+class SparseMaxPoolFunction(Function):
+    """functional.py:77-92 of the reference"""
+
+    @staticmethod
+    def forward(ctx, features, indice_pairs, indice_pair_num, num_activate_out):
+        out = ops.indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out)
+        ctx.save_for_backward(indice_pairs, indice_pair_num, features, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        indice_pairs, indice_pair_num, features, out = ctx.saved_tensors
+        # (the rulebook's device-side tables hang on the indice_pairs OBJECT the forward saw; saved tensors come back as
+        # new objects, so the table for the backward direction is derived once more from the pairs)
+        return ops.indice_maxpool_backward(features, out, grad_output, indice_pairs, indice_pair_num), None, None, None
+
+
 indice_conv = SparseConvFunction.apply
 indice_inverse_conv = SparseInverseConvFunction.apply
 indice_subm_conv = SubMConvFunction.apply
+indice_maxpool = SparseMaxPoolFunction.apply

@@ -971,6 +971,35 @@ def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, nu
                        subm, bias=bias)
 
 
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    """ops.py:162-172 of the reference (indice_maxpool_fp32 / _half): out[o] = max(0, features[i] over the pairs (i, o)) --
+    the reference's output starts at zero (pool_ops.h:34, src/maxpool.cc:9-27).  float32 or bfloat16 (its half)."""
+    L.require_device(features, indice_pairs)
+    if features.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError
+    x = features.contiguous()
+    rb, (table, _, rows) = _tables_for(indice_pairs, indice_pair_num, False, 'fwd', int(num_activate_out), False)
+    out = torch.empty((int(num_activate_out), x.size(1)), dtype=x.dtype, device=x.device)
+    L.check(L.lib.ococc_indice_maxpool(L.ptr(x), L.dtype_code(x.dtype), x.size(0), x.size(1), L.ptr(table), table.size(0),
+                                       int(num_activate_out), L.ptr(out), L.stream()), 'indice_maxpool')
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    """ops.py:175-184: input_bp[i] += out_bp[o] for every pair (i, o) with features[i] == out_features[o]
+    (src/maxpool.cc:31-53), offsets in ascending order."""
+    L.require_device(features, out_features, out_bp, indice_pairs)
+    if features.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError
+    x, y, dy = features.contiguous(), out_features.contiguous(), out_bp.to(features.dtype).contiguous()
+    rb, (table, _, rows) = _tables_for(indice_pairs, indice_pair_num, False, 'bwd', x.size(0), False)
+    din = torch.empty_like(x)
+    L.check(L.lib.ococc_indice_maxpool_backward(L.ptr(x), L.ptr(y), L.ptr(dy), L.dtype_code(x.dtype), x.size(0), x.size(1),
+                                                L.ptr(table), table.size(0), y.size(0), L.ptr(din), L.stream()),
+            'indice_maxpool_backward')
+    return din
+
+
 def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False,
                          subm=False, _x_bf16=None, need_input_grad=True, need_filter_grad=True, _autograd=False,
                          _ln_link=None):

@@ -231,3 +231,27 @@ def layernorm_act(x, gamma, beta, eps, act):
     if act:
         z = 0.5 * z * (1.0 + erf(z / sqrt(2.0)))
     return z
+
+
+def indice_maxpool(features, pairs, num, n_out):
+    """src/maxpool.cc:9-27 with the zero-initialised output of pool_ops.h:34 -> out [n_out, C] f32."""
+    features = _f(features)
+    pairs, num = _i(pairs), _i(num)
+    out = np.zeros((n_out, features.shape[1]), np.float32)
+    for k in range(pairs.shape[0]):
+        for r in range(int(num[k])):
+            i, o = int(pairs[k, 0, r]), int(pairs[k, 1, r])
+            out[o] = np.where(out[o] < features[i], features[i], out[o])
+    return out
+
+
+def indice_maxpool_backward(features, out_features, dout, pairs, num):
+    """src/maxpool.cc:31-53 (din zero-initialised, pool_ops.h:71) -> din [n_in, C] f32."""
+    features, out_features, dout = _f(features), _f(out_features), _f(dout)
+    pairs, num = _i(pairs), _i(num)
+    din = np.zeros_like(features)
+    for k in range(pairs.shape[0]):
+        for r in range(int(num[k])):
+            i, o = int(pairs[k, 0, r]), int(pairs[k, 1, r])
+            din[i] += np.where(out_features[o] == features[i], dout[o], np.float32(0))
+    return din

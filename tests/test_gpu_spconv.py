@@ -651,3 +651,46 @@ def test_sparse_bottleneck_block_vs_dense_math(dev):
     want = np.maximum(bnf(blk.norm3, h @ w3.reshape(planes, planes * 4)) + x, 0)
     got = out.features.detach().float().cpu().numpy()
     assert got.shape == want.shape and float(np.abs(got - want).max()) < 2e-2 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_sparse_maxpool_vs_oracle_and_dense(dev, dtype):
+    """SparseMaxPool3d (pool.py:20-87) / indice_maxpool(_backward) (ops.py:162-184): forward and input gradient bit for
+    bit against the restatement of the reference's CPU functor (output starting at ZERO, the gradient to every input
+    equal to the maximum, offsets ascending), and -- on positive inputs -- against torch's dense max_pool3d."""
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, SparseMaxPool3d, ops
+    rng = np.random.default_rng(51)
+    B, shape, c = 2, (9, 10, 12), 16
+    idx = _voxels(rng, B, shape, 0.3, True)
+    n = len(idx)
+    x = O.bf16_round(rng.standard_normal((n, c)).astype(np.float32))
+    x[rng.random(x.shape) < 0.1] = 0.0                                   # ties with the zero start and among inputs
+    x[1::7] = x[0::7][:len(x[1::7])]
+    xt = torch.from_numpy(x).to(dev).to(dtype).requires_grad_(True)
+    pool = SparseMaxPool3d(3, stride=2, padding=1)
+    out = pool(SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B))
+    oshape = [(s + 2 - 3) // 2 + 1 for s in shape]
+    assert list(out.spatial_shape) == oshape
+    eo, ep, en = O.conv_rulebook(idx, B, oshape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1))
+    order, _ = _match_sorted(eo)
+    want = O.indice_maxpool(x, ep, en, len(eo))
+    got = out.features.detach().float().cpu().numpy()
+    assert np.array_equal(got, want[order])
+    dy = O.bf16_round(rng.standard_normal(want.shape).astype(np.float32))
+    dyt = torch.from_numpy(dy[order]).to(dev).to(dtype)
+    out.features.backward(dyt)
+    edin = O.indice_maxpool_backward(x, want, dy, ep, en)
+    gin = xt.grad.float().cpu().numpy()
+    if dtype == torch.float32:
+        assert np.array_equal(gin, edin)
+    else:
+        assert np.allclose(gin, edin, rtol=1e-2, atol=1e-2)            # (the sum over offsets is rounded to bf16)
+    # dense cross-check on positive features (zero start = the dense pool's implicit padding then)
+    xp = np.abs(x) + 0.5
+    dense = torch.zeros((B, c) + shape)
+    dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = torch.from_numpy(xp)
+    yd = torch.nn.functional.max_pool3d(dense, 3, stride=2, padding=1)
+    outp = pool(SparseConvTensor(torch.from_numpy(xp).to(dev).to(dtype), torch.from_numpy(idx).to(dev), list(shape), B))
+    oi = outp.indices.cpu().numpy()
+    ref = yd[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]].to(dtype).float().numpy()
+    assert np.array_equal(outp.features.float().cpu().numpy(), ref)
