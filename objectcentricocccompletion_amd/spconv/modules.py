@@ -3,6 +3,7 @@ mmdet3d/ops/spconv/modules.py:44-214 (container logic only; no device code)."""
 import os
 from collections import OrderedDict
 
+import torch
 from torch import nn
 
 from .structure import SparseConvTensor
@@ -27,6 +28,21 @@ FUSE_CONV_LN = os.environ.get('OCOCC_FUSE_CONV_LN', '0') == '1'
 # configs[1]) disappears.  On by default for the layers that run on that kernel, and for the 16 -> 32 input layer
 # (resident-weights kernel, 19.9 us fused against 15.5 + 7.4 us).
 FUSE_TILE_CONV_LN = os.environ.get('OCOCC_FUSE_TILE_CONV_LN', '1') == '1'
+
+
+def is_sparse_conv(module):
+    """modules.py:27-29"""
+    from .conv import SparseConvolution
+    return isinstance(module, SparseConvolution)
+
+
+def _mean_update(vals, m_vals, t):
+    """running mean of one value or a list of values after t earlier updates (modules.py:32-43)"""
+    single = not isinstance(vals, list)
+    vals = [vals] if single else vals
+    m_vals = m_vals if isinstance(m_vals, list) else [m_vals]
+    outputs = [t / float(t + 1) * m_val + 1 / float(t + 1) * val for val, m_val in zip(vals, m_vals)]
+    return outputs[0] if len(outputs) == 1 else outputs
 
 
 def _is_fusable_norm(module):
@@ -91,6 +107,44 @@ class SparseSequential(SparseModule):
             else:
                 input = module(input)
         return input
+
+
+    def fused(self):
+        """A copy of the container with every (sparse conv, BatchNorm1d) pair folded into one conv with a bias, for
+        inference (modules.py:139-185; the reference marks it "don't use this").  Same folding arithmetic as there --
+        including its ``sqrt(running_var) + eps`` denominator, which is not BatchNorm's ``sqrt(running_var + eps)``."""
+        from .conv import SparseConvolution
+        mods = list(self._modules.values())
+        fused_mods, idx = [], 0
+        while idx < len(mods):
+            if is_sparse_conv(mods[idx]) and idx < len(mods) - 1 and isinstance(mods[idx + 1], nn.BatchNorm1d):
+                old, bn = mods[idx], mods[idx + 1]
+                conv = SparseConvolution(ndim=old.ndim, in_channels=old.in_channels, out_channels=old.out_channels,
+                                         kernel_size=old.kernel_size, stride=old.stride, padding=old.padding,
+                                         dilation=old.dilation, groups=old.groups, bias=True, subm=old.subm,
+                                         output_padding=old.output_padding, transposed=old.transposed,
+                                         inverse=old.inverse, indice_key=old.indice_key, fused_bn=True)
+                conv.load_state_dict(old.state_dict(), False)
+                conv.to(old.weight.device)
+                with torch.no_grad():
+                    scale = bn.weight / (torch.sqrt(bn.running_var) + bn.eps)
+                    conv.bias.zero_()
+                    conv.weight.mul_(scale)
+                    conv.bias.copy_((conv.bias - bn.running_mean) * scale + bn.bias)
+                fused_mods.append(conv)
+                idx += 2
+            else:
+                fused_mods.append(mods[idx])
+                idx += 1
+        return SparseSequential(*fused_mods)
+
+
+class RemoveGrid(SparseModule):
+    """drops the pre-allocated grid buffer of the tensor passing through (modules.py:197-202)"""
+
+    def forward(self, x: SparseConvTensor):
+        x.grid = None
+        return x
 
 
 class ToDense(SparseModule):

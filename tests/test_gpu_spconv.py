@@ -694,3 +694,28 @@ def test_sparse_maxpool_vs_oracle_and_dense(dev, dtype):
     oi = outp.indices.cpu().numpy()
     ref = yd[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]].to(dtype).float().numpy()
     assert np.array_equal(outp.features.float().cpu().numpy(), ref)
+
+
+def test_sequential_fused_folds_batchnorm_into_the_conv(dev):
+    """SparseSequential.fused() (modules.py:139-185): conv + BatchNorm1d folded into one conv with a bias (the
+    reference's arithmetic, whose denominator is sqrt(var) + eps); equal to the unfused eval-mode chain to that
+    difference."""
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, SparseSequential, SubMConv3d
+    rng = np.random.default_rng(61)
+    torch.manual_seed(6)
+    B, shape = 2, (8, 9, 10)
+    idx = _voxels(rng, B, shape, 0.3, True)
+    seq = SparseSequential(SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key='s'), torch.nn.BatchNorm1d(32),
+                           torch.nn.ReLU()).to(dev).eval()
+    with torch.no_grad():
+        seq[1].running_mean.normal_(0, 0.2)
+        seq[1].running_var.uniform_(0.5, 2.0)
+        seq[1].weight.uniform_(0.5, 1.5)
+        seq[1].bias.normal_(0, 0.2)
+    x = torch.from_numpy(O.bf16_round(rng.standard_normal((len(idx), 16)).astype(np.float32))).to(dev)
+    mk = lambda: SparseConvTensor(x.clone(), torch.from_numpy(idx).to(dev), list(shape), B)
+    fused = seq.fused().eval()
+    assert len(fused) == 2 and fused[0].fused_bn and fused[0].bias is not None
+    with torch.no_grad():
+        a, b = seq(mk()).features, fused(mk()).features
+    assert float((a - b).abs().max()) < 2e-2 * float(a.abs().max())
