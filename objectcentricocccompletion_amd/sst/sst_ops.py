@@ -167,6 +167,49 @@ def get_inner_win_inds(win_inds):
     return group_rank(win_inds)[1].to(win_inds.dtype)
 
 
+class IngroupIndicesFunction(torch.autograd.Function):
+    """The reference's wrapper around TorchEx's ingroup_indices (sst_ops.py:245-263): forward only, the result marked
+    non-differentiable.  ``get_inner_win_inds`` above is the same computation."""
+
+    @staticmethod
+    def forward(ctx, group_inds):
+        out_inds = group_rank(group_inds)[1].to(group_inds.dtype)
+        ctx.mark_non_differentiable(out_inds)
+        return out_inds
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
+
+
+@torch.no_grad()
+def get_inner_win_inds_deprecated(win_inds):
+    """The torch-only formulation the reference keeps beside the TorchEx kernel (sst_ops.py:193-241): sort the window
+    ids, number the members of every run, undo the sort.  Any order inside a window is a valid answer there (its sort is
+    unstable); the sort here is stable, so the result equals get_inner_win_inds.  Host of the comparison in the tests,
+    and usable on CPU tensors."""
+    sort_inds, order = torch.sort(win_inds, stable=True)
+    n = win_inds.numel()
+    if n == 0:
+        return torch.zeros_like(win_inds)
+    pos = torch.arange(n, device=win_inds.device, dtype=torch.long)
+    new_run = torch.ones(n, dtype=torch.bool, device=win_inds.device)
+    new_run[1:] = sort_inds[1:] != sort_inds[:-1]
+    run_start = torch.cummax(torch.where(new_run, pos, torch.zeros_like(pos)), 0)[0]
+    inner = torch.empty(n, dtype=torch.long, device=win_inds.device)
+    inner[order] = pos - run_start
+    return inner.to(win_inds.dtype)
+
+
+def filter_almost_empty(pts_coors, min_points=5):
+    """Mask of the points whose voxel holds at least ``min_points`` points (sst_ops.py:183-190; the reference's body
+    names an undefined ``coors`` in the counting branch -- the evident intent is restated here)."""
+    if min_points > 0:
+        _, unq_inv, unq_cnt = unique_with_inverse(pts_coors, return_counts=True)
+        return unq_cnt.to(torch.long)[unq_inv.long()] >= min_points
+    return torch.ones(len(pts_coors), device=pts_coors.device, dtype=torch.bool)
+
+
 @torch.no_grad()
 def make_continuous_inds(inds):
     """sst_ops.py:316-330: relabel window ids 0..num_windows-1 in sorted order."""

@@ -36,6 +36,16 @@ def test_group_rank_vs_numpy(dev):
     assert torch.equal(get_inner_win_inds(kt), inner.long()) and torch.equal(make_continuous_inds(kt), conti.long())
     c2, i2, n2 = group_rank(torch.zeros(0, dtype=torch.long, device=dev))
     assert c2.numel() == i2.numel() == n2.numel() == 0
+    # the reference's torch-only formulation and its TorchEx wrapper class give the same (stable) answer
+    from objectcentricocccompletion_amd.sst import IngroupIndicesFunction, filter_almost_empty, get_inner_win_inds_deprecated
+    assert torch.equal(get_inner_win_inds_deprecated(kt), inner.long())
+    assert torch.equal(get_inner_win_inds_deprecated(kt.cpu()), inner.long().cpu())
+    assert torch.equal(IngroupIndicesFunction.apply(kt), inner.long())
+    # filter_almost_empty (sst_ops.py:183-190): points whose voxel holds at least min_points points
+    coors = torch.from_numpy(rng.integers(0, 6, size=(5000, 4)).astype(np.int32)).to(dev)
+    _, inv, cnt = np.unique(coors.cpu().numpy(), axis=0, return_inverse=True, return_counts=True)
+    assert np.array_equal(filter_almost_empty(coors, 5).cpu().numpy(), cnt[inv.reshape(-1)] >= 5)
+    assert bool(filter_almost_empty(coors, 0).all())
 
 
 def test_input_layer_vs_reference_golden(dev, gold):
