@@ -26,6 +26,7 @@ from .occ.layers import PositionalEncoding, SimpleEncoderLayer, TransformerEncod
 from .occ.occ_base import OccDecoder
 from .registry import BACKBONES, HEADS
 from .sir import SIRLayer
+from . import voxel_encoders  # noqa: F401  (registers DynamicVFE / DynamicSimpleVFE)
 from .sst.sst_ops import build_mlp, unique_with_inverse
 
 

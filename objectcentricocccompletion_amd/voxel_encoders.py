@@ -1,0 +1,101 @@
+"""The voxel encoders in front of the SST backbone -- host mirror of mmdet3d/models/voxel_encoders/voxel_encoder.py:
+DynamicSimpleVFE (:53-89), DynamicVFE (:92-299) and its DynamicVFELayer (voxel_encoders/utils.py:107-144), the `type`s
+the reference's SST configs name (configs/sst/sst_waymoD5_1x_3class_8heads.py:35-45).  (SIRLayer, the DynamicVFE
+subclass OcOccNet uses, lives in sir.py.)
+
+The reference groups the points of a voxel with one DynamicScatter per use and maps voxel rows back to points through
+a dense canvas of the whole range (map_voxel_center_to_point, :179-215: batch x Z x Y x X int64 per call).  Here the
+grouping is done ONCE per forward -- the unique (b, z, y, x) rows and the inverse map of sst_ops.unique_with_inverse --
+and serves the cluster mean, every layer's pooled features and every gather back to the points."""
+import torch
+from torch import nn
+
+from .registry import VOXEL_ENCODERS, build_norm_layer
+from .sst.sst_ops import scatter_v2
+
+
+class DynamicVFELayer(nn.Module):
+    """Linear(no bias) -> norm -> ReLU (utils.py:107-144)"""
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01)):
+        super().__init__()
+        self.fp16_enabled = False
+        self.norm = build_norm_layer(norm_cfg, out_channels)[1]
+        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, inputs):
+        return torch.relu(self.norm(self.linear(inputs)))
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicSimpleVFE(nn.Module):
+    """mean of the points of every voxel (:53-89)"""
+
+    def __init__(self, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1)):
+        super().__init__()
+        self.voxel_size, self.point_cloud_range = voxel_size, point_cloud_range
+        self.fp16_enabled = False
+
+    @torch.no_grad()
+    def forward(self, features, coors):
+        return scatter_v2(features, coors, 'mean', return_inv=False)
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicVFE(nn.Module):
+    """Point features [xyz..., offset to the voxel's point mean, offset to the voxel centre, (range)] through
+    ``len(feat_channels)`` DynamicVFELayers, each followed by a max (or mean) over the voxel whose result is handed back
+    to the points for the next layer (:92-299).  Constructor arguments, attribute and parameter names as there."""
+
+    def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
+                 with_voxel_center=False, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), mode='max', fusion_layer=None,
+                 return_point_feats=False):
+        super().__init__()
+        assert len(feat_channels) > 0
+        if fusion_layer is not None:
+            raise NotImplementedError('image fusion layers are outside this package')
+        in_channels += 3 * (int(with_cluster_center) + int(with_voxel_center) + int(with_distance))   # (as there: + 3 each)
+        self.in_channels = in_channels
+        self._with_distance, self._with_cluster_center = with_distance, with_cluster_center
+        self._with_voxel_center = with_voxel_center
+        self.return_point_feats = return_point_feats
+        self.fp16_enabled = False
+        self.vx, self.vy, self.vz = voxel_size[0], voxel_size[1], voxel_size[2]
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.z_offset = self.vz / 2 + point_cloud_range[2]
+        self.point_cloud_range = point_cloud_range
+        self.mode = mode
+        chans = [self.in_channels] + list(feat_channels)
+        self.vfe_layers = nn.ModuleList(
+            [DynamicVFELayer(chans[i] * (2 if i > 0 else 1), chans[i + 1], norm_cfg) for i in range(len(chans) - 1)])
+        self.num_vfe = len(self.vfe_layers)
+        self.fusion_layer = None
+
+    def forward(self, features, coors, points=None, img_feats=None, img_metas=None):
+        """features [N, C] (xyz first), coors [N, 4] (b, z, y, x) -> (voxel_feats [V, feat_channels[-1]], voxel_coors
+        [V, 4]) in sorted (b, z, y, x) order, or the per-point features with ``return_point_feats``."""
+        features_ls = [features]
+        voxel_coors = unq_inv = None
+        if self._with_cluster_center:
+            voxel_mean, voxel_coors, unq_inv = scatter_v2(features, coors, 'mean')
+            features_ls.append(features[:, :3] - voxel_mean.to(features.dtype)[unq_inv.long(), :3])
+        if self._with_voxel_center:
+            c = coors.to(features.dtype)
+            features_ls.append(torch.stack([features[:, 0] - (c[:, 3] * self.vx + self.x_offset),
+                                            features[:, 1] - (c[:, 2] * self.vy + self.y_offset),
+                                            features[:, 2] - (c[:, 1] * self.vz + self.z_offset)], 1))
+        if self._with_distance:
+            features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
+        features = torch.cat(features_ls, dim=-1)
+        reduce = 'max' if self.mode == 'max' else 'mean'
+        voxel_feats = point_feats = None
+        for i, vfe in enumerate(self.vfe_layers):
+            point_feats = vfe(features)
+            voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, reduce, unq_inv=unq_inv, new_coors=voxel_coors)
+            if i != len(self.vfe_layers) - 1:
+                features = torch.cat([point_feats, voxel_feats.to(point_feats.dtype)[unq_inv.long()]], dim=1)
+        if self.return_point_feats:
+            return point_feats
+        return voxel_feats, voxel_coors

@@ -377,3 +377,48 @@ def test_a_window_population_in_no_drop_range_is_reported(dev):
     lvl[-1] = 0
     out = sst_ops.get_flat2win_inds(win, lvl, info, key_bound=3)
     assert sorted(out) == [0, 1] and out[0][0].numel() == 3 and out[1][0].numel() == 3
+
+
+def test_dynamic_vfe_vs_plain_torch_restatement(dev):
+    """DynamicVFE / DynamicSimpleVFE (voxel_encoder.py:53-299 of the reference, the voxel encoder of its SST configs):
+    cluster-centre and voxel-centre offsets, two VFE layers with a max over the voxel handed back to the points --
+    against the same arithmetic with torch.unique on the host-visible keys; built through the registry."""
+    from objectcentricocccompletion_amd import heads  # noqa: F401  (registers the voxel encoders)
+    from objectcentricocccompletion_amd.registry import VOXEL_ENCODERS
+    torch.manual_seed(8)
+    vs, rng = (0.5, 0.5, 1.0), (0.0, -4.0, -2.0, 8.0, 4.0, 2.0)
+    n = 4000
+    pts = torch.rand(n, 5, device=dev) * torch.tensor([8.0, 8.0, 4.0, 1.0, 1.0], device=dev) + torch.tensor([0, -4.0, -2.0, 0, 0], device=dev)
+    b = torch.randint(0, 3, (n,), device=dev)
+    zyx = torch.stack([((pts[:, 2] - rng[2]) / vs[2]).floor(), ((pts[:, 1] - rng[1]) / vs[1]).floor(),
+                       ((pts[:, 0] - rng[0]) / vs[0]).floor()], 1).to(torch.int32)
+    coors = torch.cat([b.view(-1, 1).to(torch.int32), zyx], 1)
+    vfe = VOXEL_ENCODERS.build(dict(type='DynamicVFE', in_channels=5, feat_channels=[32, 64], with_distance=False,
+                                    voxel_size=vs, with_cluster_center=True, with_voxel_center=True, point_cloud_range=rng,
+                                    norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01))).to(dev).eval()
+    with torch.no_grad():
+        for layer in vfe.vfe_layers:
+            layer.norm.running_mean.normal_(0, 0.1)
+            layer.norm.running_var.uniform_(0.5, 1.5)
+    assert {'vfe_layers.0.linear.weight', 'vfe_layers.1.norm.running_var'} <= set(vfe.state_dict())
+    assert tuple(vfe.vfe_layers[0].linear.weight.shape) == (32, 11) and tuple(vfe.vfe_layers[1].linear.weight.shape) == (64, 64)
+    pts_g = pts.clone().requires_grad_(True)
+    vf, vc = vfe(pts_g, coors)
+    # restatement
+    uq, inv = torch.unique(coors.long(), dim=0, return_inverse=True)
+    V = uq.shape[0]
+    cnt = torch.zeros(V, device=dev).index_add_(0, inv, torch.ones(n, device=dev))
+    mean = torch.zeros(V, 5, device=dev).index_add_(0, inv, pts) / cnt[:, None]
+    f = torch.cat([pts, pts[:, :3] - mean[inv, :3],
+                   torch.stack([pts[:, 0] - (coors[:, 3] * vs[0] + vs[0] / 2 + rng[0]), pts[:, 1] - (coors[:, 2] * vs[1] + vs[1] / 2 + rng[1]),
+                                pts[:, 2] - (coors[:, 1] * vs[2] + vs[2] / 2 + rng[2])], 1)], 1)
+    for i, layer in enumerate(vfe.vfe_layers):
+        pf = torch.relu(layer.norm(layer.linear(f)))
+        pooled = torch.full((V, pf.shape[1]), -float('inf'), device=dev).scatter_reduce(0, inv[:, None].expand_as(pf), pf, 'amax')
+        f = torch.cat([pf, pooled[inv]], 1)
+    assert torch.equal(vc.long(), uq) and float((vf.detach() - pooled.detach()).abs().max()) < 1e-5
+    vf.pow(2).sum().backward()
+    assert bool(torch.isfinite(pts_g.grad).all()) and float(pts_g.grad.abs().sum()) > 0
+    simple = VOXEL_ENCODERS.build(dict(type='DynamicSimpleVFE', voxel_size=vs, point_cloud_range=rng))
+    sf, sc = simple(pts, coors)
+    assert torch.equal(sc.long(), uq) and float((sf - mean).abs().max()) < 1e-5
