@@ -143,3 +143,29 @@ class SparseBottleneck(SparseModule):
             identity = self.downsample(x)
         out = replace_feature(out, out.features + identity)
         return replace_feature(out, self.relu(out.features))
+
+
+class AdaptiveSparseBasicBlock(SparseBasicBlock):
+    """SparseBasicBlock on ``planes`` channels with an adaptive front (sparse_block.py:146-213): when the channel count
+    changes or the block strides, a regular sparse conv (kernel = stride with ``merge``, else 3 with padding 1) + norm +
+    ReLU brings the input to ``planes`` channels and the strided sites first."""
+
+    def __init__(self, inplanes, planes, stride=1, merge=True, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__(planes, planes, stride=1, downsample=downsample, conv_cfg=conv_cfg, norm_cfg=norm_cfg)
+        is_stride = max(stride) > 1 if isinstance(stride, (tuple, list)) else stride > 1
+        if inplanes != planes or is_stride:
+            ndim = int(conv_cfg['type'][-2])
+            assert ndim in (1, 2, 3, 4)
+            ada_conv_cfg = dict(type=f'SparseConv{ndim}d', indice_key=conv_cfg['indice_key'] + '.adaptive')
+            if merge:
+                self.ada_conv = build_conv_layer(ada_conv_cfg, inplanes, planes, stride, stride=stride, padding=0)
+            else:
+                self.ada_conv = build_conv_layer(ada_conv_cfg, inplanes, planes, 3, stride=stride, padding=1)
+            self.ada_norm = build_norm_layer(norm_cfg, planes)[1]
+            self.ada_relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        if hasattr(self, 'ada_conv'):
+            x = self.ada_conv(x)
+            x = replace_feature(x, self.ada_relu(self.ada_norm(x.features)))
+        return super().forward(x)

@@ -94,6 +94,12 @@ def test_sparse_convmodule_tree_and_state_dict_names():
     sd = bot.state_dict()   # mmdet's Bottleneck names (sparse_block.py:22-78): 1x1 -> 3x3 -> 1x1 onto planes * 4
     assert {'conv1.weight', 'bn1.weight', 'conv2.weight', 'bn2.weight', 'conv3.weight', 'bn3.running_var'} <= set(sd)
     assert tuple(sd['conv1.weight'].shape) == (1, 1, 1, 64, 16) and tuple(sd['conv3.weight'].shape) == (1, 1, 1, 16, 64)
+    from objectcentricocccompletion_amd.sparse_block import AdaptiveSparseBasicBlock
+    ada = AdaptiveSparseBasicBlock(16, 32, stride=2, conv_cfg=dict(type='SubMConv3d', indice_key='a'), norm_cfg=dict(type='BN1d'))
+    sd = ada.state_dict()   # sparse_block.py:146-213: a strided SparseConv3d named '<key>.adaptive' in front of the block
+    assert {'ada_conv.weight', 'ada_norm.running_mean', 'conv1.weight', 'bn2.weight'} <= set(sd)
+    assert tuple(sd['ada_conv.weight'].shape) == (2, 2, 2, 16, 32) and ada.ada_conv.indice_key == 'a.adaptive'
+    assert not hasattr(AdaptiveSparseBasicBlock(32, 32, conv_cfg=dict(type='SubMConv3d', indice_key='a'), norm_cfg=dict(type='BN1d')), 'ada_conv')
 
 
 def test_spconv_container_helpers():

@@ -719,3 +719,22 @@ def test_sequential_fused_folds_batchnorm_into_the_conv(dev):
     with torch.no_grad():
         a, b = seq(mk()).features, fused(mk()).features
     assert float((a - b).abs().max()) < 2e-2 * float(a.abs().max())
+
+
+def test_adaptive_sparse_basic_block_runs_on_strided_sites(dev):
+    """AdaptiveSparseBasicBlock (sparse_block.py:146-213): the strided adaptive conv moves the tensor to the coarser
+    sites, the basic block keeps them; forward / backward finite, output sites = those of the strided rulebook."""
+    from objectcentricocccompletion_amd.sparse_block import AdaptiveSparseBasicBlock
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, ops
+    rng = np.random.default_rng(71)
+    torch.manual_seed(7)
+    B, shape = 2, (8, 10, 12)
+    idx = _voxels(rng, B, shape, 0.3, True)
+    blk = AdaptiveSparseBasicBlock(16, 32, stride=2, conv_cfg=dict(type='SubMConv3d', indice_key='a'),
+                                   norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01)).to(dev).train()
+    x = torch.randn(len(idx), 16, device=dev, requires_grad=True)
+    out = blk(SparseConvTensor(x, torch.from_numpy(idx).to(dev), list(shape), B))
+    want_ids, _, _ = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), [2, 2, 2], [2, 2, 2], [0, 0, 0])
+    assert list(out.spatial_shape) == [4, 5, 6] and torch.equal(out.indices, want_ids) and out.features.shape[1] == 32
+    out.features.pow(2).sum().backward()
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().sum()) > 0
