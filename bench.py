@@ -379,6 +379,7 @@ def bench_sst(args, world, rank, dev):
         step()
     torch.cuda.synchronize()
     fb.set_probe(None)
+    dump_params(args, rank, params)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

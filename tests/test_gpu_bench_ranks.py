@@ -103,3 +103,23 @@ def test_two_ranks_on_one_gpu_ococcnet_parameters_stay_identical(dev, tmp_path):
     m = DETECTORS.build(cfg)
     init = torch.cat([p.detach().float().reshape(-1) for p in m.parameters() if p.requires_grad])
     assert float((a - init).abs().max()) > 0
+
+
+def test_two_ranks_on_one_gpu_sst_parameters_stay_identical(dev, tmp_path):
+    """configs[4]'s path (--workload sst: voxelise -> scatter-mean -> SST input layer -> shifted-window blocks) as two
+    ranks on their own shards: gradients averaged through GradBuckets, parameters bit-identical on both ranks, moved
+    from the initial ones."""
+    dump = str(tmp_path / 's')
+    out = _two_ranks(['--workload', 'sst', '--warmup', '1', '--steps', '2'], dump)
+    import json
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['config']['grids_per_gpu'] == 32
+    a, b = torch.load(dump + '.rank0.pt'), torch.load(dump + '.rank1.pt')
+    assert a.numel() > 500000 and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    from objectcentricocccompletion_amd.sst import sst_modules as sm
+    torch.manual_seed(0)
+    sm.SSTInputLayerV2({0: dict(max_tokens=30, drop_range=(0, 30))}, (8, 8, 8), (80, 80, 64), shuffle_voxels=False, debug=False, mute=True)
+    model = sm.SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, dropout=0.0, activation='gelu',
+                     num_attached_conv=0, to_bev=False, debug=False, layer_cfg=dict(compute_dtype=torch.bfloat16))
+    init = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+    assert float((a[:init.numel()] - init).abs().max()) > 0
