@@ -164,7 +164,15 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   const OrderHdr o = *hdr;
   const int hb = __builtin_amdgcn_readfirstlane(o.heavy_blocks), mb = __builtin_amdgcn_readfirstlane(o.mid_blocks);
   const int dense_k = __builtin_amdgcn_readfirstlane(o.dense_k);
-  const int t_heavy = (o.b_heavy + hb - 1) / hb;
+  // One block per wave (the 64-row tiles of the many-neighbour rows: ~all offsets each) is bound by LDS reads: every
+  // wave reads the offset's whole weight slice for its 16 rows, 64 KB per offset and workgroup.  Such a tile is
+  // therefore taken by TWO workgroups, each with one half of the output columns: half the slice staged and read, half
+  // the matrix instructions, the same rows gathered twice (a few KB), every output element still summed by one lane in
+  // ascending offset order -- the results do not change.
+  constexpr bool kCanSplit = CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
+  const bool split = kCanSplit && hb == NWAVES;
+  const int t_heavy1 = (o.b_heavy + hb - 1) / hb;
+  const int t_heavy = split ? 2 * t_heavy1 : t_heavy1;            // tiles of the many-neighbour class (halves count)
   const int t_mid = t_heavy + (o.b_mid - o.b_heavy + mb - 1) / mb;
   const int tiles = __builtin_amdgcn_readfirstlane(t_mid + (o.b_total - o.b_mid + 15) / 16);
 
@@ -189,9 +197,10 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
     const int lrow = lane & 15;
     const int kg = lane >> 4;
     // tile -> first block and blocks per wave
-    int blk0, bpw;
+    int blk0, bpw, half = 0;
     if (t < t_heavy) {
-      blk0 = t * hb;
+      blk0 = (split ? t >> 1 : t) * hb;
+      half = split ? (t & 1) : 0;
       bpw = hb / NWAVES;
     } else if (t < t_mid) {
       blk0 = o.b_heavy + (t - t_heavy) * mb;
@@ -263,11 +272,12 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       return k;
     };
 
-    auto stage_w = [&](int k, int buf) {
+    auto stage_w = [&](int k, int buf, auto cs_c) {
+      constexpr int CS = decltype(cs_c)::value;   // 2: only this workgroup's half of the columns (chunks are whole weight rows)
       const int kk = k < 0 ? 0 : k;
 #pragma unroll
-      for (int u = 0; u < CPW; ++u) {
-        int c = u * NWAVES + wave;
+      for (int u = 0; u < CPW / CS; ++u) {
+        int c = (CS == 2 ? half * (CHUNKS / 2) : 0) + u * NWAVES + wave;
         if (CHUNKS % NWAVES != 0 && c >= CHUNKS) c = c % CHUNKS;
         const int q = c * 64 + lane;
         const int row = q / PPR, slot_ = q % PPR;
@@ -287,14 +297,17 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
 
     // the walk for a wave of BPW blocks: groups of G = 4 / BPW offsets; virtual block v = j * BPW + b is block b at
     // the group's j-th offset
-    auto walk = [&](auto bpw_c) {
+    auto walk = [&](auto bpw_c, auto cs_c) {
       constexpr int BPW = decltype(bpw_c)::value;
+      constexpr int CS = decltype(cs_c)::value;      // workgroups that share the tile's columns
+      constexpr int NBL = NB / CS, CPWL = CPW / CS;  // column blocks and weight chunks per wave of THIS workgroup
       constexpr int G = 4 / BPW;
-      f32x4 acc[BPW][NB];
+      const int cb0 = CS == 2 ? half * NBL : 0;      // first column block
+      f32x4 acc[BPW][NBL];
 #pragma unroll
       for (int b = 0; b < BPW; ++b)
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < NBL; ++cb) acc[b][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
       int K[2 * G + 1];   // offsets of this group, of the next, and one more (the weights run two offsets ahead)
 #pragma unroll
       for (int i = 0; i < 2 * G + 1; ++i) K[i] = next_k();
@@ -338,15 +351,16 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
         for (int b = 0; b < BPW; ++b) act |= ((m[b] >> (k & 31)) & 1u) << b;
         if (!act) return;
         const char* wbuf = (const char*)(wl + buf * PIECES);
-        constexpr int FG = (NB >= 8) ? 1 : ((8 / NB) < KSTEPS ? (8 / NB) : KSTEPS);
+        constexpr int FG = (NBL >= 8) ? 1 : ((8 / NBL) < KSTEPS ? (8 / NBL) : KSTEPS);
 #pragma unroll
         for (int k0 = 0; k0 < KSTEPS; k0 += FG) {
-          bf16x8 w[FG][NB];
+          bf16x8 w[FG][NBL];
 #pragma unroll
           for (int f = 0; f < FG; ++f)
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-              const uint32_t a = wb[cb & 1] + (uint32_t)((cb >> 1) * 32 * PPR * 16) + ((uint32_t)((k0 + f) * 64) ^ wh[cb & 1]);
+            for (int cb = 0; cb < NBL; ++cb) {
+              // (cb0 is even: the pair (cb & 1) and the 32-row group (cb >> 1) of the global column block cb0 + cb)
+              const uint32_t a = wb[cb & 1] + (uint32_t)(((cb0 + cb) >> 1) * 32 * PPR * 16) + ((uint32_t)((k0 + f) * 64) ^ wh[cb & 1]);
               w[f][cb] = __builtin_bit_cast(bf16x8, *(const u32x4*)(wbuf + a));
             }
 #pragma unroll
@@ -355,7 +369,7 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
 #pragma unroll
               for (int f = 0; f < FG; ++f)
 #pragma unroll
-                for (int cb = 0; cb < NB; ++cb)
+                for (int cb = 0; cb < NBL; ++cb)
                   acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[f][cb], __builtin_bit_cast(bf16x8, x[j * BPW + b][k0 + f]),
                                                                        acc[b][cb], 0, 0, 0);
             }
@@ -366,10 +380,10 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       u32x4 xa[4][KSTEPS], xb[4][KSTEPS];
       if (BPW == 4 && K[2] < 0) {
         // at most two offsets (most tiles of rows with 0 or 1 neighbours): everything is asked for at once, no loop
-        stage_w(K[0], 0);
+        stage_w(K[0], 0, cs_c);
         gather(xa, 0);
         if (K[1] >= 0) {
-          stage_w(K[1], 1);
+          stage_w(K[1], 1, cs_c);
           gather(xb, 1);
         }
         wait_vmcnt_barrier<0>();
@@ -378,8 +392,8 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
         if (K[1] >= 0) mma(xb, 0, 1, K[1]);
       } else {
         int bc = 0, bn = 1, b2 = 2;   // weight buffers of the offset at hand, the next, the one after
-        stage_w(K[0], bc);
-        stage_w(K[1], bn);
+        stage_w(K[0], bc, cs_c);
+        stage_w(K[1], bn, cs_c);
         gather(xa, 0);
         wait_vmcnt_barrier<0>();
         SSTAMP(t, 2);
@@ -390,17 +404,17 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
           gather(xn, G);
 #pragma unroll
           for (int j = 0; j < G; ++j) {
-            stage_w(K[j + 2], b2);
+            stage_w(K[j + 2], b2, cs_c);
             if (j == 0) {
-              stream_wait_vm<CPW + NG>();
+              stream_wait_vm<CPWL + NG>();
             } else {
-              stream_wait_vm<CPW>();
+              stream_wait_vm<CPWL>();
             }
             mma(xc, j, bc, K[j]);
             if (j == 0) {
-              wait_vmcnt_barrier<CPW + NG>();
+              wait_vmcnt_barrier<CPWL + NG>();
             } else {
-              wait_vmcnt_barrier<CPW>();
+              wait_vmcnt_barrier<CPWL>();
             }
             const int b0 = bc;
             bc = bn;
@@ -428,8 +442,8 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
         const int32_t r = __shfl(myrow, b * 16 + lrow, 64);
         if (r < 0) continue;
 #pragma unroll
-        for (int p = 0; p < NB / 2; ++p) {
-          const int ch = p * 32 + kg * 8;
+        for (int p = 0; p < NBL / 2; ++p) {
+          const int ch = (cb0 / 2 + p) * 32 + kg * 8;
           f32x4 v0 = acc[b][2 * p], v1 = acc[b][2 * p + 1];
           if (bias) {
             v0 += *(const f32x4*)(bias + ch);
@@ -449,9 +463,15 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
         }
       }
     };
-    if (bpw == 1) walk(std::integral_constant<int, 1>{});
-    else if (bpw == 2) walk(std::integral_constant<int, 2>{});
-    else walk(std::integral_constant<int, 4>{});
+    if (split && t < t_heavy) {   // (bpw == 1 there; a 4-block plan for the two-neighbour class has bpw == 1 too, unsplit)
+      if constexpr (kCanSplit) walk(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    } else if (bpw == 1) {
+      walk(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    } else if (bpw == 2) {
+      walk(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    } else {
+      walk(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+    }
     SSTAMP(t, 4);
   }
 }
