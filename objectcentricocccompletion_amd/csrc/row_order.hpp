@@ -5,27 +5,29 @@
 
 namespace {
 
-// buckets, heaviest class first: 3+ neighbours (ONE bucket: their tiles walk nearly every offset whatever the order
-// inside the class), 2 neighbours by their two offsets a < b (triangular index b (b - 1) / 2 + a, 496), 1 neighbour by
-// its offset (32), no neighbour (1).  Every counting workgroup reserves its share of a bucket with ONE atomic that
-// returns the counter's value; same-address atomics with a return take ~150 ns each, in a queue, and the vector-memory
-// counter retires in order, so whatever the kernel waits for next waits for them too (grid_emit_kernel: 4 us, measured
-// by compiling them out).  The global counters therefore exist in copies side by side (copy = workgroup mod copies):
-// kHotCopies for the buckets every workgroup adds to (3+, 1 and 0 neighbours: 87 % of the rows), kMidCopies for the
-// 2-neighbour pairs (~50 of them per workgroup of 500 rows: 40 atomics per counter without copies).  A workgroup's own
-// (LDS) histogram needs no copies.
+// buckets, heaviest class first: 3+ neighbours and 2 neighbours by their two lowest neighbour offsets a < b (triangular
+// index b (b - 1) / 2 + a, 496 each), 1 neighbour by its offset (32), no neighbour (1).  (One bucket for the whole 3+
+// class was tried: nothing lost at the benchmark's density, where the class is 4 % of the rows and its tiles walk
+// nearly every offset anyway, but 70 -> 84 us at 2.5 pairs per row, where it is a third of them.)  Every counting
+// workgroup reserves its share of a bucket with ONE atomic that returns the counter's value; same-address atomics with
+// a return take ~130 ns each, in a queue, and the vector-memory counter retires in order, so whatever the kernel waits
+// for next waits for them too (grid_emit_kernel: 4 us, measured by compiling them out).  The global counters therefore
+// exist in copies side by side (copy = workgroup mod copies): kHotCopies for the 33 buckets every workgroup adds to (1
+// and 0 neighbours: 82 % of the rows), kMidCopies / kHeavyCopies for the pair buckets (~50 + ~20 of them per workgroup
+// of 500 rows: 40 atomics per counter without copies).  A workgroup's own (LDS) histogram needs no copies.
 constexpr int kPairKeys = 32 * 31 / 2;
-constexpr int kLocalMid = 1;                                     // first 2-neighbour bucket of a workgroup's histogram
-constexpr int kLocalHot = 1 + kPairKeys;                         // first 1-neighbour bucket
-constexpr int kLocalBuckets = 1 + kPairKeys + 33;                // 530
+constexpr int kLocalMid = kPairKeys;                             // first 2-neighbour bucket of a workgroup's histogram
+constexpr int kLocalHot = 2 * kPairKeys;                         // first 1-neighbour bucket
+constexpr int kLocalBuckets = 2 * kPairKeys + 33;                // 1025
 constexpr int kHotCopies = 32;
 constexpr int kMidCopies = 4;
-constexpr int kGlobalMid = kHotCopies;                           // end of the 3+ class in the global counters
+constexpr int kHeavyCopies = 2;
+constexpr int kGlobalMid = kPairKeys * kHeavyCopies;             // end of the 3+ class in the global counters
 constexpr int kGlobalHot = kGlobalMid + kPairKeys * kMidCopies;  // end of the 2-neighbour class
-constexpr int kOrderBuckets = kGlobalHot + 33 * kHotCopies;      // 3072: the global counters
+constexpr int kOrderBuckets = 4096;                              // the global counters: 4032 used (whole counters per scanning thread)
 constexpr int kOrderKeyBits = 12;                                // a row record's first word: bucket | place in the bucket << 12
 constexpr int64_t kOrderMaxRows = 1ll << (32 - kOrderKeyBits);
-static_assert(kOrderBuckets <= (1 << kOrderKeyBits), "bucket index must fit the key bits");
+static_assert(kGlobalHot + 33 * kHotCopies <= kOrderBuckets && kOrderBuckets <= (1 << kOrderKeyBits), "bucket index must fit the key bits");
 
 constexpr int kOrderCounterWords = kOrderBuckets;
 
@@ -45,21 +47,20 @@ __device__ __forceinline__ int order_key_local(uint32_t mask, int dense_k) {
   uint32_t m = order_neighbours(mask, dense_k);
   const int pc = __builtin_popcount(m);
   if (pc == 0) return kLocalHot + 32;
-  if (pc > 2) return 0;
   const int a = __builtin_ctz(m);
   if (pc == 1) return kLocalHot + a;
   m &= m - 1;
   const int b = __builtin_ctz(m);
-  return kLocalMid + b * (b - 1) / 2 + a;
+  return (pc == 2 ? kLocalMid : 0) + b * (b - 1) / 2 + a;
 }
 // a workgroup's bucket -> the global counter workgroup ``wg`` adds to, and back
 __device__ __forceinline__ int order_global(int local, int wg) {
-  if (local < kLocalMid) return wg % kHotCopies;
+  if (local < kLocalMid) return local * kHeavyCopies + wg % kHeavyCopies;
   if (local < kLocalHot) return kGlobalMid + (local - kLocalMid) * kMidCopies + wg % kMidCopies;
   return kGlobalHot + (local - kLocalHot) * kHotCopies + wg % kHotCopies;
 }
 __device__ __forceinline__ int order_local(int global) {
-  if (global < kGlobalMid) return 0;
+  if (global < kGlobalMid) return global / kHeavyCopies;
   if (global < kGlobalHot) return kLocalMid + (global - kGlobalMid) / kMidCopies;
   return kLocalHot + (global - kGlobalHot) / kHotCopies;
 }

@@ -170,8 +170,11 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   // the matrix instructions, the same rows gathered twice (a few KB), every output element still summed by one lane in
   // ascending offset order -- the results do not change.
   constexpr bool kCanSplit = CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
-  const bool split = kCanSplit && hb == NWAVES;
+  // ... while such tiles are FEW: they are then the launch's tail on slots that would idle (the benchmark: 79 tiles on
+  // 512 slots).  Where they are many, two workgroups per tile double their fixed cost (table batch, first operands) for
+  // nothing: 2.5 pairs per row took 103 us split against 70 us unsplit.
   const int t_heavy1 = (o.b_heavy + hb - 1) / hb;
+  const bool split = kCanSplit && hb == NWAVES && t_heavy1 * 4 <= (int)gridDim.x;
   const int t_heavy = split ? 2 * t_heavy1 : t_heavy1;            // tiles of the many-neighbour class (halves count)
   const int t_mid = t_heavy + (o.b_mid - o.b_heavy + mb - 1) / mb;
   const int tiles = __builtin_amdgcn_readfirstlane(t_mid + (o.b_total - o.b_mid + 15) / 16);
