@@ -134,7 +134,8 @@ order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, const uint32_t
 //  - a wave owns BPW = 4, 2 or 1 blocks of 16 rows; its 2 x 4 row-register sets hold 4 / BPW offsets each, gathered a
 //    whole group (4 / BPW offsets) ahead: the 64-row tiles of the many-neighbour rows walk ~27 offsets with the rows
 //    of offsets i+4 .. i+7 in flight.
-// Workgroups are persistent and take tiles round-robin, the second round in reverse (the first tiles are the long ones).
+// Workgroups are persistent and take tiles round-robin (the first tiles are the long ones); in the second round the
+// workgroups behind the long tiles go first.
 template <int KD, int NC>
 constexpr int sorted_lds_bytes(int kvol) {
   return 3 * NC * (KD / 8) * 16 + kvol * kSortThreads * 4 + 2 * (kSortThreads / 64) * 4;
@@ -190,7 +191,12 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
 
 #pragma unroll 1
   for (int round = 0;; ++round) {
-    const int t = round * (int)gridDim.x + ((round & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    // (second round: the workgroups behind those of the long many-neighbour tiles go first -- they hold the
+    // two-neighbour tiles, which end earliest and most evenly; reversed order paired the second tiles with the
+    // 2-3-offset light tiles, whose first operands take up to 4 us longer)
+    const int G_ = (int)gridDim.x;
+    const int shift = t_heavy < G_ ? t_heavy : 0;
+    const int t = round * G_ + ((round & 1) ? ((int)blockIdx.x + G_ - shift) % G_ : (int)blockIdx.x);
     if (round * (int)gridDim.x >= tiles) break;
     if (t >= tiles) continue;   // (only in the last round; the workgroup leaves as a whole)
     int tid_ = threadIdx.x;
