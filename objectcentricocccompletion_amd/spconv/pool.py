@@ -1,46 +1,49 @@
-"""Sparse max pooling -- host mirror of mmdet3d/ops/spconv/pool.py (SparseMaxPool :20-73, SparseMaxPool2d / 3d :76-87).
-The pooling itself: spconv.ops.indice_maxpool (csrc/sparse_pool.hip), with the reference's zero-initialised output."""
+"""Sparse max pooling modules -- the API of mmdet3d/ops/spconv/pool.py (SparseMaxPool :20-73, SparseMaxPool2d / 3d
+:76-87).  The pooling itself is spconv.ops.indice_maxpool (csrc/sparse_pool.hip), with the reference's zero-initialised
+output; the rulebook is the regular (or sub-manifold) one of the convolutions, never cached under an indice_key."""
 from . import functional as Fsp
 from . import ops
 from .modules import SparseModule
 from .structure import SparseConvTensor
 
 
+def _axes(value, ndim):
+    return list(value) if isinstance(value, (list, tuple)) else [value] * ndim
+
+
 class SparseMaxPool(SparseModule):
+    """``ndim``-dimensional window maximum over the active sites; ``subm=True`` keeps the input's sites."""
 
     def __init__(self, ndim, kernel_size, stride=1, padding=0, dilation=1, subm=False):
         super().__init__()
-        per_axis = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
-        self.ndim = ndim
-        self.kernel_size, self.stride = per_axis(kernel_size), per_axis(stride)
-        self.padding, self.dilation = per_axis(padding), per_axis(dilation)
-        self.subm = subm
+        self.ndim, self.subm = ndim, subm
+        self.kernel_size, self.stride = _axes(kernel_size, ndim), _axes(stride, ndim)
+        self.padding, self.dilation = _axes(padding, ndim), _axes(dilation, ndim)
+
+    def output_shape(self, spatial_shape):
+        if self.subm:
+            return spatial_shape
+        return ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation)
 
     def forward(self, input):
-        assert isinstance(input, SparseConvTensor)
-        features, indices = input.features, input.indices
-        spatial_shape, batch_size = input.spatial_shape, input.batch_size
-        if not self.subm:
-            out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
-                                                         self.dilation)
-        else:
-            out_spatial_shape = spatial_shape
-        outids, indice_pairs, indice_pairs_num = ops.get_indice_pairs(indices, batch_size, spatial_shape, self.kernel_size,
-                                                                      self.stride, self.padding, self.dilation, 0, self.subm)
-        out_features = Fsp.indice_maxpool(features, indice_pairs, indice_pairs_num, outids.shape[0])
-        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
-        out_tensor.indice_dict = input.indice_dict
-        out_tensor.grid = input.grid
-        return out_tensor
+        if not isinstance(input, SparseConvTensor):
+            raise TypeError(f'{type(self).__name__} takes a SparseConvTensor, got {type(input).__name__}')
+        out_ids, pairs, pair_num = ops.get_indice_pairs(input.indices, input.batch_size, input.spatial_shape,
+                                                        self.kernel_size, self.stride, self.padding, self.dilation, 0,
+                                                        self.subm)
+        pooled = Fsp.indice_maxpool(input.features, pairs, pair_num, out_ids.shape[0])
+        result = SparseConvTensor(pooled, out_ids, self.output_shape(input.spatial_shape), input.batch_size, input.grid)
+        result.indice_dict = input.indice_dict
+        return result
 
 
-class SparseMaxPool2d(SparseMaxPool):
+def _fixed_ndim(ndim):
+    class _Pool(SparseMaxPool):
+        def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
+            super().__init__(ndim, kernel_size, stride, padding, dilation)
+    _Pool.__name__ = _Pool.__qualname__ = f'SparseMaxPool{ndim}d'
+    return _Pool
 
-    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
-        super().__init__(2, kernel_size, stride, padding, dilation)
 
-
-class SparseMaxPool3d(SparseMaxPool):
-
-    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
-        super().__init__(3, kernel_size, stride, padding, dilation)
+SparseMaxPool2d = _fixed_ndim(2)
+SparseMaxPool3d = _fixed_ndim(3)
