@@ -707,6 +707,10 @@ int ococc_point_mlp_segment_argmax(const float* y, const float* seg_max, const i
 int32_t ococc_point_mlp_wgrad_slices(int64_t rows);
 int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, int64_t rows, int32_t n, int32_t k, float* partial,
                               ococc_stream_t stream);
+/* The same product for ``count`` (1..8) layers over the same rows in one launch: dz[j] [rows, n[j]], x_cat[j]
+ * [rows, k[j]], partial[j] as above.  (The blocks of one SIR layer's backward.) */
+int ococc_point_mlp_wgrad_multi_f32(int32_t count, const float* const* dz, const float* const* x_cat, int64_t rows,
+                                    const int32_t* n, const int32_t* k, float* const* partial, ococc_stream_t stream);
 int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float* mul, int32_t ldm, const float* colscale,
                             const float* b, int32_t kb, int32_t ldb, float bscale, const float* v, int32_t kv,
                             const int32_t* inv, int64_t rows, const float* w_frag, const float* wt_frag, int32_t n,

@@ -607,14 +607,14 @@ segment_argmax_kernel(const float* __restrict__ y, const float* __restrict__ vma
 // host-bound step.  Workgroup = one 64 x 64 tile of the product over one row slice, 32 rows per pass through LDS;
 // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) as 2 x 2 v_mfma_f32_16x16x4_f32 tiles.
 constexpr int kWgLd = 80;   // LDS row stride in floats: the 4 k-groups of an operand read start 16 banks apart
-__global__ void __launch_bounds__(256)
-point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ xc, int64_t rows, int n, int k,
-                       int64_t rows_per_slice, float* __restrict__ partial) {
+__device__ __forceinline__ void point_mlp_wgrad_tile(const float* __restrict__ dz, const float* __restrict__ xc, int64_t rows,
+                                                     int n, int k, int64_t rows_per_slice, float* __restrict__ partial,
+                                                     int slice, int tile_n, int tile_k) {
   __shared__ float zs[32 * kWgLd];
   __shared__ float xs[32 * kWgLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
-  const int64_t r_lo = (int64_t)blockIdx.x * rows_per_slice;
+  const int n0 = tile_n * 64, k0 = tile_k * 64;
+  const int64_t r_lo = (int64_t)slice * rows_per_slice;
   const int64_t r_hi = r_lo + rows_per_slice < rows ? r_lo + rows_per_slice : rows;
   f32x4 acc[2][2];
 #pragma unroll
@@ -661,7 +661,7 @@ point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
-  float* out = partial + (int64_t)blockIdx.x * n * k;
+  float* out = partial + (int64_t)slice * n * k;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -671,6 +671,32 @@ point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x
         const int ch = n0 + nq + 16 * i + 4 * kg + q, in = k0 + kq + 16 * j + l16;
         if (ch < n && in < k) out[(int64_t)ch * k + in] = acc[i][j][q];
       }
+}
+
+__global__ void __launch_bounds__(256)
+point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ xc, int64_t rows, int n, int k,
+                       int64_t rows_per_slice, float* __restrict__ partial) {
+  point_mlp_wgrad_tile(dz, xc, rows, n, k, rows_per_slice, partial, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// the products of SEVERAL layers over the same rows in one launch (the five layers of a SIR layer's backward: 60 of the
+// 1.5 k launches of a 4-tracklet step were these, 13 us each for a dozen workgroups of work)
+constexpr int kWgradMulti = 8;
+struct PointWgradPack {
+  const float* dz[kWgradMulti];
+  const float* xc[kWgradMulti];
+  float* partial[kWgradMulti];
+  int32_t n[kWgradMulti], k[kWgradMulti], first[kWgradMulti + 1];
+  int32_t count;
+};
+__global__ void __launch_bounds__(256)
+point_mlp_wgrad_multi_kernel(PointWgradPack pk, int64_t rows, int64_t rows_per_slice, int slices) {
+  int j = 0;
+  while (j + 1 < pk.count && (int)blockIdx.x >= pk.first[j + 1]) ++j;
+  const int local = (int)blockIdx.x - pk.first[j];
+  const int tiles_n = (pk.n[j] + 63) / 64;
+  const int slice = local % slices, t = local / slices;
+  point_mlp_wgrad_tile(pk.dz[j], pk.xc[j], rows, pk.n[j], pk.k[j], rows_per_slice, pk.partial[j], slice, t % tiles_n, t / tiles_n);
 }
 
 __global__ void __launch_bounds__(256) fill_kernel(float* p, int64_t count, float v) {
@@ -880,6 +906,29 @@ extern "C" int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, in
   const int64_t per = ococc_align_up(ococc_cdiv(rows, slices), 32);   // (the last slice may come out short or empty: zeros)
   hipLaunchKernelGGL(point_mlp_wgrad_kernel, dim3(slices, (n + 63) / 64, (k + 63) / 64), dim3(256), 0,
                      (hipStream_t)stream_, dz, x_cat, rows, (int)n, (int)k, per, partial);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+
+extern "C" int ococc_point_mlp_wgrad_multi_f32(int32_t count, const float* const* dz, const float* const* x_cat, int64_t rows,
+                                               const int32_t* n, const int32_t* k, float* const* partial,
+                                               ococc_stream_t stream_) {
+  OCOCC_REQUIRE(count >= 1 && count <= kWgradMulti && rows >= 0, "1..8 layers per call");
+  OCOCC_REQUIRE(dz && x_cat && n && k && partial, "null pointer table");
+  if (rows == 0) return OCOCC_OK;
+  const int slices = ococc_point_mlp_wgrad_slices(rows);
+  const int64_t per = ococc_align_up(ococc_cdiv(rows, slices), 32);
+  PointWgradPack pk;
+  int blocks = 0;
+  for (int j = 0; j < count; ++j) {
+    OCOCC_REQUIRE(dz[j] && x_cat[j] && partial[j] && n[j] >= 1 && k[j] >= 1, "bad layer");
+    pk.dz[j] = dz[j]; pk.xc[j] = x_cat[j]; pk.partial[j] = partial[j]; pk.n[j] = n[j]; pk.k[j] = k[j];
+    pk.first[j] = blocks;
+    blocks += slices * ((n[j] + 63) / 64) * ((k[j] + 63) / 64);
+  }
+  pk.first[count] = blocks;
+  pk.count = count;
+  hipLaunchKernelGGL(point_mlp_wgrad_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, pk, rows, per, slices);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -59,23 +59,24 @@ inline void fwd_layout(const Dims& D, int64_t rows, int64_t groups, FwdLayout* L
 }
 
 struct BwdLayout {
-  int64_t dz, xcat, da[2], dgate, dv[kMaxBlocks], dm, arg, dy0, lnp[kMaxBlocks], wp[kMaxBlocks], total;
+  int64_t dz[kMaxBlocks], xcat[kMaxBlocks], da[2], dgate, dv[kMaxBlocks], dm, arg, dy0, lnp[kMaxBlocks], wp[kMaxBlocks], total;
   int64_t tiles;
   int slices;
 };
 inline void bwd_layout(const Dims& D, int feat_cols, int64_t rows, int64_t groups, BwdLayout* L) {
-  int max_n = 0, max_k = 0, max_ka = 1;
+  int max_n = 0, max_ka = 1;
   for (int b = 0; b < D.nl; ++b) {
     max_n = D.n[b] > max_n ? D.n[b] : max_n;
-    max_k = D.k[b] > max_k ? D.k[b] : max_k;
     if (b != 0 && b != D.nr) max_ka = D.n[b - 1] > max_ka ? D.n[b - 1] : max_ka;   // blocks fed by another block's y
   }
   L->tiles = ococc_point_mlp_tiles(rows);
   L->slices = ococc_point_mlp_wgrad_slices(rows);
   int64_t off = 0;
   auto take = [&](int64_t c) { int64_t o = off; off += pad64(c > 0 ? c : 1); return o; };
-  L->dz = take(rows * max_n);
-  L->xcat = take(rows * max_k);
+  // (dz and the assembled input of EVERY block stay until the end of the pass: the blocks' weight-gradient products
+  // then share one launch)
+  for (int b = 0; b < D.nl; ++b) L->dz[b] = take(rows * D.n[b]);
+  for (int b = 0; b < D.nl; ++b) L->xcat[b] = take(rows * D.k[b]);
   L->da[0] = take(rows * max_ka);
   L->da[1] = take(rows * max_ka);
   L->dgate = take(rows * feat_cols);
@@ -230,8 +231,8 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   bwd_layout(D, d->feat_cols, rows, groups, &L);
   const int last = D.nl - 1;
   auto y_of = [&](int b) -> const float* { return (b == last && !d->shortcut) ? y_out : fwd_slab + F.y[b]; };
-  float* dz = slab + L.dz;
-  float* xcat = slab + L.xcat;
+  auto dz_of = [&](int b) -> float* { return slab + L.dz[b]; };
+  auto xcat_of = [&](int b) -> float* { return slab + L.xcat[b]; };
   int32_t* arg = (int32_t*)(slab + L.arg);
   const float* dy_cur = dy;
   if (!dy_cur) {
@@ -261,7 +262,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
                                    d->with_cluster_center ? f_cluster : nullptr, d->with_cluster_center ? d->cluster_cols : 0,
                                    d->with_cluster_center ? d->cluster_cols : 0, d->bscale, nullptr, 0, inv, rows, d->w_frag[q],
                                    d->wt_frag[q], n, d->ln_weight[q], d->ln_bias[q], d->eps[q], d->act[q], dy_cur, dm,
-                                   dm ? arg : nullptr, dz, xcat, dfeat, gate ? slab + L.dgate : nullptr, nullptr, nullptr,
+                                   dm ? arg : nullptr, dz_of(q), xcat_of(q), dfeat, gate ? slab + L.dgate : nullptr, nullptr, nullptr,
                                    slab + L.lnp[q], stream_);
     } else {
       float* dv = slab + L.dv[i];
@@ -269,14 +270,13 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
       float* da = slab + L.da[pp];
       rc = ococc_point_mlp_bwd_f32(y_of(q - 1), D.n[q - 1], D.n[q - 1], nullptr, 0, nullptr, nullptr, 0, 0, 1.f,
                                    fwd_slab + F.m[i - 1], D.n[q - 1], inv, rows, d->w_frag[q], d->wt_frag[q], n,
-                                   d->ln_weight[q], d->ln_bias[q], d->eps[q], d->act[q], dy_cur, dm, dm ? arg : nullptr, dz,
-                                   xcat, da, nullptr, nullptr, dv, slab + L.lnp[q], stream_);
+                                   d->ln_weight[q], d->ln_bias[q], d->eps[q], d->act[q], dy_cur, dm, dm ? arg : nullptr,
+                                   dz_of(q), xcat_of(q), da, nullptr, nullptr, dv, slab + L.lnp[q], stream_);
       dy_cur = da;
       carry = dv;
       pp ^= 1;
     }
     if (rc) return rc;
-    if (int rc2 = ococc_point_mlp_wgrad_f32(dz, xcat, rows, n, D.k[q], slab + L.wp[q], stream_)) return rc2;
   }
   if (d->shortcut && dfeat) {
     const int n = D.n[last];
@@ -291,12 +291,22 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     float* da = j > 0 ? slab + L.da[pp] : nullptr;
     if (int rc = ococc_point_mlp_bwd_f32(x_in, D.k[j], ldx, nullptr, 0, j == 0 ? d->rel_colscale : nullptr, nullptr, 0, 0,
                                          1.f, nullptr, 0, nullptr, rows, d->w_frag[j], d->wt_frag[j], D.n[j],
-                                         d->ln_weight[j], d->ln_bias[j], d->eps[j], d->act[j], dgate, nullptr, nullptr, dz,
-                                         xcat, da, nullptr, nullptr, nullptr, slab + L.lnp[j], stream_))
+                                         d->ln_weight[j], d->ln_bias[j], d->eps[j], d->act[j], dgate, nullptr, nullptr, dz_of(j),
+                                         xcat_of(j), da, nullptr, nullptr, nullptr, slab + L.lnp[j], stream_))
       return rc;
-    if (int rc2 = ococc_point_mlp_wgrad_f32(dz, xcat, rows, D.n[j], D.k[j], slab + L.wp[j], stream_)) return rc2;
     dgate = da;
     pp ^= 1;
+  }
+  // dW partials of all blocks: one launch
+  {
+    const float *zs[kMaxBlocks], *xs[kMaxBlocks];
+    float* ps[kMaxBlocks];
+    for (int b = 0; b < D.nl; ++b) {
+      zs[b] = dz_of(b);
+      xs[b] = xcat_of(b);
+      ps[b] = slab + L.wp[b];
+    }
+    if (int rc = ococc_point_mlp_wgrad_multi_f32(D.nl, zs, xs, rows, D.n, D.k, ps, stream_)) return rc;
   }
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;

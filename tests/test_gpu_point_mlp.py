@@ -241,3 +241,29 @@ def test_weight_gradient_kernel(dev, rows, n, k):
     exp = dz.double().t() @ xc.double()
     assert bool(torch.isfinite(got).all())
     assert float((got - exp).abs().max()) <= 2e-6 * float(exp.abs().max()) * max(1.0, rows ** 0.5 / 8)
+
+
+@pytest.mark.parametrize('rows', [1, 300, 8192, 70001])
+def test_weight_gradients_of_several_layers_in_one_launch(dev, rows):
+    """ococc_point_mlp_wgrad_multi_f32 (the blocks of one SIR layer's backward): every layer's slices bit for bit those of
+    its own ococc_point_mlp_wgrad_f32 launch."""
+    import ctypes
+    from objectcentricocccompletion_amd import _lib as L
+    shapes = [(16, 13), (32, 32), (128, 131), (144, 256), (64, 24), (128, 64), (8, 3), (70, 70)]
+    g = torch.Generator().manual_seed(rows)
+    slices = int(L.lib.ococc_point_mlp_wgrad_slices(rows))
+    for count in (1, 5, 8):
+        dz = [torch.randn(rows, n, generator=g).to(dev) for n, _ in shapes[:count]]
+        xc = [torch.randn(rows, k, generator=g).to(dev) for _, k in shapes[:count]]
+        one = [torch.full((slices, n, k), float('nan'), device=dev) for n, k in shapes[:count]]
+        many = [torch.full((slices, n, k), float('nan'), device=dev) for n, k in shapes[:count]]
+        for j, (n, k) in enumerate(shapes[:count]):
+            L.check(L.lib.ococc_point_mlp_wgrad_f32(dz[j].data_ptr(), xc[j].data_ptr(), rows, n, k, one[j].data_ptr(), L.stream()), 'wgrad')
+        ptrs = lambda ts: (ctypes.c_void_p * count)(*[t.data_ptr() for t in ts])
+        ints = lambda vs: (ctypes.c_int32 * count)(*vs)
+        L.check(L.lib.ococc_point_mlp_wgrad_multi_f32(count, ptrs(dz), ptrs(xc), rows, ints([n for n, _ in shapes[:count]]),
+                                                       ints([k for _, k in shapes[:count]]), ptrs(many), L.stream()), 'wgrad_multi')
+        torch.cuda.synchronize()
+        for a_, b_ in zip(one, many):
+            assert torch.equal(a_, b_)
+    assert L.lib.ococc_point_mlp_wgrad_multi_f32(9, None, None, rows, None, None, None, None) != 0
