@@ -35,6 +35,33 @@ gr_mark_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t bound, uint3
   }
 }
 
+// The same for key ranges whose bitmap fits a workgroup's LDS (window ids of a batch of grids: a few thousand words):
+// every workgroup marks a CONTIGUOUS stretch of the keys in its own LDS bitmap and hands over only the words it
+// touched.  Voxels arrive in coordinate order, a stretch names a handful of words: ~10^3 global atomics for 260 k
+// window ids instead of one per run of equal keys on a few hundred words (same-address atomics queue: 41 us).
+constexpr int kMarkLdsWords = 8192;   // 262 k keys: three drop levels of 35 k window ids and more
+__global__ void __launch_bounds__(256)
+gr_mark_lds_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t bound, int64_t per_block,
+                   uint32_t* __restrict__ bitmap, int32_t* __restrict__ status) {
+  __shared__ uint32_t bits[kMarkLdsWords];
+  const int words = (bound + 31) >> 5;
+  for (int w = threadIdx.x; w < words; w += 256) bits[w] = 0u;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per_block, hi = min(n, lo + per_block);
+  bool bad = false;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const int32_t k = keys[i];
+    if (k >= bound) bad = true;
+    else if (k >= 0) atomicOr(&bits[k >> 5], 1u << (k & 31));
+  }
+  if (bad) *status = 1;
+  __syncthreads();
+  for (int w = threadIdx.x; w < words; w += 256) {
+    const uint32_t v = bits[w];
+    if (v && (__builtin_nontemporal_load(bitmap + w) & v) != v) atomicOr(bitmap + w, v);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 gr_rank_count_kernel(const int32_t* __restrict__ keys, int64_t n, int32_t bound,
                      const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ prefix,
@@ -132,7 +159,13 @@ extern "C" int ococc_group_rank_i32(const int32_t* keys, int64_t n, int64_t key_
   uint32_t* scratch = (uint32_t*)(ws + L.o_scratch);
   const int g1 = ococc_grid_1d(n, 256);
   OCOCC_HIP(hipMemsetAsync(bitmap, 0, (size_t)(L.o_prefix - L.o_bitmap), stream));   // bitmap, counts, cursor
-  hipLaunchKernelGGL(gr_mark_kernel, dim3(g1), dim3(256), 0, stream, keys, n, (int32_t)key_bound, bitmap, status);
+  if (key_bound <= (int64_t)kMarkLdsWords * 32) {
+    const int64_t per = ococc_align_up(ococc_cdiv(n, 1024), 256);   // <= 1024 workgroups, whole passes of 256 keys
+    hipLaunchKernelGGL(gr_mark_lds_kernel, dim3((unsigned)ococc_cdiv(n, per)), dim3(256), 0, stream, keys, n,
+                       (int32_t)key_bound, per, bitmap, status);
+  } else {
+    hipLaunchKernelGGL(gr_mark_kernel, dim3(g1), dim3(256), 0, stream, keys, n, (int32_t)key_bound, bitmap, status);
+  }
   OCOCC_CHECK_LAUNCH();
   OCOCC_HIP(ococc_scan::exclusive_scan<ococc_scan::POPC>(bitmap, L.words, L.words, 1, prefix, L.words, scratch,
                                                          (uint32_t*)num_groups, stream));

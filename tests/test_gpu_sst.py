@@ -20,6 +20,26 @@ def gold(golden_dir):
     return np.load(os.path.join(golden_dir, 'sst.npz'))
 
 
+@pytest.mark.parametrize('bound', [1, 100, 40_000, 262_144, 262_145, 2_000_000])
+@pytest.mark.parametrize('ordered', [False, True])
+def test_group_rank_marking_paths(dev, bound, ordered):
+    """both marking kernels of ococc_group_rank_i32 (the bitmap in LDS up to 262 144 keys, global atomics above), keys in
+    coordinate order and shuffled, 1 .. 300 k elements"""
+    from objectcentricocccompletion_amd.sst import group_rank
+    rng = np.random.default_rng(bound)
+    for n in (1, 255, 257, 300_000):
+        keys = rng.integers(0, bound, size=n).astype(np.int64)
+        if ordered:
+            keys.sort()
+        conti, inner, counts = group_rank(torch.from_numpy(keys).to(dev), bound)
+        uniq, inv, cnt = np.unique(keys, return_inverse=True, return_counts=True)
+        assert np.array_equal(conti.cpu().numpy(), inv) and np.array_equal(counts.cpu().numpy(), cnt)
+        order = np.argsort(keys, kind='stable')
+        exp = np.empty(n, np.int64)
+        exp[order] = np.arange(n) - np.repeat(np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt)
+        assert np.array_equal(inner.cpu().numpy(), exp)
+
+
 def test_group_rank_vs_numpy(dev):
     from objectcentricocccompletion_amd.sst import get_inner_win_inds, group_rank, make_continuous_inds
     rng = np.random.default_rng(0)
