@@ -2,7 +2,8 @@
 DynamicSimpleVFE (:53-89), DynamicVFE (:92-299) and its DynamicVFELayer (voxel_encoders/utils.py:107-144), the `type`s
 the reference's SST configs name (configs/sst/sst_waymoD5_1x_3class_8heads.py:35-45); and the encoders of the HARD
 voxel layout ([voxels, max_points, C] + points per voxel, what `voxel.hard_voxelize` emits): HardSimpleVFE (:18-50),
-HardVFE (:301-500) with VFELayer and get_paddings_indicator (utils.py:8-104).  (SIRLayer, the DynamicVFE subclass
+HardVFE (:301-500) with VFELayer and get_paddings_indicator (utils.py:8-104); DynamicScatterVFE and
+DynamicRangeScatterVFE (:503-683).  (SIRLayer, the DynamicVFE subclass
 OcOccNet uses, lives in sir.py.)
 
 The reference groups the points of a voxel with one DynamicScatter per use and maps voxel rows back to points through
@@ -101,6 +102,70 @@ class DynamicVFE(nn.Module):
         if self.return_point_feats:
             return point_feats
         return voxel_feats, voxel_coors
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicScatterVFE(DynamicVFE):
+    """DynamicVFE as the FSD-style configs spell it (:503-612): the cluster offset divided by ``rel_dist_scaler``, the
+    pooling ``mode`` handed to scatter_v2 as written ('max' / 'avg' / 'sum'), optionally the inverse map as a third
+    result.  ``unique_once`` is accepted and has nothing left to switch: the rows are grouped once per forward here
+    in any case (module docstring)."""
+
+    def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
+                 with_voxel_center=False, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), mode='max', fusion_layer=None,
+                 return_point_feats=False, return_inv=True, rel_dist_scaler=1.0, unique_once=False):
+        super().__init__(in_channels, feat_channels, with_distance, with_cluster_center, with_voxel_center, voxel_size,
+                         point_cloud_range, norm_cfg, mode, fusion_layer, return_point_feats)
+        self.scatter = self.vfe_scatter = self.cluster_scatter = None
+        self.rel_dist_scaler = rel_dist_scaler
+        self.unique_once = unique_once
+
+    def map_voxel_center_to_point(self, voxel_mean, voxel2point_inds):
+        return voxel_mean[voxel2point_inds.long()]
+
+    def _voxel_origin(self, features, extra):
+        """lower corner + half a cell of the grid the voxel indices count from, per axis (x, y, z)"""
+        return self.x_offset, self.y_offset, self.z_offset
+
+    def _scatter_forward(self, features, coors, extra, return_inv):
+        parts = [features]
+        voxel_coors = unq_inv = None
+        if self._with_cluster_center:
+            mean, voxel_coors, unq_inv = scatter_v2(features[:, :3], coors, 'avg')
+            parts.append((features[:, :3] - self.map_voxel_center_to_point(mean.to(features.dtype), unq_inv)) / self.rel_dist_scaler)
+        if self._with_voxel_center:
+            c = coors.to(features.dtype)
+            ox, oy, oz = self._voxel_origin(features, extra)
+            parts.append(torch.stack([features[:, 0] - (c[:, 3] * self.vx + ox), features[:, 1] - (c[:, 2] * self.vy + oy),
+                                      features[:, 2] - (c[:, 1] * self.vz + oz)], 1))
+        if self._with_distance:
+            parts.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
+        x = torch.cat(parts, dim=-1)
+        voxel_feats = point_feats = None
+        for i, vfe in enumerate(self.vfe_layers):
+            point_feats = vfe(x)
+            voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, self.mode, unq_inv=unq_inv, new_coors=voxel_coors)
+            if i != len(self.vfe_layers) - 1:
+                x = torch.cat([point_feats, self.map_voxel_center_to_point(voxel_feats.to(point_feats.dtype), unq_inv)], dim=1)
+        if self.return_point_feats:
+            return point_feats
+        return (voxel_feats, voxel_coors, unq_inv) if return_inv else (voxel_feats, voxel_coors)
+
+    def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False):
+        return self._scatter_forward(features, coors, None, return_inv)
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicRangeScatterVFE(DynamicScatterVFE):
+    """the same with the grid's origin given per point (``pts_min_bounds`` [N, 3] (x, y, z): a grid per object), taken
+    as written there -- WITHOUT the half-cell the fixed-range classes add (:615-683)"""
+
+    def _voxel_origin(self, features, extra):
+        return extra[:, 0], extra[:, 1], extra[:, 2]
+
+    def forward(self, features, coors, pts_min_bounds, points=None, img_feats=None, img_metas=None, return_inv=False):
+        return self._scatter_forward(features, coors, pts_min_bounds, return_inv)
 
 
 def get_paddings_indicator(actual_num, max_num, axis=0):

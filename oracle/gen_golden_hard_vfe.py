@@ -33,6 +33,16 @@ def inputs():
     return feats, num, coors
 
 
+def dynamic_inputs(feats, num, coors):
+    keep = torch.arange(feats.shape[1])[None, :] < num[:, None]
+    pts = feats[keep]
+    pc = coors[:, None, :].expand(-1, feats.shape[1], -1)[keep]
+    perm = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(3))
+    pts, pc = pts[perm].contiguous(), pc[perm].contiguous()
+    bounds = torch.tensor([0.0, -4.0, -2.0]).expand(pts.shape[0], 3) + 0.01 * pc[:, :1].float()   # (a grid origin per sample)
+    return pts, pc, bounds.contiguous()
+
+
 def main():
     R.install()
     ve = R.load('mmdet3d.models.voxel_encoders.voxel_encoder')
@@ -59,6 +69,20 @@ def main():
     out['train_dw0'] = m.vfe_layers[0].linear.weight.grad.numpy()
     out['pad'] = ve.get_paddings_indicator(num, 10, axis=0).numpy() if hasattr(ve, 'get_paddings_indicator') else \
         sys.modules['mmdet3d.models.voxel_encoders.utils'].get_paddings_indicator(num, 10, axis=0).numpy()
+    # the dynamic layout's scatter variants (:503-683), on the points of the same voxels in a shuffled order
+    pts, pc, bounds = dynamic_inputs(feats, num, coors)
+    out.update(d_pts=pts.numpy(), d_coors=pc.numpy(), d_bounds=bounds.numpy())
+    for tag, cls, extra in (('ds', ve.DynamicScatterVFE, ()), ('dr', ve.DynamicRangeScatterVFE, (bounds,))):
+        torch.manual_seed(6)
+        d = cls(**dict(CFG, mode='max', rel_dist_scaler=10.0, unique_once=True)).eval()
+        with torch.no_grad():
+            for layer in d.vfe_layers:
+                layer.norm.running_mean.normal_(0, 0.1)
+                layer.norm.running_var.uniform_(0.5, 1.5)
+            for k, v in d.state_dict().items():
+                out[tag + '.p.' + k] = v.numpy().copy()
+            vf, vc, inv = d(pts, pc, *extra, return_inv=True)
+        out[tag + '.feats'], out[tag + '.coors'], out[tag + '.inv'] = vf.numpy(), vc.numpy(), inv.numpy()
     path = os.path.join(os.path.dirname(HERE), 'tests', 'golden', 'hard_vfe.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, {k: v.shape for k, v in out.items() if not k.startswith('p.')})

@@ -442,3 +442,28 @@ def test_dynamic_vfe_vs_plain_torch_restatement(dev):
     simple = VOXEL_ENCODERS.build(dict(type='DynamicSimpleVFE', voxel_size=vs, point_cloud_range=rng))
     sf, sc = simple(pts, coors)
     assert torch.equal(sc.long(), uq) and float((sf - mean).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('tag,typ', [('ds', 'DynamicScatterVFE'), ('dr', 'DynamicRangeScatterVFE')])
+def test_scatter_vfes_equal_the_reference(dev, golden_dir, tag, typ):
+    """DynamicScatterVFE / DynamicRangeScatterVFE (voxel_encoder.py:503-683) against the reference's own modules run on
+    the same shuffled points (tests/golden/hard_vfe.npz, oracle/gen_golden_hard_vfe.py): voxel rows and inverse map
+    exact, features to f32 rounding."""
+    from objectcentricocccompletion_amd import heads  # noqa: F401  (registers the voxel encoders)
+    from objectcentricocccompletion_amd.registry import VOXEL_ENCODERS
+    from oracle.gen_golden_hard_vfe import CFG
+    g = np.load(os.path.join(golden_dir, 'hard_vfe.npz'))
+    m = VOXEL_ENCODERS.build(dict(type=typ, **dict(CFG, mode='max', rel_dist_scaler=10.0, unique_once=True))).eval()
+    state = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + '.p.')}
+    assert set(state) == set(m.state_dict())
+    m.load_state_dict(state)
+    m = m.to(dev)
+    pts, pc = torch.from_numpy(g['d_pts']).to(dev), torch.from_numpy(g['d_coors']).to(dev)
+    extra = (torch.from_numpy(g['d_bounds']).to(dev),) if tag == 'dr' else ()
+    with torch.no_grad():
+        vf, vc, inv = m(pts, pc, *extra, return_inv=True)
+        two = m(pts, pc, *extra)
+    assert len(two) == 2 and torch.allclose(two[0], vf, rtol=1e-5, atol=1e-6)   # (the cluster mean is a sum of float atomics)
+    assert np.array_equal(vc.cpu().numpy(), g[tag + '.coors']) and np.array_equal(inv.cpu().numpy(), g[tag + '.inv'])
+    want = g[tag + '.feats']
+    assert float(np.abs(vf.cpu().numpy() - want).max()) <= 1e-5 * float(np.abs(want).max())
