@@ -34,11 +34,34 @@ sys.path.insert(0, ROOT)
 GRIDS_PER_GPU = 64
 POINTS_PER_GRID = 2000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# dominant kernel of the step (profiles/r01_*_kernel_stats.csv): the forward of the 64->128 SubMConv3d,
-# gather_gemm_stream_kernel<64,128>: gathers X rows (64 ch), writes Y rows (128 ch).  (Its dgrad, which
-# gathers dY[.,128] and writes dX[.,64], was the dominant one until it moved to subm_tile_conv_kernel.)
-PROBE_KD, PROBE_NC = 64, 128
-PMC_JSON = {'stream': 'r02_pmc_gather_gemm_stream_64_128.json', 'sorted': 'r04_pmc_gather_gemm_sorted_64_128.json'}
+# The roofline object is reported on the LONGEST convolution kernel of the step: every conv launch is bracketed with HIP
+# events (spconv.ops.KernelProbe, keyed family<kd,ncols>) and the key with the largest average launch time is the one
+# reported, with its own algorithmic bytes (conv_algorithmic_bytes).  `traffic` comes from the committed PMC passes of
+# that kernel (tools/pmc_hbm.sh), keyed the same way; null for a kernel no PMC pass exists for.
+PMC_JSON = {'stationary<64,128>': 'r02_pmc_gather_gemm_stream_64_128.json',
+            'sorted<64,128>': 'r04_pmc_gather_gemm_sorted_64_128.json',
+            'sorted_lnbwd<128,64>': 'r05_pmc_sorted_lnbwd_128_64.json',
+            'tile_lnbwd<128,64>': 'r05_pmc_tile_lnbwd_128_64.json'}
+KERNEL_NAMES = {'stationary': 'gather_gemm_stream_kernel', 'stationary_ln': 'gather_gemm_kernel (+LN epilogue)',
+                'sorted': 'gather_gemm_sorted_kernel', 'sorted_lnbwd': 'gather_gemm_sorted_kernel (+LN-backward epilogue)',
+                'tile': 'subm_tile_conv_kernel', 'tile_ln': 'subm_tile_conv_kernel (+LN epilogue)',
+                'tile_lnbwd': 'subm_tile_conv_kernel (+LN-backward epilogue)'}
+
+
+def conv_algorithmic_bytes(key, n_vox, n_pairs):
+    """compulsory bytes of one sub-manifold convolution launch, Nact*kd*s + Nact*nc*s + P*8 + 27*kd*nc*s
+    with s = 2 (bf16) -- plus what a fused epilogue must move: LN forward writes the activation beside the conv output
+    and the row statistics (Nact*nc*2 + Nact*8); LN backward reads the block's conv output and statistics
+    (Nact*nc*2 + Nact*8).  Returns (bytes, description)."""
+    family, dims = key.split('<')
+    kd, nc = (int(v) for v in dims.rstrip('>').split(','))
+    conv = n_vox * kd * 2 + n_vox * nc * 2 + n_pairs * 8 + 27 * kd * nc * 2
+    extra, note = 0, ''
+    if family.endswith('_ln'):
+        extra, note = n_vox * nc * 2 + n_vox * 8, ' + LN/GELU epilogue: writes the activation and row statistics'
+    elif family.endswith('_lnbwd'):
+        extra, note = n_vox * nc * 2 + n_vox * 8, " + LN-backward epilogue: reads the block's conv output and row statistics"
+    return conv + extra, 'gathers %d channels, writes %d channels%s' % (kd, nc, note)
 
 
 def parse():
@@ -119,9 +142,11 @@ def cpu_baseline(sample_grids, points, model):
                       'oracle/encoder_torch_cpu.py'}
 
 
-def pmc_traffic(kernel='stream'):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON[kernel])."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the reported kernel from the committed PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/PMC_JSON[kernel]); None when no pass exists for it."""
+    if kernel not in PMC_JSON:
+        return None
     try:
         with open(os.path.join(ROOT, 'profiles', PMC_JSON[kernel])) as f:
             return json.load(f)['traffic_bytes_per_launch']
@@ -560,12 +585,12 @@ def main():
         del ref_out
 
     def sorted_kernel_in_use():
-        """does the 64 -> 128 forward of a rulebook built now run on the neighbour-pattern row order?  (and its over-issue:
-        16-row blocks of SLOTS with any neighbour at an offset)"""
+        """does a rulebook built now carry the neighbour-pattern row order?  (and the order's over-issue: 16-row blocks of
+        SLOTS with any neighbour at an offset)"""
         with torch.no_grad():
             o = model(xyz, feats, bidx, B)
             rb2 = getattr(o.indice_dict['subm1'][2], '_ococc', None)
-            if rb2 is None or not sp_ops._use_sorted_kernel(rb2, PROBE_KD, PROBE_NC):
+            if rb2 is None or not sp_ops._sorted_regime(rb2):
                 return False, None
             table, _, rows = rb2.tables[(False, 'fwd')]
             rec, _ = sp_ops.row_order(rb2, table, rows)
@@ -610,13 +635,13 @@ def main():
         opt.step()
         return out
 
-    # dominant kernel: the 64->128 forward gather-GEMM, HIP events on the launch stream.  Event-record
+    # every convolution kernel of the step, HIP events on the launch stream.  Event-record
     # nodes inside a captured graph are rejected by this ROCm (hipEventRecordExternal: invalid argument),
-    # so in graph mode the events go around the same kernel in eager steps run right after the timed
+    # so in graph mode the events go around the same kernels in eager steps run right after the timed
     # replays (same process, same inputs); the rocprofv3 trace of the replays is the cross-check.
-    # Graph mode: each event pair brackets 8 back-to-back launches of the kernel (it only writes its output), so the
+    # Graph mode: each event pair brackets 8 back-to-back launches of the kernel (they only write their outputs), so the
     # event-record overhead (~10 us around one 40 us launch) does not end up in the average.
-    probe = sp_ops.KernelProbe(kd=PROBE_KD, ncols=PROBE_NC, repeat=8 if use_graph else 1)
+    probe = sp_ops.KernelProbe(repeat=8 if use_graph else 1)
 
     graph_note = 'eager launches'
     pipelined = False
@@ -746,12 +771,22 @@ def main():
 
     if rank == 0:
         n_vox = int(n_act)
-        kern_ms = probe.mean_ms()
         sorted_used, sorted_over_issue = sorted_kernel_in_use()
-        # algorithmic (compulsory) bytes of one launch on the 64<->128 layer, SURVEY.md 8d:
-        # Nact*Cin*s + Nact*Cout*s + P*8 + 27*Cin*Cout*s, s = 2 (bf16)
-        alg_bytes = n_vox * 64 * 2 + n_vox * 128 * 2 + n_pairs * 8 + 27 * 64 * 128 * 2
+        # the longest convolution kernel of the step, and every other one beside it
+        per_kernel = {}
+        for key in probe.keys():
+            ms = probe.mean_ms(key)
+            if ms:
+                nbytes, what = conv_algorithmic_bytes(key, n_vox, n_pairs)
+                per_kernel[key] = {'avg_launch_ms': round(ms, 5), 'launches_timed': probe.count(key),
+                                   'algorithmic_bytes_per_launch': nbytes,
+                                   'frac': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        top = max(per_kernel, key=lambda k: per_kernel[k]['avg_launch_ms']) if per_kernel else None
+        kern_ms = per_kernel[top]['avg_launch_ms'] if top else None
+        alg_bytes, what = conv_algorithmic_bytes(top, n_vox, n_pairs) if top else (None, '')
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms else None
+        family = top.split('<')[0] if top else ''
+        kd_top, nc_top = (int(v) for v in top.split('<')[1].rstrip('>').split(',')) if top else (0, 0)
         res = {
             'metric': 'object-grids/sec (fwd+bwd)',
             'value': round(world * B * args.steps / dt, 1),
@@ -774,21 +809,25 @@ def main():
                 'host_us_to_queue_one_step': round(host_us, 1),
             },
             'roofline': {
-                'kernel': ('gather_gemm_sorted_kernel<64,128,true>' if sorted_used else 'gather_gemm_stream_kernel<64,128,true>') +
-                          ' (SubMConv3d 64->128 forward: gathers X[.,64], writes Y[.,128])',
+                'kernel': ('%s<%d,%d> (SubMConv3d %d->%d %s: %s)' % (
+                    KERNEL_NAMES.get(family, family), kd_top, nc_top, *((kd_top, nc_top, 'forward') if kd_top < nc_top
+                                                                       else (nc_top, kd_top, 'input gradient')), what)) if top else None,
+                'key': top,
+                'chosen_as': 'the convolution kernel with the largest average launch time in this run',
                 'bound': 'hbm',
                 'achieved': round(achieved, 1) if achieved else None,
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                'traffic': pmc_traffic('sorted' if sorted_used else 'stream'),
+                'traffic': pmc_traffic(top),
                 'algorithmic_bytes_per_launch': alg_bytes,
-                'mfma_over_issue': sorted_over_issue if sorted_used else over_issue,   # rows the kernel multiplies / rows that have a neighbour (16-row blocks)
+                'mfma_over_issue_pattern_order': sorted_over_issue if sorted_used else None,   # 16-row blocks multiplied x 16 / rulebook pairs
                 'mfma_over_issue_voxel_order': over_issue,
                 'avg_launch_ms': round(kern_ms, 5) if kern_ms else None,
-                'launches_timed': probe.count(),
+                'launches_timed': probe.count(top) if top else 0,
                 'timed_in': 'timed region' if not use_graph else
                             'eager steps after the timed graph replays, 8 back-to-back launches per event pair',
+                'per_kernel': per_kernel,
             },
         }
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier)

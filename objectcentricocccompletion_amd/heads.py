@@ -18,7 +18,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from ._lib import const_tensor
+from ._lib import const_tensor, log_once
 from .bbox import build_bbox_coder, rotation_3d_in_axis
 from .losses import build_loss, reduce_mean
 from .occ import occ_ops
@@ -117,15 +117,22 @@ def graphed_call(owner, make_wrapper, args, slot=''):
             table[key] = False                                        # gradient: frozen parameters -> eager, for good)
             return None
         if not GRAPH_AUTOGRAD_THREADS and torch.autograd.is_multithreading_enabled():
+            # process-wide and for good: the replayed backward runs inside the CALLER's loss.backward(), there is no scope
+            # of ours to restore it in.  Said once, documented in INTEGRATION.md ("Error behaviour"), OCOCC_GRAPH_AUTOGRAD_THREADS=1
+            # keeps the engine's threads, OCOCC_GRAPH_TRANSFORMER=0 keeps the eager form.
             torch.autograd.set_multithreading_enabled(False)   # replays on the calling thread from here on (see above)
+            log_once('autograd-threads', 'graphed temporal transformer: torch.autograd multithreading switched OFF for this '
+                       'process (HIP-graph backward replays run on the calling thread); OCOCC_GRAPH_AUTOGRAD_THREADS=1 keeps it on, '
+                       'OCOCC_GRAPH_TRANSFORMER=0 runs the eager form', level='warning')
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        was = getattr(torch._C, '_warn_on_accumulate_grad_stream_mismatch', lambda: True)()
         if quiet is not None:
             quiet(False)
         try:
             g = table[key] = torch.cuda.make_graphed_callables(wrapper, sample, allow_unused_input=True)
         finally:
             if quiet is not None:
-                quiet(True)   # (the warning is about the capture's side stream only; later mismatches are reported again)
+                quiet(was)   # (silenced for the capture's side stream only; the caller's setting is back afterwards)
     return g(*args) if g is not False else None
 
 

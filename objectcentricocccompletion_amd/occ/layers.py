@@ -1,6 +1,6 @@
 """Temporal transformer pieces -- host mirror of mmdet3d/models/occ/layers.py:
-PositionalEncoding (:8-32), SimpleEncoderLayer (:35-87), TransformerEncoder (:89-99), TransformerDecoder (:101-117),
-SimpleDecoderLayer (:119-186).
+PositionalEncoding (:8-32), SimpleEncoderLayer (:35-87), TransformerEncoder (:89-99).  (The reference file also holds
+a TransformerDecoder / SimpleDecoderLayer that nothing in ococcnet.py instantiates: not on the path, not built.)
 Parameter names match nn.MultiheadAttention / the reference (self_attn.in_proj_weight, ...,
 linear1, linear2, norm1, norm2) so checkpoints load."""
 import copy
@@ -114,61 +114,4 @@ class TransformerEncoder(nn.Module):
         output = src
         for layer in self.layers:
             output = layer(output, key_padding_mask, pos_enc, attn_mask)
-        return output
-
-
-class SimpleDecoderLayer(nn.Module):
-    """Post-LN decoder layer (layers.py:119-186): self-attention with q = k = tgt + query_pos_enc, v = tgt;
-    cross-attention with q = tgt + query_pos_enc, k = memory + pos_enc, v = memory; feed-forward.  Imported by the
-    reference's OccBBoxHead next to SimpleEncoderLayer, not instantiated by ococcnet.py."""
-
-    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='gelu', mlp_dropout=0):
-        super().__init__()
-        self.self_attn = MultiheadAttention(d_model, nhead, dropout)
-        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
-        self.dropout = nn.Dropout(mlp_dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
-        self.norm1 = nn.LayerNorm(d_model)
-        self.norm2 = nn.LayerNorm(d_model)
-        self.norm3 = nn.LayerNorm(d_model)
-        self.dropout1 = nn.Dropout(mlp_dropout)
-        self.dropout2 = nn.Dropout(mlp_dropout)
-        self.dropout3 = nn.Dropout(mlp_dropout)
-        self.activation = get_activation_layer(activation)
-        self.fp16_enabled = False
-
-    def with_pos_embed(self, tensor, pos):
-        return tensor if pos is None else tensor + pos
-
-    def _norm(self, norm, x):  # nn.LayerNorm parameters, HIP kernel
-        return layer_norm_act(x, norm.weight, norm.bias, norm.eps, 'none')
-
-    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
-                memory_key_padding_mask=None, pos_enc=None, query_pos_enc=None):
-        q = k = self.with_pos_embed(tgt, query_pos_enc)
-        tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-        tgt = self._norm(self.norm1, tgt + self.dropout1(tgt2))
-        tgt2 = self.multihead_attn(self.with_pos_embed(tgt, query_pos_enc), self.with_pos_embed(memory, pos_enc),
-                                   value=memory, attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self._norm(self.norm2, tgt + self.dropout2(tgt2))
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
-        return self._norm(self.norm3, tgt + self.dropout3(tgt2))
-
-
-class TransformerDecoder(nn.Module):
-    """layers.py:101-117"""
-
-    def __init__(self, decoder_layer, num_layers):
-        super().__init__()
-        self.layers = _get_clones(decoder_layer, num_layers)
-        self.num_layers = num_layers
-
-    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
-                memory_key_padding_mask=None, pos_enc=None, query_pos_enc=None):
-        output = tgt
-        for layer in self.layers:
-            output = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
-                           tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask,
-                           pos_enc=pos_enc, query_pos_enc=query_pos_enc)
         return output

@@ -6,6 +6,7 @@ ococc_weight_prepare_bf16, ococc_sparse_conv_gather_gemm_bf16 (forward and dgrad
 ococc_sparse_conv_wgrad_bf16.  The reference's per-offset gather/GEMM/scatter loop
 (include/spconv/spconv_ops.h:260-456) does not exist here.
 """
+import collections
 import contextlib
 import os
 import weakref
@@ -18,45 +19,57 @@ from .. import _lib as L
 
 _KD_OK = (16, 32, 64, 128)
 
+# launches per convolution kernel family ('tile', 'tile_ln', 'tile_lnbwd', 'sorted', 'sorted_lnbwd', 'stationary',
+# 'stationary_ln') since import: what tests, __graft_entry__.smoke() and bench.py read to state WHICH kernel produced
+# the numbers they check (the choice depends on the measured rulebook density, see DensityTracker)
+launches = collections.Counter()
+
 
 class KernelProbe(object):
-    """HIP-event timer for one gather-GEMM shape (bench.py's roofline line): events are
-    recorded on the stream the kernel is launched on, around every matching launch (forward
-    with kd = Cin / ncols = Cout, or dgrad with kd = Cout / ncols = Cin), and read back after
-    the final synchronize.  repeat > 1 puts that many back-to-back launches of the (idempotent) kernel between
-    one event pair and divides: the ~10 us an event pair adds around a single launch then weighs 1/repeat."""
+    """HIP-event timer for EVERY convolution kernel launch of a step (bench.py's roofline line reports the longest): events
+    are recorded on the stream the kernel is launched on, around each launch, keyed by ``family<kd,ncols>`` (forward with
+    kd = Cin / ncols = Cout, dgrad with kd = Cout / ncols = Cin; family as in ``launches``), and read back after the final
+    synchronize.  repeat > 1 puts that many back-to-back launches of the (idempotent) kernel between one event pair and
+    divides: the ~10 us an event pair adds around a single launch then weighs 1/repeat.  The probe never changes which
+    kernel runs."""
 
-    def __init__(self, kd, ncols, max_events=4096, external=False, repeat=1):
-        self.kd, self.ncols, self.max_events, self.repeat = kd, ncols, max_events, int(repeat)
+    def __init__(self, max_events=4096, external=False, repeat=1):
+        self.max_events, self.repeat = max_events, int(repeat)
         self.external = external  # events recorded while a HIP graph is being captured
-        self.pairs = []
-        self.samples = []
+        self.pairs = collections.OrderedDict()   # key -> [(start, stop)]
+        self.samples = collections.OrderedDict()
 
-    def wrap(self, kd, ncols, launch):
-        if kd != self.kd or ncols != self.ncols or len(self.pairs) >= self.max_events:
+    def wrap(self, key, launch):
+        got = self.pairs.setdefault(key, [])
+        if len(got) >= self.max_events:
             return launch()
         a, b = L.Timer(), L.Timer()  # HIP events behind the C ABI (ococc_timer_*)
         a.record(self.external)  # torch's current stream == the stream handed to the C ABI (_lib.stream())
         for _ in range(self.repeat):
             out = launch()
         b.record(self.external)
-        self.pairs.append((a, b))
+        got.append((a, b))
         return out
 
     def sample(self):
-        """Graph mode: read the in-graph event pair after a (synchronised) replay."""
-        for a, b in self.pairs:
-            self.samples.append(a.elapsed_ms(b))
+        """Graph mode: read the in-graph event pairs after a (synchronised) replay."""
+        for key, got in self.pairs.items():
+            self.samples.setdefault(key, []).extend(a.elapsed_ms(b) for a, b in got)
 
-    def count(self):
-        return (len(self.samples) if self.external else len(self.pairs)) * self.repeat
+    def keys(self):
+        return list(self.pairs)
 
-    def mean_ms(self):
+    def count(self, key):
+        return (len(self.samples.get(key, ())) if self.external else len(self.pairs.get(key, ()))) * self.repeat
+
+    def mean_ms(self, key):
         if self.external:
-            return sum(self.samples) / len(self.samples) / self.repeat if self.samples else None
-        if not self.pairs:
+            got = self.samples.get(key)
+            return sum(got) / len(got) / self.repeat if got else None
+        got = self.pairs.get(key)
+        if not got:
             return None
-        return sum(a.elapsed_ms(b) for a, b in self.pairs) / len(self.pairs) / self.repeat
+        return sum(a.elapsed_ms(b) for a, b in got) / len(got) / self.repeat
 
 
 _probe = None
@@ -65,6 +78,14 @@ _probe = None
 def set_probe(probe):
     global _probe
     _probe = probe
+
+
+def _launch(family, kd, ncols, fn):
+    """one convolution kernel launch: counted per family, timed if a probe is set"""
+    launches[family] += 1
+    if _probe is not None:
+        return _probe.wrap('%s<%d,%d>' % (family, kd, ncols), fn)
+    return fn()
 
 
 def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
@@ -685,15 +706,26 @@ def _use_sorted_kernel(rb, kd, ncols):
             and not _use_tile_kernel(rb, kd, ncols))
 
 
-_order_counters = {}   # device -> the zero-in / zero-out counters of ococc_subm_row_order
+_order_counters = {}   # (device, stream) -> the zero-in / zero-out counters of ococc_subm_row_order
 ORDER_MAX_ROWS = 1 << 20   # a row record holds places below 2^20
 
 
-def order_counters(dev):
-    hit = _order_counters.get(dev)
+def order_counters(dev, stream=None):
+    """the counter buffer of the row-order builds that run on ``stream`` (default: the current one).  A build clears,
+    counts into and reads its counters, and builds run on several streams at once (graph.PipelinedStep: the next
+    batch's geometry on a side stream beside a lazily built order in train(); OCOCC_ORDER_SIDE_STREAM) -- so every
+    stream has its own buffer: builds on one stream are ordered by the stream, builds on two never share counters."""
+    stream = torch.cuda.current_stream(dev) if stream is None else stream
+    key = (dev, int(stream.cuda_stream))
+    hit = _order_counters.get(key)
     if hit is None:
-        hit = _order_counters[dev] = torch.zeros((int(L.lib.ococc_subm_row_order_counter_bytes()),), dtype=torch.uint8,
-                                                 device=dev)
+        with torch.cuda.stream(stream):
+            hit = _order_counters[key] = torch.zeros((int(L.lib.ococc_subm_row_order_counter_bytes()),), dtype=torch.uint8,
+                                                     device=dev)
+    busy = getattr(hit, '_ococc_busy', None)
+    if busy is not None:    # a placing pass on ANOTHER stream (side-stream builds) still owns the buffer: wait for it
+        stream.wait_event(busy)
+        hit._ococc_busy = None
     return hit
 
 
@@ -738,7 +770,6 @@ def build_row_order(rb, table, rows, rowrec=None):
     rec = torch.empty((max(rows, 1), 4), dtype=torch.int32, device=dev)
     hdr = torch.empty((8,), dtype=torch.int32, device=dev)
     dense_k = kvol // 2 if kvol % 2 == 1 else -1
-    counters = order_counters(dev)
     ws = None if rowrec is not None else L.workspace(L.lib.ococc_subm_row_order_scratch_bytes(rows), dev)
     side = None
     if ORDER_SIDE_STREAM:
@@ -746,6 +777,11 @@ def build_row_order(rb, table, rows, rowrec=None):
         if side is None:
             side = _order_streams[dev] = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream())
+    # row records left by the geometry kernel were counted into the buffer of the stream THAT kernel ran on: the placing
+    # pass reads (and clears) the same one; a build from the table counts on the stream it runs on
+    counters = getattr(rowrec, '_ococc_counters', None) if rowrec is not None else None
+    if counters is None:
+        counters = order_counters(dev, side)
     with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
         if rowrec is not None:
             L.check(L.lib.ococc_subm_row_order_place(L.ptr(rowrec), kvol, dense_k, rows, SORTED_TILES[0], SORTED_TILES[1],
@@ -759,6 +795,8 @@ def build_row_order(rb, table, rows, rowrec=None):
         if side is not None:
             ev = torch.cuda.Event()
             ev.record(side)
+            if counters is not _order_counters.get((dev, int(side.cuda_stream))):
+                counters._ococc_busy = ev   # (the stream that owns these counters waits before its next build)
             for t in (rec, hdr, rowrec, ws, table, counters):
                 if t is not None:
                     t.record_stream(side)
@@ -811,23 +849,24 @@ def _gather_gemm(x_bf16, wn, table, mask, rows, bias, out_dtype, rb=None):
         return acc if out_dtype == torch.float32 else acc.to(out_dtype)
     out = torch.empty((rows, ncols), dtype=out_dtype, device=x_bf16.device)
     if _use_tile_kernel(rb, kd, ncols):  # (the caller prepared wn in fragment-major order under the same test)
-        L.check(L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
-                                                  L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
-                                                  L.dtype_code(out_dtype), L.stream()),
-                'sparse_conv_tile')
+        _launch('tile', kd, ncols, lambda: L.check(
+            L.lib.ococc_sparse_conv_tile_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
+                                              L.ptr(table), kvol // 2, rows, L.ptr(bias), L.ptr(out),
+                                              L.dtype_code(out_dtype), L.stream()), 'sparse_conv_tile'))
         return out
     if _use_sorted_kernel(rb, kd, ncols) and 0 < rows < ORDER_MAX_ROWS:
         rec, hdr = row_order(rb, table, rows)
-        L.check(L.lib.ococc_sparse_conv_sorted_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
-                                                    L.ptr(table), L.ptr(rec), L.ptr(hdr), rows,
-                                                    L.ptr(bias), L.ptr(out), L.dtype_code(out_dtype), L.stream()),
-                'sparse_conv_sorted')
+        _launch('sorted', kd, ncols, lambda: L.check(
+            L.lib.ococc_sparse_conv_sorted_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn), kvol, ncols,
+                                                L.ptr(table), L.ptr(rec), L.ptr(hdr), rows,
+                                                L.ptr(bias), L.ptr(out), L.dtype_code(out_dtype), L.stream()),
+            'sparse_conv_sorted'))
         return out
-    L.check(L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn),
-                                                     kvol, ncols, L.ptr(table), L.ptr(mask), rows,
-                                                     L.ptr(bias), L.ptr(out),
-                                                     L.dtype_code(out_dtype), L.stream()),
-            'sparse_conv_gather_gemm')
+    _launch('stationary', kd, ncols, lambda: L.check(
+        L.lib.ococc_sparse_conv_gather_gemm_bf16(L.ptr(x_bf16), x_bf16.size(0), kd, L.ptr(wn),
+                                                 kvol, ncols, L.ptr(table), L.ptr(mask), rows,
+                                                 L.ptr(bias), L.ptr(out),
+                                                 L.dtype_code(out_dtype), L.stream()), 'sparse_conv_gather_gemm'))
     return out
 
 
@@ -900,10 +939,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
         b = torch.zeros((nc,), dtype=torch.float32, device=features.device)
         b[:cout] = bias.float()
     out_dtype = torch.bfloat16 if features.dtype == torch.bfloat16 else torch.float32
-    if _probe is not None:
-        out = _probe.wrap(kd, nc, lambda: _gather_gemm(x, wn, table, mask, rows, b, out_dtype, rb if subm else None))
-    else:
-        out = _gather_gemm(x, wn, table, mask, rows, b, out_dtype, rb if subm else None)
+    out = _gather_gemm(x, wn, table, mask, rows, b, out_dtype, rb if subm else None)
     if _saved is not None:
         _saved['x_bf16'] = x
     return out if nc == cout else out[:, :cout].contiguous()
@@ -932,7 +968,7 @@ def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indic
     kernel epilogue.  Returns (conv_out, y, mean_rstd), or None when the shape has no fused kernel
     (caller then runs the two ops separately).  bf16 features only."""
     cin, cout = filters.shape[-2], filters.shape[-1]
-    if features.dtype != torch.bfloat16 or cin not in _KD_OK or cout % 16 != 0 or _probe is not None:
+    if features.dtype != torch.bfloat16 or cin not in _KD_OK or cout % 16 != 0:
         return None
     L.require_device(features, filters, indice_pairs)
     rb, (table, mask, rows) = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd',
@@ -946,15 +982,20 @@ def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indic
     g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
     kvol = wn.shape[0]
     if tile:
-        rc = L.lib.ococc_sparse_conv_tile_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
-                                                  kvol // 2, rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
-                                                  L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
+        def run():
+            return L.lib.ococc_sparse_conv_tile_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
+                                                        kvol // 2, rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
+                                                        L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
     else:
-        rc = L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout,
-                                                         L.ptr(table), L.ptr(mask), rows, L.ptr(g32), L.ptr(b32),
-                                                         float(eps), int(act), L.ptr(conv_out), L.ptr(y),
-                                                         L.ptr(stats), L.stream())
+        def run():
+            return L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout,
+                                                               L.ptr(table), L.ptr(mask), rows, L.ptr(g32), L.ptr(b32),
+                                                               float(eps), int(act), L.ptr(conv_out), L.ptr(y),
+                                                               L.ptr(stats), L.stream())
+    family = 'tile_ln' if tile else 'stationary_ln'
+    rc = _launch(family, cin, cout, run)
     if rc == -3:  # OCOCC_EUNSUPPORTED: no fused kernel for this shape
+        launches[family] -= 1
         return None
     L.check(rc, 'sparse_conv_gather_gemm_ln')
     if _saved is not None:
@@ -1082,16 +1123,13 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
             partials = L.empty((prows, 2 * nc), torch.float32, features.device)
             gin = L.empty((rows, nc), torch.bfloat16, features.device)
             kvol = wn.shape[0]
-            L.check(L.lib.ococc_sparse_conv_tile_lnbwd_bf16(
+            _launch('tile_lnbwd', kd_out, nc, lambda: L.check(L.lib.ococc_sparse_conv_tile_lnbwd_bf16(
                 L.ptr(dy), dy.size(0), kd_out, L.ptr(wn), kvol, nc, L.ptr(table), kvol // 2, rows,
                 L.ptr(_ln_link.conv_out), L.ptr(_ln_link.stats), L.ptr(_ln_link.g32), L.ptr(_ln_link.b32),
-                int(_ln_link.act), L.ptr(gin), L.ptr(partials), prows, L.stream()), 'sparse_conv_tile_lnbwd')
+                int(_ln_link.act), L.ptr(gin), L.ptr(partials), prows, L.stream()), 'sparse_conv_tile_lnbwd'))
             _ln_link.fused, _ln_link.partials, _ln_link.rows = True, partials, prows
             _ln_link.expect = (gin.data_ptr(), gin._version)   # (the engine may add a second consumer's gradient in place)
             return gin, filters_bp
-        if _probe is not None:
-            gin = _probe.wrap(kd_out, nc, lambda: _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None))
-        else:
-            gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None)
+        gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()
     return input_bp, filters_bp

@@ -295,11 +295,13 @@ def object_grid_geometry(points, batch_idx, feats, voxel_size, coors_range, grid
     order = None
     if rowrec is not None and not sp_ops.ORDER_SIDE_STREAM:
         order = (L.empty((cap, 4), torch.int32, dev), L.empty((8,), torch.int32, dev))
+    if rowrec is not None:
+        rowrec._ococc_counters = sp_ops.order_counters(dev)   # (this stream's: whoever places the records uses the same)
     L.check(L.lib.ococc_object_grid_geometry_order_f32(
         L.ptr(pts), pts.size(1), L.ptr(bidx), n, L.ptr(fts), c, L.f3(voxel_size), L.f6(coors_range), int(batch_size),
         L.i3(grid_zyx), int(slices), L.ptr(coors), cap, L.ptr(inv), L.ptr(counts), L.ptr(out), L.ptr(out16),
         meta.data_ptr(), meta.data_ptr() + 4, L.ptr(nbr_t), L.ptr(mask), L.ptr(pairs), L.ptr(num), L.ptr(ws), ws.numel(),
-        L.ptr(sp_ops.order_counters(dev)) if rowrec is not None else None, L.ptr(rowrec),
+        L.ptr(rowrec._ococc_counters) if rowrec is not None else None, L.ptr(rowrec),
         L.ptr(order[0]) if order else None, L.ptr(order[1]) if order else None, sp_ops.SORTED_TILES[0], sp_ops.SORTED_TILES[1],
         L.stream()), 'object_grid_geometry')
     vfeats = out16 if want16 else out

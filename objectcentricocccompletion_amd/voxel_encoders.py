@@ -17,6 +17,18 @@ from .registry import VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import scatter_v2
 
 
+def _drop_invalid_voxels(voxel_feats, voxel_coors):
+    """The reference's DynamicVFE / DynamicSimpleVFE pool through DynamicScatter, which sets every row with a negative
+    coordinate to (-1, ..., -1) and slices that group off its outputs (scatter_points_cuda.cu:202-209): out-of-range
+    points of dynamic voxelisation (coors -1) produce no voxel.  scatter_v2 keeps such rows as groups of their own (as
+    the reference's scatter_v2 does, for DynamicScatterVFE), so they are removed here.  One read-back, like the
+    reference's unique."""
+    keep = (voxel_coors >= 0).all(1)
+    if bool(keep.all()):
+        return voxel_feats, voxel_coors
+    return voxel_feats[keep], voxel_coors[keep]
+
+
 class DynamicVFELayer(nn.Module):
     """Linear(no bias) -> norm -> ReLU (utils.py:107-144)"""
 
@@ -41,7 +53,7 @@ class DynamicSimpleVFE(nn.Module):
 
     @torch.no_grad()
     def forward(self, features, coors):
-        return scatter_v2(features, coors, 'mean', return_inv=False)
+        return _drop_invalid_voxels(*scatter_v2(features, coors, 'mean', return_inv=False))
 
 
 @VOXEL_ENCODERS.register_module()
@@ -101,7 +113,8 @@ class DynamicVFE(nn.Module):
                 features = torch.cat([point_feats, voxel_feats.to(point_feats.dtype)[unq_inv.long()]], dim=1)
         if self.return_point_feats:
             return point_feats
-        return voxel_feats, voxel_coors
+        # (the invalid points still took part in the norm layers' batch statistics above, as in the reference)
+        return _drop_invalid_voxels(voxel_feats, voxel_coors)
 
 
 @VOXEL_ENCODERS.register_module()

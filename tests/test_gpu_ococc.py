@@ -562,45 +562,3 @@ def test_transformer_various_length_vs_reference_golden(dev, gold, head):
     finally:
         head.train_cfg['fixed_length'] = old
         head.eval()
-
-
-def test_simple_decoder_layer_vs_torch_modules(dev):
-    """SimpleDecoderLayer / TransformerDecoder (layers.py:101-186 of the reference) against the same chain written with
-    torch's own nn.MultiheadAttention and nn.LayerNorm on the same weights: self-attention with a causal mask and a key
-    padding mask, cross-attention onto a longer memory, forward and the gradients of both inputs."""
-    from objectcentricocccompletion_amd.occ.layers import SimpleDecoderLayer, TransformerDecoder
-    torch.manual_seed(5)
-    E, H, F, L, S, B = 64, 4, 128, 9, 13, 3
-    dec = TransformerDecoder(SimpleDecoderLayer(E, H, F, dropout=0.0, activation='gelu'), 2).to(dev).eval()
-    with torch.no_grad():                       # (the clones start identical: make the two layers differ)
-        for p in dec.layers[1].parameters():
-            p.add_(torch.randn_like(p) * 0.05)
-    tgt = torch.randn(L, B, E, device=dev, requires_grad=True)
-    mem = torch.randn(S, B, E, device=dev, requires_grad=True)
-    qpos, pos = torch.randn(L, B, E, device=dev), torch.randn(S, B, E, device=dev)
-    causal = torch.triu(torch.ones(L, L, dtype=torch.bool, device=dev), 1)
-    mem_pad = torch.zeros(B, S, dtype=torch.bool, device=dev)
-    mem_pad[1, -4:] = True
-    out = dec(tgt, mem, tgt_mask=causal, memory_key_padding_mask=mem_pad, pos_enc=pos, query_pos_enc=qpos)
-    out.pow(2).sum().backward()
-    got = (out.detach().clone(), tgt.grad.clone(), mem.grad.clone())
-
-    def reference(tgt, mem):
-        x = tgt
-        for layer in dec.layers:
-            sa = torch.nn.MultiheadAttention(E, H, 0.0).to(dev)
-            ca = torch.nn.MultiheadAttention(E, H, 0.0).to(dev)
-            for mine, theirs in ((layer.self_attn, sa), (layer.multihead_attn, ca)):
-                theirs.load_state_dict(mine.state_dict())
-            ln = lambda n, v: torch.nn.functional.layer_norm(v, (E,), n.weight, n.bias, n.eps)
-            x = ln(layer.norm1, x + sa(x + qpos, x + qpos, x, attn_mask=causal)[0])
-            x = ln(layer.norm2, x + ca(x + qpos, mem + pos, mem, key_padding_mask=mem_pad)[0])
-            x = ln(layer.norm3, x + layer.linear2(torch.nn.functional.gelu(layer.linear1(x))))
-        return x
-    t2, m2 = tgt.detach().clone().requires_grad_(True), mem.detach().clone().requires_grad_(True)
-    want = reference(t2, m2)
-    want.pow(2).sum().backward()
-    rel = lambda a, b: float((a - b).norm() / b.norm())
-    assert rel(got[0], want.detach()) < 1e-4 and rel(got[1], t2.grad) < 1e-3 and rel(got[2], m2.grad) < 1e-3
-    assert {'layers.0.self_attn.in_proj_weight', 'layers.1.multihead_attn.out_proj.bias', 'layers.0.norm3.weight',
-            'layers.1.linear2.bias'} <= set(dec.state_dict())

@@ -1,6 +1,9 @@
 """GPU parity, sparse-conv side (B3, B4, B5): rulebook bit-exact vs the oracle, conv
 forward/backward vs the oracle on the same bf16-rounded operands, module level autograd,
 and size-independent properties at the benchmark shape (64 x 40^3)."""
+import collections
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -77,10 +80,45 @@ def _conv_case(rng, dev, B, shape, density, cin, cout, shuffle=True):
 TOL = dict(rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (64, 128), (128, 128), (16, 16), (5, 7), (48, 96)])
+@contextlib.contextmanager
+def _kernel_family(ops, family):
+    """pin the convolution kernel family for one test (None: what an unmeasured density selects -- the voxel-order
+    output-stationary kernels; 'sorted': rows in neighbour-pattern order, the kernel bench.py's configs[1] step runs;
+    'tile': the compact-then-multiply tile kernel) and hand back the launch counter to assert on"""
+    keep = ops.SORTED_CONV, ops.SPARSE_TILE_CONV
+    ops.SORTED_CONV = True if family == 'sorted' else keep[0]
+    ops.SPARSE_TILE_CONV = {'sorted': False, 'tile': True}.get(family, keep[1])
+    before = collections.Counter(ops.launches)
+    ran = collections.Counter()
+    try:
+        yield ran
+    finally:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = keep
+        ran.update(ops.launches - before)
+
+
+# channel pairs the neighbour-pattern-order kernel is instantiated for (csrc/sparse_conv_sorted.hip)
+_SORTED_SHAPES = {(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (32, 128), (128, 32)}
+
+
+@pytest.mark.parametrize('family', [None, 'sorted'])
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (64, 128), (128, 64), (64, 32), (128, 128), (16, 16), (5, 7), (48, 96)])
 @pytest.mark.parametrize('density', [0.04, 0.6])
-def test_subm_conv_forward_backward_vs_oracle(dev, cin, cout, density):
+def test_subm_conv_forward_backward_vs_oracle(dev, cin, cout, density, family):
+    """every kernel family against the oracle DIRECTLY (the pattern-order kernel was only compared
+    with the voxel-order kernel)"""
     from objectcentricocccompletion_amd.spconv import ops
+    if family == 'sorted' and (cin, cout) not in _SORTED_SHAPES:
+        pytest.skip('no pattern-order instantiation for this channel pair: the default case covers it')
+    with _kernel_family(ops, family) as ran:
+        _subm_conv_vs_oracle(ops, dev, cin, cout, density)
+    if family == 'sorted':
+        assert ran['sorted'] >= 3 and ran['stationary'] == 0 and ran['tile'] == 0, dict(ran)   # f32 fwd, bf16 fwd, dgrad
+    else:
+        assert ran['sorted'] == 0, dict(ran)
+
+
+def _subm_conv_vs_oracle(ops, dev, cin, cout, density):
     rng = np.random.default_rng(cin * 1000 + cout)
     idx, x, w, dy, pairs, num, ep, en = _conv_case(rng, dev, 2, (14, 15, 16), density, cin, cout)
     n = len(idx)
@@ -448,14 +486,23 @@ def test_regular_rulebook_equals_reference_geometry_h(dev, golden_dir, name):
         assert (p[k, :, en[k]:] == -1).all()
 
 
+@pytest.mark.parametrize('family', [None, 'sorted'])
+@pytest.mark.parametrize('cin,cout', [(16, 32), (64, 128)])
 @pytest.mark.parametrize('dil', [(2, 2, 2), (1, 2, 3)])
-def test_dilated_subm_conv_vs_oracle(dev, dil):
+def test_dilated_subm_conv_vs_oracle(dev, dil, cin, cout, family):
     """SubMConv3d(dilation != 1): the reference keeps padding = k/2 (spconv_ops.h:66-83), so the rulebook is not
     symmetric, and indiceConv treats the offset with the most pairs as "own row" (spconv_ops.h:273-303).  Rulebook
-    bit-exact, forward / dgrad / wgrad against the oracle's indiceConv restatement."""
+    bit-exact, forward / dgrad / wgrad against the oracle's indiceConv restatement -- with the pattern-order switch
+    forced on as well (a dilated rulebook is not its own mirror image, so ops keeps the voxel-order kernels for it
+    whatever the switch says: the results must not depend on it)."""
     from objectcentricocccompletion_amd.spconv import ops
+    with _kernel_family(ops, family):
+        _dilated_vs_oracle(ops, dev, dil, cin, cout)
+
+
+def _dilated_vs_oracle(ops, dev, dil, cin, cout):
     rng = np.random.default_rng(31)
-    B, shape, cin, cout = 2, (9, 11, 13), 16, 32
+    B, shape = 2, (9, 11, 13)
     idx = _voxels(rng, B, shape, 0.3, True)
     n = len(idx)
     _, pairs, num = ops.get_indice_pairs(torch.from_numpy(idx).to(dev), B, list(shape), 3, 1, 0, list(dil), 0, subm=True)
@@ -473,8 +520,13 @@ def test_dilated_subm_conv_vs_oracle(dev, dil):
     assert np.allclose(dw.cpu().numpy(), edw, rtol=1e-4, atol=2e-4 * max(1.0, float(np.abs(edw).max())))
 
 
+# bench.py's configs[1] batch has 221 211 rulebook pairs on 126 005 rows: at that density the step runs the tile kernels
+# (32 -> 64 forward with LN, both LN-backward dgrads) and the pattern-order kernel (64 -> 128 forward)
+BENCH_PAIRS_PER_ROW = 1.755
+
+
 @pytest.mark.parametrize('fused_front_end', [True, False])
-@pytest.mark.parametrize('tile', [None, True])
+@pytest.mark.parametrize('tile', [None, True, 'bench', 'sorted'])
 def test_occupancy_encoder_vs_oracle_restatement(dev, fused_front_end, tile):
     """The configs[1] encoder end to end (voxelise -> scatter-mean -> rulebook -> 3 x (SubMConv3d, LN, GELU),
     loss = mean(out^2), backward) against oracle/encoder_ref.py, which rounds to bf16 exactly where the HIP path stores
@@ -492,13 +544,27 @@ def test_occupancy_encoder_vs_oracle_restatement(dev, fused_front_end, tile):
         for l in model.conv_layers:
             l[1].weight.add_(0.2 * torch.randn_like(l[1].weight))
             l[1].bias.add_(0.1 * torch.randn_like(l[1].bias))
-    ops.SPARSE_TILE_CONV = tile
+    keep = ops.SPARSE_TILE_CONV, ops.DEFAULT_PAIRS_PER_ROW, ops.SORTED_CONV
+    before = collections.Counter(ops.launches)
+    if tile == 'bench':      # the kernel mix of the benchmark step: chosen by ops from the benchmark's density
+        ops.DEFAULT_PAIRS_PER_ROW = BENCH_PAIRS_PER_ROW
+    elif tile == 'sorted':   # every layer the pattern order is instantiated for runs on it
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = True, False
+    else:
+        ops.SPARSE_TILE_CONV = tile
     try:
         out = model(xyz, feats, bidx, B)
         out.features.float().pow(2).mean().backward()
     finally:
-        ops.SPARSE_TILE_CONV = None
+        ops.SPARSE_TILE_CONV, ops.DEFAULT_PAIRS_PER_ROW, ops.SORTED_CONV = keep
     torch.cuda.synchronize()
+    ran = ops.launches - before
+    if tile == 'bench':
+        assert ran['sorted'] + ran['sorted_lnbwd'] >= 1 and ran['tile_ln'] + ran['tile'] >= 1, dict(ran)
+    elif tile == 'sorted':
+        assert ran['sorted'] + ran['sorted_lnbwd'] >= 3 and ran['tile'] + ran['tile_ln'] + ran['tile_lnbwd'] == 0, dict(ran)
+    elif tile is None:
+        assert ran['sorted'] + ran['sorted_lnbwd'] == 0, dict(ran)
     ws = [l[0].weight.detach().cpu().numpy() for l in model.conv_layers]
     gs = [l[1].weight.detach().cpu().numpy() for l in model.conv_layers]
     bs = [l[1].bias.detach().cpu().numpy() for l in model.conv_layers]

@@ -444,6 +444,38 @@ def test_dynamic_vfe_vs_plain_torch_restatement(dev):
     assert torch.equal(sc.long(), uq) and float((sf - mean).abs().max()) < 1e-5
 
 
+def test_dynamic_vfe_drops_out_of_range_points_like_dynamic_scatter(dev):
+    """Points dynamic voxelisation marks out of range (coors (b, -1, -1, -1)) produce NO voxel in DynamicVFE /
+    DynamicSimpleVFE: the reference pools through DynamicScatter, which fills every row holding a negative coordinate
+    with -1 and slices that group off its outputs (mmdet3d/ops/voxel/src/scatter_points_cuda.cu:202-209).  The valid
+    voxels are those of the in-range points alone (eval mode: no batch statistics), in sorted order."""
+    from objectcentricocccompletion_amd import heads  # noqa: F401
+    from objectcentricocccompletion_amd.registry import VOXEL_ENCODERS
+    torch.manual_seed(3)
+    vs, rng = (0.5, 0.5, 1.0), (0.0, -4.0, -2.0, 8.0, 4.0, 2.0)
+    n = 3000
+    pts = torch.rand(n, 5, device=dev) * torch.tensor([8.0, 8.0, 4.0, 1.0, 1.0], device=dev) + torch.tensor([0, -4.0, -2.0, 0, 0], device=dev)
+    b = torch.randint(0, 3, (n,), device=dev)
+    zyx = torch.stack([((pts[:, 2] - rng[2]) / vs[2]).floor(), ((pts[:, 1] - rng[1]) / vs[1]).floor(),
+                       ((pts[:, 0] - rng[0]) / vs[0]).floor()], 1).to(torch.int32)
+    coors = torch.cat([b.view(-1, 1).to(torch.int32), zyx], 1)
+    out = torch.rand(n, device=dev) < 0.2            # a fifth of the points fall outside the range
+    coors_all = coors.clone()
+    coors_all[out, 1:] = -1
+    vfe = VOXEL_ENCODERS.build(dict(type='DynamicVFE', in_channels=5, feat_channels=[16, 32], voxel_size=vs,
+                                    with_cluster_center=True, with_voxel_center=True, point_cloud_range=rng)).to(dev).eval()
+    simple = VOXEL_ENCODERS.build(dict(type='DynamicSimpleVFE', voxel_size=vs, point_cloud_range=rng))
+    with torch.no_grad():
+        vf, vc = vfe(pts, coors_all)
+        vf_in, vc_in = vfe(pts[~out], coors[~out])
+        sf, sc = simple(pts, coors_all)
+        sf_in, sc_in = simple(pts[~out], coors[~out])
+    assert int((vc < 0).sum()) == 0 and torch.equal(vc, vc_in) and torch.allclose(vf, vf_in, rtol=1e-5, atol=1e-6)
+    assert torch.equal(sc, sc_in) and torch.allclose(sf, sf_in, rtol=1e-5, atol=1e-6)
+    uq = torch.unique(coors[~out].long(), dim=0)
+    assert torch.equal(vc.long(), uq)
+
+
 @pytest.mark.parametrize('tag,typ', [('ds', 'DynamicScatterVFE'), ('dr', 'DynamicRangeScatterVFE')])
 def test_scatter_vfes_equal_the_reference(dev, golden_dir, tag, typ):
     """DynamicScatterVFE / DynamicRangeScatterVFE (voxel_encoder.py:503-683) against the reference's own modules run on
