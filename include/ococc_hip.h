@@ -362,6 +362,19 @@ int ococc_subm_row_order_place(const int32_t* rowrec, int32_t kvol, int32_t dens
 int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                   int32_t ncols, const int32_t* table, const int32_t* rec, const int32_t* hdr,
                                   int64_t n_out, const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
+/* ococc_sparse_conv_sorted_bf16 as the input-gradient pass of layer L+1 with the LayerNorm (+ GELU) BACKWARD of the
+ * conv -> LN -> act block L in its epilogue -- the contract of ococc_sparse_conv_tile_lnbwd_bf16 below (same operands
+ * besides the row order rec / hdr and the row-major dgrad operand wn; d_conv_out bit-identical to it and to
+ * ococc_layernorm_act_bwd on the bf16 dgrad output), for rulebooks that run in neighbour-pattern order.  One row of
+ * partial sums [d gamma | d beta] per workgroup: partial_rows >= ococc_sparse_conv_sorted_lnbwd_partial_rows(n_out),
+ * every row written.  ncols in {32, 64}.  Replaces indiceConvBackward's input-gradient loop (spconv_ops.h:363-456)
+ * followed by the LayerNorm backward of sparse_block.py:216-289's norm layer. */
+int64_t ococc_sparse_conv_sorted_lnbwd_partial_rows(int64_t n_out);
+int ococc_sparse_conv_sorted_lnbwd_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
+                                        int32_t ncols, const int32_t* table, const int32_t* rec, const int32_t* hdr,
+                                        int64_t n_out, const uint16_t* block_conv_out, const float* mean_rstd,
+                                        const float* gamma, const float* beta, int32_t act, uint16_t* d_conv_out,
+                                        float* partials, int64_t partial_rows, ococc_stream_t stream);
 /* The same kernel with the LayerNorm (+ GELU) that follows the convolution in the reference's
  * make_sparse_convmodule block (mmdet3d/ops/sparse_block.py:216-289: conv -> LN(eps) -> GELU) applied in the
  * epilogue, where the finished f32 row sits in LDS: conv_out [n_out, ncols] bf16 (what the LN backward needs), y =

@@ -81,6 +81,9 @@ SIGNATURES = {
     'ococc_subm_row_order': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_sorted_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
                                               c_vp, c_vp, c_i32, c_vp]),
+    'ococc_sparse_conv_sorted_lnbwd_partial_rows': (c_i64, [c_i64]),
+    'ococc_sparse_conv_sorted_lnbwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                                    c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),
     'ococc_sparse_conv_gather_gemm_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64,
                                                       c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ococc_weight_prepare_multi_bf16': (c_i32, [c_i32, ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),

@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "stream_ops.hpp"
 #include "row_order.hpp"
+#include "ln_math.hpp"
 #include <type_traits>
 
 namespace {
@@ -136,17 +137,33 @@ order_place_kernel(const i32x4_t* __restrict__ rowrec, int64_t n, const uint32_t
 //    of offsets i+4 .. i+7 in flight.
 // Workgroups are persistent and take tiles round-robin (the first tiles are the long ones); in the second round the
 // workgroups behind the long tiles go first.
-template <int KD, int NC>
+// LayerNorm (+ GELU) BACKWARD in the epilogue (LNB instantiations: the input-gradient convolution behind a
+// conv -> LayerNorm -> act block, functional.LnBackwardLink): the finished f32 row of d(block output) is in the
+// accumulators of the four lanes that share a slot, so the block's LayerNorm backward happens there and d(block's conv
+// output) leaves instead -- the arithmetic and its order are those of ln_act_bwd_vec_kernel and of the tile kernel's LNB
+// epilogue (ln_math.hpp; the row sums are combined over the 8-channel pieces in the same butterfly order), so the rows
+// are bit-identical to both; the d gamma / d beta sums are grouped per workgroup (partials [gridDim.x][2 NC]).
+struct SortedLn {
+  const uint16_t* y;       // [n_out, NC] bf16: the block's conv output
+  const float* mean_rstd;  // [n_out, 2]
+  const float* gamma;
+  const float* beta;
+  int act;                 // 0 none, 1 GELU(erf)
+  float* partials;         // [gridDim.x][2 NC]
+};
+
+template <int KD, int NC, bool LNB = false>
 constexpr int sorted_lds_bytes(int kvol) {
-  return 3 * NC * (KD / 8) * 16 + kvol * kSortThreads * 4 + 2 * (kSortThreads / 64) * 4;
+  return 3 * NC * (KD / 8) * 16 + kvol * kSortThreads * 4 + 2 * (kSortThreads / 64) * 4 +
+         (LNB ? (kSortThreads / 64) * 2 * NC * 4 : 0);
 }
 
-template <int KD, int NC, bool OUT_BF16>
+template <int KD, int NC, bool OUT_BF16, bool LNB = false>
 __global__ void __launch_bounds__(kSortThreads, 2)
 gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn, int kvol,
                           const int32_t* __restrict__ table, const i32x4_t* __restrict__ rec,
                           const OrderHdr* __restrict__ hdr, int64_t n_out, const float* __restrict__ bias,
-                          void* __restrict__ out_) {
+                          void* __restrict__ out_, SortedLn ln) {
   constexpr int KSTEPS = KD / 32;
   constexpr int NB = NC / 16;
   constexpr int PPR = KD / 8;             // 16-byte pieces per weight row
@@ -161,6 +178,10 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   u32x4* wl = (u32x4*)smem;                                // [3][PIECES] (layout and swizzle: see gather_gemm_stream_kernel)
   int32_t* sidx = (int32_t*)(wl + 3 * PIECES);             // [kvol][256]: table entry of offset k for the tile's slot
   uint32_t* wg_mask = (uint32_t*)(sidx + kvol * kSortThreads);   // [2][NWAVES]
+  float* ln_sums = (float*)(wg_mask + 2 * NWAVES);               // LNB: [NWAVES][2 NC] d gamma | d beta of the wave's rows so far
+  if constexpr (LNB) {
+    for (int i = threadIdx.x; i < NWAVES * 2 * NC; i += kSortThreads) ln_sums[i] = 0.f;   // (each wave clears and uses its own strip)
+  }
 
   const OrderHdr o = *hdr;
   const int hb = __builtin_amdgcn_readfirstlane(o.heavy_blocks), mb = __builtin_amdgcn_readfirstlane(o.mid_blocks);
@@ -170,7 +191,8 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   // therefore taken by TWO workgroups, each with one half of the output columns: half the slice staged and read, half
   // the matrix instructions, the same rows gathered twice (a few KB), every output element still summed by one lane in
   // ascending offset order -- the results do not change.
-  constexpr bool kCanSplit = CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
+  // (never with the LayerNorm-backward epilogue: a row's statistics need all of its columns in one place)
+  constexpr bool kCanSplit = !LNB && CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
   // ... while such tiles are FEW: they are then the launch's tail on slots that would idle (the benchmark: 79 tiles on
   // 512 slots).  Where they are many, two workgroups per tile double their fixed cost (table batch, first operands) for
   // nothing: 2.5 pairs per row took 103 us split against 70 us unsplit.
@@ -446,6 +468,97 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       SSTAMP(t, 3);
 
       // ---- epilogue: lane holds channels 32p + 8kg .. +7 of slot lrow of block b in acc[b][2p], acc[b][2p+1] ----
+      if constexpr (LNB) {
+        static_assert(CS == 1 || !LNB, "the LayerNorm-backward epilogue needs whole rows");
+        constexpr int NP = NB / 2;   // 8-channel pieces per lane: piece (p, kg) is the tile kernel's c8 = 4 p + kg
+        // everything the rows need is asked for at once: the block's conv output and statistics, gamma, beta
+        int32_t rr[BPW];
+        u32x4 xin[BPW][NP];
+        float mean[BPW], rstd[BPW];
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          rr[b] = __shfl(myrow, b * 16 + lrow, 64);
+          const int64_t rc = rr[b] < 0 ? 0 : rr[b];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) xin[b][p] = *(const u32x4*)(ln.y + rc * NC + p * 32 + kg * 8);
+          mean[b] = ln.mean_rstd[rc * 2];
+          rstd[b] = ln.mean_rstd[rc * 2 + 1];
+        }
+        ln_f32x2 g[NP][4], bt[NP][4], dg[NP][4], db[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const f32x4 g0 = *(const f32x4*)(ln.gamma + p * 32 + kg * 8), g1 = *(const f32x4*)(ln.gamma + p * 32 + kg * 8 + 4);
+          const f32x4 b0 = *(const f32x4*)(ln.beta + p * 32 + kg * 8), b1 = *(const f32x4*)(ln.beta + p * 32 + kg * 8 + 4);
+          g[p][0] = ln_f32x2{g0.x, g0.y}; g[p][1] = ln_f32x2{g0.z, g0.w}; g[p][2] = ln_f32x2{g1.x, g1.y}; g[p][3] = ln_f32x2{g1.z, g1.w};
+          bt[p][0] = ln_f32x2{b0.x, b0.y}; bt[p][1] = ln_f32x2{b0.z, b0.w}; bt[p][2] = ln_f32x2{b1.x, b1.y}; bt[p][3] = ln_f32x2{b1.z, b1.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dg[p][q] = db[p][q] = ln_f32x2{0.f, 0.f};
+        }
+        auto rb16 = [](float v) -> float { return ococc_bf16_to_f32(ococc_f32_to_bf16(v)); };
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          if (rr[b] < 0) continue;   // (the four lanes of a slot agree: the exchanges below stay inside a slot)
+          ln_f32x2 xv[NP][4], dzg[NP][4];
+          float t1[NP], t2[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const f32x4 v0 = acc[b][2 * p], v1 = acc[b][2 * p + 1];
+            ln_f32x2 dv[4];
+            // (the incoming gradient rounded to bf16 first, as the unfused pair of kernels sees it)
+            dv[0] = ln_f32x2{rb16(v0.x), rb16(v0.y)};
+            dv[1] = ln_f32x2{rb16(v0.z), rb16(v0.w)};
+            dv[2] = ln_f32x2{rb16(v1.x), rb16(v1.y)};
+            dv[3] = ln_f32x2{rb16(v1.z), rb16(v1.w)};
+            ln_unpack8(xin[b][p], xv[p]);
+            if (ln.act == 1) ln_bwd_piece8<true>(xv[p], dv, mean[b], rstd[b], g[p], bt[p], dg[p], db[p], dzg[p], t1[p], t2[p]);
+            else ln_bwd_piece8<false>(xv[p], dv, mean[b], rstd[b], g[p], bt[p], dg[p], db[p], dzg[p], t1[p], t2[p]);
+          }
+          // the row's two sums over its NC / 8 pieces, in the butterfly order of the other LayerNorm-backward kernels
+          // (piece c8 with c8 ^ NC/16, ..., c8 ^ 1): the high bits of c8 are p (in this lane), the low two are kg
+          float s1, s2;
+          if constexpr (NP == 4) {
+            s1 = (t1[0] + t1[2]) + (t1[1] + t1[3]);
+            s2 = (t2[0] + t2[2]) + (t2[1] + t2[3]);
+          } else if constexpr (NP == 2) {
+            s1 = t1[0] + t1[1];
+            s2 = t2[0] + t2[1];
+          } else {
+            s1 = t1[0];
+            s2 = t2[0];
+          }
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          s1 += __shfl_xor(s1, 16, 64);
+          s2 += __shfl_xor(s2, 16, 64);
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            *(u32x4*)((uint16_t*)out_ + (int64_t)rr[b] * NC + p * 32 + kg * 8) =
+                ln_bwd_finish8(xv[p], dzg[p], rstd[b], s1 * (1.f / NC), s2 * (1.f / NC));
+        }
+        // d gamma / d beta of the tile's rows: over the 16 slots of a lane group, then into this wave's strip
+        float* mine = ln_sums + wave * 2 * NC;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a0 = dg[p][q].x, a1 = dg[p][q].y, c0 = db[p][q].x, c1 = db[p][q].y;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+              a0 += __shfl_xor(a0, d, 64);
+              a1 += __shfl_xor(a1, d, 64);
+              c0 += __shfl_xor(c0, d, 64);
+              c1 += __shfl_xor(c1, d, 64);
+            }
+            if (lrow == 0) {
+              const int ch = p * 32 + kg * 8 + 2 * q;
+              mine[ch] += a0;
+              mine[ch + 1] += a1;
+              mine[NC + ch] += c0;
+              mine[NC + ch + 1] += c1;
+            }
+          }
+        return;
+      }
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         const int32_t r = __shfl(myrow, b * 16 + lrow, 64);
@@ -483,19 +596,46 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
     }
     SSTAMP(t, 4);
   }
+  if constexpr (LNB) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NC; i += kSortThreads) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) sum += ln_sums[w * 2 * NC + i];
+      ln.partials[(int64_t)blockIdx.x * 2 * NC + i] = sum;
+    }
+  }
+}
+
+inline unsigned sorted_grid(int64_t n_out) {
+  // persistent workgroups, two per CU; never more than the 64-row tiles there could be
+  const int64_t most = ococc_cdiv(n_out, 64) + 3;
+  return (unsigned)(most < 512 ? most : 512);
 }
 
 template <int KD, int NC>
 int launch_sorted(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, const int32_t* table, const int32_t* rec,
-                  const OrderHdr* hdr, int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream) {
-  // persistent workgroups, two per CU; never more than the 64-row tiles there could be
-  const int64_t most = ococc_cdiv(n_out, 64) + 3;
-  const dim3 grid((unsigned)(most < 512 ? most : 512));
+                  const OrderHdr* hdr, int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream,
+                  const SortedLn* ln = nullptr) {
+  const dim3 grid(sorted_grid(n_out));
+  if (ln) {
+    if constexpr (NC <= 64) {
+      const int lds = sorted_lds_bytes<KD, NC, true>(kvol);
+      auto kern = gather_gemm_sorted_kernel<KD, NC, true, true>;
+      OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, grid, dim3(kSortThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table,
+                         (const i32x4_t*)rec, hdr, n_out, bias, out, *ln);
+      OCOCC_CHECK_LAUNCH();
+      return OCOCC_OK;
+    } else {
+      return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused LayerNorm backward epilogue: 32 or 64 output columns");
+    }
+  }
   const int lds = sorted_lds_bytes<KD, NC>(kvol);
   auto kern = out_dtype == OCOCC_BF16 ? gather_gemm_sorted_kernel<KD, NC, true> : gather_gemm_sorted_kernel<KD, NC, false>;
   OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, grid, dim3(kSortThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table,
-                     (const i32x4_t*)rec, hdr, n_out, bias, out);
+                     (const i32x4_t*)rec, hdr, n_out, bias, out, SortedLn{});
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
@@ -503,12 +643,12 @@ int launch_sorted(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kv
 template <int KD>
 int dispatch_sorted(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol, int ncols, const int32_t* table,
                     const int32_t* rec, const OrderHdr* hdr, int64_t n_out, const float* bias, void* out, int out_dtype,
-                    hipStream_t stream) {
+                    hipStream_t stream, const SortedLn* ln = nullptr) {
   switch (ncols) {
-    case 32: return launch_sorted<KD, 32>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream);
-    case 64: return launch_sorted<KD, 64>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream);
+    case 32: return launch_sorted<KD, 32>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream, ln);
+    case 64: return launch_sorted<KD, 64>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream, ln);
     case 128:
-      if constexpr (KD <= 64) return launch_sorted<KD, 128>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream);
+      if constexpr (KD <= 64) return launch_sorted<KD, 128>(feat, n_in, wn, kvol, table, rec, hdr, n_out, bias, out, out_dtype, stream, ln);
       break;
     default: break;
   }
@@ -571,11 +711,10 @@ extern "C" int ococc_subm_row_order_place(const int32_t* rowrec, int32_t kvol, i
                             (hipStream_t)stream_);
 }
 
-extern "C" int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
-                                             int32_t kvol, int32_t ncols, const int32_t* table, const int32_t* rec,
-                                             const int32_t* hdr, int64_t n_out, const float* bias, void* out,
-                                             int32_t out_dtype, ococc_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+namespace {
+int sorted_entry(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol, int32_t ncols,
+                 const int32_t* table, const int32_t* rec, const int32_t* hdr, int64_t n_out, const float* bias, void* out,
+                 int32_t out_dtype, hipStream_t stream, const SortedLn* ln) {
   OCOCC_REQUIRE(n_in >= 0 && n_out >= 0, "negative row count");
   OCOCC_REQUIRE(kvol >= 1 && kvol <= 32, "kernel volume must be 1..32");
   OCOCC_REQUIRE(out_dtype == OCOCC_BF16 || out_dtype == OCOCC_F32, "out_dtype must be f32/bf16");
@@ -584,11 +723,39 @@ extern "C" int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in,
   OCOCC_REQUIRE(feat || n_in == 0, "null feat");
   OCOCC_REQUIRE(n_in * kd * 2 < 0xffffff00ll, "feat must stay below 4 GB (32-bit buffer offsets)");
   switch (kd) {
-    case 32: return dispatch_sorted<32>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream);
-    case 64: return dispatch_sorted<64>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream);
-    case 128: return dispatch_sorted<128>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream);
+    case 32: return dispatch_sorted<32>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream, ln);
+    case 64: return dispatch_sorted<64>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream, ln);
+    case 128: return dispatch_sorted<128>(feat, n_in, wn, kvol, ncols, table, rec, (const OrderHdr*)hdr, n_out, bias, out, out_dtype, stream, ln);
     default: return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "kd must be 32/64/128");
   }
+}
+}  // namespace
+
+extern "C" int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                             int32_t kvol, int32_t ncols, const int32_t* table, const int32_t* rec,
+                                             const int32_t* hdr, int64_t n_out, const float* bias, void* out,
+                                             int32_t out_dtype, ococc_stream_t stream_) {
+  return sorted_entry(feat, n_in, kd, wn, kvol, ncols, table, rec, hdr, n_out, bias, out, out_dtype, (hipStream_t)stream_,
+                      nullptr);
+}
+
+extern "C" int64_t ococc_sparse_conv_sorted_lnbwd_partial_rows(int64_t n_out) {
+  return n_out < 0 ? -1 : (int64_t)sorted_grid(n_out > 0 ? n_out : 1);
+}
+
+extern "C" int ococc_sparse_conv_sorted_lnbwd_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                                   int32_t kvol, int32_t ncols, const int32_t* table, const int32_t* rec,
+                                                   const int32_t* hdr, int64_t n_out, const uint16_t* block_conv_out,
+                                                   const float* mean_rstd, const float* gamma, const float* beta,
+                                                   int32_t act, uint16_t* d_conv_out, float* partials,
+                                                   int64_t partial_rows, ococc_stream_t stream_) {
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(ncols == 32 || ncols == 64, "fused LayerNorm backward: 32 or 64 output columns");
+  OCOCC_REQUIRE(n_out == 0 || (gamma && beta && block_conv_out && mean_rstd && d_conv_out && partials), "null pointer");
+  OCOCC_REQUIRE(partial_rows >= ococc_sparse_conv_sorted_lnbwd_partial_rows(n_out), "partials too small");
+  const SortedLn ln{block_conv_out, mean_rstd, gamma, beta, act, partials};
+  return sorted_entry(feat, n_in, kd, wn, kvol, ncols, table, rec, hdr, n_out, nullptr, d_conv_out, OCOCC_BF16,
+                      (hipStream_t)stream_, &ln);
 }
 
 #ifdef OCOCC_SORTED_STAMPS

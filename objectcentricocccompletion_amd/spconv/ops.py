@@ -650,6 +650,11 @@ def density_regime(kd, ncols):
 # (tools/density_sweep.py: random cells per 40^3 grid, 64 grids; 128 -> 64: 85 vs 109 us at 2.5 pairs / row, 249 vs
 # 224 us at 4.1; 32 <-> 64: 31 vs 32 us at 1.8, 58 vs 48 us at 2.5)
 _TILE_SHAPES = {(128, 64): 3.0, (64, 32): 2.0, (32, 64): 2.0}
+# OCOCC_TILE_SHAPES="128x64:3.0,64x32:2.0" replaces the table (a shape left out never takes the tile kernel: an A/B switch
+# for the pattern-order kernel on the same layer)
+if os.environ.get('OCOCC_TILE_SHAPES') is not None:
+    _TILE_SHAPES = {tuple(int(v) for v in item.split(':')[0].split('x')): float(item.split(':')[1])
+                    for item in os.environ['OCOCC_TILE_SHAPES'].split(',') if item}
 
 
 def set_rulebook_density(indice_pairs, pairs_per_row):
@@ -1129,6 +1134,23 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
                 int(_ln_link.act), L.ptr(gin), L.ptr(partials), prows, L.stream()), 'sparse_conv_tile_lnbwd'))
             _ln_link.fused, _ln_link.partials, _ln_link.rows = True, partials, prows
             _ln_link.expect = (gin.data_ptr(), gin._version)   # (the engine may add a second consumer's gradient in place)
+            return gin, filters_bp
+        if (_ln_link is not None and FUSE_LN_BACKWARD and mode == 1 and nc == cin and nc in (32, 64)
+                and out_dtype == torch.bfloat16 and _ln_link.conv_out is not None
+                and tuple(_ln_link.conv_out.shape) == (rows, nc) and _use_sorted_kernel(rb, kd_out, nc)
+                and 0 < rows < ORDER_MAX_ROWS):
+            # the same fusion on the neighbour-pattern-order kernel (the finished f32 row sits in four lanes' accumulators)
+            rec, hdr = row_order(rb, table, rows)
+            prows = int(L.lib.ococc_sparse_conv_sorted_lnbwd_partial_rows(rows))
+            partials = L.empty((prows, 2 * nc), torch.float32, features.device)
+            gin = L.empty((rows, nc), torch.bfloat16, features.device)
+            kvol = wn.shape[0]
+            _launch('sorted_lnbwd', kd_out, nc, lambda: L.check(L.lib.ococc_sparse_conv_sorted_lnbwd_bf16(
+                L.ptr(dy), dy.size(0), kd_out, L.ptr(wn), kvol, nc, L.ptr(table), L.ptr(rec), L.ptr(hdr), rows,
+                L.ptr(_ln_link.conv_out), L.ptr(_ln_link.stats), L.ptr(_ln_link.g32), L.ptr(_ln_link.b32),
+                int(_ln_link.act), L.ptr(gin), L.ptr(partials), prows, L.stream()), 'sparse_conv_sorted_lnbwd'))
+            _ln_link.fused, _ln_link.partials, _ln_link.rows = True, partials, prows
+            _ln_link.expect = (gin.data_ptr(), gin._version)
             return gin, filters_bp
         gin = _gather_gemm(dy, wn, table, mask, rows, None, out_dtype, rb if mode in (1, 5) else None)
         input_bp = gin if nc == cin else gin[:, :cin].contiguous()

@@ -174,3 +174,50 @@ def test_density_selects_the_order(dev):
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
         ops.DEFAULT_PAIRS_PER_ROW = keep
+
+
+@pytest.mark.parametrize('static', [False, True])
+def test_layernorm_backward_in_the_pattern_order_dgrad(dev, static):
+    """ococc_sparse_conv_sorted_lnbwd_bf16: the LayerNorm (+ GELU) backward of block L in the epilogue of block L+1's
+    input-gradient pass, on the neighbour-pattern-order kernel (128 -> 64 and 64 -> 32 gathered -> written channels, the
+    two LNB shapes of the configs[1] encoder).  Against (a) the same pass with the separate LN-backward launches and (b)
+    the tile kernel's LNB epilogue: the gradients of the conv outputs are bit-identical in all three, hence the conv
+    weight gradients; d gamma / d beta are sums of the same terms grouped by other workgroups (tolerance).  The oracle
+    comparison of this kernel is test_occupancy_encoder_vs_oracle_restatement[sorted-*] / [bench-*]."""
+    from objectcentricocccompletion_amd.occ_encoder import SubMOccEncoder, synthetic_object_grids
+    from objectcentricocccompletion_amd.spconv import ops
+    torch.manual_seed(0)
+    enc = SubMOccEncoder(grouped_points=True).to(dev).train()
+    xyz, feats, bidx = synthetic_object_grids(6, 1500, seed=3, device=dev)
+    keep = ops.FUSE_LN_BACKWARD, ops._TILE_SHAPES, ops.DEFAULT_PAIRS_PER_ROW
+    grads, outs, ran = {}, {}, {}
+    # forward kernels identical in all three runs (tile kernel with LN epilogue for 32 -> 64: it leaves the link);
+    # 'sorted': no tile kernel for the two dgrad shapes, so they run in pattern order
+    fwd_only = {(32, 64): 2.0}
+    for mode, fused, shapes in (('unfused', False, fwd_only), ('sorted', True, fwd_only), ('tile', True, dict(keep[1]))):
+        ops.FUSE_LN_BACKWARD, ops._TILE_SHAPES, ops.DEFAULT_PAIRS_PER_ROW = fused, shapes, 1.755
+        before = dict(ops.launches)
+        try:
+            for p in enc.parameters():
+                p.grad = None
+            out = enc(xyz, feats, bidx, 6, static=static)
+            f = out.features.float()
+            gen = torch.Generator(device=dev).manual_seed(5)
+            (f * torch.randn(f.shape, generator=gen, device=dev)).sum().backward()
+            outs[mode] = f.detach().clone()
+            grads[mode] = {k: p.grad.detach().clone() for k, p in enc.named_parameters()}
+        finally:
+            ops.FUSE_LN_BACKWARD, ops._TILE_SHAPES, ops.DEFAULT_PAIRS_PER_ROW = keep
+        ran[mode] = {k: v - before.get(k, 0) for k, v in ops.launches.items() if v - before.get(k, 0)}
+    assert ran['sorted'].get('sorted_lnbwd') == 2 and 'tile_lnbwd' not in ran['sorted'], ran
+    assert ran['tile'].get('tile_lnbwd') == 2 and 'sorted_lnbwd' not in ran['tile'], ran
+    assert 'sorted_lnbwd' not in ran['unfused'] and ran['unfused'].get('sorted', 0) >= 3, ran
+    for mode in ('sorted', 'tile'):
+        assert torch.equal(outs['unfused'], outs[mode])
+        for k in grads['unfused']:
+            a, b = grads['unfused'][k], grads[mode][k]
+            assert bool(torch.isfinite(b).all()), (mode, k)
+            if k.endswith('0.weight'):           # conv weights: same d conv_out rows -> the same contraction
+                assert torch.equal(a, b), (mode, k)
+            else:                                # LayerNorm gamma / beta
+                assert float((a - b).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6), (mode, k)
