@@ -41,6 +41,10 @@ __device__ long long* s_stamps = nullptr;
 #endif
 
 constexpr int kSortThreads = 256;
+#ifndef OCOCC_SORTED_LIGHT_BLOCKS
+#define OCOCC_SORTED_LIGHT_BLOCKS 16
+#endif
+constexpr int kLightBlocks = OCOCC_SORTED_LIGHT_BLOCKS;   // 16-row blocks per tile of the rows with at most one neighbour
 constexpr int kOrderRowsPerWg = 512;
 
 // rowrec[r] = {bucket | place in the bucket << 11, offset mask, table entry at the lowest neighbour offset, at the
@@ -200,7 +204,7 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   const bool split = kCanSplit && hb == NWAVES && t_heavy1 * 4 <= (int)gridDim.x;
   const int t_heavy = split ? 2 * t_heavy1 : t_heavy1;            // tiles of the many-neighbour class (halves count)
   const int t_mid = t_heavy + (o.b_mid - o.b_heavy + mb - 1) / mb;
-  const int tiles = __builtin_amdgcn_readfirstlane(t_mid + (o.b_total - o.b_mid + 15) / 16);
+  const int tiles = __builtin_amdgcn_readfirstlane(t_mid + (o.b_total - o.b_mid + kLightBlocks - 1) / kLightBlocks);
 
   i32x4 frs;  // raw buffer descriptor: base, stride 0, size in bytes, 32-bit data format
   frs.x = (int)(uint32_t)(uintptr_t)feat;
@@ -237,8 +241,8 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
       blk0 = o.b_heavy + (t - t_heavy) * mb;
       bpw = mb / NWAVES;
     } else {
-      blk0 = o.b_mid + (t - t_mid) * 16;
-      bpw = 16 / NWAVES;
+      blk0 = o.b_mid + (t - t_mid) * kLightBlocks;
+      bpw = kLightBlocks / NWAVES;
     }
     const int blk_end = t < t_heavy ? o.b_heavy : (t < t_mid ? o.b_mid : o.b_total);
     SSTAMP(t, 0);
