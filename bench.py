@@ -215,6 +215,10 @@ def bench_ococcnet(args, world, rank, dev):
     if world > 1:
         dist.barrier()
     decoder.forward = timed_forward
+    # (the decoder's own kernels -- the one-launch forward and the one-launch backward with recompute -- bracketed one by one)
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    kprobe = BlockProbe()
+    fm.set_probe(kprobe)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -224,6 +228,7 @@ def bench_ococcnet(args, world, rank, dev):
         dist.barrier()
     dt = time.perf_counter() - t0
     decoder.forward = real_forward
+    fm.set_probe(None)
     dump_params(args, rank, params)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -250,13 +255,19 @@ def bench_ococcnet(args, world, rank, dev):
             'roofline': {'kernel': 'OccDecoder forward (MLP 60|1536 -> 512 -> 1024 -> 1024 -> 1 over all query points: '
                                    + ('library f32 GEMMs + LN/GELU kernels)' if args.f32_decoder else
                                       'positional encoding, weight fragments, per-RoI GEMM and the one-launch bf16 MLP kernel in its '
-                                      'training instantiation, which also writes z / row statistics / y of every layer -- 10 KB '
-                                      'per query row)' if occ_base_fused_train() else 'library bf16 GEMMs + fused LN/GELU kernels)'),
+                                      'training instantiation' + (': keeps nothing but the logits, the backward recomputes)'
+                                                                  if fm.RECOMPUTE_BACKWARD else
+                                                                  ', which also writes z / row statistics / y of every layer -- 10 KB '
+                                                                  'per query row)') if occ_base_fused_train()
+                                      else 'library bf16 GEMMs + fused LN/GELU kernels)'),
                          'bound': 'mfma', 'achieved': round(flops / (dec_ms * 1e-3) / 1e12, 2) if dec_ms else None,
                          'peak': peak, 'unit': 'TFLOP/s',
                          'frac': round(flops / (dec_ms * 1e-3) / 1e12 / peak, 4) if dec_ms else None, 'traffic': None,
                          'algorithmic_flops_per_launch': flops, 'avg_launch_ms': round(dec_ms, 4),
-                         'launches_timed': len(dec_events), 'query_points': queries, 'rois': rois},
+                         'launches_timed': len(dec_events), 'query_points': queries, 'rois': rois,
+                         # per own kernel: the forward launch alone, and the backward launch (forward again + two
+                         # input-gradient GEMMs per tile: 2 x (60 x 512 + 2 x 512 x 1024 + 2 x 1024 x 1024) flop per query)
+                         'per_kernel': {k: dict(v, frac=round(v['tflops'] / peak, 4)) for k, v in probe_summary(kprobe)[2].items()}},
             'cpu_baseline': None}
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline_ococcnet(L)

@@ -820,6 +820,34 @@ int ococc_occ_mlp_train_fwd_bf16(const uint16_t* pe, int64_t rows, const float* 
                                  float eps, const float* head_weight, const float* head_bias, uint32_t drop_threshold,
                                  const uint64_t* dropout_seeds, void* const* z_out, void* const* y_out,
                                  void* const* stats_out, float* out, ococc_stream_t stream);
+/* (z_out, y_out and stats_out may be null, all three: the forward of the recomputing backward below -- the same numbers,
+ * nothing kept but the logits.)
+ *
+ * The BACKWARD pass of that forward in one launch, with recompute -- replaces what autograd derives for
+ * OccDecoder.forward's conv_occ (mmdet3d/models/occ/occ_base.py:99-153; the Sequential(Linear, LN, GELU, Dropout) blocks
+ * of mmdet3d/ops/sst/sst_ops.py:333-360): per 64-row tile the three layers are run forward again from the positional
+ * encodings (same numbers as the training forward), then d logit is taken back through the head, the three
+ * LayerNorm / GELU / dropout backward steps and the two input-gradient GEMMs (w_t_frag: fragments of W1^T [512, 1024] and
+ * W2^T [1024, 1024], ococc_linear_fragments32_bf16 on the transposed views; a third entry is ignored).  Leaves what the
+ * weight gradients contract over the rows -- y_out[0] = y0 [rows, 512], y_out[1] = y1 [rows, 1024], dz_out[l] = d z_l
+ * (bf16; d z_0 is also the gradient of the gathered per-RoI rows add_rows[add_index]) -- and per workgroup the sums
+ * [d gamma_0 | d beta_0 | d gamma_1 | d beta_1 | d gamma_2 | d beta_2 | d head_weight] in partials
+ * [ococc_occ_mlp_bwd_workgroups(rows)][ococc_occ_mlp_bwd_partial_cols()] f32, which must be ZERO on entry (a column sum
+ * finishes them).  scratch: ococc_occ_mlp_bwd_scratch_bytes(rows), 16-byte aligned, contents unspecified.
+ *
+ * Without recompute: z_parked[l] / stats[l] non-null -- what ococc_occ_mlp_train_fwd_bf16 left when its y_out[2] was null
+ * (z_out[l] then hold the LayerNorm inputs in the kernel's own per-tile lane order, bf16 [ceil(rows / 64) * 64, n_l]
+ * elements; y_out[0], y_out[1] row-major as always; y2 is not kept).  The kernel then starts at d logit: pe, add_rows,
+ * add_index, w_frag, y_out and scratch are ignored. */
+int ococc_occ_mlp_bwd_bf16(const uint16_t* pe, int64_t rows, const float* add_rows, const int32_t* add_index,
+                           const void* const* w_frag, const void* const* w_t_frag, const void* const* ln_weight,
+                           const void* const* ln_bias, float eps, const float* head_weight, const float* dlogit,
+                           uint32_t drop_threshold, const uint64_t* dropout_seeds, const void* const* z_parked,
+                           const void* const* stats, void* const* y_out, void* const* dz_out, float* partials,
+                           void* scratch, int64_t scratch_bytes, ococc_stream_t stream);
+int64_t ococc_occ_mlp_bwd_workgroups(int64_t rows);
+int64_t ococc_occ_mlp_bwd_partial_cols(void);
+int64_t ococc_occ_mlp_bwd_scratch_bytes(int64_t rows);
 
 /* ------------------------------------------------------------------------
  * B6, element-wise halves of the SST input layer, one launch each (the mirror ran 20-50 torch operators per call):

@@ -163,6 +163,13 @@ SIGNATURES = {
                                              ctypes.POINTER(c_vp), c_f32, c_vp, c_vp, ctypes.c_uint32,
                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                              ctypes.POINTER(c_vp), c_vp, c_vp]),
+    'ococc_occ_mlp_bwd_workgroups': (c_i64, [c_i64]),
+    'ococc_occ_mlp_bwd_partial_cols': (c_i64, []),
+    'ococc_occ_mlp_bwd_scratch_bytes': (c_i64, [c_i64]),
+    'ococc_occ_mlp_bwd_bf16': (c_i32, [c_vp, c_i64, c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                       ctypes.POINTER(c_vp), c_f32, c_vp, c_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                       c_vp, c_vp, c_i64, c_vp]),
     'ococc_sst_window_coors_i64': (c_i32, [c_vp, c_i64, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp, c_vp, c_vp]),
     'ococc_sst_drop_level_i64': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                          ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_vp, c_vp, c_vp]),

@@ -169,6 +169,117 @@ def wgrad_rows_bf16(dz, y, slices=32):
     return out
 
 
+# Three realisations of the backward pass (BACKWARD_MODE / OCOCC_DECODER_BACKWARD), the same numbers in all of them (z
+# rounded to bf16 in front of every LayerNorm, bf16 d y between the layers, dropout masks from (threshold, seed)):
+#   'chain' (default)  the forward leaves z / statistics / y of every layer row-major (10 KB per query row); the backward is
+#                      the operator chain of _OccMlpTrain: own LayerNorm-backward kernels, library GEMMs for dX and dW.
+#   'fused'            the forward parks z in the backward kernel's own lane order (+ statistics, y0, y1: 8 KB per row);
+#                      the backward is ONE launch from d logit to d z0 (ococc_occ_mlp_bwd_bf16) + the weight gradients.
+#   'recompute'        the forward keeps nothing but the logits; the one-launch backward runs the three layers forward
+#                      again per 64-row tile.  Saves 10 KB of HBM per query row (10.7 GB at 64 tracklets).
+# Measured on MI355X at 1 M query rows, dropout 0.1 (tools/probe/decoder_train_bench.py; tools/ab_decoder.sh inside the
+# configs[2] step): forward + backward 18.7 ms chain / 19.9 ms fused / 23.3 ms recompute; step at 64 tracklets 56.5 / 61.1
+# / 61.7 ms.  Why the one-launch forms lose although they move a fifth of the bytes: a workgroup that owns 64 rows and ALL
+# channels streams the layer's whole weight matrix from L2 per 64 rows (the forward's design point, L2-bound at 0.28-0.36
+# of the bf16 peak), while the library's 256 x 256 macro-tiles run the two input-gradient GEMMs at 1.3 PFLOP/s (0.52 of
+# peak, 3.3 ms for both) -- and at 8 TB/s the activations' round trip through HBM that the fusion saves costs less than
+# that difference; recompute adds the forward's 3.2 MFLOP per row on top.  The chain therefore stays the default; the
+# one-launch kernel is the memory-saving option.  (EXPERIMENTS.md.)
+RECOMPUTE_BACKWARD = True   # (kept for callers of round 5's first revision: False forces 'chain')
+BACKWARD_MODE = os.environ.get('OCOCC_DECODER_BACKWARD', 'chain')
+
+
+class _OccMlpTrainRecompute(torch.autograd.Function):
+    """Same contract and the same numbers as _OccMlpTrain (z rounded to bf16 in front of every LayerNorm, bf16 operands,
+    f32 accumulation, dropout masks from (threshold, seed)); the backward is ONE launch (+ the weight-gradient
+    contractions), in BACKWARD_MODE 'fused' on what the forward parked, in 'recompute' on nothing but the inputs."""
+
+    @staticmethod
+    def forward(ctx, pe, roi_part, idx, w_pe, w1, w2, g0, b0, g1, b1, g2, b2, head_w, head_b, eps, drop_threshold, seeds,
+                cache):
+        M, dev = pe.size(0), pe.device
+        frags = cache.get([w_pe, w1, w2], [pe.shape[1], w1.shape[1], w2.shape[1]])
+        f32 = lambda t: t.detach().float().contiguous()
+        gs, bs = [f32(g0), f32(g1), f32(g2)], [f32(b0), f32(b1), f32(b2)]
+        add = f32(roi_part)
+        hw, hb = f32(head_w).view(-1), f32(head_b).view(-1)
+        out = torch.empty((M,), dtype=torch.float32, device=dev)
+        sd = (ctypes.c_uint64 * 3)(*[int(v) for v in seeds]) if drop_threshold else None
+        flops = 2.0 * M * sum(OCC_MLP_WIDTHS[i + 1] * OCC_MLP_WIDTHS[i] for i in range(3))
+        recompute = BACKWARD_MODE == 'recompute'
+        kept = []
+        if recompute:
+            zv = yv = sv = None
+        else:   # z parked in whole 64-row tiles, the statistics, y0 / y1 (the weight gradients' operands)
+            Mt = (M + 63) // 64 * 64
+            zs = [torch.empty((Mt, n), dtype=torch.bfloat16, device=dev) for n in OCC_MLP_WIDTHS[1:]]
+            ys = [torch.empty((M, n), dtype=torch.bfloat16, device=dev) for n in OCC_MLP_WIDTHS[1:3]]
+            stats = [torch.empty((M, 2), dtype=torch.float32, device=dev) for _ in range(3)]
+            zv, yv, sv = _vp([z.data_ptr() for z in zs]), _vp([y.data_ptr() for y in ys] + [0]), _vp([t.data_ptr() for t in stats])
+            kept = zs + ys + stats
+        _run('occ_mlp_fwd_kernel (training)', flops, lambda: L.check(L.lib.ococc_occ_mlp_train_fwd_bf16(
+            L.ptr(pe), M, L.ptr(add), L.ptr(idx), _vp([w.data_ptr() for w in frags]), _vp([g.data_ptr() for g in gs]),
+            _vp([b.data_ptr() for b in bs]), float(eps), L.ptr(hw), L.ptr(hb), int(drop_threshold), sd,
+            zv, yv, sv, L.ptr(out), L.stream()), 'occ_mlp_train_fwd'))
+        ctx.save_for_backward(pe, idx, add, w_pe, w1, w2, head_w, *gs, *bs, *kept)
+        ctx.ln_params = ((g0, b0), (g1, b1), (g2, b2))
+        ctx.misc = (float(eps), int(drop_threshold), tuple(int(v) for v in seeds), roi_part.size(0), cache, frags, recompute)
+        return out.view(M, 1)
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        from ..linear import sliced_wgrad
+        t = ctx.saved_tensors
+        pe, idx, add, w_pe, w1, w2, head_w = t[:7]
+        gs, bs = t[7:10], t[10:13]
+        eps, thr, seeds, K, cache, frags, recompute = ctx.misc
+        M, dev = pe.size(0), pe.device
+        bf = torch.bfloat16
+        if not hasattr(cache, 'transposed'):
+            cache.transposed = DecoderWeights()
+        frags = cache.get([w_pe, w1, w2], [pe.shape[1], w1.shape[1], w2.shape[1]])   # (unchanged parameters: the forward's)
+        frags_t = cache.transposed.get([w1.t(), w2.t()], [w1.shape[0], w2.shape[0]])
+        n0, n1, n2 = OCC_MLP_WIDTHS[1:]
+        if recompute:
+            y0, y1 = torch.empty((M, n0), dtype=bf, device=dev), torch.empty((M, n1), dtype=bf, device=dev)
+            scratch = L.workspace(int(L.lib.ococc_occ_mlp_bwd_scratch_bytes(M)), dev)
+            zv = sv = None
+        else:
+            zs, (y0, y1), stats = t[13:16], t[16:18], t[18:21]
+            scratch = None
+            zv, sv = _vp([z.data_ptr() for z in zs]), _vp([x.data_ptr() for x in stats])
+        dz0, dz1, dz2 = (torch.empty((M, n), dtype=bf, device=dev) for n in (n0, n1, n2))
+        wgs, cols = int(L.lib.ococc_occ_mlp_bwd_workgroups(M)), int(L.lib.ococc_occ_mlp_bwd_partial_cols())
+        partials = torch.zeros((wgs, cols), dtype=torch.float32, device=dev)
+        d = dlogit.reshape(M).float().contiguous()
+        hw = head_w.detach().float().contiguous().view(-1)
+        sd = (ctypes.c_uint64 * 3)(*[int(v) for v in seeds]) if thr else None
+        flops = 2.0 * M * ((sum(OCC_MLP_WIDTHS[i + 1] * OCC_MLP_WIDTHS[i] for i in range(3)) if recompute else 0) + n2 * n1 + n1 * n0)
+        _run('occ_mlp_bwd_kernel' + (' (recompute)' if recompute else ''), flops, lambda: L.check(L.lib.ococc_occ_mlp_bwd_bf16(
+            L.ptr(pe), M, L.ptr(add), L.ptr(idx), _vp([w.data_ptr() for w in frags]), _vp([w.data_ptr() for w in frags_t] + [0]),
+            _vp([g.data_ptr() for g in gs]), _vp([b.data_ptr() for b in bs]), float(eps), L.ptr(hw), L.ptr(d), int(thr), sd,
+            zv, sv, _vp([y0.data_ptr(), y1.data_ptr(), 0]), _vp([dz0.data_ptr(), dz1.data_ptr(), dz2.data_ptr()]),
+            L.ptr(partials), L.ptr(scratch), scratch.numel() if scratch is not None else 0, L.stream()), 'occ_mlp_bwd'))
+        sums = partials.sum(0)
+        off, grads_ln = 0, []
+        for l, n in enumerate((n0, n1, n2)):
+            lw, lb = ctx.ln_params[l]
+            grads_ln += [sums[off:off + n].to(lw.dtype), sums[off + n:off + 2 * n].to(lb.dtype)]
+            off += 2 * n
+        d_head_w = sums[off:off + n2].view(1, n2).to(head_w.dtype)
+        d_head_b = dlogit.sum().reshape(1)
+        # weight gradients: contractions over the rows of what the kernel left
+        dw2 = wgrad_rows_bf16(dz2, y1).to(w2.dtype)
+        dw1 = wgrad_rows_bf16(dz1, y0).to(w1.dtype)
+        dz0f = dz0.float()
+        dw0 = sliced_wgrad(dz0f, pe[:, :w_pe.shape[1]].float()).to(w_pe.dtype)
+        d_roi = torch.empty((K, n0), dtype=torch.float32, device=dev)
+        L.check(L.lib.ococc_segment_reduce_f32(L.ptr(dz0f), L.ptr(idx), M, n0, 0, None, L.ptr(d_roi), None, K, L.stream()),
+                'occ_mlp_train_bwd: roi_part')
+        return (None, d_roi, None, dw0, dw1, dw2, grads_ln[0], grads_ln[1], grads_ln[2], grads_ln[3], grads_ln[4],
+                grads_ln[5], d_head_w, d_head_b, None, None, None, None)
+
+
 class _OccMlpTrain(torch.autograd.Function):
 
     @staticmethod
@@ -242,5 +353,6 @@ class _OccMlpTrain(torch.autograd.Function):
 def occ_mlp_train(pe, roi_part, idx, w_pe, w1, w2, ln_weights, ln_biases, eps, head_w, head_b, drop_threshold, seeds, cache):
     """logits f32 [M, 1] with a backward pass; see _OccMlpTrain."""
     assert pe.dtype == torch.bfloat16 and pe.shape[1] == OCC_MLP_WIDTHS[0] and idx.dtype == torch.int32
-    return _OccMlpTrain.apply(pe, roi_part, idx, w_pe, w1, w2, ln_weights[0], ln_biases[0], ln_weights[1], ln_biases[1],
-                              ln_weights[2], ln_biases[2], head_w, head_b, eps, drop_threshold, seeds, cache)
+    fn = _OccMlpTrain if (BACKWARD_MODE == 'chain' or not RECOMPUTE_BACKWARD) else _OccMlpTrainRecompute
+    return fn.apply(pe, roi_part, idx, w_pe, w1, w2, ln_weights[0], ln_biases[0], ln_weights[1], ln_biases[1],
+                    ln_weights[2], ln_biases[2], head_w, head_b, eps, drop_threshold, seeds, cache)

@@ -264,7 +264,7 @@ def test_fused_decoder_training_step(dev, golden_dir, dropout, monkeypatch):
             fm.set_probe(None)
             monkeypatch.setattr(torch, 'randint', real_randint)
         runs.append((out.detach().float(), f.grad.clone(), {k: v.grad.clone() for k, v in dec.named_parameters()}))
-    assert calls == ['occ_mlp_fwd_kernel (training)']
+    assert calls == ['occ_mlp_fwd_kernel (training)']   # (default backward mode: the operator chain; the one-launch modes: below)
     a, b = runs[0], runs[1]
     rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp(min=1e-30))
     # (the operator path runs the first layer's GEMM in f32 and rounds z to bf16 afterwards; here its operands are bf16)
@@ -282,3 +282,55 @@ def test_fused_decoder_training_step(dev, golden_dir, dropout, monkeypatch):
         for k in a[2]:
             ea, eb = rel(a[2][k], c[2][k]), rel(b[2][k], c[2][k])
             assert ea < 1.5 * eb + 2e-3, (k, ea, eb)
+
+
+@pytest.mark.parametrize('mode', ['fused', 'recompute'])
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+@pytest.mark.parametrize('rows_per_roi', [512, 37])
+def test_decoder_backward_in_one_launch_equals_the_stored_activation_chain(dev, golden_dir, dropout, rows_per_roi, mode, monkeypatch):
+    """ococc_occ_mlp_bwd_bf16 -- one launch, 'fused': from the z the forward parked; 'recompute': forward again per 64-row
+    tile, nothing saved by the forward -- against the backward it replaces: the forward leaves z / statistics / y of every
+    layer row-major and the operator chain (LayerNorm-backward kernels, library GEMMs) walks back through them.  Same
+    numbers by construction (z rounded to bf16 in front of every LayerNorm, bf16 d y between the layers, the same dropout
+    masks): logits bit-identical, gradients equal up to the order of the f32 sums (measured below: <= 4e-4; asserted at
+    1e-3 norm-wise -- north_star's bar -- except d head_w, 2e-3: the CHAIN rounds it to bf16 below 16 k rows, the kernel
+    keeps f32).  rows_per_roi = 37: a row count that is no multiple of the 64-row tile."""
+    from objectcentricocccompletion_amd.occ import fused_mlp as fm
+    from objectcentricocccompletion_amd.occ.occ_base import OccDecoder
+    gold = np.load(os.path.join(golden_dir, 'ococc_head.npz'))
+    P = decoder_params()
+    feats = torch.from_numpy(gold['out_fused_roi_feats']).to(dev)
+    xyz = torch.from_numpy(gold['dec_xyz'])[:, :rows_per_roi].contiguous()
+    R, K, _ = xyz.shape
+    idx = torch.arange(R).repeat_interleave(K).to(dev)
+    xyz = xyz.reshape(-1, 3).to(dev)
+    g = torch.Generator().manual_seed(5)
+    dl = torch.randn(R * K, 1, generator=g).to(dev)
+    real_randint = torch.randint
+
+    def fixed_randint(*a, **k):
+        return torch.full_like(real_randint(*a, **k), 12345)
+
+    runs = []
+    for how in (mode, 'chain'):
+        dec = OccDecoder(1536, [512, 1024, 1024], pos_encode_L=10, norm_cfg=dict(type='LN', eps=1e-3), act='gelu',
+                         occ_dropout=dropout, use_ln=True)
+        dec.load_state_dict({k[len(PREFIX):]: v for k, v in P.items()})
+        dec = dec.to(dev).train()
+        dec.compute_dtype = torch.bfloat16
+        monkeypatch.setattr(fm, 'BACKWARD_MODE', how)
+        monkeypatch.setattr(torch, 'randint', fixed_randint)
+        try:
+            f = feats.clone().requires_grad_(True)
+            out = dec(f, xyz, idx)
+            out.backward(dl)
+        finally:
+            monkeypatch.setattr(torch, 'randint', real_randint)
+        runs.append((out.detach().float(), f.grad.clone(), {k: v.grad.clone() for k, v in dec.named_parameters()}))
+    a, b = runs
+    assert torch.equal(a[0], b[0])
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm().clamp(min=1e-30))
+    errs = {'d roi feats': rel(a[1], b[1]), **{k: rel(a[2][k], b[2][k]) for k in a[2]}}
+    print(f'{mode} backward vs the operator chain (norm-wise):', {k: f'{v:.2e}' for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < (2e-3 if k == 'conv_occ.3.weight' else 1e-3), (k, v)
