@@ -17,7 +17,15 @@ CPU restatement, in float64, of one SST encoder layer and of the window partitio
   'core'   q, k, v, P and the attention output: the reference-shaped f32 block of the product, whose attention core
            (csrc/window_attn.hip) works on bf16 operands;
   'bf16'   every value the fused kernels of csrc/window_block.hip store: x + pos, the weights, q, k, v, P, the attention
-           output, y1, act(h), y2, and in the backward every gradient that is an MFMA operand or leaves a kernel.
+           output, y1, act(h), y2, and in the backward every gradient that is an MFMA operand or leaves a kernel;
+  'ops'    the bf16 layer run operator by operator (layer_cfg compute_dtype=bf16 on a layer the fused kernels do not
+           cover, e.g. the cosine variant): every operator's output is a bf16 tensor -- the projections after a
+           bf16-rounded bias, the residual sums, both LayerNorm outputs, the hidden activation before and after the
+           non-linearity, the second linear's output.
+``cosine=(tau, tau_min)`` selects scaled cosine attention (CosineMultiheadAttention, mmdet3d/models/sst/cosine_msa.py:
+123-185,449-466): per-head unit vectors, logits cos / clamp(tau, tau_min); tau a scalar or one value per head.  The product
+hands the attention core q^ sqrt(d) / tau and k^ (its fixed 1 / sqrt(d) scale leaves cos / tau), rounded to bf16 where the
+core reads bf16 ('core', 'ops').
 Sums (GEMM accumulators, softmax, LayerNorm statistics, residual adds) are float64 here and float32 in the kernels.
 """
 import math
@@ -108,21 +116,31 @@ def _params(P, rounding, detach=True):
                 b2=f('linear2.bias'), g1=f('norm1.weight'), be1=f('norm1.bias'), g2=f('norm2.weight'), be2=f('norm2.bias'))
 
 
-def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e-5, keep=False, detach=True, ops_rows=None):
+def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e-5, keep=False, detach=True, ops_rows=None,
+                  cosine=None):
     """x, pos [V, E]; win [V] window id of every token -> y2 [V, E] float64 (and the intermediates when keep).
     ``ops_rows`` (bool [V], with rounding='bf16'): rows whose attention block runs operator by operator in the product
     (windows of more than 64 tokens: bf16 library GEMMs with bf16 biases, the per-window attention kernels, a bf16
     residual sum, a stand-alone LayerNorm) -- the forward of those rows gets that path's store points: projections
     rounded after a bf16-rounded bias, the out-projection and the residual sum rounded before the norm."""
+    ops = rounding == 'ops'
+    if ops:   # the whole layer operator by operator: the 'bf16' store points + those of ops_rows on every row + the FFN's
+        rounding = 'bf16'
+        ops_rows = torch.ones(x.shape[0], dtype=torch.bool)
     rq = r16 if rounding in ('core', 'bf16') else (lambda t: t)      # operands of the attention core
     ra = r16 if rounding == 'bf16' else (lambda t: t)                # everything else the fused kernels store
+    ro = r16 if ops else (lambda t: t)                               # operator outputs of the bf16 operator path
     p = _params(P, rounding, detach)   # detach=False: the parameters stay on the autograd tape (tests)
     x, pos = x.to(F64), pos.to(F64)
+    if ops:
+        x, pos = r16(x), r16(pos)
     V, E = x.shape
     D = E // num_heads
     xp = ra(x + pos)
-    q = rq(xp @ p['wqkv'][:E].t() + p['bqkv'][:E])
-    k = rq(xp @ p['wqkv'][E:2 * E].t() + p['bqkv'][E:2 * E])
+    # (cosine attention in the f32 block: q and k are normalised in f32 and only then rounded for the core)
+    rqk = (lambda t: t) if (cosine is not None and not ops) else rq
+    q = rqk(xp @ p['wqkv'][:E].t() + p['bqkv'][:E])
+    k = rqk(xp @ p['wqkv'][E:2 * E].t() + p['bqkv'][E:2 * E])
     v = rq(x @ p['wqkv'][2 * E:].t() + p['bqkv'][2 * E:])
     if ops_rows is not None:
         sel = ops_rows[:, None]
@@ -130,6 +148,12 @@ def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e
         q = torch.where(sel, r16(xp @ p['wqkv'][:E].t() + b16[:E]), q)
         k = torch.where(sel, r16(xp @ p['wqkv'][E:2 * E].t() + b16[E:2 * E]), k)
         v = torch.where(sel, r16(x @ p['wqkv'][2 * E:].t() + b16[2 * E:]), v)
+    if cosine is not None:
+        tau, tau_min = cosine
+        tau = torch.as_tensor(tau, dtype=F64).reshape(-1).clamp(min=tau_min)          # [1] or [H]
+        unit = lambda t: t.view(V, num_heads, D) / t.view(V, num_heads, D).norm(dim=-1, keepdim=True).clamp(min=1e-12)
+        q = rq((unit(q) * (float(D) ** 0.5 / tau.view(1, -1, 1))).reshape(V, E))
+        k = rq(unit(k).reshape(V, E))
     idx = _windows(win)
     nW, T = idx.shape
     valid = idx >= 0
@@ -148,9 +172,9 @@ def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e
     y1f, xh1, rstd1 = _ln(z1, p['g1'], p['be1'], eps)
     y1 = ra(y1f)
     fa, fg = _act(act)
-    h = y1 @ p['w1'].t() + p['b1']
+    h = ro(y1 @ p['w1'].t() + (r16(p['b1']) if ops else p['b1']))
     a = ra(fa(h))
-    z2 = a @ p['w2'].t() + p['b2'] + y1
+    z2 = ro(ro(a @ p['w2'].t() + (r16(p['b2']) if ops else p['b2'])) + y1)
     y2f, xh2, rstd2 = _ln(z2, p['g2'], p['be2'], eps)
     y2 = ra(y2f)
     if not keep:
@@ -205,7 +229,8 @@ def encoder_layer_backward(dy2, c):
             'linear2.bias': g_b2, 'norm1.weight': g_n1, 'norm1.bias': b_n1, 'norm2.weight': g_n2, 'norm2.bias': b_n2}
 
 
-def sst_blocks(feats, coors, sd, sparse_shape, window_shape, num_blocks=2, num_heads=8, rounding=None, act='gelu'):
+def sst_blocks(feats, coors, sd, sparse_shape, window_shape, num_blocks=2, num_heads=8, rounding=None, act='gelu',
+               ops_windows_above=None):
     """SSTv2 without the attached convolutions (to_bev=False): blocks of two encoder layers, the second of each on the
     shifted windows (BasicShiftBlockV2, sst_basic_block_v2.py:130-169; SSTv2.forward, backbones/sst_v2.py:115-154).
     sd: state dict with the module's names (block_list.{i}.encoder_list.{j}....).  No voxel may be dropped."""
@@ -214,11 +239,18 @@ def sst_blocks(feats, coors, sd, sparse_shape, window_shape, num_blocks=2, num_h
     poss = [pos_embed(w[1], window_shape, feats.shape[1]).to(F64) for w in wins]
     if rounding == 'bf16':
         out, poss = r16(out), [r16(t) for t in poss]
+    # ops_windows_above (with rounding='bf16'): the rows of windows with more tokens than this run operator by operator in
+    # the product (64: the fused kernels' tile) -- see encoder_layer(ops_rows=)
+    big = [None, None]
+    if ops_windows_above is not None:
+        for j in range(2):
+            _, inv, cnt = torch.unique(wins[j][0], return_inverse=True, return_counts=True)
+            big[j] = cnt[inv] > ops_windows_above
     for b in range(num_blocks):
         for j in range(2):
             pre = f'block_list.{b}.encoder_list.{j}.'
             P = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
-            out = encoder_layer(out, poss[j], wins[j][0], P, num_heads, rounding, act)
+            out = encoder_layer(out, poss[j], wins[j][0], P, num_heads, rounding, act, ops_rows=big[j])
     return out
 
 

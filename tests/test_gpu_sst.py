@@ -122,6 +122,40 @@ def test_window_attention_core_vs_torch(dev):
     print(f'window attention core vs the rounded oracle: worst norm-wise error {worst:.2e}')
 
 
+def _layer_errors(model, info, feats, coors, rounding, ops_windows_above=None):
+    """norm-wise error of every encoder layer of a 2-block SSTv2 against oracle/sst_ref.py with the given store points, each
+    layer on the PRODUCT's own input (what one layer deviates -- without the flips of bf16 values the layers in front hand
+    on, which every later layer amplifies), and of the whole stack end to end"""
+    from oracle import sst_ref
+    sdc = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    per_layer, cur = [], feats
+    with torch.no_grad():
+        for b in range(2):
+            for j in range(2):
+                nxt = model.block_list[b].encoder_list[j](cur, info[f'pos_dict_shift{j}'], info[f'flat2win_inds_shift{j}'],
+                                                          info[f'key_mask_shift{j}'])
+                wj, cj = sst_ref.window_ids(coors.cpu(), SPARSE, WINDOW, j == 1)
+                pos = sst_ref.pos_embed(cj, WINDOW, 128)
+                big = None
+                if ops_windows_above is not None:
+                    _, inv, cnt = torch.unique(wj, return_inverse=True, return_counts=True)
+                    big = cnt[inv] > ops_windows_above
+                pre = f'block_list.{b}.encoder_list.{j}.'
+                x_in = cur.float().cpu()
+                if rounding == 'bf16':   # (the bf16 path's residual stream and positional embedding are bf16 tensors)
+                    x_in, pos = x_in.bfloat16().float(), pos.bfloat16().float()
+                exp = sst_ref.encoder_layer(x_in, pos, wj, {k[len(pre):]: v for k, v in sdc.items() if k.startswith(pre)},
+                                            rounding=rounding, ops_rows=big)
+                per_layer.append(float((nxt.float().cpu().double() - exp).norm() / exp.norm()))
+                if big is not None and bool(big.any()):
+                    d = nxt.float().cpu().double() - exp
+                    print(f'  layer {b}.{j}: rows of windows above {ops_windows_above} tokens ({int(big.sum())} of {len(big)}) '
+                          f'{float(d[big].norm() / exp[big].norm()):.2e}, other rows {float(d[~big].norm() / exp[~big].norm()):.2e}')
+                cur = nxt
+    whole = sst_ref.sst_blocks(feats.cpu(), coors.cpu(), sdc, SPARSE, WINDOW, rounding=rounding, ops_windows_above=ops_windows_above)
+    return per_layer, float((cur.float().cpu().double() - whole).norm() / whole.norm())
+
+
 def test_sst_backbone_vs_reference_golden(dev, gold):
     from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2, SSTv2
     layer = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=False, mute=True).eval()
@@ -139,8 +173,24 @@ def test_sst_backbone_vs_reference_golden(dev, gold):
                                                   info['key_mask_shift0'])
         out = model(info)[0]['voxel_feats']
     rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
-    assert rel(one.cpu().numpy(), gold['one_layer']) < 2e-2      # bf16 attention core inside an fp32 block
-    assert rel(out.cpu().numpy(), gold['out']) < 3e-2
+    nrm = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+    # against the oracle with this path's store points (rounding='core': q, k, v, P and the attention output are bf16, the
+    # rest of the block f32): north_star's 1e-3, norm-wise.  The oracle itself is pinned to the imported reference without
+    # roundings (tests/test_sst_oracle_cpu.py, 5e-7).
+    from oracle import sst_ref
+    sdc = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    win, ciw = sst_ref.window_ids(coors.cpu(), SPARSE, WINDOW, False)
+    pre = 'block_list.0.encoder_list.0.'
+    e_one = nrm(one.cpu().numpy(), sst_ref.encoder_layer(feats.cpu(), sst_ref.pos_embed(ciw, WINDOW, 128), win,
+                                                         {k[len(pre):]: v for k, v in sdc.items() if k.startswith(pre)},
+                                                         rounding='core').numpy())
+    g_one, g_out = rel(one.cpu().numpy(), gold['one_layer']), rel(out.cpu().numpy(), gold['out'])
+    per_layer, e_out = _layer_errors(model, info, feats, coors, 'core')
+    print(f'f32 block with the bf16 attention core vs the rounded oracle (norm-wise): each layer on the same input '
+          f'{[f"{e:.1e}" for e in per_layer]}, two shifted blocks end to end {e_out:.2e}; largest deviation from the f32 '
+          f'reference golden (what the bf16 core itself costs): {g_one:.2e}, {g_out:.2e}')
+    assert e_one < 1e-3 and max(per_layer) < 1e-3 and e_out < 3e-3
+    assert g_one < 5e-3 and g_out < 1e-2      # bf16 attention core inside an fp32 block, against the UNROUNDED reference (measured 1.8e-3, 3.5e-3)
     # training step runs
     model.train()
     x = feats.clone().requires_grad_(True)
@@ -176,7 +226,21 @@ def test_sst_bf16_flat_path_vs_f32_path(dev, gold):
         grads.append([x.grad.float()] + [p.grad.float() for p in m.parameters()])
     assert outs[1].dtype == torch.float32 and bool(torch.isfinite(outs[1]).all())
     rel = float((outs[1] - outs[0]).abs().max() / outs[0].abs().max())
-    assert rel < 5e-2, rel
+    assert rel < 5e-2, rel      # (two realisations of the product: what the bf16 path costs against the f32 path)
+    # ... and each against the oracle with ITS store points, norm-wise at north_star's 1e-3: the f32 path with the bf16
+    # attention core ('core'), the bf16 path on the fused block kernels ('bf16'; windows of more than 64 tokens operator by
+    # operator)
+    info = layer(feats, coors)
+    l_ref, e_ref = _layer_errors(ref.eval(), info, feats, coors, 'core')
+    # (the fused kernels take the drop levels whose padded length fits their 64-token tile; a level with more slots -- here
+    # level 2: windows of 60 tokens and more, 100 slots -- runs operator by operator, whatever a window's real population)
+    ops_from = min(lo for lv, d in DROP.items() for lo in [d['drop_range'][0]] if d['max_tokens'] > 64)
+    l_fast, e_fast = _layer_errors(fast.eval(), info, feats, coors, 'bf16', ops_windows_above=ops_from - 1)
+    print(f'vs the rounded oracles (norm-wise): f32 path per layer {[f"{e:.1e}" for e in l_ref]} / end to end {e_ref:.2e}, bf16 path '
+          f'per layer {[f"{e:.1e}" for e in l_fast]} / end to end {e_fast:.2e}; largest deviation between the two paths {rel:.2e}')
+    # (end to end the bf16 residual stream hands flipped bf16 values from layer to layer: measured 1.4e-3 / 4.9e-3 after four
+    # layers, bounded here; the per-layer figures are the parity statement)
+    assert max(l_ref) < 1e-3 and max(l_fast) < 1e-3 and e_ref < 3e-3 and e_fast < 1e-2
     for a, b in zip(grads[0], grads[1]):
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.99, cos
@@ -219,19 +283,31 @@ def test_cosine_window_attention_vs_reference_golden(dev, gold):
     feats, coors = torch.from_numpy(gold['feats']).to(dev), torch.from_numpy(gold['coors']).to(dev)
     info = layer(feats, coors)
     ref_shapes = dict(zip(gold['cos_param_names'].tolist(), gold['cos_param_shapes'].tolist()))
-    for cfg, tol in ((dict(), 2e-2), (dict(compute_dtype=torch.bfloat16), 4e-2)):
+    from oracle import sst_ref
+    win, ciw = sst_ref.window_ids(coors.cpu(), SPARSE, WINDOW, False)
+    pos = sst_ref.pos_embed(ciw, WINDOW, 128)
+    tau = torch.linspace(0.05, 0.4, 8)
+    for cfg, tol, rounding in ((dict(), 8e-3, 'core'), (dict(compute_dtype=torch.bfloat16), 3e-2, 'ops')):   # (measured 3.3e-3, 1.2e-2)
         enc = EncoderLayer(128, 8, 256, 0.0, 'gelu', layer_id=0,
                            layer_cfg=dict(cosine=True, tau_min=0.01, non_shared_tau=True, **cfg))
         sd = enc.state_dict()
         assert set(sd) == set(ref_shapes) and all(','.join(map(str, v.shape)) == ref_shapes[k] for k, v in sd.items())
         new = synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, seed=9)
-        new['win_attn.self_attn.tau'] = torch.linspace(0.05, 0.4, 8).view(1, 8, 1, 1)
+        new['win_attn.self_attn.tau'] = tau.view(1, 8, 1, 1)
         enc.load_state_dict(new)
         enc = enc.to(dev).eval()
         with torch.no_grad():
             out = enc(feats, info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
         err = float(np.abs(out.float().cpu().numpy() - gold['cos_out']).max() / np.abs(gold['cos_out']).max())
-        assert err < tol, (cfg, err)
+        # against the oracle with this path's store points (cosine_msa.py:123-185 restated in oracle/sst_ref.py, pinned to
+        # the imported reference without roundings at 5e-7): north_star's 1e-3, norm-wise
+        exp = sst_ref.encoder_layer(feats.cpu(), pos, win, {k: v for k, v in new.items() if not k.endswith('.tau')},
+                                    rounding=rounding, cosine=(tau, 0.01))
+        e_or = float((out.float().cpu().double() - exp).norm() / exp.norm())
+        print(f'cosine attention, {"bf16 operator path" if cfg else "f32 block, bf16 core"}: vs the rounded oracle {e_or:.2e} '
+              f'(norm-wise); largest deviation from the f32 reference golden {err:.2e}')
+        assert e_or < 1e-3, (cfg, e_or)
+        assert err < tol, (cfg, err)      # (against the UNROUNDED reference: what bf16 storage costs)
     # tau receives a gradient
     enc.train()
     x = feats.clone().requires_grad_(True)
@@ -313,6 +389,16 @@ def test_sst_at_the_configs4_grid_shape(dev):
             assert float(((out.detach().double() - ref.detach()) * (~pad)[:, :, None]).abs().max()) < 3e-2   # bf16 P and V
             for got, exp in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
                 assert float((got.double() - exp).abs().max()) < 3e-2 * float(exp.abs().max())
+            # (that was the UNROUNDED attention: what bf16 P / V / outputs cost.)  Against the oracle with the kernel's
+            # store points, north_star's 1e-3 norm-wise, at this level's real key lengths:
+            from oracle import sst_ref
+            o, dq, dk, dv = sst_ref.window_attention_core(q.detach().cpu(), k.detach().cpu(), v.detach().cpu(), key_len.cpu(), H,
+                                                          dout=dout.cpu(), rounding='window')
+            keep = (~pad)[:, :, None].cpu()
+            for name, got, exp in (('out', out.detach().cpu() * keep, o * keep), ('dq', q.grad.cpu(), dq), ('dk', k.grad.cpu(), dk),
+                                   ('dv', v.grad.cpu(), dv)):
+                err = float((got.double() - exp).norm() / exp.norm())
+                assert err < 1e-3, (i, lv, name, err)
         assert total == kept
     # the backbone does not care in which order the voxels arrive
     model = SSTv2(d_model=[128] * 2, nhead=[8] * 2, num_blocks=2, dim_feedforward=[256] * 2, dropout=0.0, activation='gelu',

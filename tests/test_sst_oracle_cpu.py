@@ -91,3 +91,24 @@ def test_window_attention_core_equals_autograd_and_its_rounded_form_stays_close(
     for got, exp in ((ow, o), (dqw, dq), (dkw, dk), (dvw, dv)):
         rel = float((got - exp).norm() / exp.norm())
         assert 1e-5 < rel < 6e-3, rel          # rounded, and by bf16 steps only
+
+
+def test_cosine_encoder_layer_vs_reference_golden(golden_dir):
+    """the oracle's scaled-cosine attention (cosine=(tau, tau_min)) without roundings equals the imported reference's
+    EncoderLayer with layer_cfg cosine / non_shared_tau (tests/golden/sst.npz cos_out, oracle/gen_golden_sst.py;
+    CosineMultiheadAttention, cosine_msa.py:123-185) -- before the HIP paths are compared with its rounded forms"""
+    gold = _gold(golden_dir)
+    shapes = {k: tuple(int(v) for v in s.split(',')) for k, s in zip(gold['cos_param_names'].tolist(), gold['cos_param_shapes'].tolist())}
+    sd = synth.synth_state_dict(shapes, seed=9)
+    tau = torch.linspace(0.05, 0.4, 8)
+    coors, feats = torch.from_numpy(gold['coors']), torch.from_numpy(gold['feats'])
+    win, ciw = S.window_ids(coors, SPARSE, WINDOW, False)
+    P = {k: v for k, v in sd.items() if k != 'win_attn.self_attn.tau'}
+    out = S.encoder_layer(feats, S.pos_embed(ciw, WINDOW, 128), win, P, cosine=(tau, 0.01))
+    err = float(np.abs(out.numpy() - gold['cos_out']).max() / np.abs(gold['cos_out']).max())
+    print(f'cosine oracle (no rounding) vs imported reference: {err:.2e}')
+    assert err < 1e-5
+    # a shared tau is the same thing with one value
+    one = S.encoder_layer(feats[:500], S.pos_embed(ciw[:500], WINDOW, 128), win[:500], P, cosine=(torch.tensor([0.2]), 0.01))
+    per = S.encoder_layer(feats[:500], S.pos_embed(ciw[:500], WINDOW, 128), win[:500], P, cosine=(torch.full((8,), 0.2), 0.01))
+    assert torch.equal(one, per)
