@@ -29,9 +29,9 @@ constexpr int TM = 64;           // token slots per tile
 constexpr int E = 128;           // d_model
 constexpr int NH = 8, HD = 16;   // heads, head dim
 constexpr int FF = 256;          // feed-forward width
-constexpr int LDX = E + 16;      // LDS row strides (elements): +32 B keeps ds_read_b128 of 16 rows conflict free
-constexpr int LDQ = 3 * E + 16;
-constexpr int LDH = FF + 16;
+constexpr int LDX = E + 8;       // LDS row strides (elements): an ODD number of 16-byte pieces, so that the ds_read_b128 of 16 consecutive rows (a GEMM operand) start in 16 different bank quads (+32 B, rounds 2-4: rows r and r + 8 shared theirs -- SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles)
+constexpr int LDQ = 3 * E + 8;
+constexpr int LDH = FF + 8;
 constexpr int kThreads = 256;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
