@@ -648,6 +648,23 @@ int ococc_window_attn_block_bwd_bf16(const uint16_t* x, const uint16_t* pos, con
                                      const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag, uint16_t* dx,
                                      uint16_t* dqkv, uint16_t* dz, uint16_t* attn_out, float* ln_partial,
                                      ococc_stream_t stream);
+/* The same pair for a training step that keeps the attention output and the softmax's log-sum-exp (round 5): the forward
+ * also writes attn_save [num_tokens, d_model] bf16 (rows of the plan's tokens) and lse_save [num_tokens, num_heads] f32; the
+ * backward reads them back instead of running the attention forward again (28 % of its time, for 288 B per token) and
+ * no longer writes attn_out -- the weight gradient of the out-projection reads attn_saved.  Same results as the pair
+ * above (the attention forward it skips is deterministic). */
+int ococc_window_attn_block_train_fwd_bf16(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows,
+                                           const int32_t* tile_span, int64_t num_tiles, int32_t d_model, int32_t num_heads,
+                                           const uint16_t* wqkv_frag, const float* bqkv, const uint16_t* wo_frag,
+                                           const float* bo, const float* ln_weight, const float* ln_bias, float eps,
+                                           uint16_t* y, uint16_t* attn_save, float* lse_save, ococc_stream_t stream);
+int ococc_window_attn_block_bwd_saved_bf16(const uint16_t* x, const uint16_t* pos, const uint16_t* dy,
+                                           const int32_t* tile_rows, const int32_t* tile_span, int64_t num_tiles,
+                                           int32_t d_model, int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
+                                           const uint16_t* wo_frag, const float* bo, const float* ln_weight, float eps,
+                                           const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag,
+                                           const uint16_t* attn_saved, const float* lse_saved, uint16_t* dx, uint16_t* dqkv,
+                                           uint16_t* dz, float* ln_partial, ococc_stream_t stream);
 int ococc_token_ffn_block_fwd_bf16(const uint16_t* x, int64_t num_tokens, int32_t d_model, int32_t d_ffn,
                                    const uint16_t* w1_frag, const float* b1, const uint16_t* w2_frag, const float* b2,
                                    const float* ln_weight, const float* ln_bias, float eps, int32_t act, uint16_t* y,

@@ -127,6 +127,10 @@ SIGNATURES = {
                                                  c_vp, c_vp, c_f32, c_vp, c_vp]),
     'ococc_window_attn_block_bwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp,
                                                  c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_window_attn_block_train_fwd_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                                       c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_window_attn_block_bwd_saved_bf16': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                                       c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_token_ffn_block_fwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
                                                c_i32, c_vp, c_vp]),
     'ococc_token_ffn_block_bwd_bf16': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,

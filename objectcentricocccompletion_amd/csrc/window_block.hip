@@ -34,6 +34,26 @@ constexpr int LDQ = 3 * E + 8;
 constexpr int LDH = FF + 8;
 constexpr int kThreads = 256;
 
+// Workgroup barrier of the block kernels: everything the waves exchange goes through LDS, so the barrier waits for this
+// wave's LDS operations only.  __syncthreads() also waits for every global load in flight (s_waitcnt vmcnt(0)) -- i.e. the
+// first barrier behind a prefetch of the next tile's rows waited for that prefetch: 2-5 us per tile (stamps,
+// tools/probe/sst_bwd_stamps.py).  Global results reach their consumers in registers (the compiler's own waits).
+#ifndef OCOCC_WB_FULL_BARRIERS
+#define TILE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define TILE_BARRIER() __syncthreads()
+#endif
+
+#ifdef OCOCC_WB_STAMPS
+// diagnostic build only (tools/probe/sst_bwd_stamps.py): wall-clock stamps (100 MHz) per workgroup and phase of its SECOND tile
+__device__ long long* wb_stamps = nullptr;
+#define WSTAMP(it, slot) do { if ((it) == 1 && threadIdx.x == 0 && wb_stamps) wb_stamps[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define WSTAMP_F(slot) do { if (NW == 8 && threadIdx.x == 0 && wb_stamps) wb_stamps[(int64_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(it, slot) do { } while (0)
+#define WSTAMP_F(slot) do { } while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ bf16x8 tr_pair(const uint16_t* lo_rows, const uint16_t* hi_rows) {
@@ -113,7 +133,7 @@ __device__ __forceinline__ void token_sums(const int tid_, float (&part)[4], flo
     p += __shfl_xor(p, 32, 64);
     if (g == 0) red[wave * TM + mb * 16 + c] = p;
   }
-  __syncthreads();
+  TILE_BARRIER();
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
     const int t = mb * 16 + c;
@@ -311,8 +331,10 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
                                            uint16_t* qs, F0 first, F between, F2 after_qk) {
   const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
   constexpr int NQK = 16 / NW, NV = 8 / NW;
+  WSTAMP_F(11);
   xv.stash(xs, LDX);
-  __syncthreads();
+  TILE_BARRIER();
+  WSTAMP_F(12);
   first();   // every thread has left the previous tile behind
   bf16x8 fqk[NQK][4];
   {
@@ -327,7 +349,8 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(acc[nb][mb] + b);
     }
   }
-  __syncthreads();
+  TILE_BARRIER();
+  WSTAMP_F(13);
   if (has_pos) {
 #pragma unroll
     for (int j = 0; j < TilePieces<NW>::P; ++j) {   // xs <- bf16(x + pos), every thread its own pieces
@@ -339,7 +362,8 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
     xv.stash(xs, LDX);
   }
   between();
-  __syncthreads();
+  TILE_BARRIER();
+  WSTAMP_F(14);
   {
     f32x4 acc[NQK][4];
     if (RES) tile_gemm<NQK, 4, true>(tid_, fqk_res, xs, LDX, acc);
@@ -353,7 +377,7 @@ __device__ __forceinline__ void attn_front(const int tid_, const uint16_t* __res
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(acc[nb][mb] + b);
     }
   }
-  __syncthreads();
+  TILE_BARRIER();
 }
 
 // key-tile range [lo, hi] that the 16 queries of query tile qt can see (union of their windows); hi < lo: none
@@ -477,20 +501,21 @@ window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
                              int64_t num_tiles, const uint16_t* __restrict__ wqkv, const float* __restrict__ bqkv,
                              const uint16_t* __restrict__ wo, const float* __restrict__ bo,
                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
-                             uint16_t* __restrict__ y) {
+                             uint16_t* __restrict__ y, uint16_t* __restrict__ o_save, float* __restrict__ lse_save) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* xs = (uint16_t*)smem;                 // x | x + pos | attention output
   uint16_t* qs = xs + TM * LDX;                   // Q | K | V, then y staging
   float* red0 = (float*)(qs + TM * LDQ);
   float* red1 = red0 + NW * TM;
   TileMeta* tms = (TileMeta*)(red1 + NW * TM);    // [2]: this tile's and the next one's
+  float* lse_s = (float*)(tms + 2);               // [8 heads][64] (training: the backward reads it back)
   const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6, g = lane >> 4;
   (void)g;
   bf16x8 fv[2][4], fo[2][4], fqk_none[4][4] = {};   // (fqk_none: unused, the forward streams Wqk inside attn_front)
   load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);
   int64_t tile = blockIdx.x;
   load_meta(tid_, &tms[0], tile_rows, tile_span, tile);
-  __syncthreads();
+  TILE_BARRIER();
   TilePieces<NW> xv, pv;
   xv.fetch(x, tms[0].rows, 0, 0);
   pv.fetch(pos, tms[0].rows, 0, 0);
@@ -518,15 +543,31 @@ window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
         [&]() {
           if (next < num_tiles) load_meta(tid_, &tms[(it & 1) ^ 1], tile_rows, tile_span, next);
         },
+        [&]() {},
         [&]() {
-          if (next < num_tiles) {   // (the next tile's meta: written behind the first barrier, read behind the second)
+          load_frags<2, 4>(tid_, wo, 2 * wave, fo);
+          // the next tile's rows are asked for HERE, behind the last wait in front of the attention (LDS and matrix work
+          // only, ~8 us): the vector-memory counter retires in order, and asked for in front of the Q | K GEMM (rounds 3-4)
+          // they were waited for by its weight fragments (the next tile's meta: written behind the first barrier)
+          if (next < num_tiles) {
             xv.fetch(x, tms[(it & 1) ^ 1].rows, 0, 0);
             pv.fetch(pos, tms[(it & 1) ^ 1].rows, 0, 0);
           }
-        },
-        [&]() { load_frags<2, 4>(tid_, wo, 2 * wave, fo); });
-    attn_tile_fwd<NW>(tid_, tm, qs, xs, nullptr);   // o goes where x + pos was (its last reader was the Q | K GEMM)
-    __syncthreads();
+        });
+    attn_tile_fwd<NW>(tid_, tm, qs, xs, o_save ? lse_s : nullptr);   // o goes where x + pos was (its last reader was the Q | K GEMM)
+    TILE_BARRIER();
+    if (o_save) {
+      // training: the attention output and the softmax's log-sum-exp of every (token, head) leave for the backward kernel,
+      // which then starts behind the attention instead of running it again (288 B per token against 28 % of its time)
+      tile_store_rows<NW, E>(xs, LDX, o_save, tm->rows, 0, 0);
+      for (int i = tid_; i < TM * 2; i += NW * 64) {
+        const int s_ = i >> 1, hq = (i & 1) * 4;
+        const int r = tm->rows[s_];
+        if (r >= 0)
+          *(f32x4*)(lse_save + (int64_t)r * NH + hq) = f32x4{lse_s[hq * TM + s_], lse_s[(hq + 1) * TM + s_],
+                                                           lse_s[(hq + 2) * TM + s_], lse_s[(hq + 3) * TM + s_]};
+      }
+    }
     f32x4 z[2][4];
     tile_gemm<2, 4, true>(tid_, fo, xs, LDX, z);
     load_frags<2, 4>(tid_, wqkv, 16 + 2 * wave, fv);    // the next tile's first GEMM
@@ -548,7 +589,7 @@ window_attn_block_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(qs + (mb * 16 + c) * LDQ + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
     }
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(qs, LDQ, y, tm->rows, 0, 0);
     // (the next iteration writes xs before its first barrier: xs was last read by the out-projection GEMM, before the
     // LayerNorm barriers; it writes qs and this tile's meta slot only behind that barrier)
@@ -590,7 +631,7 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
     const int64_t row0 = tile * TM;
     xv.stash(xs, LDX);
     if (tile + gridDim.x < tiles) xv.fetch(x, nullptr, (tile + gridDim.x) * TM, num_tokens);
-    __syncthreads();
+    TILE_BARRIER();
     {
       f32x4 acc[4][4];
       tile_gemm<4, 4, true>(tid_, f1, xs, LDX, acc);
@@ -603,7 +644,7 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
         for (int mb = 0; mb < 4; ++mb) *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(act_fwd4<ACT>(acc[nb][mb] + b));
       }
     }
-    __syncthreads();
+    TILE_BARRIER();
     f32x4 z[2][4];
     tile_gemm<2, 8, true>(tid_, f2, hs, LDH, z);
     load_frags<4, 4>(tid_, w1, 4 * wave, f1);           // the next tile's first GEMM
@@ -626,7 +667,7 @@ token_ffn_block_fwd_kernel(const uint16_t* __restrict__ x, int64_t num_tokens, c
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(z[nb][mb] * gam[nb] + bet[nb]);
     }
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(hs, LDH, y, nullptr, row0, num_tokens);
   }
 }
@@ -664,6 +705,20 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
   int64_t tile = blockIdx.x;
   TilePieces<NW> xv;
   xv.fetch(x, nullptr, tile * TM, num_tokens);
+  // dy at the lanes' output positions, one tile ahead like x (rows past the end read the last row: their gradient is zeroed
+  // where it is used) -- straight-line loads, see window_attn_block_bwd_kernel
+  u32x2 dy_n[4];
+  auto side = [&](int64_t t0) {
+    int t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));
+    const int c_ = t_ & 15, n_ = 16 * (t_ >> 6) + 4 * ((t_ & 63) >> 4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int64_t r = t0 + mb * 16 + c_;
+      dy_n[mb] = *(const u32x2*)(dy + (r < num_tokens ? r : num_tokens - 1) * E + n_);
+    }
+  };
+  side(tile * TM);
 #pragma unroll 1
   for (; tile < tiles; tile += gridDim.x) {
     // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
@@ -673,8 +728,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
     const int lane = tid_ & 63, wave = tid_ >> 6, c = lane & 15, g = lane >> 4;
     const int64_t row0 = tile * TM;
     xv.stash(xs, LDX);
-    if (tile + gridDim.x < tiles) xv.fetch(x, nullptr, (tile + gridDim.x) * TM, num_tokens);
-    __syncthreads();
+    TILE_BARRIER();
     const int n1 = 16 * wave + 4 * g;   // the lane's 4 channels of the 128-wide tensors
     u32x2 gact[2][4];
     {
@@ -694,7 +748,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
         }
       }
     }
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, FF>(hs, LDH, a_out, nullptr, row0, num_tokens);
     f32x4 z[1][4], dz[1][4];
     {
@@ -708,9 +762,15 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
       for (int mb = 0; mb < 4; ++mb) {
         z[0][mb] = z[0][mb] + b + unpack4(*(const u32x2*)(xs + (mb * 16 + c) * LDX + n1));
         const int64_t r = row0 + mb * 16 + c;
-        dz[0][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r < num_tokens) dz[0][mb] = unpack4(*(const u32x2*)(dy + r * E + n1));
+        dz[0][mb] = r < num_tokens ? unpack4(dy_n[mb]) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    }
+    // the next tile's rows are asked for HERE, in front of the LayerNorm (LDS and arithmetic only, ~3 us): the vector-memory
+    // counter retires in order, and asked for at the top of the tile (rounds 3-4) they were waited for by the first GEMM's
+    // weight fragments
+    if (tile + gridDim.x < tiles) {
+      xv.fetch(x, nullptr, (tile + gridDim.x) * TM, num_tokens);
+      side((tile + gridDim.x) * TM);
     }
     float rstd[4];
     tile_layernorm<NW, 1>(tid_, z, eps, red0, red1, rstd);                       // z = xhat2
@@ -718,7 +778,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)   // (every wave is past its reads of y1: the barriers of the LN sums)
       *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(dz[0][mb]);
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(xs, LDX, dz_out, nullptr, row0, num_tokens);
     {
       bf16x8 f[2][4];
@@ -733,7 +793,7 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
           *(u32x2*)(hs + (mb * 16 + c) * LDH + n) = pack4(da[nb][mb] * unpack4(gact[nb][mb]));
       }
     }
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, FF>(hs, LDH, dh_out, nullptr, row0, num_tokens);
     f32x4 gx[1][4];
     {
@@ -744,9 +804,9 @@ token_ffn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __res
     // (the dz tile in xs -- B operand of the d act GEMM, source of dz_out -- was last read before the barrier above)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(gx[0][mb] + dz[0][mb]);
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(xs, LDX, dx, nullptr, row0, num_tokens);
-    __syncthreads();   // the next tile's y1 goes into xs
+    TILE_BARRIER();   // the next tile's y1 goes into xs
   }
   store_param_partials<1>(tid_, dgam, dbet, wave, ln_partial + (int64_t)blockIdx.x * 2 * E);
 }
@@ -763,7 +823,8 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
                              const float* __restrict__ ln_w, float eps, const uint16_t* __restrict__ wot,
                              const uint16_t* __restrict__ wqkvt, uint16_t* __restrict__ dx,
                              uint16_t* __restrict__ dqkv_out, uint16_t* __restrict__ dz_out,
-                             uint16_t* __restrict__ o_out, float* __restrict__ ln_partial) {
+                             uint16_t* __restrict__ o_out, float* __restrict__ ln_partial,
+                             const uint16_t* __restrict__ o_in, const float* __restrict__ lse_in) {
   constexpr int NW = 8;                           // one head per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint16_t* xs = (uint16_t*)smem;                 // x | x + pos | o | dz1 | dO | dx staging
@@ -780,10 +841,39 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
   f32x4 dgam[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dbet[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
   int64_t tile = blockIdx.x;
   load_meta(tid_, &tms[0], tile_rows, tile_span, tile);
-  __syncthreads();
+  TILE_BARRIER();
   TilePieces<NW> xv, pv;
   xv.fetch(x, tms[0].rows, 0, 0);
   pv.fetch(pos, tms[0].rows, 0, 0);
+  TilePieces<NW> ov_n;
+  float lse_n = 0.f;
+  u32x2 res_n[4], dy_n[4];
+  auto side = [&](const TileMeta* m) {   // the side inputs of the tile described by m (see the top of the loop)
+    // Straight-line code: rows of empty slots read row 0 (their values are never used: dy is zeroed at the top of the
+    // loop, nothing of such a row is stored).  With the loads behind `if (row >= 0)` the wait for the Q | K weight fragments
+    // that follows became a wait for everything in flight (the counter is tracked per basic block): +3 us per tile.
+    int t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));
+    const int c_ = t_ & 15, n_ = 16 * (t_ >> 6) + 4 * ((t_ & 63) >> 4);
+    if (o_in) {
+#pragma unroll
+      for (int j = 0; j < TilePieces<NW>::P; ++j) {
+        const int i = t_ + j * NW * 64, s_ = i >> 4, p = i & 15;
+        const int r = m->rows[s_];
+        ov_n.v[j] = *(const u32x4*)(o_in + (int64_t)(r < 0 ? 0 : r) * E + p * 8);
+      }
+      const int r = m->rows[t_ >> 3];
+      lse_n = lse_in[(int64_t)(r < 0 ? 0 : r) * NH + (t_ & 7)];
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int r = m->rows[mb * 16 + c_];
+      const int64_t rc = r < 0 ? 0 : r;
+      res_n[mb] = *(const u32x2*)(x + rc * E + n_);
+      dy_n[mb] = *(const u32x2*)(dy + rc * E + n_);
+    }
+  };
+  side(&tms[0]);
 #pragma unroll 1
   for (int it = 0; tile < num_tiles; tile += gridDim.x, ++it) {
     // (thread coordinates re-derived per tile from an opaque copy of threadIdx.x: hoisted out of the loop, the address
@@ -794,41 +884,45 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     const int q_ = c >> 2, p_ = c & 3;
     const TileMeta* tm = &tms[it & 1];
     const int64_t next = tile + gridDim.x;
+    WSTAMP(it, 0);
+    // the tile's side inputs -- the kept attention output and log-sum-exp rows (o_in), the residual and dy at the lanes'
+    // output positions -- were asked for one tile ahead (`side` below): every wait of this kernel is counted in order,
+    // so loads issued in front of a tile's first GEMM would be waited for there
+    const int n1 = 16 * wave + 4 * g;   // the lane's 4 channels of the 128-wide tensors
+    TilePieces<NW> ov = ov_n;
+    const float lse_mine = lse_n;
+    u32x2 res[4];
+    f32x4 dz[1][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      res[mb] = res_n[mb];
+      dz[0][mb] = tm->rows[mb * 16 + c] >= 0 ? unpack4(dy_n[mb]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (tm->rows[mb * 16 + c] < 0) res[mb] = u32x2{0u, 0u};
+    }
     attn_front<NW, false>(tid_, 
         wqkv, fv, fqk_none, bqkv, xv, pv, pos != nullptr, xs, qs,
         [&]() {
           if (next < num_tiles) load_meta(tid_, &tms[(it & 1) ^ 1], tile_rows, tile_span, next);
         },
-        [&]() {
-          if (next < num_tiles) {
-            xv.fetch(x, tms[(it & 1) ^ 1].rows, 0, 0);
-            pv.fetch(pos, tms[(it & 1) ^ 1].rows, 0, 0);
-          }
-        },
+        [&]() {},
         [&]() {});
-    // the residual and dy at the lanes' output positions: asked for now, used after the attention
-    const int n1 = 16 * wave + 4 * g;   // the lane's 4 channels of the 128-wide tensors
-    u32x2 res[4];
-    f32x4 dz[1][4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-      const int r = tm->rows[mb * 16 + c];
-      res[mb] = u32x2{0u, 0u};
-      dz[0][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (r >= 0) {
-        res[mb] = *(const u32x2*)(x + (int64_t)r * E + n1);
-        dz[0][mb] = unpack4(*(const u32x2*)(dy + (int64_t)r * E + n1));
-      }
+    WSTAMP(it, 1);   // front: x + pos, Q | K | V
+    if (o_in) {   // (o goes where x + pos was: its last reader was the Q | K GEMM, in front of attn_front's last barrier)
+      ov.stash(xs, LDX);
+      lse_s[(tid_ & 7) * TM + (tid_ >> 3)] = lse_mine;
+    } else {
+      attn_tile_fwd<NW>(tid_, tm, qs, xs, lse_s);
     }
-    attn_tile_fwd<NW>(tid_, tm, qs, xs, lse_s);
-    __syncthreads();
-    tile_store_rows<NW, E>(xs, LDX, o_out, tm->rows, 0, 0);
+    TILE_BARRIER();
+    WSTAMP(it, 2);   // attention forward
+    if (!o_in) tile_store_rows<NW, E>(xs, LDX, o_out, tm->rows, 0, 0);
     f32x4 z[1][4];
     {
       bf16x8 f[1][4];
       load_frags<1, 4>(tid_, wo, wave, f);
       tile_gemm<1, 4, true>(tid_, f, xs, LDX, z);
     }
+    WSTAMP(it, 3);   // o stored, out-projection
     {
       const f32x4 b = *(const f32x4*)(bo + n1);
 #pragma unroll
@@ -837,21 +931,32 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
     float rstd[4];
     tile_layernorm<NW, 1>(tid_, z, eps, red0, red1, rstd);
     tile_layernorm_bwd<NW, 1>(tid_, z, dz, gam, rstd, red0, red1, dgam, dbet);   // dz = dz1, kept for the residual
+    WSTAMP(it, 4);   // LayerNorm forward + backward
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)   // over o: every wave is past the out-projection GEMM and the o_out copy
       *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(dz[0][mb]);
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(xs, LDX, dz_out, tm->rows, 0, 0);
     {
       f32x4 go[1][4];
       bf16x8 f[1][4];
       load_frags<1, 4>(tid_, wot, wave, f);
       tile_gemm<1, 4, true>(tid_, f, xs, LDX, go);    // dO = Wo^T dz1
-      __syncthreads();                     // dz1 tile: read by every wave's GEMM and by the copy above
+      TILE_BARRIER();                     // dz1 tile: read by every wave's GEMM and by the copy above
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(go[0][mb]);
     }
-    __syncthreads();
+    TILE_BARRIER();
+    WSTAMP(it, 5);   // dz1 stored, dO = Wo^T dz1
+    // The next tile's rows (x, pos, the kept attention output and log-sum-exp, the residual and dy pieces) are asked for
+    // HERE: the two attention passes below are LDS and matrix work only, ~7 us without a wait on the vector-memory
+    // counter.  That counter retires in order: asked for inside the front (rounds 3-4), the prefetch was waited for by
+    // the Q | K GEMM's weight fragments right behind it -- 3 us per tile (tools/probe/sst_bwd_stamps.py).
+    if (next < num_tiles) {
+      xv.fetch(x, tms[(it & 1) ^ 1].rows, 0, 0);
+      pv.fetch(pos, tms[(it & 1) ^ 1].rows, 0, 0);
+      side(&tms[(it & 1) ^ 1]);
+    }
     // attention backward, one head per wave.  Pass 1 (lanes own queries): dQ and delta; pass 2 (lanes own
     // keys): dK, dV.  Both recompute the probabilities with 16x16x16 MFMAs; the gradients of a head replace its Q, K, V
     // in place once both passes have read them (only this wave touches the head's columns).
@@ -914,6 +1019,7 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
         }
         gq[qt] = acc;   // dQ^T: d = 4g + r of query c
       }
+      WSTAMP(it, 6);   // attention backward pass 1 (dQ, delta)
       // (delta written by this wave's g == 0 lanes, read below by all its lanes: LDS ops of a wave complete in order)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -962,6 +1068,7 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
         gk[kt] = acck;
         gv[kt] = accv;
       }
+      WSTAMP(it, 7);   // pass 2 (dK, dV)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -972,25 +1079,35 @@ window_attn_block_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __r
         *(u32x2*)(row + 2 * E) = pack4(gv[t]);
       }
     }
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, 3 * E>(qs, LDQ, dqkv_out, tm->rows, 0, 0);
+    WSTAMP(it, 8);   // dqkv stored
     f32x4 gx[1][4];
     {
       bf16x8 f[1][12];
       load_frags<1, 12>(tid_, wqkvt, wave, f);
       tile_gemm<1, 12, true>(tid_, f, qs, LDQ, gx);   // dx = Wqkv^T dqkv (+ dz1: the residual)
     }
+    WSTAMP(it, 9);   // dx GEMM
     load_frags<1, 4>(tid_, wqkv, 16 + wave, fv);   // the next tile's first GEMM
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)   // over dO: its last readers were the attention passes, before the barrier above
       *(u32x2*)(xs + (mb * 16 + c) * LDX + n1) = pack4(gx[0][mb] + dz[0][mb]);
-    __syncthreads();
+    TILE_BARRIER();
     tile_store_rows<NW, E>(xs, LDX, dx, tm->rows, 0, 0);
-    __syncthreads();   // the next tile's x goes into xs, its Q | K | V into qs, its meta into this tile's slot
+    TILE_BARRIER();   // the next tile's x goes into xs, its Q | K | V into qs, its meta into this tile's slot
+    WSTAMP(it, 10);
   }
   store_param_partials<1>(tid_, dgam, dbet, wave, ln_partial + (int64_t)blockIdx.x * 2 * E);
 }
 
+#ifdef OCOCC_WB_STAMPS
+}  // namespace
+extern "C" int ococc_wb_set_stamps(long long* dev_buffer) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(wb_stamps), &dev_buffer, sizeof(dev_buffer)) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
 // ---------------------------------------------------------------------------------------------------------------
 // f32 matrices (any strides) -> bf16 MFMA A-operand fragments: dst[rb][cs][lane = 16 g + r][j] = S[16 rb + r][32 cs + 8 g + j]
 constexpr int kMaxFrag = 16;
@@ -1359,12 +1476,11 @@ extern "C" int ococc_window_tile_plan(const int32_t* win_len, const int64_t* win
 #define OCOCC_BLOCK_DIMS_OK(d_model, heads, ffn) \
   OCOCC_REQUIRE((d_model) == E && (heads) == NH && (ffn) == FF, "the fused encoder-layer kernels are built for d_model 128, 8 heads, feed-forward 256")
 
-extern "C" int ococc_window_attn_block_fwd_bf16(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows,
-                                                const int32_t* tile_span, int64_t num_tiles, int32_t d_model,
-                                                int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
-                                                const uint16_t* wo_frag, const float* bo, const float* ln_weight,
-                                                const float* ln_bias, float eps, uint16_t* y,
-                                                ococc_stream_t stream) {
+namespace {
+int attn_block_fwd(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows, const int32_t* tile_span,
+                   int64_t num_tiles, int32_t d_model, int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
+                   const uint16_t* wo_frag, const float* bo, const float* ln_weight, const float* ln_bias, float eps,
+                   uint16_t* y, uint16_t* attn_save, float* lse_save, ococc_stream_t stream) {
   OCOCC_BLOCK_DIMS_OK(d_model, num_heads, FF);
   OCOCC_REQUIRE(num_tiles >= 0, "bad sizes");
   if (num_tiles == 0) return OCOCC_OK;
@@ -1377,10 +1493,61 @@ extern "C" int ococc_window_attn_block_fwd_bf16(const uint16_t* x, const uint16_
                                 attn_lds<4>()));
   hipLaunchKernelGGL(window_attn_block_fwd_kernel, dim3((unsigned)block_grid(num_tiles, 2)), dim3(256), attn_lds<4>(),
                      (hipStream_t)stream, x, pos, tile_rows, tile_span, num_tiles, wqkv_frag, bqkv, wo_frag, bo,
-                     ln_weight, ln_bias, eps, y);
+                     ln_weight, ln_bias, eps, y, attn_save, lse_save);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }
+}  // namespace
+
+extern "C" int ococc_window_attn_block_fwd_bf16(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows,
+                                                const int32_t* tile_span, int64_t num_tiles, int32_t d_model,
+                                                int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
+                                                const uint16_t* wo_frag, const float* bo, const float* ln_weight,
+                                                const float* ln_bias, float eps, uint16_t* y, ococc_stream_t stream) {
+  return attn_block_fwd(x, pos, tile_rows, tile_span, num_tiles, d_model, num_heads, wqkv_frag, bqkv, wo_frag, bo, ln_weight,
+                        ln_bias, eps, y, nullptr, nullptr, stream);
+}
+
+extern "C" int ococc_window_attn_block_train_fwd_bf16(const uint16_t* x, const uint16_t* pos, const int32_t* tile_rows,
+                                                      const int32_t* tile_span, int64_t num_tiles, int32_t d_model,
+                                                      int32_t num_heads, const uint16_t* wqkv_frag, const float* bqkv,
+                                                      const uint16_t* wo_frag, const float* bo, const float* ln_weight,
+                                                      const float* ln_bias, float eps, uint16_t* y, uint16_t* attn_save,
+                                                      float* lse_save, ococc_stream_t stream) {
+  OCOCC_REQUIRE(num_tiles == 0 || (attn_save && lse_save && aligned16(attn_save) && aligned16(lse_save)),
+                "attn_save / lse_save: 16-byte aligned device buffers");
+  return attn_block_fwd(x, pos, tile_rows, tile_span, num_tiles, d_model, num_heads, wqkv_frag, bqkv, wo_frag, bo, ln_weight,
+                        ln_bias, eps, y, attn_save, lse_save, stream);
+}
+
+namespace {
+int attn_block_bwd(const uint16_t* x, const uint16_t* pos, const uint16_t* dy, const int32_t* tile_rows,
+                   const int32_t* tile_span, int64_t num_tiles, int32_t d_model, int32_t num_heads, const uint16_t* wqkv_frag,
+                   const float* bqkv, const uint16_t* wo_frag, const float* bo, const float* ln_weight, float eps,
+                   const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag, uint16_t* dx, uint16_t* dqkv, uint16_t* dz,
+                   uint16_t* attn_out, float* ln_partial, const uint16_t* attn_saved, const float* lse_saved,
+                   ococc_stream_t stream) {
+  OCOCC_BLOCK_DIMS_OK(d_model, num_heads, FF);
+  OCOCC_REQUIRE(num_tiles >= 0, "bad sizes");
+  if (num_tiles == 0) return OCOCC_OK;
+  OCOCC_REQUIRE(x && dy && tile_rows && tile_span && wqkv_frag && bqkv && wo_frag && bo && ln_weight && wo_t_frag &&
+                    wqkv_t_frag && dx && dqkv && dz && (attn_out || attn_saved) && ln_partial,
+                "null pointer");
+  OCOCC_REQUIRE((attn_saved == nullptr) == (lse_saved == nullptr) && aligned16(attn_saved) && aligned16(lse_saved),
+                "attn_saved and lse_saved go together, 16-byte aligned");
+  OCOCC_REQUIRE(aligned16(x) && aligned16(pos) && aligned16(dy) && aligned16(dx) && aligned16(dqkv) && aligned16(dz) &&
+                    aligned16(attn_out) && aligned16(wqkv_frag) && aligned16(wo_frag) && aligned16(wo_t_frag) &&
+                    aligned16(wqkv_t_frag) && aligned16(bqkv) && aligned16(bo) && aligned16(ln_weight),
+                "buffers must be 16-byte aligned");
+  OCOCC_HIP(hipFuncSetAttribute((const void*)window_attn_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                attn_lds<8>()));
+  hipLaunchKernelGGL(window_attn_block_bwd_kernel, dim3((unsigned)block_grid(num_tiles, 1)), dim3(512), attn_lds<8>(),
+                     (hipStream_t)stream, x, pos, dy, tile_rows, tile_span, num_tiles, wqkv_frag, bqkv, wo_frag, bo,
+                     ln_weight, eps, wo_t_frag, wqkv_t_frag, dx, dqkv, dz, attn_out, ln_partial, attn_saved, lse_saved);
+  OCOCC_CHECK_LAUNCH();
+  return OCOCC_OK;
+}
+}  // namespace
 
 extern "C" int ococc_window_attn_block_bwd_bf16(const uint16_t* x, const uint16_t* pos, const uint16_t* dy,
                                                 const int32_t* tile_rows, const int32_t* tile_span,
@@ -1390,23 +1557,23 @@ extern "C" int ococc_window_attn_block_bwd_bf16(const uint16_t* x, const uint16_
                                                 const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag, uint16_t* dx,
                                                 uint16_t* dqkv, uint16_t* dz, uint16_t* attn_out, float* ln_partial,
                                                 ococc_stream_t stream) {
-  OCOCC_BLOCK_DIMS_OK(d_model, num_heads, FF);
-  OCOCC_REQUIRE(num_tiles >= 0, "bad sizes");
-  if (num_tiles == 0) return OCOCC_OK;
-  OCOCC_REQUIRE(x && dy && tile_rows && tile_span && wqkv_frag && bqkv && wo_frag && bo && ln_weight && wo_t_frag &&
-                    wqkv_t_frag && dx && dqkv && dz && attn_out && ln_partial,
-                "null pointer");
-  OCOCC_REQUIRE(aligned16(x) && aligned16(pos) && aligned16(dy) && aligned16(dx) && aligned16(dqkv) && aligned16(dz) &&
-                    aligned16(attn_out) && aligned16(wqkv_frag) && aligned16(wo_frag) && aligned16(wo_t_frag) &&
-                    aligned16(wqkv_t_frag) && aligned16(bqkv) && aligned16(bo) && aligned16(ln_weight),
-                "buffers must be 16-byte aligned");
-  OCOCC_HIP(hipFuncSetAttribute((const void*)window_attn_block_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                attn_lds<8>()));
-  hipLaunchKernelGGL(window_attn_block_bwd_kernel, dim3((unsigned)block_grid(num_tiles, 1)), dim3(512), attn_lds<8>(),
-                     (hipStream_t)stream, x, pos, dy, tile_rows, tile_span, num_tiles, wqkv_frag, bqkv, wo_frag, bo,
-                     ln_weight, eps, wo_t_frag, wqkv_t_frag, dx, dqkv, dz, attn_out, ln_partial);
-  OCOCC_CHECK_LAUNCH();
-  return OCOCC_OK;
+  return attn_block_bwd(x, pos, dy, tile_rows, tile_span, num_tiles, d_model, num_heads, wqkv_frag, bqkv, wo_frag, bo,
+                        ln_weight, eps, wo_t_frag, wqkv_t_frag, dx, dqkv, dz, attn_out, ln_partial, nullptr, nullptr, stream);
+}
+
+extern "C" int ococc_window_attn_block_bwd_saved_bf16(const uint16_t* x, const uint16_t* pos, const uint16_t* dy,
+                                                      const int32_t* tile_rows, const int32_t* tile_span,
+                                                      int64_t num_tiles, int32_t d_model, int32_t num_heads,
+                                                      const uint16_t* wqkv_frag, const float* bqkv, const uint16_t* wo_frag,
+                                                      const float* bo, const float* ln_weight, float eps,
+                                                      const uint16_t* wo_t_frag, const uint16_t* wqkv_t_frag,
+                                                      const uint16_t* attn_saved, const float* lse_saved, uint16_t* dx,
+                                                      uint16_t* dqkv, uint16_t* dz, float* ln_partial,
+                                                      ococc_stream_t stream) {
+  OCOCC_REQUIRE(num_tiles == 0 || (attn_saved && lse_saved), "null pointer");
+  return attn_block_bwd(x, pos, dy, tile_rows, tile_span, num_tiles, d_model, num_heads, wqkv_frag, bqkv, wo_frag, bo,
+                        ln_weight, eps, wo_t_frag, wqkv_t_frag, dx, dqkv, dz, nullptr, ln_partial, attn_saved, lse_saved,
+                        stream);
 }
 
 extern "C" int ococc_token_ffn_block_fwd_bf16(const uint16_t* x, int64_t num_tokens, int32_t d_model, int32_t d_ffn,

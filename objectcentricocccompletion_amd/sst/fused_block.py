@@ -10,6 +10,7 @@ ococc_window_tile_plan); windows of drop levels above 64 tokens keep the per-win
 own (sst_modules.WindowMultiheadAttention.forward_flat) and both halves meet again in the FFN block, which does not
 care about windows.  Nothing but the layer input is saved for backward: the backward kernels recompute."""
 import ctypes
+import os
 
 import torch
 
@@ -55,6 +56,11 @@ def linear_fragments(mats):
                                                   _vp([d.data_ptr() for d in dst]), L.stream()), 'linear_fragments')
         outs += dst
     return outs
+
+
+# training keeps the attention output + log-sum-exp of the attention block for its backward (OCOCC_SST_KEEP_ATTENTION=0: the
+# backward kernel runs the attention forward again, rounds 3-4)
+KEEP_ATTENTION = os.environ.get('OCOCC_SST_KEEP_ATTENTION', '1') == '1'
 
 
 class TilePlan(object):
@@ -135,16 +141,29 @@ class AttnBlock(torch.autograd.Function):
         # algorithmic flops on the real tokens: in-projection 2*3E*E, out-projection 2*E*E per token, attention 4*n*E per
         # token of an n-token window (what the reference's nn.MultiheadAttention computes without its padding)
         flops = plan.tokens * 8.0 * E * E + 4.0 * E * plan.sum_sq
-        _run('window_attn_block_fwd', flops, lambda: L.check(L.lib.ococc_window_attn_block_fwd_bf16(
-            L.ptr(x), L.ptr(pos), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, num_heads, L.ptr(wqkv), L.ptr(bq),
-            L.ptr(wo), L.ptr(bo), L.ptr(g1), L.ptr(b1), float(eps), L.ptr(y), L.stream()), 'window_attn_block_fwd'))
-        ctx.save_for_backward(x, pos, in_w, in_b, out_w, out_b, ln_w)
+        # a pass that will be differentiated keeps the attention output and the softmax's log-sum-exp (288 B per token): the
+        # backward kernel reads them back instead of running the attention forward again (KEEP_ATTENTION = False: recompute)
+        keep = KEEP_ATTENTION and any(ctx.needs_input_grad)
+        o_save = lse_save = None
+        if keep:
+            o_save = (torch.empty if covered else torch.zeros)((V, E), dtype=torch.bfloat16, device=x.device)
+            lse_save = torch.empty((V, num_heads), dtype=torch.float32, device=x.device)
+            _run('window_attn_block_fwd', flops, lambda: L.check(L.lib.ococc_window_attn_block_train_fwd_bf16(
+                L.ptr(x), L.ptr(pos), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, num_heads, L.ptr(wqkv), L.ptr(bq),
+                L.ptr(wo), L.ptr(bo), L.ptr(g1), L.ptr(b1), float(eps), L.ptr(y), L.ptr(o_save), L.ptr(lse_save), L.stream()),
+                'window_attn_block_train_fwd'))
+        else:
+            _run('window_attn_block_fwd', flops, lambda: L.check(L.lib.ococc_window_attn_block_fwd_bf16(
+                L.ptr(x), L.ptr(pos), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, num_heads, L.ptr(wqkv), L.ptr(bq),
+                L.ptr(wo), L.ptr(bo), L.ptr(g1), L.ptr(b1), float(eps), L.ptr(y), L.stream()), 'window_attn_block_fwd'))
+        ctx.save_for_backward(x, pos, in_w, in_b, out_w, out_b, ln_w, *([o_save, lse_save] if keep else []))
         ctx.misc = (plan, float(eps), int(num_heads), bool(covered), wqkv, wo, bq, bo, g1)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pos, in_w, in_b, out_w, out_b, ln_w = ctx.saved_tensors
+        x, pos, in_w, in_b, out_w, out_b, ln_w = ctx.saved_tensors[:7]
+        kept = ctx.saved_tensors[7:]
         plan, eps, H, covered, wqkv, wo, bq, bo, g1 = ctx.misc
         V, E = x.shape
         dy = dy.to(torch.bfloat16).contiguous()
@@ -153,13 +172,20 @@ class AttnBlock(torch.autograd.Function):
         dx = new((V, E), dtype=torch.bfloat16, device=x.device)
         dqkv = new((V, 3 * E), dtype=torch.bfloat16, device=x.device)
         dz = new((V, E), dtype=torch.bfloat16, device=x.device)
-        o = new((V, E), dtype=torch.bfloat16, device=x.device)
         prow = int(L.lib.ococc_window_block_partial_rows(plan.num_tiles))
         lnp = torch.empty((prow, 2, E), dtype=torch.float32, device=x.device)
-        L.check(L.lib.ococc_window_attn_block_bwd_bf16(
-            L.ptr(x), L.ptr(pos), L.ptr(dy), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, H, L.ptr(wqkv),
-            L.ptr(bq), L.ptr(wo), L.ptr(bo), L.ptr(g1), eps, L.ptr(wot), L.ptr(wqkvt), L.ptr(dx), L.ptr(dqkv), L.ptr(dz),
-            L.ptr(o), L.ptr(lnp), L.stream()), 'window_attn_block_bwd')
+        if kept:
+            o, lse = kept
+            L.check(L.lib.ococc_window_attn_block_bwd_saved_bf16(
+                L.ptr(x), L.ptr(pos), L.ptr(dy), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, H, L.ptr(wqkv),
+                L.ptr(bq), L.ptr(wo), L.ptr(bo), L.ptr(g1), eps, L.ptr(wot), L.ptr(wqkvt), L.ptr(o), L.ptr(lse), L.ptr(dx),
+                L.ptr(dqkv), L.ptr(dz), L.ptr(lnp), L.stream()), 'window_attn_block_bwd_saved')
+        else:
+            o = new((V, E), dtype=torch.bfloat16, device=x.device)
+            L.check(L.lib.ococc_window_attn_block_bwd_bf16(
+                L.ptr(x), L.ptr(pos), L.ptr(dy), L.ptr(plan.rows), L.ptr(plan.span), plan.num_tiles, E, H, L.ptr(wqkv),
+                L.ptr(bq), L.ptr(wo), L.ptr(bo), L.ptr(g1), eps, L.ptr(wot), L.ptr(wqkvt), L.ptr(dx), L.ptr(dqkv), L.ptr(dz),
+                L.ptr(o), L.ptr(lnp), L.stream()), 'window_attn_block_bwd')
         # rows outside the plan hold zeros in dqkv / dz: they add nothing to the sums below
         (dwqkv, dbqkv), (dwo, dbo), (dg, db) = _wgrad([(dqkv, 3 * E, x, pos, 2 * E), (dz, E, o, None, 0)], V, x.device, lnp, prow)
         return (dx, None, None, dwqkv.to(in_w.dtype), dbqkv.to(in_b.dtype), dwo.to(out_w.dtype), dbo.to(out_b.dtype),

@@ -315,3 +315,35 @@ def test_fused_sst_at_the_configs4_per_gpu_share(dev):
     torch.cuda.synchronize()
     assert torch.equal(captured[0], a[0]) and torch.equal(captured[1], a[1])
     assert all(torch.equal(p, q) for p, q in zip(captured[2], a[2]))
+
+
+@pytest.mark.parametrize('small_only', [True, False])
+def test_kept_attention_output_gives_the_backward_of_the_recomputing_kernel(dev, golden_dir, small_only, monkeypatch):
+    """Training keeps the attention output and the softmax's log-sum-exp of the attention block
+    (ococc_window_attn_block_train_fwd_bf16) and the backward kernel reads them back
+    (ococc_window_attn_block_bwd_saved_bf16) instead of running the attention forward again: the same arithmetic on the
+    same values -- output, input gradient and every parameter gradient BIT-identical to the recomputing pair (which is the
+    one the oracle tests above pin)."""
+    from objectcentricocccompletion_amd.sst import fused_block as fb
+    from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2
+    coors, feats = _scene(golden_dir, small_only)
+    enc, sd = _layer(dev, compute_dtype=torch.bfloat16)
+    enc.train()
+    inp = SSTInputLayerV2(DROP, WINDOW, SPARSE, shuffle_voxels=False, debug=False, mute=True).eval()
+    info = inp(feats.to(dev), coors.to(dev))
+    args = (info['pos_dict_shift0'], info['flat2win_inds_shift0'], info['key_mask_shift0'])
+    g = torch.Generator().manual_seed(6)
+    dy = (torch.randn(len(feats), 128, generator=g) * 0.1).bfloat16().to(dev)
+    runs = []
+    for keep in (True, False):
+        monkeypatch.setattr(fb, 'KEEP_ATTENTION', keep)
+        for p in enc.parameters():
+            p.grad = None
+        x = feats.to(dev).clone().requires_grad_(True)
+        y = enc(x, *args)
+        y.backward(dy)
+        runs.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}))
+    a, b = runs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
