@@ -47,6 +47,11 @@ __device__ long long* t_stamps = nullptr;
 #endif
 
 constexpr int kTileThreads = 512;
+#ifndef OCOCC_TILE_LNB_ROWS
+#define OCOCC_TILE_LNB_ROWS 512
+#endif
+// rows per tile of the 128-gathered-channel instantiation WITH the LayerNorm-backward epilogue
+constexpr int kTileLnbRows = OCOCC_TILE_LNB_ROWS;
 constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kTileOffsetsPerWave = 4;  // offsets a wave carries through one pass (8 x 4 = 32 >= 26)
 
@@ -492,6 +497,8 @@ int launch_tile(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kvol
   } else {
     // (128 input channels at 256 rows: fits 128 registers only with two offsets per wave and pass and one set of
     // weight fragments -- 30.6 us against 29.5 us for the 512-row tile at one workgroup per CU)
+    if (ln && ln->partials)   // LayerNorm-backward epilogue (10 us of arithmetic per 512-row tile): see kTileLnbRows
+      return launch_tile_t<KD, NC, kTileLnbRows>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
     return launch_tile_t<KD, NC, 512>(feat, n_in, wn, kvol, dense_k, table, n_out, bias, out, out_dtype, stream, ln);
   }
 }
@@ -564,7 +571,7 @@ extern "C" int ococc_sparse_conv_tile_ln_bf16(const uint16_t* feat, int64_t n_in
 
 namespace {
 // rows of the tile the launcher picks for a shape (launch_tile above)
-inline int tile_rows_for(int kd, int ncols) { return (ncols >= 128 || kd <= 64) ? 256 : 512; }
+inline int tile_rows_for(int kd, int ncols) { return (ncols >= 128 || kd <= 64) ? 256 : kTileLnbRows; }   // (only the LNB entry asks)
 }  // namespace
 
 extern "C" int64_t ococc_sparse_conv_tile_lnbwd_partial_rows(int64_t n_out, int32_t kd, int32_t ncols) {

@@ -1,6 +1,6 @@
 """Phase timings of the compact-then-multiply sub-manifold convolution (csrc/sparse_conv_tile.hip) from in-kernel
 wall-clock stamps.  Builds its own copy of the translation unit with -DOCOCC_TILE_STAMPS (the product library carries no
-stamps).  Run on the GPU box: python tools/probe/tile_stamps.py <kd> <ncols>"""
+stamps).  Run on the GPU box: python tools/probe/tile_stamps.py <kd> <ncols> [lnbwd]"""
 import ctypes
 import os
 import subprocess
@@ -41,9 +41,29 @@ lib.ococc_sparse_conv_tile_bf16.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, 
                                             ctypes.c_int64, vp, vp, ctypes.c_int32, vp]
 
 
+LNB = len(sys.argv) > 3 and sys.argv[3] == 'lnbwd'   # the input-gradient instantiation with the LayerNorm-backward epilogue
+if LNB:
+    conv_out = torch.randn(n, nc, generator=g).to(dev).bfloat16()
+    mu = conv_out.float().mean(1)
+    stats = torch.stack([mu, 1.0 / torch.sqrt(conv_out.float().var(1, unbiased=False) + 1e-3)], 1).contiguous()
+    gamma, beta = torch.ones(nc, device=dev), torch.zeros(nc, device=dev)
+    lib.ococc_sparse_conv_tile_lnbwd_partial_rows.restype = ctypes.c_int64
+    lib.ococc_sparse_conv_tile_lnbwd_partial_rows.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    prows = lib.ococc_sparse_conv_tile_lnbwd_partial_rows(n, kd, nc)
+    partials = torch.empty((prows, 2 * nc), dtype=torch.float32, device=dev)
+    lib.ococc_sparse_conv_tile_lnbwd_bf16.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32, vp,
+                                                      ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int32, vp, vp,
+                                                      ctypes.c_int64, vp]
+
+
 def run():
-    rc = lib.ococc_sparse_conv_tile_bf16(x.data_ptr(), n, kd, wn.data_ptr(), 27, nc, table.data_ptr(), 13, n, None, out.data_ptr(),
-                                         L.BF16, None)
+    if LNB:
+        rc = lib.ococc_sparse_conv_tile_lnbwd_bf16(x.data_ptr(), n, kd, wn.data_ptr(), 27, nc, table.data_ptr(), 13, n,
+                                                   conv_out.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                                                   out.data_ptr(), partials.data_ptr(), prows, None)
+    else:
+        rc = lib.ococc_sparse_conv_tile_bf16(x.data_ptr(), n, kd, wn.data_ptr(), 27, nc, table.data_ptr(), 13, n, None,
+                                             out.data_ptr(), L.BF16, None)
     assert rc == 0, rc
 
 
@@ -64,8 +84,9 @@ wf = w.view(27, kd, nc).bfloat16().float()
 for k in range(27):
     m = tb[k] >= 0
     ref[m] += x[tb[k][m]].float() @ wf[k]
-err = (out.float() - ref).abs().max().item()
-print('max |out - f32 reference|', err, 'of', ref.abs().max().item(), '(bf16 output rounding: 2^-9 relative)')
+if not LNB:
+    err = (out.float() - ref).abs().max().item()
+    print('max |out - f32 reference|', err, 'of', ref.abs().max().item(), '(bf16 output rounding: 2^-9 relative)')
 st = stamps.cpu().numpy().reshape(-1, 16).astype(np.float64) / 100.0
 st = st[st[:, 0] > 0]
 if len(st) == 0:
