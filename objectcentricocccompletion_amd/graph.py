@@ -51,12 +51,26 @@ class GraphedStep(object):
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with (capture_ctx if capture_ctx is not None else contextlib.nullcontext()):
+        from .spconv import ops as sp_ops
+        self._operands = sp_ops.graph_operand_scope()   # the weight-operand buffers this capture pins (released with it)
+        with (capture_ctx if capture_ctx is not None else contextlib.nullcontext()), self._operands:
             # thread_local: other threads (RCCL watchdog, autograd workers) may keep calling the runtime
             with torch.cuda.graph(self.graph, pool=pool, stream=self.stream, capture_error_mode='thread_local'):
                 self.out = fn()
                 _join_side_streams()
         torch.cuda.synchronize()
+
+    def release(self):
+        """let go of what the capture pinned in spconv.ops (call when the graph is discarded or about to be re-captured)"""
+        ops = getattr(self, '_operands', None)
+        if ops is not None:
+            ops.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def pool(self):
         return self.graph.pool()

@@ -537,6 +537,8 @@ def prepare_weights(items):
             if torch.cuda.is_current_stream_capturing():
                 _graph_operands.append(hit[0])   # a captured graph reads and rewrites this buffer: it must outlive the cache
                 _graph_entries[key] = hit
+                if _capture_log is not None:
+                    _capture_log.append((key, hit[0]))
             continue
         wn = torch.empty((kvol, nc, kd), dtype=torch.bfloat16, device=filters.device)
         todo.append((filters, mode, kvol, cin, cout, wn))
@@ -549,6 +551,40 @@ def prepare_weights(items):
             n, vp(*[c[0].data_ptr() for c in ch]), i32(*[c[2] for c in ch]), i32(*[c[3] for c in ch]),
             i32(*[c[4] for c in ch]), i32(*[c[1] for c in ch]), vp(*[c[5].data_ptr() for c in ch]), L.stream()),
             'weight_prepare_multi')
+
+
+_capture_log = None   # [(key, operand buffer)] of the capture in progress (graph.GraphedStep)
+
+
+class graph_operand_scope(object):
+    """Around a graph capture: remembers which operand buffers the capture pinned (``_graph_entries`` / ``_graph_operands``:
+    a captured graph reads and rewrites them, so they are kept alive and kept current for it) -- ``release()`` lets go of
+    them when the graph is discarded or re-captured.  Without it the tables only grew: a discarded graph's buffers stayed
+    alive, stayed optimizer refresh targets and were checked on every replay."""
+
+    def __init__(self):
+        self.items = []
+
+    def __enter__(self):
+        global _capture_log
+        self._prev, _capture_log = _capture_log, self.items
+        return self
+
+    def __exit__(self, *exc):
+        global _capture_log
+        _capture_log = self._prev
+        return False
+
+    def release(self):
+        for key, wn in self.items:
+            hit = _graph_entries.get(key)
+            if hit is not None and hit[0] is wn:
+                del _graph_entries[key]
+            for i in range(len(_graph_operands) - 1, -1, -1):
+                if _graph_operands[i] is wn:
+                    del _graph_operands[i]
+                    break
+        self.items = []
 
 
 def refresh_targets(param):
@@ -1021,6 +1057,8 @@ def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
     """ops.py:162-172 of the reference (indice_maxpool_fp32 / _half): out[o] = max(0, features[i] over the pairs (i, o)) --
     the reference's output starts at zero (pool_ops.h:34, src/maxpool.cc:9-27).  float32 or bfloat16 (its half)."""
     L.require_device(features, indice_pairs)
+    if features.dtype == torch.float16:   # (the reference's _half instantiation: the maximum is exact in any format)
+        return indice_maxpool(features.float(), indice_pairs, indice_pair_num, num_activate_out).half()
     if features.dtype not in (torch.float32, torch.bfloat16):
         raise NotImplementedError
     x = features.contiguous()
@@ -1035,6 +1073,9 @@ def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice
     """ops.py:175-184: input_bp[i] += out_bp[o] for every pair (i, o) with features[i] == out_features[o]
     (src/maxpool.cc:31-53), offsets in ascending order."""
     L.require_device(features, out_features, out_bp, indice_pairs)
+    if features.dtype == torch.float16:   # (f16 values are exact in f32: the equality test selects the same rows)
+        return indice_maxpool_backward(features.float(), out_features.float(), out_bp.float(), indice_pairs,
+                                       indice_pair_num).half()
     if features.dtype not in (torch.float32, torch.bfloat16):
         raise NotImplementedError
     x, y, dy = features.contiguous(), out_features.contiguous(), out_bp.to(features.dtype).contiguous()

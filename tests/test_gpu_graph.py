@@ -265,3 +265,9 @@ def test_graph_on_cached_operands_follows_parameter_writes(dev):
     for a, p in zip(g_g, model.parameters()):
         assert torch.equal(p.grad, a)
     assert ops.refresh_graph_operands() == 0
+    #  a discarded graph lets go of what its capture pinned: the operand buffers are no refresh targets any more
+    mine = {k for k, _ in g._operands.items}
+    assert len(mine) >= 5 and mine <= set(ops._graph_entries)
+    others = set(ops._graph_entries) - mine
+    g.release()
+    assert set(ops._graph_entries) == others

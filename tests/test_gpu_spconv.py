@@ -762,6 +762,37 @@ def test_sparse_maxpool_vs_oracle_and_dense(dev, dtype):
     assert np.array_equal(outp.features.float().cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_submanifold_maxpool_and_half_precision(dev, dtype):
+    """SparseMaxPool(subm=True) (pool.py:20-87 with the sub-manifold rulebook: the output keeps the input's sites) and the
+    reference's half instantiation (indice_maxpool_half, ops.py:162-184): forward and input gradient bit for bit against the
+    restatement of the CPU functor on the oracle's sub-manifold rulebook (this path was unexercised; the
+    backward derives its table from saved pairs that were built without -1 tails)."""
+    from objectcentricocccompletion_amd.spconv import SparseConvTensor, ops
+    from objectcentricocccompletion_amd.spconv.pool import SparseMaxPool
+    rng = np.random.default_rng(52)
+    B, shape, c = 2, (9, 10, 12), 16
+    idx = _voxels(rng, B, shape, 0.3, False)
+    n = len(idx)
+    x = rng.standard_normal((n, c)).astype(np.float16).astype(np.float32)      # f16-representable values
+    x[rng.random(x.shape) < 0.1] = 0.0
+    xt = torch.from_numpy(x).to(dev).to(dtype).requires_grad_(True)
+    pool = SparseMaxPool(3, 3, stride=1, padding=1, subm=True)
+    out = pool(SparseConvTensor(xt, torch.from_numpy(idx).to(dev), list(shape), B))
+    assert torch.equal(out.indices.cpu(), torch.from_numpy(idx)) and out.features.dtype == dtype
+    ep, en = O.subm_rulebook(idx, B, shape)
+    want = O.indice_maxpool(x, ep, en, n)
+    assert np.array_equal(out.features.detach().float().cpu().numpy(), want)
+    dy = rng.standard_normal(want.shape).astype(np.float16).astype(np.float32)
+    out.features.backward(torch.from_numpy(dy).to(dev).to(dtype))
+    edin = O.indice_maxpool_backward(x, want, dy, ep, en)
+    gin = xt.grad.float().cpu().numpy()
+    if dtype == torch.float32:
+        assert np.array_equal(gin, edin)
+    else:
+        assert np.allclose(gin, edin, rtol=2e-3, atol=2e-3)                   # (the sum over offsets is rounded to f16)
+
+
 def test_sequential_fused_folds_batchnorm_into_the_conv(dev):
     """SparseSequential.fused() (modules.py:139-185): conv + BatchNorm1d folded into one conv with a bias (the
     reference's arithmetic, whose denominator is sqrt(var) + eps); equal to the unfused eval-mode chain to that
