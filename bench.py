@@ -245,7 +245,9 @@ def bench_ococcnet(args, world, rank, dev):
             'metric': 'object-grids/sec (fwd+bwd)', 'value': round(world * B * L * args.steps / dt, 1),
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.f32_decoder else 'f32 (occupancy-decoder MLP in bf16)',
+            'vs_baseline': None, 'dtype': ('f32' if args.f32_decoder else 'f32 (occupancy-decoder MLP in bf16)')
+            + (' (library products on bf16 operands, f32 accumulation: OCOCC_GEMM_DTYPE=bf16)'
+               if os.environ.get('OCOCC_GEMM_DTYPE', '') == 'bf16' else ''),
             'data': 'synthetic',
             'config': {'workload': f'configs[2]: full ococcnet.py model (66.55 M parameters), {B} tracklets x {L} '
                                    f'frames = {B * L} object grids/GPU/step, 64 points/frame, K=512 occupancy '
@@ -519,12 +521,18 @@ def also_workloads():
     for key, extra in (('ococcnet_b4', ['--workload', 'ococcnet', '--tracklets', '4']),
                        ('ococcnet_b16', ['--workload', 'ococcnet', '--tracklets', '16']),
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
+                       ('ococcnet_b64_bf16_operands', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('sst', ['--workload', 'sst']),
                        ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
         steps = '30' if key in ('ococcnet_b4', 'ococcnet_b16') else '10'   # (the short steps: more of them, the host's load shows)
         cmd = [sys.executable, here, '--steps', steps, '--warmup', '8', '--no-cpu-baseline'] + extra
+        env = dict(os.environ)
+        if key.endswith('_bf16_operands'):
+            # the opt-in product mode of objectcentricocccompletion_amd/gemm.py (library products on bf16-rounded operands, f32
+            # accumulation): reported beside the f32 line, never instead of it
+            env['OCOCC_GEMM_DTYPE'] = 'bf16'
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
             d = json.loads(line[-1]) if line else {'error': (r.stderr or 'no output')[-300:]}
             out[key] = {k: d[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'error')

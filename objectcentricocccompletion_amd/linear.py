@@ -77,6 +77,9 @@ def tall_addmm(base, x, w):
 class Linear(nn.Linear):
 
     def forward(self, x):
+        from . import gemm
+        if gemm.GEMM_DTYPE is not None and x.is_cuda and x.dtype == torch.float32 and min(self.in_features, self.out_features) >= 16:
+            return gemm.linear(x, self.weight, self.bias)   # bf16 operands on the matrix cores, f32 sums (opt-in: gemm.py)
         if (x.dim() == 2 and x.size(0) >= TALL_ROWS and max(self.in_features, self.out_features) <= 256
                 and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled()):
             return _TallLinear.apply(x, self.weight, self.bias)

@@ -9,6 +9,7 @@ import math
 import torch
 from torch import nn
 
+from .. import gemm
 from ..norm import layer_norm_act
 from ..sst.sst_ops import get_activation_layer
 
@@ -30,7 +31,11 @@ class PositionalEncoding(nn.Module):
 class MultiheadAttention(nn.Module):
     """Self-attention with the parameter layout of nn.MultiheadAttention (in_proj_weight
     [3E,E], in_proj_bias, out_proj.{weight,bias}); sequence-first tensors [L, B, E].
-    Supports the boolean attn_mask / key_padding_mask forms the reference passes."""
+    Supports the boolean attn_mask / key_padding_mask forms the reference passes.
+
+    Own formulation: q and k share their input (x + pos), so they leave ONE product with the first 2E rows of in_proj
+    (the reference's nn.MultiheadAttention runs three), heads are taken as views of that [L B, 2E] result; all products go
+    through ``gemm`` (f32 as the reference, or bf16 operands on the matrix cores when gemm.GEMM_DTYPE says so)."""
 
     def __init__(self, embed_dim, num_heads, dropout=0.0):
         super().__init__()
@@ -43,34 +48,38 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
+    def _heads(self, t, n):
+        """[n * B, E] token-major -> [B * H, n, D]"""
+        return t.reshape(n, -1, self.head_dim).transpose(0, 1)
+
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
         L, B, E = query.shape
         S = key.shape[0]
-        H, D = self.num_heads, self.head_dim
+        H = self.num_heads
         w, b = self.in_proj_weight, self.in_proj_bias
-        q = torch.addmm(b[:E], query.reshape(L * B, E), w[:E].t())
-        k = torch.addmm(b[E:2 * E], key.reshape(S * B, E), w[E:2 * E].t())
-        v = torch.addmm(b[2 * E:], value.reshape(S * B, E), w[2 * E:].t())
-        q = q.view(L, B * H, D).transpose(0, 1) * (D ** -0.5)
-        k = k.view(S, B * H, D).transpose(0, 1)
-        v = v.view(S, B * H, D).transpose(0, 1)
-        att = torch.bmm(q, k.transpose(1, 2))  # [B*H, L, S]
+        if key is query:      # (the encoder layers: q = k = src + pos)
+            qk = gemm.linear(query.reshape(L * B, E), w[:2 * E], b[:2 * E])
+            q, k = qk[:, :E], qk[:, E:]
+        else:
+            q = gemm.linear(query.reshape(L * B, E), w[:E], b[:E])
+            k = gemm.linear(key.reshape(S * B, E), w[E:2 * E], b[E:2 * E])
+        v = gemm.linear(value.reshape(S * B, E), w[2 * E:], b[2 * E:])
+        scores = gemm.bmm(self._heads(q * (self.head_dim ** -0.5), L), self._heads(k, S).transpose(1, 2))   # [B H, L, S]
         if attn_mask is not None:
-            att = att.masked_fill(attn_mask[None], float('-inf')) if attn_mask.dtype == torch.bool \
-                else att + attn_mask[None]
+            scores = scores.masked_fill(attn_mask[None], float('-inf')) if attn_mask.dtype == torch.bool \
+                else scores + attn_mask[None]
         if key_padding_mask is not None:
-            att = att.view(B, H, L, S).masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
-            att = att.view(B * H, L, S)
-        att = torch.softmax(att, dim=-1)
+            scores = scores.view(B, H, L, S).masked_fill(key_padding_mask[:, None, None, :], float('-inf')).view(B * H, L, S)
+        prob = torch.softmax(scores, dim=-1)
         if self.dropout > 0 and self.training:
-            att = torch.nn.functional.dropout(att, self.dropout)
-        out = torch.bmm(att, v).transpose(0, 1).reshape(L * B, E)
-        out = self.out_proj(out).view(L, B, E)
-        return out, None
+            prob = torch.nn.functional.dropout(prob, self.dropout)
+        ctx = gemm.bmm(prob, self._heads(v, S)).transpose(0, 1).reshape(L * B, E)
+        return gemm.linear(ctx, self.out_proj.weight, self.out_proj.bias).view(L, B, E), None
 
 
 class SimpleEncoderLayer(nn.Module):
-    """Post-LN encoder layer with q = k = src + pos, v = src (layers.py:35-87)."""
+    """Post-LN encoder layer with q = k = src + pos, v = src (layers.py:35-87): attention block, then feed-forward block,
+    each `x <- LayerNorm(x + dropout(block(x)))` with the LayerNorm on the HIP kernel."""
 
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='gelu', mlp_dropout=0):
         super().__init__()
@@ -88,16 +97,18 @@ class SimpleEncoderLayer(nn.Module):
     def with_pos_embed(self, tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def _norm(self, norm, x):  # nn.LayerNorm parameters, HIP kernel
-        return layer_norm_act(x, norm.weight, norm.bias, norm.eps, 'none')
+    def _residual_norm(self, norm, x, branch, drop):
+        return layer_norm_act(x + drop(branch), norm.weight, norm.bias, norm.eps, 'none')   # nn.LayerNorm parameters, HIP kernel
+
+    def _feed_forward(self, x):
+        hidden = self.dropout(self.activation(gemm.linear(x, self.linear1.weight, self.linear1.bias)))
+        return gemm.linear(hidden, self.linear2.weight, self.linear2.bias)
 
     def forward(self, src, key_padding_mask=None, pos_enc=None, attn_mask=None):
-        q = k = self.with_pos_embed(src, pos_enc)
-        src2 = self.self_attn(q, k, value=src, attn_mask=attn_mask, key_padding_mask=key_padding_mask)[0]
-        src = self._norm(self.norm1, src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
-        src = self._norm(self.norm2, src + self.dropout2(src2))
-        return src
+        qk_in = self.with_pos_embed(src, pos_enc)
+        attended, _ = self.self_attn(qk_in, qk_in, value=src, attn_mask=attn_mask, key_padding_mask=key_padding_mask)
+        x = self._residual_norm(self.norm1, src, attended, self.dropout1)
+        return self._residual_norm(self.norm2, x, self._feed_forward(x), self.dropout2)
 
 
 def _get_clones(module, N):
@@ -105,13 +116,15 @@ def _get_clones(module, N):
 
 
 class TransformerEncoder(nn.Module):
+    """``num_layers`` copies of an encoder layer applied in turn (layers.py:89-99; parameter names layers.<i>....)"""
+
     def __init__(self, encoder_layer, num_layers):
         super().__init__()
         self.layers = _get_clones(encoder_layer, num_layers)
         self.num_layers = num_layers
 
     def forward(self, src, key_padding_mask=None, pos_enc=None, attn_mask=None):
-        output = src
+        x = src
         for layer in self.layers:
-            output = layer(output, key_padding_mask, pos_enc, attn_mask)
-        return output
+            x = layer(x, key_padding_mask=key_padding_mask, pos_enc=pos_enc, attn_mask=attn_mask)
+        return x

@@ -562,3 +562,39 @@ def test_transformer_various_length_vs_reference_golden(dev, gold, head):
     finally:
         head.train_cfg['fixed_length'] = old
         head.eval()
+
+
+def test_temporal_transformer_with_bf16_operands(dev, monkeypatch):
+    """gemm.GEMM_DTYPE = bf16 (opt-in): the temporal transformer's products (layers.py:35-87 of the reference, f32 there)
+    with bf16 OPERANDS on the matrix cores and f32 sums.  (a) It computes what it says: ONE layer equals f32 GEMMs on
+    operands ROUNDED to bf16, forward and backward (gemm.EMULATE), up to the order of the f32 sums and the few bf16 values
+    that order flips (a sharp softmax amplifies a flipped q / k element) -- output and every gradient within 3e-3
+    norm-wise (measured 1e-5 .. 1.4e-3; through two layers up to 3.4e-3, bounded at 1e-2); (b) what the rounding costs against the f32
+    path (the reference's arithmetic) is measured and bounded."""
+    from objectcentricocccompletion_amd import gemm
+    from objectcentricocccompletion_amd.occ.layers import SimpleEncoderLayer, TransformerEncoder
+    E, H, FFN, L, B = 1536, 4, 512, 32, 4
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+    for layers, bound in ((1, 3e-3), (2, 1e-2)):
+        torch.manual_seed(3)
+        enc = TransformerEncoder(SimpleEncoderLayer(E, H, FFN, dropout=0.0, activation='gelu'), layers).to(dev).train()
+        x0 = torch.randn(L, B, E, device=dev)
+        pos = torch.randn(L, B, E, device=dev) * 0.1
+        mask = torch.triu(torch.ones(L, L, dtype=torch.bool, device=dev), 1)
+        dy = torch.randn(L, B, E, device=dev)
+        runs = {}
+        for mode, dt, emu in (('f32', None, False), ('rounded', torch.bfloat16, True), ('bf16', torch.bfloat16, False)):
+            monkeypatch.setattr(gemm, 'GEMM_DTYPE', dt)
+            monkeypatch.setattr(gemm, 'EMULATE', emu)
+            for p in enc.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = enc(x, pos_enc=pos, attn_mask=mask)
+            y.backward(dy)
+            runs[mode] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in enc.parameters()]
+        same = max(rel(a, b) for a, b in zip(runs['bf16'], runs['rounded']))
+        cost = [rel(a, b) for a, b in zip(runs['bf16'], runs['f32'])]
+        print(f'{layers} layer(s): bf16-operand products vs f32 GEMMs on rounded operands: worst {same:.2e}; against the f32 path: '
+              f'output {cost[0]:.2e}, d input {cost[1]:.2e}, parameter gradients worst {max(cost[2:]):.2e}')
+        assert same < bound
+        assert cost[0] < 5e-3 and cost[1] < 1e-2 and max(cost[2:]) < 2e-2
