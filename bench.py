@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+T_START = time.time()
+
 # ROCm 7.2's graph "packet capture" fast path faults when device memory is allocated between two
 # replays of a large graph (tools/graph_bisect.py); must be off before the HIP runtime loads.
 os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
@@ -107,6 +109,24 @@ def dump_params(args, rank, params):
         torch.save(torch.cat([p.detach().float().reshape(-1) for p in params]).cpu(), f'{args.dump_params}.rank{rank}.pt')
 
 
+def host_cores(limit=16):
+    """Threads the CPU baseline may use: the smallest of the process's CPU affinity, its cgroup CPU quota and `limit`.
+    (os.cpu_count() reports the machine's hardware threads; a box that hands this process a few of them -- cpuset or
+    cpu.max -- makes torch's intra-op pool with 16 spinning threads two orders of magnitude slower than with 4.)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, limit))
+
+
 def cpu_baseline(sample_grids, points, model):
     """the pure-PyTorch CPU restatement of the same step (oracle/encoder_torch_cpu.py: the reference's
     CPU formulation -- per-offset gather / torch.mm / scatter-add, fp32 -- on every host core) on a bounded sample of
@@ -116,7 +136,7 @@ def cpu_baseline(sample_grids, points, model):
     # at most 16 threads: the step is a few hundred small operators; with the 256 hardware threads of the GPU box
     # torch's intra-op pool spends its time handing them out (measured there: 0.06 grids/s with 256 threads, 4.5
     # minutes per step, against 119 grids/s with 8 threads in the build container)
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     torch.set_num_threads(cores)
     xyz, feats, bidx = synthetic_object_grids(sample_grids, points, seed=0, device='cpu')
     ws = [l[0].weight.detach().float().cpu() for l in model.conv_layers]
@@ -284,7 +304,7 @@ def cpu_baseline_ococcnet(frames):
     handing them out (measured there: 0.11 grids/s with 256 threads)."""
     from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
     from oracle import cpu_port
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = cpu_port.build_detector_cpu(seed_weights=False).train()
@@ -531,12 +551,14 @@ def also_workloads():
             # the opt-in product mode of objectcentricocccompletion_amd/gemm.py (library products on bf16-rounded operands, f32
             # accumulation): reported beside the f32 line, never instead of it
             env['OCOCC_GEMM_DTYPE'] = 'bf16'
+        t_child = time.time()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith('{')]
             d = json.loads(line[-1]) if line else {'error': (r.stderr or 'no output')[-300:]}
             out[key] = {k: d[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'error')
                         if k in d}
+            out[key]['wall_s'] = round(time.time() - t_child, 1)
         except Exception as e:   # noqa: BLE001 (timeout, missing device, ...)
             out[key] = {'error': repr(e)[:300]}
     return out
@@ -849,10 +871,16 @@ def main():
                 'per_kernel': per_kernel,
             },
         }
+        wall = {'to_result_s': round(time.time() - T_START, 1)}
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the other ranks would sit in the barrier)
+            t0 = time.time()
             res['cpu_baseline'] = cpu_baseline(16, P, model)
+            wall['cpu_baseline_s'] = round(time.time() - t0, 1)
         if world == 1 and not args.no_also:
+            t0 = time.time()
             res['also'] = also_workloads()
+            wall['also_s'] = round(time.time() - t0, 1)
+        res['wall'] = wall
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
