@@ -750,7 +750,7 @@ int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float
 
 /* ------------------------------------------------------------------------
  * A whole SIRLayer per call: SIRLayer.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:764-832) with LayerNorm
- * blocks and max pooling, as the sequence of ococc_point_mlp_* launches above plus the joins between them.
+ * blocks and max pooling: the tile bodies of the ococc_point_mlp_* launches above plus the joins between them.
  * Blocks are numbered rel_mlp first, then vfe_layers; block b is Linear(k_b -> n[b], no bias) -> LayerNorm -> act[b]
  * (0 none, 1 GELU, 2 ReLU) with k_b = cluster_cols | n[b-1] (rel), feat_cols (+ cluster_cols) (first vfe), 2 n[b-1] (later
  * vfe).  features [rows, feat_cols] (xyz first), f_cluster [rows, cluster_cols], inv int32 non-decreasing.
@@ -765,7 +765,7 @@ typedef struct {
   int32_t feat_cols, cluster_cols;
   int32_t with_cluster_center, shortcut;
   float bscale;                      /* factor of the f_cluster columns appended to the first vfe block's input */
-  int32_t reserved;
+  int32_t inference;                 /* nonzero: forward only -- the arg-max rows the backward call reads are not recorded */
   const float* rel_colscale;         /* [cluster_cols] scale of the rel_mlp input, or null */
   const float* colscale;             /* [feat_cols] scale of the feature columns, or null */
   int32_t n[8];
@@ -785,6 +785,20 @@ int ococc_sir_layer_bwd_layout(const ococc_sir_layer* layer, int64_t rows, int64
 int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features, const float* f_cluster, const int32_t* inv,
                             int64_t rows, int64_t groups, const float* fwd_slab, const float* y_out, const float* dy,
                             const float* d_groups, float* slab, float* dfeat, ococc_stream_t stream);
+/* One launch per layer and direction (+ one for the weight-gradient products): while every row tile has a workgroup of
+ * its own (MI355X: up to 1024 tiles of 32 rows = 32 k points) and the layer's blocks are one of the shapes of
+ * csrc/sir_fused.hpp (rel_mlp of 3 blocks, 2 vfe blocks: every SIRLayer of configs[2]), each of the two calls runs the
+ * blocks of a tile back to back in a persistent grid that meets at a grid-wide barrier where the segment maxima
+ * (backward: their gradients) cross tiles.  Everything that crosses workgroups inside the launch goes through
+ * device-scope atomics; the barrier words live in a per-(device, stream) buffer the library allocates at the first call on
+ * a stream (not under stream capture).  Otherwise -- and always after ococc_sir_layer_set_fused(0) -- the same tile
+ * bodies run as one launch per block: the same arithmetic, the forward results are equal to the bit.
+ * ococc_sir_layer_set_fused(1) takes the one-launch form at any row count (a workgroup then walks several tiles);
+ * -1 restores the default (OCOCC_SIR_FUSED=0 in the environment = 0).  A barrier wait is bounded (2 s): instead of
+ * hanging the device an incomplete barrier leaves its index + 1 in a status word, which ococc_sir_layer_fused_status
+ * reads back (synchronises the stream; 0 = every barrier completed). */
+int ococc_sir_layer_set_fused(int32_t mode);
+int ococc_sir_layer_fused_status(ococc_stream_t stream, int32_t* status);
 
 /* ------------------------------------------------------------------------
  * A11 / A10, fused  the occupancy decoder's per-query MLP, one launch per layer (or one for the whole MLP):

@@ -5,6 +5,7 @@
 // here: at 4 tracklets the training step is bound by the host, and a layer cost ~0.27 ms (forward) + ~0.5 ms (backward)
 // of interpreter time around ~25 launches.  Intermediates live in one caller-owned slab per direction.
 #include "common.hpp"
+#include "sir_fused.hpp"
 
 namespace {
 
@@ -43,7 +44,7 @@ inline int read_dims(const ococc_sir_layer* d, Dims* D) {
 }
 
 struct FwdLayout {
-  int64_t y[kMaxBlocks], m[kMaxBlocks], total;
+  int64_t y[kMaxBlocks], m[kMaxBlocks], arg[kMaxBlocks], total;
 };
 inline void fwd_layout(const Dims& D, int64_t rows, int64_t groups, FwdLayout* L) {
   int64_t off = 0;
@@ -55,11 +56,15 @@ inline void fwd_layout(const Dims& D, int64_t rows, int64_t groups, FwdLayout* L
     L->m[i] = off;
     off += pad64(groups * D.n[D.nr + i]);
   }
+  for (int i = 0; i < D.nv; ++i) {   // (int32) the smallest row attaining each maximum: written by the forward pass
+    L->arg[i] = off;
+    off += pad64(groups * D.n[D.nr + i]);
+  }
   L->total = off > 0 ? off : 64;
 }
 
 struct BwdLayout {
-  int64_t dz[kMaxBlocks], xcat[kMaxBlocks], da[2], dgate, dv[kMaxBlocks], dm, arg, dy0, lnp[kMaxBlocks], wp[kMaxBlocks], total;
+  int64_t dz[kMaxBlocks], xcat[kMaxBlocks], da[2], dab[kMaxBlocks], dgate, dv[kMaxBlocks], dm, dy0, lnp[kMaxBlocks], wp[kMaxBlocks], total;
   int64_t tiles;
   int slices;
 };
@@ -79,10 +84,11 @@ inline void bwd_layout(const Dims& D, int feat_cols, int64_t rows, int64_t group
   for (int b = 0; b < D.nl; ++b) L->xcat[b] = take(rows * D.k[b]);
   L->da[0] = take(rows * max_ka);
   L->da[1] = take(rows * max_ka);
+  // (one launch per layer: every block fed by another block has the gradient of its input rows in a buffer of its own)
+  for (int b = 0; b < D.nl; ++b) L->dab[b] = (b != 0 && b != D.nr) ? take(rows * D.n[b - 1]) : 0;
   L->dgate = take(rows * feat_cols);
   for (int i = 0; i < D.nv; ++i) L->dv[i] = i > 0 ? take(groups * D.n[D.nr + i - 1]) : 0;
   L->dm = take(groups * max_n);
-  L->arg = take(groups * max_n);
   L->dy0 = take(rows * D.n[D.nl - 1]);
   for (int b = 0; b < D.nl; ++b) L->lnp[b] = take(L->tiles * 2 * D.n[b]);
   for (int b = 0; b < D.nl; ++b) L->wp[b] = take((int64_t)L->slices * D.n[b] * D.k[b]);
@@ -129,6 +135,45 @@ join_cols_kernel(const float* __restrict__ a, int lda, const float* __restrict__
   }
 }
 
+// the one-launch form's view of a layer: the descriptor + where the forward slab keeps every block's rows
+void fused_args(const ococc_sir_layer* d, const Dims& D, const FwdLayout& F, const float* feats, const float* f_cluster,
+                const int32_t* inv, int64_t rows, int64_t groups, float* fwd_slab, float* y_out, SirFusedArgs* A) {
+  *A = SirFusedArgs{};
+  A->feats = feats;
+  A->fc = f_cluster;
+  A->inv = inv;
+  A->rel_cs = d->rel_colscale;
+  A->col = d->colscale;
+  A->feat_cols = d->feat_cols;
+  A->cluster_cols = d->cluster_cols;
+  A->with_cc = d->with_cluster_center;
+  A->shortcut = d->shortcut;
+  A->nr = D.nr;
+  A->nv = D.nv;
+  A->sum_n = D.sum_n;
+  A->bscale = d->bscale;
+  A->rows = rows;
+  A->groups = groups;
+  const int last = D.nl - 1;
+  for (int b = 0; b < D.nl; ++b) {
+    SirBlockArgs& B = A->b[b];
+    B.wf = d->w_frag[b];
+    B.wtf = d->wt_frag[b];
+    B.ln_w = d->ln_weight[b];
+    B.ln_b = d->ln_bias[b];
+    B.eps = d->eps[b];
+    B.n = D.n[b];
+    B.k = D.k[b];
+    B.act = d->act[b];
+    B.y = (b == last && !d->shortcut) ? y_out : fwd_slab + F.y[b];
+    if (b >= D.nr) {
+      B.m = fwd_slab + F.m[b - D.nr];
+      B.arg = (int32_t*)(fwd_slab + F.arg[b - D.nr]);
+    }
+  }
+  A->y_out = y_out;
+}
+
 }  // namespace
 
 extern "C" int64_t ococc_sir_layer_fwd_floats(const ococc_sir_layer* d, int64_t rows, int64_t groups) {
@@ -168,6 +213,13 @@ extern "C" int ococc_sir_layer_fwd_f32(const ococc_sir_layer* d, const float* fe
   FwdLayout L;
   fwd_layout(D, rows, groups, &L);
   const int last = D.nl - 1;
+  if (rows > 0 && groups > 0 && sir_fused_enabled()) {   // the whole layer in one launch (csrc/sir_fused.hpp)
+    SirFusedArgs A;
+    fused_args(d, D, L, feats, f_cluster, inv, rows, groups, slab, y_out, &A);
+    A.groups_out = groups_out;
+    const int rc = sir_fused_forward(A, stream);
+    if (rc >= 0) return rc;   // (negative: not available for this call -- the per-block launches below)
+  }
   auto y_of = [&](int b) -> float* { return (b == last && !d->shortcut) ? y_out : slab + L.y[b]; };
   const float* x = f_cluster;
   int ldx = d->cluster_cols;
@@ -194,6 +246,10 @@ extern "C" int ococc_sir_layer_fwd_f32(const ococc_sir_layer* d, const float* fe
                                    slab + L.m[i - 1], D.n[q - 1], inv, rows, d->w_frag[q], D.n[q], d->ln_weight[q],
                                    d->ln_bias[q], d->eps[q], d->act[q], y_of(q), m, groups, stream_);
     if (rc) return rc;
+    // the smallest row attaining each maximum, for the backward pass (either form reads it from the forward slab)
+    if (!d->inference && groups > 0)
+      if (int rc2 = ococc_point_mlp_segment_argmax(y_of(q), m, inv, rows, D.n[q], groups, (int32_t*)(slab + L.arg[i]), stream_))
+        return rc2;
   }
   if (groups > 0) {
     int off = 0;
@@ -233,7 +289,38 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   auto y_of = [&](int b) -> const float* { return (b == last && !d->shortcut) ? y_out : fwd_slab + F.y[b]; };
   auto dz_of = [&](int b) -> float* { return slab + L.dz[b]; };
   auto xcat_of = [&](int b) -> float* { return slab + L.xcat[b]; };
-  int32_t* arg = (int32_t*)(slab + L.arg);
+  OCOCC_REQUIRE(!d->inference, "the forward pass of this descriptor recorded no arg-max rows (inference = 1)");
+  if (groups > 0 && sir_fused_enabled()) {
+    SirFusedArgs A;
+    fused_args(d, D, F, feats, f_cluster, inv, rows, groups, const_cast<float*>(fwd_slab), const_cast<float*>(y_out), &A);
+    for (int b = 0; b < D.nl; ++b) {
+      SirBlockArgs& B = A.b[b];
+      B.dz = dz_of(b);
+      B.xcat = xcat_of(b);
+      B.lnp = slab + L.lnp[b];
+      B.wp = slab + L.wp[b];
+      B.dv = b > D.nr ? slab + L.dv[b - D.nr] : nullptr;
+      B.da = (b != 0 && b != D.nr) ? slab + L.dab[b] : nullptr;
+    }
+    A.dy = dy;
+    A.d_groups = d_groups;
+    A.dfeat = dfeat;
+    A.dgate = slab + L.dgate;
+    A.slices = L.slices;
+    A.rows_per_slice = ococc_align_up(ococc_cdiv(rows, L.slices), 32);
+    const int rc = sir_fused_backward(A, stream);
+    if (rc > 0) return rc;
+    if (rc == 0) {   // dW partials of all blocks: they read every tile's dz and input rows -- a launch of their own
+      const float *zs[kMaxBlocks], *xs[kMaxBlocks];
+      float* ps[kMaxBlocks];
+      for (int b = 0; b < D.nl; ++b) {
+        zs[b] = dz_of(b);
+        xs[b] = xcat_of(b);
+        ps[b] = slab + L.wp[b];
+      }
+      return ococc_point_mlp_wgrad_multi_f32(D.nl, zs, xs, rows, D.n, D.k, ps, stream_);
+    }
+  }
   const float* dy_cur = dy;
   if (!dy_cur) {
     OCOCC_HIP(hipMemsetAsync(slab + L.dy0, 0, (size_t)rows * D.n[last] * 4, stream));
@@ -253,8 +340,8 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
       } else {
         dm = carry;
       }
-      if (int rc = ococc_point_mlp_segment_argmax(y_of(q), fwd_slab + F.m[i], inv, rows, n, groups, arg, stream_)) return rc;
     }
+    const int32_t* arg = (const int32_t*)(fwd_slab + F.arg[i]);   // (recorded by the forward pass)
     int rc;
     if (i == 0) {
       const float* gate = D.nr ? y_of(D.nr - 1) : nullptr;

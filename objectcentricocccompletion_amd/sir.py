@@ -44,15 +44,16 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
-# ... and one library call per direction for the whole layer (csrc/sir_layer.hip issues the launches the node below issues
-# from Python): the rest of the ~0.3 + 0.5 ms per layer.
+# ... and one library call per direction for the whole layer (csrc/sir_layer.hip): ONE launch per direction + the
+# weight-gradient launch while every row tile has a workgroup of its own (csrc/sir_fused_impl.hpp: <= 32 k points on
+# MI355X; whole step at 4 tracklets 13.9 -> 13.2 ms), the launches the node below issues from Python otherwise.
 NATIVE_LAYER = os.environ.get('OCOCC_SIR_NATIVE_LAYER', '1') == '1'
 
 
 class _SirLayerDesc(ctypes.Structure):   # ococc_sir_layer of include/ococc_hip.h
     _fields_ = [('n_rel', ctypes.c_int32), ('n_vfe', ctypes.c_int32), ('feat_cols', ctypes.c_int32),
                 ('cluster_cols', ctypes.c_int32), ('with_cluster_center', ctypes.c_int32), ('shortcut', ctypes.c_int32),
-                ('bscale', ctypes.c_float), ('reserved', ctypes.c_int32), ('rel_colscale', ctypes.c_void_p),
+                ('bscale', ctypes.c_float), ('inference', ctypes.c_int32), ('rel_colscale', ctypes.c_void_p),
                 ('colscale', ctypes.c_void_p), ('n', ctypes.c_int32 * 8), ('act', ctypes.c_int32 * 8),
                 ('eps', ctypes.c_float * 8), ('w_frag', ctypes.c_void_p * 8), ('wt_frag', ctypes.c_void_p * 8),
                 ('ln_weight', ctypes.c_void_p * 8), ('ln_bias', ctypes.c_void_p * 8)]
@@ -141,6 +142,7 @@ class _SirLayerNative(torch.autograd.Function):
         rows, dev = feats.shape[0], feats.device
         d = plan.desc
         d.shortcut = int(shortcut)
+        d.inference = 0 if torch.is_grad_enabled() or any(ctx.needs_input_grad) else 1
         slab = torch.empty((int(L.lib.ococc_sir_layer_fwd_floats(plan.ref, rows, G)),), dtype=torch.float32, device=dev)
         y = torch.empty((rows, plan.n_last), dtype=torch.float32, device=dev)
         groups = torch.empty((G, plan.sum_n), dtype=torch.float32, device=dev)

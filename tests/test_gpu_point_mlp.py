@@ -226,6 +226,63 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
             assert rel(p, q) < 1e-3
 
 
+@pytest.mark.parametrize('rows', [40, 3000, 40000])
+@pytest.mark.parametrize('cfg', [dict(in_channels=24, rel_in=13, cluster=False), dict(in_channels=144, rel_in=13, cluster=False),
+                                 dict(in_channels=15, rel_in=3, cluster=True), dict(in_channels=131, rel_in=3, cluster=True)])
+@pytest.mark.parametrize('use', ['both', 'groups'])
+def test_sir_layer_in_one_launch_equals_the_launch_per_block(dev, cfg, rows, use):
+    """ococc_sir_layer_{fwd,bwd}_f32 as ONE launch per direction (csrc/sir_fused_impl.hpp: persistent grid, grid-wide
+    barriers where the segment maxima cross tiles) against the same calls issuing one launch per block: the tile bodies
+    are the same code, so the forward results agree to the bit; in the backward pass only the float atomics that sum a
+    group's gradient over its tiles arrive in another order.  40 000 rows at 16-row tiles = 2 500 tiles on at most 512
+    resident workgroups: several tiles per workgroup.  Groups of 1 .. 300 rows span up to 20 tiles; duplicated rows tie
+    for the maximum (the smallest row must win in both forms).  The four SIRLayer shapes of configs[2]."""
+    from objectcentricocccompletion_amd import _lib as L, sir
+    g = torch.Generator().manual_seed(13)
+    layer = sir.SIRLayer(in_channels=cfg['in_channels'], feat_channels=[128, 128], with_cluster_center=cfg['cluster'],
+                         rel_mlp_hidden_dims=[16, 32], rel_mlp_in_channel=cfg['rel_in'], norm_cfg=dict(type='LN', eps=1e-3),
+                         mode='max', return_point_feats=True, rel_dist_scaler=10.0, xyz_normalizer=[20, 20, 4], act='gelu',
+                         dropout=0).to(dev)
+    sizes = torch.randint(1, 300, (rows // 100 + 2,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(sizes.numel()), sizes)[:rows].to(dev)
+    M, G = inv.numel(), int(inv.max()) + 1
+    feats = torch.randn(M, cfg['in_channels'], generator=g)
+    if M > 30:
+        feats[10:14] = feats[10]          # ties inside a group ...
+        feats[M - 3:] = feats[M - 3]      # ... and in the last tile
+    feats = feats.to(dev)
+    # (the cluster offsets are handed in: derived inside the layer they come from a segment mean whose float atomics differ
+    # from run to run in the last bit)
+    fc = torch.randn(M, cfg['rel_in'], generator=g).to(dev)
+    dp, dg = torch.randn(M, 128, generator=g).to(dev), torch.randn(G, 256, generator=g).to(dev)
+
+    def run(fused):
+        L.check(L.lib.ococc_sir_layer_set_fused(int(fused)), 'set_fused')
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = feats.clone().requires_grad_(True)
+            pf, gf = layer(x, inv, fc)
+            loss = (gf * dg).sum()
+            if use == 'both':
+                loss = loss + (pf * dp).sum()
+            loss.backward()
+            import ctypes
+            status = ctypes.c_int32(-1)
+            L.check(L.lib.ococc_sir_layer_fused_status(L.stream(), ctypes.byref(status)), 'fused_status')
+            assert status.value == 0, f'a grid barrier of the one-launch layer did not complete (barrier {status.value - 1})'
+            return pf.detach(), gf.detach(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()]
+        finally:
+            L.check(L.lib.ococc_sir_layer_set_fused(-1), 'set_fused')
+
+    one = run(True)
+    per_block = run(False)
+    assert torch.equal(one[0], per_block[0]) and torch.equal(one[1], per_block[1])
+    rel = lambda p, q: float((p - q).abs().max() / q.abs().max().clamp(min=1e-30))
+    assert rel(one[2], per_block[2]) < 1e-5, rel(one[2], per_block[2])
+    for p, q in zip(one[3], per_block[3]):
+        assert rel(p, q) < 1e-5, rel(p, q)
+
+
 @pytest.mark.parametrize('rows,n,k', [(1, 16, 13), (31, 32, 3), (300, 128, 131), (5000, 144, 256), (70001, 64, 24),
                                        (8192, 128, 259 - 3)])
 def test_weight_gradient_kernel(dev, rows, n, k):
