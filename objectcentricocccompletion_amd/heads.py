@@ -1057,9 +1057,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             # (the same counts with the validity mask ANDed in instead of eight boolean compactions and their read-backs)
             lab, valid, pred_cls = occ_labels.view(-1), occ_weights.view(-1) > 0, pred_cls.view(-1)
             l0, l1, p0, p1 = (lab == 0) & valid, (lab == 1) & valid, (pred_cls == 0) & valid, (pred_cls == 1) & valid
-            neg_tp, pos_tp = (l0 & p0).sum(), (l1 & p1).sum()
-            losses['recall_neg'] = neg_tp / (l0.sum() + 1e-6)
-            losses['recall_pos'] = pos_tp / (l1.sum() + 1e-6)
-            losses['precision_neg'] = neg_tp / (p0.sum() + 1e-6)
-            losses['precision_pos'] = pos_tp / (p1.sum() + 1e-6)
+            # ... and the six counts from one reduction, the four ratios from one division
+            c = torch.stack([l0 & p0, l1 & p1, l0, l1, p0, p1]).sum(1)
+            ratios = c[[0, 1, 0, 1]] / (c[[2, 3, 4, 5]] + 1e-6)
+            losses['recall_neg'], losses['recall_pos'], losses['precision_neg'], losses['precision_pos'] = ratios.unbind(0)
         return losses

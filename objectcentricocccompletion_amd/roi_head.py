@@ -246,12 +246,14 @@ class TrackletRoIHeadOCC(nn.Module):
         loss = self.bbox_head.loss(res, rois, *targets, transform_occ=not pre, roi_frame_inds=roi_frame_inds)
         labels = targets[0].view(-1) > 0.5
         preds = res['cls_score'].view(-1).sigmoid().detach() > 0.5
-        f = lambda m: m.float().sum()
+        # four of the reference's five logging figures (tracklet_roi_head_occ.py:803-824) from ONE reduction: the counts are sums of
+        # 0 / 1 in f32 (exact), so every figure has the value its own float().sum() chain gives -- in a dozen launches
+        # instead of three dozen
+        hit, miss = preds & labels, ~(preds | labels)
+        c = torch.stack([hit, preds, labels, miss, ~preds, ~labels]).float().sum(1)
+        ratios = c[[0, 0, 3, 3]] / (c[[1, 2, 4, 5]] + 1e-6)
         loss['acc'] = (preds == labels).float().mean().detach()
-        loss['precision_posbox'] = f(preds & labels) / (f(preds).detach() + 1e-6)
-        loss['recall_posbox'] = f(preds & labels) / (f(labels).detach() + 1e-6)
-        loss['precision_negbox'] = f(~preds & ~labels) / (f(~preds).detach() + 1e-6)
-        loss['recall_negbox'] = f(~preds & ~labels) / (f(~labels).detach() + 1e-6)
+        (loss['precision_posbox'], loss['recall_posbox'], loss['precision_negbox'], loss['recall_negbox']) = ratios.unbind(0)
         res.update(loss_bbox=loss)
         return res
 
