@@ -786,7 +786,7 @@ int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features,
                             int64_t rows, int64_t groups, const float* fwd_slab, const float* y_out, const float* dy,
                             const float* d_groups, float* slab, float* dfeat, ococc_stream_t stream);
 /* One launch per layer and direction (+ one for the weight-gradient products): while every row tile has a workgroup of
- * its own (MI355X: up to 1024 tiles of 32 rows = 32 k points) and the layer's blocks are one of the shapes of
+ * its own (MI355X: up to 896 tiles of 32 rows = 28 k points) and the layer's blocks are one of the shapes of
  * csrc/sir_fused.hpp (rel_mlp of 3 blocks, 2 vfe blocks: every SIRLayer of configs[2]), each of the two calls runs the
  * blocks of a tile back to back in a persistent grid that meets at a grid-wide barrier where the segment maxima
  * (backward: their gradients) cross tiles.  Everything that crosses workgroups inside the launch goes through

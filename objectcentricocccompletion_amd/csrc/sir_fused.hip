@@ -61,7 +61,7 @@ int launch(const SirFusedArgs& args, bool backward, hipStream_t stream) {
     floats = f > floats ? f : floats;
   }
   const int64_t tiles = ococc_cdiv(A.rows, tile_rows);
-  // By default the one-launch form is taken while every tile has a workgroup of its own (on MI355X: <= 1024 tiles of 32
+  // By default the one-launch form is taken while every tile has a workgroup of its own (on MI355X: <= 896 tiles of 32
   // rows): the blocks of a tile are latency-bound chains that want as many tiles in flight as the device holds, and a
   // persistent grid walking 1040 tiles with 1024 workgroups spends two rounds per phase (measured, whole configs[2] step:
   // 13.9 -> 13.2 ms at 4 tracklets = 256 tiles, but 21.7 -> 23.8 ms at 16 tracklets = 1040 tiles and 59.2 -> 61.6 ms at

@@ -329,7 +329,9 @@ int persistent_launch(K kernel, const SirFusedArgs& A, int lds, int64_t tiles, b
     OCOCC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     OCOCC_REQUIRE(per_cu >= 1 && cus >= 1, "the kernel does not fit a compute unit");
     cached_lds[dev] = lds;
-    cached_cap[dev] = per_cu * cus;
+    // (an eighth of the slots stays free: a collective's kernels launched from gradient hooks run beside the backward
+    // pass and must find room while this grid spins at a barrier -- every workgroup of the grid has to be resident)
+    cached_cap[dev] = per_cu * cus - per_cu * cus / 8;
   }
   if (one_tile_each && tiles > cached_cap[dev]) return -1;   // (see sir_fused.hip: more tiles than resident workgroups)
   const unsigned grid = (unsigned)(tiles < cached_cap[dev] ? tiles : cached_cap[dev]);

@@ -45,7 +45,7 @@ def _f32c(t):
 
 
 # ... and one library call per direction for the whole layer (csrc/sir_layer.hip): ONE launch per direction + the
-# weight-gradient launch while every row tile has a workgroup of its own (csrc/sir_fused_impl.hpp: <= 32 k points on
+# weight-gradient launch while every row tile has a workgroup of its own (csrc/sir_fused_impl.hpp: <= 28 k points on
 # MI355X; whole step at 4 tracklets 13.9 -> 13.2 ms), the launches the node below issues from Python otherwise.
 NATIVE_LAYER = os.environ.get('OCOCC_SIR_NATIVE_LAYER', '1') == '1'
 
