@@ -180,7 +180,7 @@ def encoder_layer(x, pos, win, P, num_heads=8, rounding=None, act='gelu', eps=1e
     if not keep:
         return y2
     return y2, dict(p=p, x=x, xp=xp, q=q, k=k, v=v, idx=idx, valid=valid, prob=prob, o=o, xh1=xh1, rstd1=rstd1, y1=y1,
-                    h=h, a=a, xh2=xh2, rstd2=rstd2, fg=fg, num_heads=num_heads, rounding=rounding)
+                    h=h, a=a, xh2=xh2, rstd2=rstd2, fg=fg, num_heads=num_heads, rounding=rounding, ops_rows=ops_rows)
 
 
 def encoder_layer_backward(dy2, c):
@@ -213,6 +213,12 @@ def encoder_layer_backward(dy2, c):
     prob = c['prob']
     dp = torch.einsum('wthd,wshd->whts', dow, vw)
     delta = (prob * dp).sum(-1, keepdim=True)
+    if c.get('ops_rows') is not None:
+        # rows of the operator path: their attention core is csrc/window_attn.hip, whose backward takes
+        # delta = sum(dO * O) from the STORED (bf16) output (window_attention_core(rounding='window') below)
+        ow = c['o'][gi].view(nW, T, H, D)
+        delta_o = (dow * ow).sum(-1).permute(0, 2, 1)[..., None]                     # [nW, H, T, 1]
+        delta = torch.where((c['ops_rows'][gi] & valid)[:, None, :, None], delta_o, delta)
     ds = r16(prob * (dp - delta) * (float(D) ** -0.5))
     ds = ds * valid[:, None, :, None]
     dq = r16(torch.einsum('whts,wshd->wthd', ds, kw)).reshape(nW, T, E)

@@ -209,11 +209,15 @@ def test_windows_above_64_tokens_take_the_per_window_kernels(dev, golden_dir):
     g_par = {name: _norm_err(p.grad, grads[name])[0] for name, p in enc.named_parameters()}
     print(f'dx: rows of small windows {g_small:.2e}, rows of big windows {g_big:.2e}; parameter gradients: worst '
           f'{max(g_par.values()):.2e} ({max(g_par, key=g_par.get)})')
-    # (the backward of the big windows' rows is autograd over bf16 operators: gradients rounded to bf16 at every operator
-    # boundary, which the oracle's hand-written chain -- the fused kernels' -- does not follow)
-    assert g_small < 1e-3 and g_big < 6e-3      # (measured 7.4e-4 / 3.1e-3)
+    # (the backward of the big windows' rows is sst_modules._BigWindowBlock: the fused kernels' chain and store points
+    # written out on those rows -- with autograd over the bf16 operators these figures were 3.1e-3 and 2.3e-3)
+    # dx of the big windows' rows: measured 1.09e-3 (small windows 7.4e-4) -- both are the flip rate of bf16 stores (an
+    # f32 sum landing on the other side of a rounding boundary than the f64 sum moves the element by 2^-8 of its value);
+    # a 100-token window sums more rounded dS terms per element than a 64-token one.  Held to 1.5e-3; every parameter
+    # gradient (sums over all rows) to 1e-3 (measured: worst 8.0e-4).
+    assert g_small < 1e-3 and g_big < 1.5e-3
     for name, err in g_par.items():
-        assert err < 5e-3, name                  # (measured: worst 2.3e-3, in_proj_weight)
+        assert err < 1e-3, name
 
 
 def test_f32_block_path_vs_oracle_with_bf16_attention_core(dev, golden_dir):
