@@ -756,7 +756,8 @@ int ococc_point_mlp_bwd_f32(const float* a, int32_t ka, int32_t lda, const float
  * vfe).  features [rows, feat_cols] (xyz first), f_cluster [rows, cluster_cols], inv int32 non-decreasing.
  *   fwd: y_out [rows, n[last]] (+ features[:, 3:] when shortcut), groups_out [groups, sum of the vfe widths]; slab: the
  *        intermediates the backward call reads (ococc_sir_layer_fwd_floats floats).
- *   bwd: dy [rows, n[last]] / d_groups [groups, sum] (either may be null = zero) -> dfeat [rows, feat_cols] (may be null),
+ *   bwd: dy [rows, ld_dy >= n[last]] / d_groups [groups, ld_dgroups >= sum] (row strides in floats: column slices of wider
+ *        gradients are read in place; either may be null = zero) -> dfeat [rows, feat_cols] (may be null),
  *        and per block the LayerNorm partial rows [tiles][2][n] and weight-gradient slices [slices][n][k] inside slab at
  *        the offsets ococc_sir_layer_bwd_layout reports (finish with ococc_layernorm_param_reduce_multi).  y_out: the
  *        forward's output when there is no shortcut (it is the last block's y), else unused. */
@@ -784,7 +785,8 @@ int ococc_sir_layer_bwd_layout(const ococc_sir_layer* layer, int64_t rows, int64
                                int64_t* w_partial_off, int64_t* tiles, int32_t* slices, int64_t* total_floats);
 int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features, const float* f_cluster, const int32_t* inv,
                             int64_t rows, int64_t groups, const float* fwd_slab, const float* y_out, const float* dy,
-                            const float* d_groups, float* slab, float* dfeat, ococc_stream_t stream);
+                            int64_t ld_dy, const float* d_groups, int64_t ld_dgroups, float* slab, float* dfeat,
+                            ococc_stream_t stream);
 /* One launch per layer and direction (+ one for the weight-gradient products): while every row tile has a workgroup of
  * its own (MI355X: up to 896 tiles of 32 rows = 28 k points) and the layer's blocks are one of the shapes of
  * csrc/sir_fused.hpp (rel_mlp of 3 blocks, 2 vfe blocks: every SIRLayer of configs[2]), each of the two calls runs the

@@ -42,7 +42,7 @@ point_mlp_bwd_kernel(PointMlpIn in, const float* __restrict__ wf, const float* _
                      float* __restrict__ dz_out, float* __restrict__ xcat, float* __restrict__ da, float* __restrict__ dmul,
                      float* __restrict__ db, float* __restrict__ dv, float* __restrict__ ln_partial) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  point_mlp_bwd_tile<NBW, KBW, MB>(in, wf, wtf, n, ln_w, ln_b, eps, act, dy, dvmax, n, nullptr, arg, dz_out, xcat, da, dmul, db, dv,
+  point_mlp_bwd_tile<NBW, KBW, MB>(in, wf, wtf, n, ln_w, ln_b, eps, act, dy, n, dvmax, n, nullptr, arg, dz_out, xcat, da, dmul, db, dv,
                                    ln_partial, Tile{(int64_t)blockIdx.x, (int64_t)blockIdx.x * 16 * MB, smem_f, (int)threadIdx.x});
 }
 

@@ -365,6 +365,7 @@ point_mlp_fwd_tile(const PointMlpIn& in, const float* __restrict__ wf, int n, co
 // null).  Writes dz [rows, n] (gradient at the Linear's output), xcat [rows, k] (the assembled input, for dW = dz^T xcat;
 // may be null), da / dmul [rows, ka], db [rows, kb] (each may be null), adds into dv [segments, kv] (zeroed by the caller)
 // and leaves one row [dgamma(n) | dbeta(n)] of LayerNorm partial sums per tile.
+// dy [rows, ldy] (row stride ldy >= n: a column slice of a wider gradient is read in place).
 // The gradient of the segment maxima may arrive in two parts that are added on the way in: dvmax [segments, ldvm] (a
 // column slice of the concatenated maxima's gradient) and dvmax2 [segments, n] (what the next block's gathered copy
 // received); either may be null.
@@ -372,7 +373,7 @@ template <int NBW, int KBW, int MB, bool COH = false>
 __device__ __forceinline__ void
 point_mlp_bwd_tile(const PointMlpIn& in, const float* __restrict__ wf, const float* __restrict__ wtf, int n,
                    const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps, int act,
-                   const float* __restrict__ dy, const float* __restrict__ dvmax, int ldvm,
+                   const float* __restrict__ dy, int ldy, const float* __restrict__ dvmax, int ldvm,
                    const float* __restrict__ dvmax2, const int32_t* __restrict__ arg,
                    float* __restrict__ dz_out, float* __restrict__ xcat, float* __restrict__ da, float* __restrict__ dmul,
                    float* __restrict__ db, float* __restrict__ dv, float* __restrict__ ln_partial, const Tile& tile) {
@@ -421,7 +422,7 @@ point_mlp_bwd_tile(const PointMlpIn& in, const float* __restrict__ wf, const flo
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (sl.live[nb][r]) {
-            float u = dy ? dy[row * n + ch + r] : 0.f;
+            float u = dy ? dy[row * ldy + ch + r] : 0.f;
             if (routed && arg[(int64_t)segs[mb] * n + ch + r] == (int32_t)row) {
               const float g1 = dvmax ? dvmax[(int64_t)segs[mb] * ldvm + ch + r] : 0.f;
               u += dvmax2 ? g1 + load_shared_result<COH>(dvmax2 + (int64_t)segs[mb] * n + ch + r) : g1;

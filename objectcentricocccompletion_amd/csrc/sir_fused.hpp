@@ -41,8 +41,9 @@ struct SirFusedArgs {
   float* y_out;          // forward: [rows, n last]
   float* groups_out;     // forward: [groups, sum_n]
   // backward only
-  const float* dy;       // [rows, n last] or null
-  const float* d_groups; // [groups, sum_n] or null
+  const float* dy;       // [rows, ld_dy >= n last] or null
+  const float* d_groups; // [groups, ld_dg >= sum_n] or null
+  int32_t ld_dy, ld_dg;  // their row strides in floats
   float* dfeat;          // [rows, feat_cols] or null
   float* dgate;          // [rows, feat_cols]
   int64_t rows_per_slice;

@@ -235,13 +235,13 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_fwd_kernel(SirFusedArgs) {
 }
 
 template <int MB, class SIG, int Q>
-__device__ __forceinline__ void sir_backward_block(KArgs* A, const float* dy, const float* dvmax, int ldvm, const float* dvmax2,
+__device__ __forceinline__ void sir_backward_block(KArgs* A, const float* dy, int ldy, const float* dvmax, int ldvm, const float* dvmax2,
                                                    float* da, float* dmul, float* dv, Tile t) {
   launder(A, t);
   const PointMlpIn in = sir_block_input<SIG, Q>(A);
   auto& B = A->b[Q];
   const int32_t* arg = (dvmax || dvmax2) ? B.arg : nullptr;
-  point_mlp_bwd_tile<SIG::nbw(Q), SIG::kbw(Q), MB, true>(in, B.wf, B.wtf, B.n, B.ln_w, B.ln_b, B.eps, B.act, dy, dvmax, ldvm, dvmax2, arg,
+  point_mlp_bwd_tile<SIG::nbw(Q), SIG::kbw(Q), MB, true>(in, B.wf, B.wtf, B.n, B.ln_w, B.ln_b, B.eps, B.act, dy, ldy, dvmax, ldvm, dvmax2, arg,
                                                    B.dz, B.xcat, da, dmul, nullptr, dv, B.lnp, t);
   tile_sync();
 }
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
       const float* d_groups = A->d_groups;
       const float* dy_cur = i == nv - 1 ? A->dy : A->b[i == nv - 1 ? q : q + 1].da;
       const float* carry = i == nv - 1 ? nullptr : A->b[i == nv - 1 ? q : q + 1].dv;
-      sir_backward_block<MB, SIG, q>(A, dy_cur, d_groups ? d_groups + off_m : nullptr, A->sum_n, carry, A->b[q].da, nullptr,
+      sir_backward_block<MB, SIG, q>(A, dy_cur, i == nv - 1 ? A->ld_dy : A->b[q].n, d_groups ? d_groups + off_m : nullptr, A->ld_dg, carry, A->b[q].da, nullptr,
                                      A->b[q].dv, t);
     }
     bar_arrive(gb, nv - i, false);
@@ -287,17 +287,18 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
     {
       const float* dy_cur = nv == 1 ? A->dy : A->b[nv == 1 ? nr : nr + 1].da;
       const float* carry = nv == 1 ? nullptr : A->b[nv == 1 ? nr : nr + 1].dv;
-      sir_backward_block<MB, SIG, nr>(A, dy_cur, A->d_groups, A->sum_n, carry, A->dfeat, nr ? A->dgate : nullptr, nullptr, t);
+      sir_backward_block<MB, SIG, nr>(A, dy_cur, nv == 1 ? A->ld_dy : A->b[nr].n, A->d_groups, A->ld_dg, carry, A->dfeat,
+                                      nr ? A->dgate : nullptr, nullptr, t);
     }
     if (A->shortcut && A->dfeat && A->dy) {   // dfeat[:, 3:] += dy
-      const int n = A->b[nl - 1].n, ldf = A->feat_cols;
+      const int n = A->b[nl - 1].n, ldf = A->feat_cols, ldy = A->ld_dy;
       float* dfeat = A->dfeat;
       const float* dy = A->dy;
       for (int i = threadIdx.x; i < TRM * n; i += kT) {
         const int64_t row = t.row0 + i / n;
         if (row >= rows) break;
         const int c = i % n;
-        dfeat[row * ldf + 3 + c] += dy[row * n + c];
+        dfeat[row * ldf + 3 + c] += dy[row * ldy + c];
       }
     }
     // (every block writes the gradient of its input rows to a buffer of its own: the blocks' row widths differ, so in a
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
     static_for<0, nr>([&](auto jj) {
       constexpr int j = nr - 1 - decltype(jj)::value;
       const float* dgate = j == nr - 1 ? A->dgate : A->b[j == nr - 1 ? j : j + 1].da;
-      sir_backward_block<MB, SIG, j>(A, dgate, nullptr, 0, nullptr, j > 0 ? A->b[j].da : nullptr, nullptr, nullptr, t);
+      sir_backward_block<MB, SIG, j>(A, dgate, A->b[j].n, nullptr, 0, nullptr, j > 0 ? A->b[j].da : nullptr, nullptr, nullptr, t);
     });
   }
   bar_arrive(gb, nv, true);   // (nobody waits: the launch's last arrival advances the epoch word)

@@ -271,8 +271,8 @@ extern "C" int ococc_sir_layer_fwd_f32(const ococc_sir_layer* d, const float* fe
 
 extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* feats, const float* f_cluster,
                                        const int32_t* inv, int64_t rows, int64_t groups, const float* fwd_slab,
-                                       const float* y_out, const float* dy, const float* d_groups, float* slab,
-                                       float* dfeat, ococc_stream_t stream_) {
+                                       const float* y_out, const float* dy, int64_t ld_dy, const float* d_groups,
+                                       int64_t ld_dgroups, float* slab, float* dfeat, ococc_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   Dims D;
   if (int rc = read_dims(d, &D)) return rc;
@@ -290,6 +290,8 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   auto dz_of = [&](int b) -> float* { return slab + L.dz[b]; };
   auto xcat_of = [&](int b) -> float* { return slab + L.xcat[b]; };
   OCOCC_REQUIRE(!d->inference, "the forward pass of this descriptor recorded no arg-max rows (inference = 1)");
+  OCOCC_REQUIRE((!dy || ld_dy >= D.n[last]) && (!d_groups || ld_dgroups >= D.sum_n) && ld_dy < (1ll << 31) && ld_dgroups < (1ll << 31),
+                "row strides of dy / d_groups shorter than their rows");
   if (groups > 0 && sir_fused_enabled()) {
     SirFusedArgs A;
     fused_args(d, D, F, feats, f_cluster, inv, rows, groups, const_cast<float*>(fwd_slab), const_cast<float*>(y_out), &A);
@@ -304,6 +306,8 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     }
     A.dy = dy;
     A.d_groups = d_groups;
+    A.ld_dy = (int32_t)ld_dy;
+    A.ld_dg = (int32_t)ld_dgroups;
     A.dfeat = dfeat;
     A.dgate = slab + L.dgate;
     A.slices = L.slices;
@@ -325,7 +329,12 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   if (!dy_cur) {
     OCOCC_HIP(hipMemsetAsync(slab + L.dy0, 0, (size_t)rows * D.n[last] * 4, stream));
     dy_cur = slab + L.dy0;
+  } else if (ld_dy != D.n[last]) {   // (the per-block launches read dense rows)
+    OCOCC_HIP(hipMemcpy2DAsync(slab + L.dy0, (size_t)D.n[last] * 4, dy, (size_t)ld_dy * 4, (size_t)D.n[last] * 4, (size_t)rows,
+                               hipMemcpyDeviceToDevice, stream));
+    dy_cur = slab + L.dy0;
   }
+  const float* dy_dense = dy ? dy_cur : nullptr;
   const float* carry = nullptr;
   int pp = 0, off_m = D.sum_n;
   for (int i = D.nv - 1; i >= 0; --i) {
@@ -335,7 +344,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     if (groups > 0 && (d_groups || carry)) {
       if (d_groups) {
         hipLaunchKernelGGL(join_cols_kernel, dim3(ococc_grid_1d(groups * n, 256, 2048)), dim3(256), 0, stream,
-                           d_groups + off_m, D.sum_n, carry, n, groups * n, slab + L.dm);
+                           d_groups + off_m, (int)ld_dgroups, carry, n, groups * n, slab + L.dm);
         dm = slab + L.dm;
       } else {
         dm = carry;
@@ -367,7 +376,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   }
   if (d->shortcut && dfeat) {
     const int n = D.n[last];
-    const float* dyo = dy ? dy : slab + L.dy0;
+    const float* dyo = dy_dense ? dy_dense : slab + L.dy0;
     hipLaunchKernelGGL(shortcut_grad_kernel, dim3(ococc_grid_1d(rows * n, 256, 4096)), dim3(256), 0, stream, dfeat,
                        d->feat_cols, dyo, n, rows * n);
   }

@@ -44,6 +44,14 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
 
+def _f32_rows(t):
+    """t [rows, cols] as f32 with unit column stride and a row stride >= cols (a copy only if it is not that already)"""
+    t = t.detach()
+    if t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.float().contiguous()
+
+
 # ... and one library call per direction for the whole layer (csrc/sir_layer.hip): ONE launch per direction + the
 # weight-gradient launch while every row tile has a workgroup of its own (csrc/sir_fused_impl.hpp: <= 28 k points on
 # MI355X; whole step at 4 tracklets 13.9 -> 13.2 ms), the launches the node below issues from Python otherwise.
@@ -165,10 +173,12 @@ class _SirLayerNative(torch.autograd.Function):
         ln_off, w_off, tiles, slices, total = plan.bwd_layout(rows, G)
         slab = torch.empty((total,), dtype=torch.float32, device=dev)
         dfeat = torch.empty_like(feats) if need[2] else None
-        dy = None if dy is None else _f32c(dy)
-        dM = None if dM is None else _f32c(dM)
+        # (gradients that are column slices of a wider tensor -- the concatenations around the layer -- are read in place)
+        dy = None if dy is None else _f32_rows(dy)
+        dM = None if dM is None else _f32_rows(dM)
         L.check(L.lib.ococc_sir_layer_bwd_f32(plan.ref, feats.data_ptr(), fc.data_ptr(), inv.data_ptr(), rows, G,
-                                              fslab.data_ptr(), y.data_ptr(), L.ptr(dy), L.ptr(dM), slab.data_ptr(),
+                                              fslab.data_ptr(), y.data_ptr(), L.ptr(dy), dy.stride(0) if dy is not None else 0,
+                                              L.ptr(dM), dM.stride(0) if dM is not None else 0, slab.data_ptr(),
                                               L.ptr(dfeat), L.stream()), 'sir_layer_bwd')
         grads = [None] * len(plan.params)
         if rows == 0:

@@ -229,7 +229,7 @@ def test_sir_layer_as_one_autograd_node(dev, in_channels, use):
 @pytest.mark.parametrize('rows', [40, 3000, 40000])
 @pytest.mark.parametrize('cfg', [dict(in_channels=24, rel_in=13, cluster=False), dict(in_channels=144, rel_in=13, cluster=False),
                                  dict(in_channels=15, rel_in=3, cluster=True), dict(in_channels=131, rel_in=3, cluster=True)])
-@pytest.mark.parametrize('use', ['both', 'groups'])
+@pytest.mark.parametrize('use', ['both', 'groups', 'sliced'])
 def test_sir_layer_in_one_launch_equals_the_launch_per_block(dev, cfg, rows, use):
     """ococc_sir_layer_{fwd,bwd}_f32 as ONE launch per direction (csrc/sir_fused_impl.hpp: persistent grid, grid-wide
     barriers where the segment maxima cross tiles) against the same calls issuing one launch per block: the tile bodies
@@ -262,9 +262,14 @@ def test_sir_layer_in_one_launch_equals_the_launch_per_block(dev, cfg, rows, use
             layer.zero_grad(set_to_none=True)
             x = feats.clone().requires_grad_(True)
             pf, gf = layer(x, inv, fc)
-            loss = (gf * dg).sum()
-            if use == 'both':
-                loss = loss + (pf * dp).sum()
+            if use == 'sliced':   # the gradients arrive as column slices of wider tensors (the concatenations around a
+                # layer in SIR.forward): read in place through their row strides, no copy
+                loss = (torch.cat([gf, gf.detach()], 1) * torch.cat([dg, dg], 1)).sum() + \
+                       (torch.cat([pf.detach()[:, :3], pf], 1) * torch.cat([dp[:, :3], dp], 1)).sum()
+            else:
+                loss = (gf * dg).sum()
+                if use == 'both':
+                    loss = loss + (pf * dp).sum()
             loss.backward()
             import ctypes
             status = ctypes.c_int32(-1)
