@@ -547,6 +547,21 @@ int ococc_dynamic_point_pool_mixed(const float* rois, const int32_t* rois_key, i
 int ococc_aligned_iou3d_f32(const float* boxes1, const float* boxes2, int64_t n, float* iou,
                             ococc_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * A12 glue, one launch each (f32; the element-wise chains they replace were 12-35 launches of a few hundred elements):
+ * ococc_rotate_z_f32: rotation_3d_in_axis(points [n, m, 3], angles [n], axis=2)
+ *   (mmdet3d/core/bbox/structures/utils.py:21-61; the reference's transposed-matrix convention: x' = x c + y s, y' = -x s + y c).
+ * ococc_points_box_to_box_f32: points [n, m, 3] given in the frame of from_boxes[i] (gravity centred) -> the frame of
+ *   to_boxes[i]: rotate by yaw_from, + centre_from, z + h_from / 2, - centre_to, z - h_to / 2, rotate by -yaw_to
+ *   (ococc_bbox_head.py:1279-1290, 714-724; boxes are rows of ld >= 7 floats: x, y, z_bottom, w, l, h, yaw).
+ * ococc_roi_box_targets_f32: GT boxes in the canonical frame of their RoIs -> DeltaXYZWLHRBBoxCoder deltas [n, 7]
+ *   (ococc_bbox_head.py:1190-1222, delta_xyzwhlr_bbox_coder.py:21-50). */
+int ococc_rotate_z_f32(const float* points, const float* angles, int64_t n, int64_t m, float* out, ococc_stream_t stream);
+int ococc_points_box_to_box_f32(const float* points, const float* from_boxes, int64_t ld_from, const float* to_boxes,
+                                int64_t ld_to, int64_t n, int64_t m, float* out, ococc_stream_t stream);
+int ococc_roi_box_targets_f32(const float* rois, int64_t ld_rois, const float* gt_boxes, int64_t ld_gt, int64_t n, float* out,
+                              ococc_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * B6  in-group ranks of integer keys (SST window bookkeeping)
  * replaces TorchEx ingroup_indices.forward (mmdet3d/ops/sst/sst_ops.py:243-263; python twin

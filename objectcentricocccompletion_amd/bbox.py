@@ -10,9 +10,28 @@ def limit_period(val, offset=0.5, period=3.141592653589793):
     return val - torch.floor(val / period + offset) * period
 
 
+def _rows7(t):
+    """a [n, >= 7] f32 device tensor with unit column stride as (tensor, row stride); a copy only if it is not that"""
+    if not (t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]):
+        t = t.float().contiguous()
+    return t, t.stride(0)
+
+
+def _plain(*tensors):
+    """device f32 tensors nobody differentiates through: the single-launch forms apply"""
+    return all(t.is_cuda and t.dtype == torch.float32 and not t.requires_grad for t in tensors)
+
+
 def rotation_3d_in_axis(points, angles, axis=0):
     """points [N,M,3] rotated by angles [N] about `axis`; note the reference multiplies by the
     TRANSPOSED matrix (einsum 'aij,jka->aik'), i.e. a clockwise turn for axis 2."""
+    if (axis == 2 or axis == -1) and points.dim() == 3 and points.shape[-1] == 3 and angles.dim() == 1 \
+            and angles.shape[0] == points.shape[0] and _plain(points, angles):
+        from . import _lib as L   # one launch instead of a dozen (csrc/target_ops.hip)
+        p, a = points.contiguous(), angles.contiguous()
+        out = torch.empty_like(p)
+        L.check(L.lib.ococc_rotate_z_f32(L.ptr(p), L.ptr(a), p.shape[0], p.shape[1], L.ptr(out), L.stream()), 'rotate_z')
+        return out
     rot_sin, rot_cos = torch.sin(angles), torch.cos(angles)
     ones, zeros = torch.ones_like(rot_cos), torch.zeros_like(rot_cos)
     if axis == 1:
@@ -25,6 +44,26 @@ def rotation_3d_in_axis(points, angles, axis=0):
         raise ValueError(f'axis should in range [0, 1, 2], got {axis}')
     rot_mat_T = torch.stack([torch.stack(r) for r in rows])
     return torch.einsum('aij,jka->aik', (points, rot_mat_T))
+
+
+def points_box_to_box(xyz, from_boxes, to_boxes):
+    """xyz [N, M, 3] given in the (gravity-centred) frame of from_boxes[i] -> the frame of to_boxes[i]: the chain of
+    ococc_bbox_head.py:1279-1290 / 714-724 (GT-box frame -> ego frame -> RoI frame); boxes [N, >= 7]."""
+    if xyz.dim() == 3 and xyz.shape[-1] == 3 and from_boxes.shape[0] == xyz.shape[0] == to_boxes.shape[0] \
+            and _plain(xyz, from_boxes, to_boxes) and from_boxes.shape[1] >= 7 and to_boxes.shape[1] >= 7:
+        from . import _lib as L
+        p = xyz.contiguous()
+        (fb, ldf), (tb, ldt) = _rows7(from_boxes), _rows7(to_boxes)
+        out = torch.empty_like(p)
+        L.check(L.lib.ococc_points_box_to_box_f32(L.ptr(p), L.ptr(fb), ldf, L.ptr(tb), ldt, p.shape[0], p.shape[1], L.ptr(out),
+                                                  L.stream()), 'points_box_to_box')
+        return out
+    xyz = rotation_3d_in_axis(xyz, from_boxes[:, 6], axis=2)
+    xyz += from_boxes[..., None, 0:3]
+    xyz[..., 2] += from_boxes[:, None, 5] / 2   # voxel centres are gravity centred
+    xyz -= to_boxes[..., None, :3]
+    xyz[..., 2] -= to_boxes[:, None, 5] / 2
+    return rotation_3d_in_axis(xyz, -(to_boxes[:, 6]), axis=2)
 
 
 def box_corners(boxes):

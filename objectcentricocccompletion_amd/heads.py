@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ._lib import const_tensor, log_once
-from .bbox import build_bbox_coder, rotation_3d_in_axis
+from .bbox import _plain, _rows7, build_bbox_coder, points_box_to_box, rotation_3d_in_axis
 from .losses import build_loss, reduce_mean
 from .occ import occ_ops
 from .occ.layers import PositionalEncoding, SimpleEncoderLayer, TransformerEncoder
@@ -830,12 +830,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
                 picked = occ_all[sel_slot]
                 roi_local_xyz, gt_occ = picked[..., 0:3], picked[..., 3:4]
                 if transform_occ:
-                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, gt_smp[:, 6], axis=2)
-                    roi_local_xyz += gt_smp[..., None, 0:3]
-                    roi_local_xyz[..., 2] += gt_smp[:, None, 5] / 2   # voxel centres are gravity centred
-                    roi_local_xyz -= roi_smp[..., None, :3]
-                    roi_local_xyz[..., 2] -= roi_smp[:, None, 5] / 2
-                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, -(roi_smp[:, 6]), axis=2)
+                    roi_local_xyz = points_box_to_box(roi_local_xyz, gt_smp, roi_smp)
                 occ_score = scores_all[sel_slot]
             occ_target_batch_idx = host_index(sel_trk, dev, torch.int32)
             pos_gt_bboxes_occ = gt_smp
@@ -870,6 +865,14 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
 
     def _canonical_box_targets(self, pos_bboxes, pos_gt_bboxes):
         """GT boxes in the canonical frame of their RoIs -> coder deltas (ococc_bbox_head.py:1190-1222)."""
+        if type(self.bbox_coder).__name__ == 'DeltaXYZWLHRBBoxCoder' and getattr(self.bbox_coder, 'code_size', 7) == 7 \
+                and pos_bboxes.shape[1] == 7 and pos_gt_bboxes.shape == pos_bboxes.shape and _plain(pos_bboxes, pos_gt_bboxes):
+            from . import _lib as L   # the frame change and the coder in one launch (csrc/target_ops.hip)
+            (rb, ldr), (gb, ldg) = _rows7(pos_bboxes), _rows7(pos_gt_bboxes)
+            out = torch.empty((rb.shape[0], 7), dtype=torch.float32, device=rb.device)
+            L.check(L.lib.ococc_roi_box_targets_f32(L.ptr(rb), ldr, L.ptr(gb), ldg, rb.shape[0], L.ptr(out), L.stream()),
+                    'roi_box_targets')
+            return out
         gt_ct = pos_gt_bboxes.clone().detach()
         roi_center = pos_bboxes[..., 0:3]
         roi_ry = pos_bboxes[..., 6] % (2 * np.pi)
@@ -943,12 +946,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
                 gt_smp, roi_smp = pos_gt_bboxes[num_gt - n_occ:num_gt], pos_bboxes[num_gt - n_occ:num_gt]
                 occ_reg_mask[num_gt - n_occ:num_gt] = 1
                 if transform_occ:
-                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, gt_smp[:, 6], axis=2)
-                    roi_local_xyz += gt_smp[..., None, 0:3]
-                    roi_local_xyz[..., 2] += gt_smp[:, None, 5] / 2   # voxel centres are gravity centred
-                    roi_local_xyz -= roi_smp[..., None, :3]
-                    roi_local_xyz[..., 2] -= roi_smp[:, None, 5] / 2
-                    roi_local_xyz = rotation_3d_in_axis(roi_local_xyz, -(roi_smp[:, 6]), axis=2)
+                    roi_local_xyz = points_box_to_box(roi_local_xyz, gt_smp, roi_smp)
                 gt_occ = gt_occ[None].repeat(len(gt_smp), 1, 1)
                 occ_score = occ_score.repeat(len(gt_smp)).float()
         else:
@@ -1035,12 +1033,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         if transform_occ:
             pr = rois[pos_rows][:, 1:]
             with torch.no_grad():
-                occ_smp_xyz = rotation_3d_in_axis(occ_smp_xyz, pos_gt_bboxes[:, 6], axis=2)
-                occ_smp_xyz += pos_gt_bboxes[..., None, 0:3]
-                occ_smp_xyz[..., 2] += pos_gt_bboxes[:, None, 5] / 2
-                occ_smp_xyz -= pr[..., None, :3]
-                occ_smp_xyz[..., 2] -= pr[:, None, 5] / 2
-                occ_smp_xyz = rotation_3d_in_axis(occ_smp_xyz, -(pr[:, 6]), axis=2)
+                occ_smp_xyz = points_box_to_box(occ_smp_xyz, pos_gt_bboxes, pr)
         if do_aug:
             occ_smp_xyz[..., 2] = -occ_smp_xyz[..., 2]
         scores = self.filter_pos_assigned_but_empty_rois(gt_occ_label_scores, pos_batch_idx, pos_inds, rb)

@@ -10,7 +10,7 @@ import os
 import torch
 from torch import nn
 
-from .bbox import rotation_3d_in_axis
+from .bbox import points_box_to_box, rotation_3d_in_axis
 from .registry import BBOX_ASSIGNERS, DETECTORS, HEADS, ROI_EXTRACTORS
 from .tracklet import SamplingResult, Tracklet
 
@@ -358,12 +358,7 @@ class TrackletRoIHeadOCC(nn.Module):
         def to_roi_frame(xyz, gb, pb):
             if not self.test_cfg.get('transform_to_gt', True):
                 return xyz
-            xyz = rotation_3d_in_axis(xyz, gb[:, 6], axis=2)       # GT box frame -> ego frame
-            xyz += gb[..., None, 0:3]
-            xyz[..., 2] += gb[:, None, 5] / 2                      # labels sit at voxel gravity centres
-            xyz -= pb[..., None, :3]                               # ego frame -> RoI frame
-            xyz[..., 2] -= pb[:, None, 5] / 2
-            return rotation_3d_in_axis(xyz, -(pb[:, 6]), axis=2)
+            return points_box_to_box(xyz, gb, pb)   # GT box frame -> ego frame -> RoI frame (labels sit at voxel gravity centres)
 
         if self.test_cfg.get('test_baseline', False):
             return self._test_occ_accumulated_points(rois, gt_rois, match, occ_xyz, occ_label, to_roi_frame, pts_xyz,
