@@ -191,10 +191,20 @@ def _filter_rows(pos_batch_idx, filtered_pos_mask, roi_batch_idx, count=None):
 class SparseHeadMixin(object):
     """Helpers OccBBoxHead / OccAutoEncoder take from FullySparseBboxHead."""
 
+    @staticmethod
+    def _spare_slot_index(out_coors, num_rois):
+        """out_coors with its -1 entries sent to the spare slot ``num_rois`` (int64), kept on the tensor: the mask and the
+        aligned features of one encoder call ask for the same index"""
+        hit = getattr(out_coors, '_ococc_slot_index', None)
+        if hit is None or hit[0] != num_rois or hit[1] != out_coors._version:
+            idx = torch.where(out_coors >= 0, out_coors, torch.full_like(out_coors, num_rois)).long()
+            hit = out_coors._ococc_slot_index = (num_rois, out_coors._version, idx)
+        return hit[2]
+
     def get_nonempty_roi_mask(self, out_coors, num_rois):
         """fsd_bbox_head.py:238-250."""
         # (-1 entries go to a spare slot instead of being compacted away: no read-back)
-        idx = torch.where(out_coors >= 0, out_coors, torch.full_like(out_coors, num_rois)).long()
+        idx = self._spare_slot_index(out_coors, num_rois)
         mask = torch.zeros(num_rois + 1, dtype=torch.bool, device=out_coors.device)
         mask.index_fill_(0, idx, True)
         return mask[:num_rois]
@@ -204,7 +214,7 @@ class SparseHeadMixin(object):
         zeros for empty RoIs (fsd_bbox_head.py:252-272)."""
         # rows whose coordinate is -1 land in a spare row that is cut off again: no mask compaction, no read-back, and
         # `features` stays connected to the result whether or not any RoI is non-empty
-        idx = torch.where(out_coors >= 0, out_coors, torch.full_like(out_coors, num_rois)).long()
+        idx = self._spare_slot_index(out_coors, num_rois)
         new_feature = features.new_zeros((num_rois + 1, features.size(1))).index_copy(0, idx, features)
         return new_feature[:num_rois]
 
@@ -788,7 +798,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         return self._get_targets_per_tracklet(sampling_results, rcnn_train_cfg, transform_occ, num_occ_per_tracklet)
 
     def _get_targets_batched(self, sampling_results, cfg, transform_occ, num_occ_per_tracklet):
-        from .tracklet import host_index
+        from .tracklet import host_index_many
         dev = sampling_results[0].iou.device
         n_i = [int(r.iou.size(0)) for r in sampling_results]           # samples per tracklet (host numbers)
         p_i = [int(r.pos_gt_bboxes.size(0)) for r in sampling_results]  # of which positives: the first p_i rows
@@ -800,7 +810,19 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         if pos_gt_bboxes.size(1) in (9, 10):
             pos_bboxes, pos_gt_bboxes = pos_bboxes[:, :7], pos_gt_bboxes[:, :7]
         starts = [sum(n_i[:t]) for t in range(len(n_i))]
-        pos_rows = host_index([starts[t] + j for t in range(len(n_i)) for j in range(p_i[t])], dev)
+        # every index list of this function is known on the host: two staging buffers (int64 / int32), two copies
+        n_occ = [(min(num_occ_per_tracklet, p) if num_occ_per_tracklet > 0 else p) for p in p_i]
+        pstart = [sum(p_i[:t]) for t in range(len(p_i))]
+        sel_trk = [t for t in range(len(p_i)) for _ in range(n_occ[t])]
+        live = [t for t in range(len(p_i)) if p_i[t] > 0]
+        slot = {t: k for k, t in enumerate(live)}
+        pos_rows, sel_pos, occ_rows, sel_slot = host_index_many([
+            [starts[t] + j for t in range(len(n_i)) for j in range(p_i[t])],
+            [pstart[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])],
+            [starts[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])],
+            [slot[t] for t in sel_trk]], dev)
+        bbox_target_batch_idx, occ_target_batch_idx = host_index_many([
+            [t for t in range(len(n_i)) for _ in range(p_i[t])], sel_trk], dev, torch.int32)
         all_gt = torch.full((N,), -1, dtype=pos_gt_labels.dtype, device=dev).index_copy(0, pos_rows, pos_gt_labels)
         label, label_weights = self._soft_label(ious, all_gt, cfg)
         reg_mask = torch.zeros(N, dtype=torch.long, device=dev).index_fill(0, pos_rows, 1)
@@ -810,21 +832,12 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             for i in range(self.num_classes):
                 bbox_weights = torch.where(all_gt == i, bbox_weights * cw[i], bbox_weights)
         occ_reg_mask = torch.zeros_like(reg_mask)
-        bbox_target_batch_idx = host_index([t for t in range(len(n_i)) for _ in range(p_i[t])], dev, torch.int32)
         if P > 0:
             bbox_targets = self._canonical_box_targets(pos_bboxes, pos_gt_bboxes)
-            n_occ = [(min(num_occ_per_tracklet, p) if num_occ_per_tracklet > 0 else p) for p in p_i]
-            pstart = [sum(p_i[:t]) for t in range(len(p_i))]
-            sel_trk = [t for t in range(len(p_i)) for _ in range(n_occ[t])]
-            sel_pos = host_index([pstart[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])], dev)
-            occ_rows = host_index([starts[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])], dev)
             occ_reg_mask = occ_reg_mask.index_fill(0, occ_rows, 1)
-            live = [t for t in range(len(p_i)) if p_i[t] > 0]
-            slot = {t: k for k, t in enumerate(live)}
             occ_all = torch.stack([sampling_results[t].occ_labels for t in live], 0)      # [B', K, 4]
             assert occ_all.dim() == 3 and occ_all.size(2) == 4
             scores_all = torch.stack([sampling_results[t].occ_scores.reshape(-1)[0] for t in live], 0).float()
-            sel_slot = host_index([slot[t] for t in sel_trk], dev)
             with torch.no_grad():
                 gt_smp, roi_smp = pos_gt_bboxes[sel_pos], pos_bboxes[sel_pos]
                 picked = occ_all[sel_slot]
@@ -832,7 +845,6 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
                 if transform_occ:
                     roi_local_xyz = points_box_to_box(roi_local_xyz, gt_smp, roi_smp)
                 occ_score = scores_all[sel_slot]
-            occ_target_batch_idx = host_index(sel_trk, dev, torch.int32)
             pos_gt_bboxes_occ = gt_smp
         else:
             bbox_targets = pos_gt_bboxes.new_empty((0, 7))
@@ -852,9 +864,10 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             pos_thrs, neg_thrs = [pos_thrs] * self.num_classes, [neg_thrs] * self.num_classes
         all_label = ious.new_zeros(ious.size(0))
         for i in range(self.num_classes):
-            pos = ious > pos_thrs[i]
-            interval = (~pos) & ~(ious < neg_thrs[i])
-            lab = torch.where(interval, (ious - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i]), pos.to(ious.dtype))
+            # 1 above the positive threshold, 0 below the negative one, linear in between: the same values as the three
+            # selects of get_multi_class_soft_label (the interpolation is exactly 1 / 0 at the thresholds; clamping leaves
+            # the values in between as they are), in three launches
+            lab = ((ious - neg_thrs[i]) / (pos_thrs[i] - neg_thrs[i])).clamp(0.0, 1.0)
             all_label = torch.where(all_gt == i, lab, all_label)
         label_weights = (all_label >= 0).float()
         cw = cfg.get('class_wise_cls_weights', None)

@@ -31,6 +31,13 @@ def host_index(values, device, dtype=torch.long):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def host_index_many(lists, device, dtype=torch.long):
+    """Several index lists in ONE pinned staging buffer and ONE asynchronous copy: views of the device buffer, in order."""
+    sizes = [len(v) for v in lists]
+    flat = host_index([x for v in lists for x in v], device, dtype)
+    return flat.split(sizes) if sizes else ()
+
+
 def _median_lower_upper_mean(x):
     """numpy.median along dim 0 (for an even count: the mean of the two middle values; torch.median
     would return the lower one)."""
