@@ -643,10 +643,9 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         f_cluster = torch.cat([pts_info['local_xyz'], pts_info['boundary_offset'],
                                pts_info['is_in_margin'][:, None], rel_xyz], dim=-1)
         cluster_feat_list = []
+        geo = f_cluster / 10 if self.geo_input else None   # (the same for every block: once, and one concatenation per block)
         for i, block in enumerate(self.block_list):
-            in_feats = torch.cat([pts_xyz, out_feats], 1)
-            if self.geo_input:
-                in_feats = torch.cat([in_feats, f_cluster / 10], 1)
+            in_feats = torch.cat([pts_xyz, out_feats] if geo is None else [pts_xyz, out_feats, geo], 1)
             if i < self.num_blocks - 1:
                 out_feats, out_cluster_feats = block(in_feats, roi_inds, f_cluster, unq_inv_once=unq_inv,
                                                      new_coors_once=new_coors)
@@ -979,11 +978,11 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         nonempty = results_dict['nonempty_roi_mask']
         n_total = cls_score.shape[0]
         assert n_total > 0 and not self.with_corner_loss
-        label_weights, bbox_weights, reg_mask = label_weights.clone(), bbox_weights.clone(), reg_mask.clone()
-        label_weights[~nonempty] = 0
-        label_weights[nonempty] = 1
-        bbox_weights[...] = 1
-        reg_mask[~nonempty] = 0
+        # (ococc_bbox_head.py:464-477 sets the weights of non-empty RoIs to 1, of empty ones to 0, every box weight to 1 and
+        # clears the regression mask of empty RoIs, on clones, with masked assignments: the same tensors in one launch each)
+        label_weights = nonempty.to(label_weights.dtype)
+        bbox_weights = torch.ones_like(bbox_weights)
+        reg_mask = torch.where(nonempty, reg_mask, 0)
         cls_avg = n_total * 1.0
         if self.train_cfg.get('sync_cls_avg_factor', False):
             cls_avg = reduce_mean(torch.full((1,), cls_avg, dtype=bbox_weights.dtype, device=bbox_weights.device))
@@ -993,8 +992,7 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         losses['num_neg_rois'] = (reg_mask <= 0).sum().float()
         # the ONE read-back of the loss: how many RoIs are positive for the box loss and for the occupancy loss (the row
         # lists below and in loss_occ are then built at a known size)
-        occ_reg_mask = occ_reg_mask.clone()
-        occ_reg_mask[~nonempty] = 0
+        occ_reg_mask = torch.where(nonempty, occ_reg_mask, 0)
         n_pos, n_occ = torch.stack([pos_inds.sum(), (occ_reg_mask > 0).sum()]).tolist()
         pos_rows = _true_rows(pos_inds, n_pos)
         reg_avg = pos_rows.numel()
