@@ -791,6 +791,8 @@ typedef struct {
   const float* wt_frag[8];           /* ... and of its transposed view (backward only) */
   const float* ln_weight[8];
   const float* ln_bias[8];
+  const float* gate;                 /* n_rel == 0 only: a gate [rows, feat_cols] computed elsewhere (ococc_sir_rel_chains_*), or null */
+  float* dgate;                      /* ... and, for the backward call, where its gradient [rows, feat_cols] goes */
 } ococc_sir_layer;
 int64_t ococc_sir_layer_fwd_floats(const ococc_sir_layer* layer, int64_t rows, int64_t groups);
 int ococc_sir_layer_fwd_f32(const ococc_sir_layer* layer, const float* features, const float* f_cluster, const int32_t* inv,
@@ -815,6 +817,36 @@ int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features,
  * hanging the device an incomplete barrier leaves its index + 1 in a status word, which ococc_sir_layer_fused_status
  * reads back (synchronises the stream; 0 = every barrier completed). */
 int ococc_sir_layer_set_fused(int32_t mode);
+/* The rel_mlp chains of several SIRLayers in one launch per direction (the layers of a SIR stack share the cluster
+ * offsets their gates are computed from: mmdet3d/models/backbones/sir.py:67-88, ococc_bbox_head.py:237-316).
+ * Chain c, block j: y = act(LayerNorm(W x)), x = f_cluster * rel_colscale (j = 0) or the block before (build_mlp,
+ * sst_ops.py:333-360); the last block's y is the layer's gate (ococc_sir_layer.gate of a descriptor with n_rel = 0).
+ * All chains of a call have the same depth (<= 3 blocks) and cluster_cols; <= 8 chains per call.  Block widths: <= 64
+ * output channels, the last block <= 64 or 129..144 -- ococc_sir_rel_chain_fwd_floats returns -1 for a chain outside
+ * that (run its rel_mlp inside its layer: n_rel > 0).
+ *   fwd: slabs[c] (ococc_sir_rel_chain_fwd_floats floats) keeps the inner blocks' rows, gates[c] [rows, n last].
+ *   bwd: dgates[c] [rows, n last] -> per block the LayerNorm partial rows [tiles][2][n] and weight-gradient slices
+ *        [slices][n][k] inside slabs[c] at the offsets ococc_sir_rel_chain_bwd_layout reports (finish with
+ *        ococc_layernorm_param_reduce_multi); f_cluster receives no gradient (the reference detaches it: voxel_encoder.py:781). */
+typedef struct {
+  int32_t n_blocks, cluster_cols;
+  const float* rel_colscale;         /* [cluster_cols] or null */
+  int32_t n[4];
+  int32_t act[4];
+  float eps[4];
+  const float* w_frag[4];
+  const float* wt_frag[4];
+  const float* ln_weight[4];
+  const float* ln_bias[4];
+} ococc_sir_rel_chain;
+int64_t ococc_sir_rel_chain_fwd_floats(const ococc_sir_rel_chain* chain, int64_t rows);
+int ococc_sir_rel_chain_bwd_layout(const ococc_sir_rel_chain* chain, int64_t rows, int64_t* ln_partial_off, int64_t* w_partial_off,
+                                   int64_t* tiles, int32_t* slices, int64_t* total_floats);
+int ococc_sir_rel_chains_fwd_f32(int32_t count, const ococc_sir_rel_chain* chains, const float* f_cluster, int64_t rows,
+                                 float* const* slabs, float* const* gates, ococc_stream_t stream);
+int ococc_sir_rel_chains_bwd_f32(int32_t count, const ococc_sir_rel_chain* chains, const float* f_cluster, int64_t rows,
+                                 const float* const* fwd_slabs, const float* const* gates, const float* const* dgates,
+                                 float* const* slabs, ococc_stream_t stream);
 int ococc_sir_layer_fused_status(ococc_stream_t stream, int32_t* status);
 
 /* ------------------------------------------------------------------------

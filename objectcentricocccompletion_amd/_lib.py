@@ -154,6 +154,10 @@ SIGNATURES = {
     'ococc_rotate_z_f32': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'ococc_points_box_to_box_f32': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'ococc_roi_box_targets_f32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'ococc_sir_rel_chain_fwd_floats': (c_i64, [c_vp, c_i64]),
+    'ococc_sir_rel_chain_bwd_layout': (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ococc_sir_rel_chains_fwd_f32': (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'ococc_sir_rel_chains_bwd_f32': (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sir_layer_set_fused': (c_i32, [c_i32]),
     'ococc_sir_layer_fused_status': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     'ococc_point_mlp_wgrad_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),

@@ -110,7 +110,7 @@ point_mlp_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x
 
 // the products of SEVERAL layers over the same rows in one launch (the five layers of a SIR layer's backward: 60 of the
 // 1.5 k launches of a 4-tracklet step were these, 13 us each for a dozen workgroups of work)
-constexpr int kWgradMulti = 8;
+constexpr int kWgradMulti = 24;
 struct PointWgradPack {
   const float* dz[kWgradMulti];
   const float* xc[kWgradMulti];
@@ -344,7 +344,7 @@ extern "C" int ococc_point_mlp_wgrad_f32(const float* dz, const float* x_cat, in
 extern "C" int ococc_point_mlp_wgrad_multi_f32(int32_t count, const float* const* dz, const float* const* x_cat, int64_t rows,
                                                const int32_t* n, const int32_t* k, float* const* partial,
                                                ococc_stream_t stream_) {
-  OCOCC_REQUIRE(count >= 1 && count <= kWgradMulti && rows >= 0, "1..8 layers per call");
+  OCOCC_REQUIRE(count >= 1 && count <= kWgradMulti && rows >= 0, "1..24 layers per call");
   OCOCC_REQUIRE(dz && x_cat && n && k && partial, "null pointer table");
   if (rows == 0) return OCOCC_OK;
   const int slices = ococc_point_mlp_wgrad_slices(rows);

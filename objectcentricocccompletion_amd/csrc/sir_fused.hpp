@@ -34,6 +34,9 @@ struct SirFusedArgs {
   const int32_t* inv;    // [rows] non-decreasing
   const float* rel_cs;   // [cluster_cols] or null
   const float* col;      // [feat_cols] or null
+  const float* gate;     // nr == 0: an external gate [rows, ld_gate >= feat_cols] multiplied into the features (the rel_mlp
+                         // output computed elsewhere: csrc/sir_rel_chains.hip), or null
+  int32_t ld_gate;
   int32_t feat_cols, cluster_cols, with_cc, shortcut, nr, nv, sum_n;
   float bscale;
   int64_t rows, groups;
@@ -45,7 +48,7 @@ struct SirFusedArgs {
   const float* d_groups; // [groups, ld_dg >= sum_n] or null
   int32_t ld_dy, ld_dg;  // their row strides in floats
   float* dfeat;          // [rows, feat_cols] or null
-  float* dgate;          // [rows, feat_cols]
+  float* dgate;          // [rows, feat_cols]: gradient of the gate (the last rel block's output, or the external gate)
   int64_t rows_per_slice;
   int32_t slices;
   uint32_t* bar;         // grid-barrier words of this stream (sir_fused_barrier_words)
@@ -60,9 +63,12 @@ struct SirSignature {
 };
 // The SIRLayers of configs[2] (ococcnet_cfg.py): rel_mlp 3|13 -> 16 -> 32 -> C, vfe C (+3) -> 128, 256 -> 128 with
 //   0: C = 131 | 144 (blocks 1..5 of both stacks)     1: C = 15 | 24 (block 0 of either stack)
-constexpr int kSirSignatures = 2;
+//   2, 3: the same two without their rel_mlp (the gate comes from outside: all rel_mlps of a stack run as one launch)
+constexpr int kSirSignatures = 4;
 constexpr SirSignature kSirSignature[kSirSignatures] = {{3, 2, {1, 1, 3, 2, 2}, {1, 1, 1, 3, 4}},
-                                                        {3, 2, {1, 1, 1, 2, 2}, {1, 1, 1, 1, 4}}};
+                                                        {3, 2, {1, 1, 1, 2, 2}, {1, 1, 1, 1, 4}},
+                                                        {0, 2, {2, 2}, {3, 4}},
+                                                        {0, 2, {2, 2}, {1, 4}}};
 
 int point_mlp_tile_rows(int64_t rows);   // csrc/point_mlp.hip
 // per tile size (csrc/sir_fused_mb{1,2,4}.hip): set the kernel up for `lds` bytes, size the persistent grid, launch

@@ -113,8 +113,11 @@ __device__ __forceinline__ PointMlpIn sir_block_input(KArgs* A) {
     in.ka = in.lda = A->feat_cols;
     in.colscale = A->col;
     if constexpr (SIG::nr > 0) {
-      in.mul = A->b[SIG::nr - 1].y;
-      in.ldm = A->b[SIG::nr - 1].n;
+      in.mul = A->b[SIG::nr > 0 ? SIG::nr - 1 : 0].y;
+      in.ldm = A->b[SIG::nr > 0 ? SIG::nr - 1 : 0].n;
+    } else if (A->gate) {
+      in.mul = A->gate;
+      in.ldm = A->ld_gate;
     }
     if (A->with_cc) {
       in.b = A->fc;
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
       const float* dy_cur = nv == 1 ? A->dy : A->b[nv == 1 ? nr : nr + 1].da;
       const float* carry = nv == 1 ? nullptr : A->b[nv == 1 ? nr : nr + 1].dv;
       sir_backward_block<MB, SIG, nr>(A, dy_cur, nv == 1 ? A->ld_dy : A->b[nr].n, A->d_groups, A->ld_dg, carry, A->dfeat,
-                                      nr ? A->dgate : nullptr, nullptr, t);
+                                      (nr || A->gate) ? A->dgate : nullptr, nullptr, t);
     }
     if (A->shortcut && A->dfeat && A->dy) {   // dfeat[:, 3:] += dy
       const int n = A->b[nl - 1].n, ldf = A->feat_cols, ldy = A->ld_dy;
@@ -357,7 +360,12 @@ int OCOCC_SIR_CAT(sir_fused_launch_mb, OCOCC_SIR_MB)(const SirFusedArgs& args, i
                                 c_lds[slot], c_cap[slot])                                                            \
             : persistent_launch(sir_fused_fwd_kernel<OCOCC_SIR_MB, Sig<S>>, args, lds, tiles, one_tile_each, stream, lds_set[slot], \
                                 c_lds[slot], c_cap[slot]))
-  static_assert(kSirSignatures == 2, "one case per signature");
-  return signature == 0 ? OCOCC_SIR_GO(0) : OCOCC_SIR_GO(1);
+  static_assert(kSirSignatures == 4, "one case per signature");
+  switch (signature) {
+    case 0: return OCOCC_SIR_GO(0);
+    case 1: return OCOCC_SIR_GO(1);
+    case 2: return OCOCC_SIR_GO(2);
+    default: return OCOCC_SIR_GO(3);
+  }
 #undef OCOCC_SIR_GO
 }

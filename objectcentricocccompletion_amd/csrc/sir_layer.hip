@@ -144,6 +144,8 @@ void fused_args(const ococc_sir_layer* d, const Dims& D, const FwdLayout& F, con
   A->inv = inv;
   A->rel_cs = d->rel_colscale;
   A->col = d->colscale;
+  A->gate = D.nr == 0 ? d->gate : nullptr;
+  A->ld_gate = d->feat_cols;
   A->feat_cols = d->feat_cols;
   A->cluster_cols = d->cluster_cols;
   A->with_cc = d->with_cluster_center;
@@ -231,13 +233,13 @@ extern "C" int ococc_sir_layer_fwd_f32(const ococc_sir_layer* d, const float* fe
     x = y_of(j);
     ldx = D.n[j];
   }
-  const float* gate = D.nr ? x : nullptr;
+  const float* gate = D.nr ? x : d->gate;   // (no rel blocks: the gate may come from outside, [rows, feat_cols])
   for (int i = 0; i < D.nv; ++i) {
     const int q = D.nr + i;
     float* m = slab + L.m[i];
     int rc;
     if (i == 0)
-      rc = ococc_point_mlp_fwd_f32(feats, d->feat_cols, d->feat_cols, gate, gate ? D.n[D.nr - 1] : 0, d->colscale,
+      rc = ococc_point_mlp_fwd_f32(feats, d->feat_cols, d->feat_cols, gate, gate ? d->feat_cols : 0, d->colscale,
                                    d->with_cluster_center ? f_cluster : nullptr, d->with_cluster_center ? d->cluster_cols : 0,
                                    d->with_cluster_center ? d->cluster_cols : 0, d->bscale, nullptr, 0, inv, rows, d->w_frag[q],
                                    D.n[q], d->ln_weight[q], d->ln_bias[q], d->eps[q], d->act[q], y_of(q), m, groups, stream_);
@@ -286,6 +288,9 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
   BwdLayout L;
   bwd_layout(D, d->feat_cols, rows, groups, &L);
   const int last = D.nl - 1;
+  // the gate's gradient: inside the slab when the gate is this layer's rel_mlp, in the caller's buffer when it came from outside
+  OCOCC_REQUIRE(D.nr > 0 || !d->gate || d->dgate, "an external gate needs a buffer for its gradient (dgate)");
+  float* dgate_buf = (D.nr == 0 && d->gate) ? d->dgate : slab + L.dgate;
   auto y_of = [&](int b) -> const float* { return (b == last && !d->shortcut) ? y_out : fwd_slab + F.y[b]; };
   auto dz_of = [&](int b) -> float* { return slab + L.dz[b]; };
   auto xcat_of = [&](int b) -> float* { return slab + L.xcat[b]; };
@@ -309,7 +314,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     A.ld_dy = (int32_t)ld_dy;
     A.ld_dg = (int32_t)ld_dgroups;
     A.dfeat = dfeat;
-    A.dgate = slab + L.dgate;
+    A.dgate = dgate_buf;
     A.slices = L.slices;
     A.rows_per_slice = ococc_align_up(ococc_cdiv(rows, L.slices), 32);
     const int rc = sir_fused_backward(A, stream);
@@ -353,12 +358,12 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     const int32_t* arg = (const int32_t*)(fwd_slab + F.arg[i]);   // (recorded by the forward pass)
     int rc;
     if (i == 0) {
-      const float* gate = D.nr ? y_of(D.nr - 1) : nullptr;
-      rc = ococc_point_mlp_bwd_f32(feats, d->feat_cols, d->feat_cols, gate, gate ? D.n[D.nr - 1] : 0, d->colscale,
+      const float* gate = D.nr ? y_of(D.nr - 1) : d->gate;
+      rc = ococc_point_mlp_bwd_f32(feats, d->feat_cols, d->feat_cols, gate, gate ? d->feat_cols : 0, d->colscale,
                                    d->with_cluster_center ? f_cluster : nullptr, d->with_cluster_center ? d->cluster_cols : 0,
                                    d->with_cluster_center ? d->cluster_cols : 0, d->bscale, nullptr, 0, inv, rows, d->w_frag[q],
                                    d->wt_frag[q], n, d->ln_weight[q], d->ln_bias[q], d->eps[q], d->act[q], dy_cur, dm,
-                                   dm ? arg : nullptr, dz_of(q), xcat_of(q), dfeat, gate ? slab + L.dgate : nullptr, nullptr, nullptr,
+                                   dm ? arg : nullptr, dz_of(q), xcat_of(q), dfeat, gate ? dgate_buf : nullptr, nullptr, nullptr,
                                    slab + L.lnp[q], stream_);
     } else {
       float* dv = slab + L.dv[i];
@@ -380,7 +385,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     hipLaunchKernelGGL(shortcut_grad_kernel, dim3(ococc_grid_1d(rows * n, 256, 4096)), dim3(256), 0, stream, dfeat,
                        d->feat_cols, dyo, n, rows * n);
   }
-  const float* dgate = slab + L.dgate;
+  const float* dgate = dgate_buf;
   for (int j = D.nr - 1; j >= 0; --j) {
     const float* x_in = j > 0 ? y_of(j - 1) : f_cluster;
     const int ldx = j > 0 ? D.n[j - 1] : d->cluster_cols;

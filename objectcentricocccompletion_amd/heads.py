@@ -25,7 +25,7 @@ from .occ import occ_ops
 from .occ.layers import PositionalEncoding, SimpleEncoderLayer, TransformerEncoder
 from .occ.occ_base import OccDecoder
 from .registry import BACKBONES, HEADS
-from .sir import SIRLayer
+from .sir import SIRLayer, rel_gates
 from . import voxel_encoders  # noqa: F401  (registers DynamicVFE / DynamicSimpleVFE)
 from .sst.sst_ops import build_mlp, unique_with_inverse
 
@@ -644,14 +644,17 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
                                pts_info['is_in_margin'][:, None], rel_xyz], dim=-1)
         cluster_feat_list = []
         geo = f_cluster / 10 if self.geo_input else None   # (the same for every block: once, and one concatenation per block)
+        # the rel_mlp gates of all blocks from the offsets they share, in one launch (None: every block runs its own)
+        gates = rel_gates(self.block_list, f_cluster) if self.unique_once else None
         for i, block in enumerate(self.block_list):
             in_feats = torch.cat([pts_xyz, out_feats] if geo is None else [pts_xyz, out_feats, geo], 1)
+            kw = {} if gates is None else {'gate': gates[i]}
             if i < self.num_blocks - 1:
                 out_feats, out_cluster_feats = block(in_feats, roi_inds, f_cluster, unq_inv_once=unq_inv,
-                                                     new_coors_once=new_coors)
+                                                     new_coors_once=new_coors, **kw)
             else:
                 out_cluster_feats, out_coors = block(in_feats, roi_inds, f_cluster, unq_inv_once=unq_inv,
-                                                     new_coors_once=new_coors)
+                                                     new_coors_once=new_coors, **kw)
             cluster_feat_list.append(out_cluster_feats)
         final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
         nonempty_roi_mask = self.get_nonempty_roi_mask(out_coors, len(rois))

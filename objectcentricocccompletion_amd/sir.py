@@ -64,7 +64,8 @@ class _SirLayerDesc(ctypes.Structure):   # ococc_sir_layer of include/ococc_hip.
                 ('bscale', ctypes.c_float), ('inference', ctypes.c_int32), ('rel_colscale', ctypes.c_void_p),
                 ('colscale', ctypes.c_void_p), ('n', ctypes.c_int32 * 8), ('act', ctypes.c_int32 * 8),
                 ('eps', ctypes.c_float * 8), ('w_frag', ctypes.c_void_p * 8), ('wt_frag', ctypes.c_void_p * 8),
-                ('ln_weight', ctypes.c_void_p * 8), ('ln_bias', ctypes.c_void_p * 8)]
+                ('ln_weight', ctypes.c_void_p * 8), ('ln_bias', ctypes.c_void_p * 8), ('gate', ctypes.c_void_p),
+                ('dgate', ctypes.c_void_p)]
 
 
 class _Ptr(object):
@@ -145,12 +146,15 @@ class _SirLayerNative(torch.autograd.Function):
     """_SirLayerFn with the launch sequences inside the library (ococc_sir_layer_fwd_f32 / _bwd_f32)."""
 
     @staticmethod
-    def forward(ctx, plan, shortcut, features, f_cluster, inv, G, *params):
+    def forward(ctx, plan, shortcut, features, f_cluster, inv, G, gate, *params):
+        # ``gate``: None, or (a plan without rel blocks) the layer's rel_mlp output computed elsewhere (rel_gates below)
         feats, fc = _f32c(features), _f32c(f_cluster)
+        gate = None if gate is None else _f32c(gate)
         rows, dev = feats.shape[0], feats.device
         d = plan.desc
         d.shortcut = int(shortcut)
         d.inference = 0 if torch.is_grad_enabled() or any(ctx.needs_input_grad) else 1
+        d.gate, d.dgate = (None if gate is None else gate.data_ptr()), None
         slab = torch.empty((int(L.lib.ococc_sir_layer_fwd_floats(plan.ref, rows, G)),), dtype=torch.float32, device=dev)
         y = torch.empty((rows, plan.n_last), dtype=torch.float32, device=dev)
         groups = torch.empty((G, plan.sum_n), dtype=torch.float32, device=dev)
@@ -158,7 +162,8 @@ class _SirLayerNative(torch.autograd.Function):
                                               slab.data_ptr(), y.data_ptr(), groups.data_ptr(), L.stream()), 'sir_layer_fwd')
         ctx.plan, ctx.shortcut, ctx.G = plan, bool(shortcut), G
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(feats, fc, inv, slab, y, *params)   # (the parameters: for autograd's version check)
+        ctx.has_gate = gate is not None
+        ctx.save_for_backward(feats, fc, inv, slab, y, *(() if gate is None else (gate,)), *params)   # (the parameters: for autograd's version check)
         return y, groups
 
     @staticmethod
@@ -166,10 +171,13 @@ class _SirLayerNative(torch.autograd.Function):
         plan, G = ctx.plan, ctx.G
         t = ctx.saved_tensors
         feats, fc, inv, fslab, y = t[:5]
+        gate = t[5] if ctx.has_gate else None
         rows, dev = feats.shape[0], feats.device
         need = ctx.needs_input_grad
         d = plan.desc
         d.shortcut = int(ctx.shortcut)
+        dgate = None if gate is None else torch.empty_like(gate)
+        d.gate, d.dgate = (None if gate is None else gate.data_ptr()), (None if dgate is None else dgate.data_ptr())
         ln_off, w_off, tiles, slices, total = plan.bwd_layout(rows, G)
         slab = torch.empty((total,), dtype=torch.float32, device=dev)
         dfeat = torch.empty_like(feats) if need[2] else None
@@ -180,29 +188,189 @@ class _SirLayerNative(torch.autograd.Function):
                                               fslab.data_ptr(), y.data_ptr(), L.ptr(dy), dy.stride(0) if dy is not None else 0,
                                               L.ptr(dM), dM.stride(0) if dM is not None else 0, slab.data_ptr(),
                                               L.ptr(dfeat), L.stream()), 'sir_layer_bwd')
-        grads = [None] * len(plan.params)
         if rows == 0:
-            return (None, None, dfeat, None, None, None, *[torch.zeros_like(p) for p in plan.params])
-        base = slab.data_ptr()
-        if all(need[6:]) and _deferred.deferrable(*plan.params):
-            out = torch.empty((sum(plan.grad_sizes),), dtype=torch.float32, device=dev)
-            views = out.split(plan.grad_sizes)
-            jobs, o = [], out.data_ptr()
-            for b in range(plan.nl):
-                n, k = plan.ns[b], plan.ks[b]
-                half = n * k // 2
-                jobs.append((_Ptr(slab, base + 4 * w_off[b]), slices, half, (_Ptr(out, o), _Ptr(out, o + 4 * half))))
-                o += 4 * n * k
-                jobs.append((_Ptr(slab, base + 4 * ln_off[b]), tiles, n, (_Ptr(out, o), _Ptr(out, o + 4 * n))))
-                o += 8 * n
-            if _deferred.defer_many('ln', jobs, list(zip(plan.params, views))):
-                return (None, None, dfeat, None, None, None, *grads)
-        for b in range(plan.nl):   # the sums right away, handed back through the engine
+            return (None, None, dfeat, None, None, None, dgate, *[torch.zeros_like(p) for p in plan.params])
+        grads = _finish_param_grads(plan, slab, ln_off, w_off, tiles, slices, all(need[7:]))
+        return (None, None, dfeat, None, None, None, dgate, *grads)
+
+
+def _finish_param_grads(plan, slab, ln_off, w_off, tiles, slices, all_needed):
+    """The parameter gradients of a plan's blocks from the partial sums a backward call left in ``slab`` (per block the
+    weight-gradient slices [slices][n][k] and the LayerNorm partial rows [tiles][2][n]): queued for the ONE reduction launch
+    at the end of the backward pass when the parameters allow it (then autograd gets None for them: the queue owns their
+    .grad), summed right away otherwise.  In the order of plan.params: (weight, ln weight, ln bias) per block."""
+    grads = [None] * len(plan.params)
+    base, dev = slab.data_ptr(), slab.device
+    if all_needed and _deferred.deferrable(*plan.params):
+        out = torch.empty((sum(plan.grad_sizes),), dtype=torch.float32, device=dev)
+        views = out.split(plan.grad_sizes)
+        jobs, o = [], out.data_ptr()
+        for b in range(plan.nl):
             n, k = plan.ns[b], plan.ks[b]
-            grads[3 * b] = slab[w_off[b]: w_off[b] + slices * n * k].view(slices, n, k).sum(0)
-            lnp = slab[ln_off[b]: ln_off[b] + tiles * 2 * n].view(tiles, 2, n).sum(0)
-            grads[3 * b + 1], grads[3 * b + 2] = lnp[0], lnp[1]
-        return (None, None, dfeat, None, None, None, *grads)
+            half = n * k // 2
+            jobs.append((_Ptr(slab, base + 4 * w_off[b]), slices, half, (_Ptr(out, o), _Ptr(out, o + 4 * half))))
+            o += 4 * n * k
+            jobs.append((_Ptr(slab, base + 4 * ln_off[b]), tiles, n, (_Ptr(out, o), _Ptr(out, o + 4 * n))))
+            o += 8 * n
+        if _deferred.defer_many('ln', jobs, list(zip(plan.params, views))):
+            return grads
+    for b in range(plan.nl):   # the sums right away, handed back through the engine
+        n, k = plan.ns[b], plan.ks[b]
+        grads[3 * b] = slab[w_off[b]: w_off[b] + slices * n * k].view(slices, n, k).sum(0)
+        lnp = slab[ln_off[b]: ln_off[b] + tiles * 2 * n].view(tiles, 2, n).sum(0)
+        grads[3 * b + 1], grads[3 * b + 2] = lnp[0], lnp[1]
+    return grads
+
+
+# ---- the rel_mlp chains of several layers in one launch per direction (csrc/sir_rel_chains.hip) ----------------------
+BATCH_REL_CHAINS = os.environ.get('OCOCC_SIR_BATCH_REL', '1') == '1'
+_REL_PLANS = weakref.WeakKeyDictionary()      # SIRLayer -> _RelPlan
+_VFE_PLANS = weakref.WeakKeyDictionary()      # SIRLayer -> _NativePlan of its vfe blocks alone (the gate comes from outside)
+
+
+class _RelChainDesc(ctypes.Structure):   # ococc_sir_rel_chain of include/ococc_hip.h
+    _fields_ = [('n_blocks', ctypes.c_int32), ('cluster_cols', ctypes.c_int32), ('rel_colscale', ctypes.c_void_p),
+                ('n', ctypes.c_int32 * 4), ('act', ctypes.c_int32 * 4), ('eps', ctypes.c_float * 4),
+                ('w_frag', ctypes.c_void_p * 4), ('wt_frag', ctypes.c_void_p * 4), ('ln_weight', ctypes.c_void_p * 4),
+                ('ln_bias', ctypes.c_void_p * 4)]
+
+
+class _RelPlan(object):
+    """Per SIRLayer: the chain descriptor of its rel_mlp (rebuilt when a parameter moves) and its weight-fragment plan."""
+
+    def __init__(self, blocks, cluster_cols, rel_cs):
+        self.params = []
+        for lin, norm, _ in blocks:
+            self.params += [lin.weight, norm.weight, norm.bias]
+        self.pack = PackPlan([lin.weight for lin, _, _ in blocks], private=True)
+        self.rel_cs = rel_cs
+        d = _RelChainDesc()
+        d.n_blocks, d.cluster_cols = len(blocks), cluster_cols
+        d.rel_colscale = None if rel_cs is None else rel_cs.data_ptr()
+        for b, (lin, norm, act) in enumerate(blocks):
+            d.n[b] = lin.out_features
+            d.act[b] = {'none': 0, 'gelu': 1, 'relu': 2}[act]
+            d.eps[b] = float(norm.eps)
+            d.w_frag[b] = self.pack.outs[2 * b].data_ptr()
+            d.wt_frag[b] = self.pack.outs[2 * b + 1].data_ptr()
+            d.ln_weight[b] = norm.weight.data_ptr()
+            d.ln_bias[b] = norm.bias.data_ptr()
+        self.desc = d
+        self.ptrs = tuple(p.data_ptr() for p in self.params)
+        self.nl = len(blocks)
+        self.ns = [lin.out_features for lin, _, _ in blocks]
+        self.ks = [lin.in_features for lin, _, _ in blocks]
+        self.grad_sizes = []
+        for n, k in zip(self.ns, self.ks):
+            self.grad_sizes += [n * k, n, n]
+        expect = [cluster_cols] + self.ns[:-1]
+        self.ok = (len(blocks) <= 3 and expect == self.ks and all((n * k) % 2 == 0 for n, k in zip(self.ns, self.ks))
+                   and all(p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in self.params)
+                   and int(L.lib.ococc_sir_rel_chain_fwd_floats(ctypes.byref(d), 64)) >= 0)
+        self._layouts = {}
+
+    def valid_for(self, params, rel_cs):
+        return rel_cs is self.rel_cs and len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params)) \
+            and tuple(p.data_ptr() for p in params) == self.ptrs
+
+    def bwd_layout(self, rows):
+        hit = self._layouts.get(rows)
+        if hit is None:
+            ln_off, w_off = (ctypes.c_int64 * 4)(), (ctypes.c_int64 * 4)()
+            tiles, slices, total = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+            L.check(L.lib.ococc_sir_rel_chain_bwd_layout(ctypes.byref(self.desc), rows, ln_off, w_off, ctypes.byref(tiles),
+                                                         ctypes.byref(slices), ctypes.byref(total)), 'sir_rel_chain_bwd_layout')
+            if len(self._layouts) > 64:
+                self._layouts.clear()
+            hit = self._layouts[rows] = (list(ln_off)[:self.nl], list(w_off)[:self.nl], tiles.value, slices.value, total.value)
+        return hit
+
+
+def _chain_array(plans):
+    arr = (_RelChainDesc * len(plans))()
+    for i, p in enumerate(plans):
+        arr[i] = p.desc
+    return arr
+
+
+def _vp(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+class _RelChains(torch.autograd.Function):
+    """gates of several SIRLayers = their rel_mlps on the cluster offsets the layers share: one launch forward, one launch
+    (+ the weight-gradient launch) backward, for all of them."""
+
+    @staticmethod
+    def forward(ctx, plans, f_cluster, *params):
+        fc = _f32c(f_cluster)
+        rows, dev = fc.shape[0], fc.device
+        slabs = [torch.empty((int(L.lib.ococc_sir_rel_chain_fwd_floats(ctypes.byref(p.desc), rows)),), dtype=torch.float32,
+                             device=dev) for p in plans]
+        gates = [torch.empty((rows, p.ns[-1]), dtype=torch.float32, device=dev) for p in plans]
+        L.check(L.lib.ococc_sir_rel_chains_fwd_f32(len(plans), _chain_array(plans), fc.data_ptr(), rows,
+                                                   _vp([t.data_ptr() for t in slabs]), _vp([t.data_ptr() for t in gates]),
+                                                   L.stream()), 'sir_rel_chains_fwd')
+        ctx.plans = plans
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(fc, *slabs, *gates, *params)
+        return tuple(gates)
+
+    @staticmethod
+    def backward(ctx, *dgates):
+        plans = ctx.plans
+        n = len(plans)
+        t = ctx.saved_tensors
+        fc, slabs, gates = t[0], t[1:1 + n], t[1 + n:1 + 2 * n]
+        rows, dev = fc.shape[0], fc.device
+        need = ctx.needs_input_grad
+        dg = [torch.zeros_like(g) if d is None else _f32c(d) for d, g in zip(dgates, gates)]
+        layouts = [p.bwd_layout(rows) for p in plans]
+        bslabs = [torch.empty((lay[4],), dtype=torch.float32, device=dev) for lay in layouts]
+        L.check(L.lib.ococc_sir_rel_chains_bwd_f32(n, _chain_array(plans), fc.data_ptr(), rows, _vp([s.data_ptr() for s in slabs]),
+                                                   _vp([g.data_ptr() for g in gates]), _vp([d.data_ptr() for d in dg]),
+                                                   _vp([s.data_ptr() for s in bslabs]), L.stream()), 'sir_rel_chains_bwd')
+        grads, at = [], 2
+        for p, lay, bs in zip(plans, layouts, bslabs):
+            if rows == 0:
+                grads += [torch.zeros_like(q) for q in p.params]
+            else:
+                ln_off, w_off, tiles, slices, _ = lay
+                grads += _finish_param_grads(p, bs, ln_off, w_off, tiles, slices, all(need[at:at + len(p.params)]))
+            at += len(p.params)
+        return (None, None, *grads)
+
+
+def rel_gates(layers, f_cluster):
+    """[gate of every layer] for SIRLayers that share ``f_cluster`` (the layers of one SIR stack), computed by ONE launch, or
+    None when that form does not apply (then every layer runs its own rel_mlp, as before)."""
+    layers = list(layers)
+    if not (BATCH_REL_CHAINS and NATIVE_LAYER and WHOLE_LAYER_NODE and POINT_LAYER_KERNEL and 2 <= len(layers) <= 8
+            and f_cluster is not None and f_cluster.is_cuda and f_cluster.dtype == torch.float32 and not f_cluster.requires_grad
+            and 0 < f_cluster.shape[0] <= POINT_LAYER_MAX_ROWS and not torch.cuda.is_current_stream_capturing()):
+        return None
+    plans, params = [], []
+    scale = None
+    for layer in layers:
+        ok, rel, vfe = layer._blocks()
+        if not (ok and rel and isinstance(layer, SIRLayer)):
+            return None
+        s = 1.0 / float(layer.rel_dist_scaler)
+        rel_cs = const_tensor([s] * rel[0][0].in_features, f_cluster.device)
+        if rel[0][0].in_features != f_cluster.shape[1]:
+            return None
+        ps = []
+        for lin, norm, _ in rel:
+            ps += [lin.weight, norm.weight, norm.bias]
+        plan = _REL_PLANS.get(layer)
+        if plan is None or not plan.valid_for(ps, rel_cs):
+            plan = _REL_PLANS[layer] = _RelPlan(rel, f_cluster.shape[1], rel_cs)
+        if not plan.ok or (plans and plan.nl != plans[0].nl):
+            return None
+        plan.pack.refresh(backward=torch.is_grad_enabled())
+        plans.append(plan)
+        params += ps
+    return list(_RelChains.apply(plans, f_cluster, *params))
 
 
 class _SirLayerFn(torch.autograd.Function):
@@ -422,7 +590,7 @@ class SIRLayer(nn.Module):
             cache[key] = (ok, rel, vfe)
         return cache[key]
 
-    def _forward_fused(self, features, f_cluster, inv, num_groups, shortcut=False):
+    def _forward_fused(self, features, f_cluster, inv, num_groups, shortcut=False, gate=None):
         dev = features.device
         _, rel, vfe = self._blocks()
         raw = self.in_channels - 3 * (self._with_cluster_center + self._with_voxel_center)   # columns of `features`
@@ -438,6 +606,18 @@ class SIRLayer(nn.Module):
         blocks = rel + vfe
         whole = (WHOLE_LAYER_NODE and features.dtype == torch.float32 and f_cluster.dtype == torch.float32
                  and not f_cluster.requires_grad and all(lin.weight.dtype == torch.float32 for lin, _, _ in blocks))
+        if gate is not None:   # the rel_mlp ran elsewhere (rel_gates: all layers of the stack in one launch): vfe blocks only
+            plan = _VFE_PLANS.get(self)
+            params = []
+            for lin, norm, _ in vfe:
+                params += [lin.weight, norm.weight, norm.bias]
+            if plan is None or not plan.valid_for(params) or plan.consts[1] is not col:
+                plan = _VFE_PLANS[self] = _NativePlan(vfe, 0, features.shape[1], f_cluster.shape[1], self._with_cluster_center,
+                                                      scale / 10.0, None, col)
+            assert whole and plan.ok and gate.shape == features.shape, 'rel_gates() hands out gates only where this form applies'
+            plan.pack.refresh(backward=torch.is_grad_enabled())
+            y, groups = _SirLayerNative.apply(plan, bool(shortcut), features, f_cluster, inv, int(num_groups), gate, *params)
+            return y, groups, shortcut
         if whole and NATIVE_LAYER and len(blocks) <= 8 and not torch.cuda.is_current_stream_capturing():
             plan = _NATIVE_PLANS.get(self)
             params = []
@@ -448,7 +628,7 @@ class SIRLayer(nn.Module):
                                                          self._with_cluster_center, scale / 10.0, rel_cs, col)
             if plan.ok and all(p.is_cuda for p in params):
                 plan.pack.refresh(backward=torch.is_grad_enabled())
-                y, groups = _SirLayerNative.apply(plan, bool(shortcut), features, f_cluster, inv, int(num_groups), *params)
+                y, groups = _SirLayerNative.apply(plan, bool(shortcut), features, f_cluster, inv, int(num_groups), None, *params)
                 return y, groups, shortcut
         # all Linears of this layer (and their transposes, when a backward pass will follow) packed in one launch
         lins = [lin.weight for lin, _, _ in blocks]
@@ -507,15 +687,18 @@ class SIRLayer(nn.Module):
         return y, torch.cat(maxima, dim=1)
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None,
-                return_inv=False, return_both=False, unq_inv_once=None, new_coors_once=None):
+                return_inv=False, return_both=False, unq_inv_once=None, new_coors_once=None, gate=None):
+        # ``gate`` (not in the reference's signature): this layer's rel_mlp output when the caller computed the gates of a
+        # whole stack at once (rel_gates); None = the layer runs its own rel_mlp
         inv, group_coors = self._groups(coors, unq_inv_once, new_coors_once)
         num_groups = group_coors.size(0)
         f_cluster = self._cluster_offsets(features[:, :3], f_cluster, inv, num_groups)
         want_points = return_both or self.return_point_feats
+        assert gate is None or (self._blocks()[0] and features.shape[0] <= POINT_LAYER_MAX_ROWS)
         if self._blocks()[0] and features.shape[0] <= POINT_LAYER_MAX_ROWS:
             n_out = self.vfe_layers[-1].linear.out_features
             shortcut = bool(want_points and self.with_shortcut and n_out == features.shape[1] - 3)
-            point_feats, group_feats, shortcut_done = self._forward_fused(features, f_cluster, inv, num_groups, shortcut)
+            point_feats, group_feats, shortcut_done = self._forward_fused(features, f_cluster, inv, num_groups, shortcut, gate)
         else:
             point_feats, group_feats = self._forward_ops(features, f_cluster, inv, num_groups)
             shortcut_done = False
@@ -560,9 +743,11 @@ class SIR(nn.Module):
             f_cluster = points - gather_rows(centre, inv)
         feats, per_block = features, []
         last = len(self.block_list) - 1
+        # the gates of all blocks from the offsets they share, in one launch (None: every block runs its own rel_mlp)
+        gates = rel_gates(self.block_list, f_cluster) if (f_cluster is not None and inv is not None) else None
         for i, block in enumerate(self.block_list):
             out = block(torch.cat([points, feats], 1), coors, f_cluster, return_both=(i == last), unq_inv_once=inv,
-                        new_coors_once=group_coors)
+                        new_coors_once=group_coors, **({} if gates is None else {'gate': gates[i]}))
             feats = out[0]
             per_block.append(out[1])
         return feats, torch.cat(per_block, dim=1), out[2]

@@ -288,6 +288,72 @@ def test_sir_layer_in_one_launch_equals_the_launch_per_block(dev, cfg, rows, use
         assert rel(p, q) < 1e-5, rel(p, q)
 
 
+@pytest.mark.parametrize('rows', [60, 5000])
+@pytest.mark.parametrize('stack', ['sir', 'head'])
+def test_rel_mlp_chains_of_a_stack_in_one_launch(dev, stack, rows):
+    """The rel_mlp gates of all blocks of a SIR stack from the cluster offsets they share -- one launch per direction
+    (csrc/sir_rel_chains.hip, sir.rel_gates) -- against every block running its own rel_mlp: the same tile bodies, so the
+    forward results agree to the bit and the gradients up to the order of the float atomics.  The two stack shapes of
+    configs[2]: the SIR backbone of the auto-encoder (15 | 131 input columns, 3 offset columns) and the blocks of
+    OccBBoxHead.roi_encode (24 | 144 input columns with the geometry columns, 13 offset columns)."""
+    from objectcentricocccompletion_amd import sir
+    g = torch.Generator().manual_seed(21)
+    nb = 3
+    if stack == 'sir':
+        net = sir.SIR(num_blocks=nb, in_channels=[15] + [131] * (nb - 1), feat_channels=[[128, 128]] * nb,
+                      rel_mlp_hidden_dims=[[16, 32]] * nb, with_rel_mlp=True, with_cluster_center=False, with_distance=False,
+                      norm_cfg=dict(type='LN', eps=1e-3), mode='max', xyz_normalizer=[1, 1, 1], act='gelu', dropout=0,
+                      unique_once=True).to(dev)
+    else:
+        net = torch.nn.ModuleList([sir.SIRLayer(in_channels=c, feat_channels=[128, 128], with_cluster_center=False,
+                                                rel_mlp_hidden_dims=[16, 32], rel_mlp_in_channel=13, norm_cfg=dict(type='LN', eps=1e-3),
+                                                mode='max', return_point_feats=i != nb - 1, rel_dist_scaler=10.0,
+                                                xyz_normalizer=[20, 20, 4], act='gelu', dropout=0)
+                                   for i, c in enumerate([24] + [144] * (nb - 1))]).to(dev)
+    sizes = torch.randint(1, 90, (rows // 30 + 2,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(sizes.numel()), sizes)[:rows]
+    M = inv.numel()
+    coors = inv.to(dev).int()
+    pts = torch.randn(M, 3, generator=g).to(dev)
+    feats = torch.randn(M, 12 if stack == 'sir' else 8, generator=g).to(dev)
+    fc = torch.randn(M, 13, generator=g).to(dev)
+
+    def run(batched):
+        sir.BATCH_REL_CHAINS = batched
+        try:
+            net.zero_grad(set_to_none=True)
+            x = feats.clone().requires_grad_(True)
+            if stack == 'sir':
+                # (the offsets handed in: derived inside they come from a segment mean whose float atomics differ run to run)
+                pf, gf, _ = net(pts, x, coors[:, None], f_cluster=fc[:, :3].contiguous(), dims=[int(inv.max()) + 1])
+                outs = [pf, gf]
+            else:
+                from objectcentricocccompletion_amd.sst.sst_ops import unique_with_inverse
+                new_coors, unq = unique_with_inverse(coors, [int(inv.max()) + 1])
+                gates = sir.rel_gates(net, fc)
+                assert (gates is not None) == batched
+                cur, outs = x, []
+                for i, block in enumerate(net):
+                    fin = torch.cat([pts, cur, fc / 10], 1)
+                    out = block(fin, coors, fc, unq_inv_once=unq, new_coors_once=new_coors, **({} if gates is None else {'gate': gates[i]}))
+                    if i < nb - 1:
+                        cur = out[0]
+                    outs.append(out[1] if i < nb - 1 else out[0])
+            loss = sum((o * torch.linspace(0.5, 1.5, o.shape[1], device=dev)).sum() for o in outs)
+            loss.backward()
+            return [o.detach() for o in outs], x.grad.clone(), [p.grad.clone() for p in net.parameters()]
+        finally:
+            sir.BATCH_REL_CHAINS = True
+
+    a, b = run(True), run(False)
+    for p, q in zip(a[0], b[0]):
+        assert torch.equal(p, q)
+    rel = lambda p, q: float((p - q).abs().max() / q.abs().max().clamp(min=1e-30))
+    assert rel(a[1], b[1]) < 1e-5
+    for p, q in zip(a[2], b[2]):
+        assert rel(p, q) < 1e-5
+
+
 @pytest.mark.parametrize('rows,n,k', [(1, 16, 13), (31, 32, 3), (300, 128, 131), (5000, 144, 256), (70001, 64, 24),
                                        (8192, 128, 259 - 3)])
 def test_weight_gradient_kernel(dev, rows, n, k):
