@@ -1066,6 +1066,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             l0, l1, p0, p1 = (lab == 0) & valid, (lab == 1) & valid, (pred_cls == 0) & valid, (pred_cls == 1) & valid
             # ... and the six counts from one reduction, the four ratios from one division
             c = torch.stack([l0 & p0, l1 & p1, l0, l1, p0, p1]).sum(1)
-            ratios = c[[0, 1, 0, 1]] / (c[[2, 3, 4, 5]] + 1e-6)
+            # (index tensors from the constant cache: a Python list as an index is a pageable host-to-device copy = a host sync)
+            num, den = const_tensor((0, 1, 0, 1), c.device, torch.long), const_tensor((2, 3, 4, 5), c.device, torch.long)
+            ratios = c[num] / (c[den] + 1e-6)
             losses['recall_neg'], losses['recall_pos'], losses['precision_neg'], losses['precision_pos'] = ratios.unbind(0)
         return losses

@@ -10,6 +10,7 @@ import os
 import torch
 from torch import nn
 
+from ._lib import const_tensor
 from .bbox import points_box_to_box, rotation_3d_in_axis
 from .registry import BBOX_ASSIGNERS, DETECTORS, HEADS, ROI_EXTRACTORS
 from .tracklet import SamplingResult, Tracklet
@@ -251,7 +252,9 @@ class TrackletRoIHeadOCC(nn.Module):
         # instead of three dozen
         hit, miss = preds & labels, ~(preds | labels)
         c = torch.stack([hit, preds, labels, miss, ~preds, ~labels]).float().sum(1)
-        ratios = c[[0, 0, 3, 3]] / (c[[1, 2, 4, 5]] + 1e-6)
+        # (index tensors from the constant cache: a Python list as an index is a pageable host-to-device copy = a host sync)
+        num, den = const_tensor((0, 0, 3, 3), c.device, torch.long), const_tensor((1, 2, 4, 5), c.device, torch.long)
+        ratios = c[num] / (c[den] + 1e-6)
         loss['acc'] = (preds == labels).float().mean().detach()
         (loss['precision_posbox'], loss['recall_posbox'], loss['precision_negbox'], loss['recall_negbox']) = ratios.unbind(0)
         res.update(loss_bbox=loss)
