@@ -10,7 +10,7 @@ from .registry import ROI_EXTRACTORS
 
 
 def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point,
-                             max_all_pts=200000, return_counts=False):
+                             max_all_pts=200000, return_counts=False, also_read=None):
     """Same arguments / returns as DynamicPointPoolMixedFunction.forward: (out_pts_idx [M] i64,
     out_roi_idx [M] i64, out_pts_feats [M,13] f32).  When nothing is inside any box the
     reference returns one fake row of -1 / zeros (dynamic_point_pool_op.py:91-95); so do we."""
@@ -32,7 +32,13 @@ def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_in
         int(max_inbox_point), int(max_all_pts), L.ptr(out_pts_idx), L.ptr(out_roi_idx),
         L.ptr(out_feats), meta.data_ptr() + 4, meta.data_ptr(), L.ptr(ws), ws.numel(), L.stream()),
         'dynamic_point_pool_mixed')
-    m = int(meta[0].item())  # the one read-back (the reference's boolean-mask compaction syncs too)
+    # the one read-back (the reference's boolean-mask compaction syncs too); ``also_read`` (a small int32 device tensor of the
+    # caller's) rides on it and comes back as a list in also_read.host
+    if also_read is None:
+        m = int(meta[0].item())
+    else:
+        got = torch.cat([meta[:1], also_read.to(torch.int32)]).tolist()
+        m, also_read.host = int(got[0]), got[1:]
     if m == 0:
         out = (out_pts_idx.new_full((1,), -1), out_roi_idx.new_full((1,), -1), out_feats.new_zeros((1, 13)))
     else:
@@ -40,6 +46,9 @@ def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_in
     if return_counts:
         return out + (meta[1:],)
     return out
+
+
+_KEY_STRIDE = 1 << 16   # frames per batch entry in the (batch, frame) match keys
 
 
 @ROI_EXTRACTORS.register_module()
@@ -58,11 +67,15 @@ class TrackletPointRoIExtractor(nn.Module):
 
     def forward(self, pts_xyz, batch_inds, pts_frame_inds, rois, roi_frame_inds, max_inbox_point=None):
         assert len(pts_xyz) > 0 and len(batch_inds) > 0 and len(rois) > 0
+        seen = None
         if self.combined:
             pts_inds, roi_inds = batch_inds.int(), rois[:, 0].int()
         else:
-            max_frames, pts_max_frames = (int(v) + 1 for v in torch.stack([roi_frame_inds.max(), pts_frame_inds.max()]).tolist())   # one read-back
-            assert pts_max_frames <= max_frames, f'{pts_max_frames} > {max_frames}'
+            # The (batch, frame) keys are only compared for equality: a fixed stride instead of the largest frame index + 1
+            # (dynamic_point_roi_extractor.py:186-190 reads both maxima back for it) -- the reference's check that no point
+            # lies in a later frame than any RoI is made from the maxima riding on the pooling's own read-back below.
+            max_frames = _KEY_STRIDE
+            seen = torch.stack([roi_frame_inds.max(), pts_frame_inds.max(), batch_inds.max()])
             pts_inds = (batch_inds * max_frames + pts_frame_inds).int()
             roi_inds = (rois[:, 0].int() * max_frames + roi_frame_inds).int()
         if isinstance(self.max_all_point, (tuple, list)):
@@ -71,7 +84,11 @@ class TrackletPointRoIExtractor(nn.Module):
             max_all_point = self.max_all_point
         all_inds, all_roi_inds, info = dynamic_point_pool_mixed(
             rois[..., 1:], roi_inds, pts_xyz, pts_inds, self.extra_wlh, self.max_inbox_point,
-            max_all_point)
+            max_all_point, also_read=seen)
+        if seen is not None:
+            roi_frames, pts_frames, batches = (int(v) + 1 for v in seen.host)
+            assert pts_frames <= roi_frames, f'{pts_frames} > {roi_frames}'
+            assert roi_frames <= _KEY_STRIDE and batches * _KEY_STRIDE < 2 ** 31, 'frame / batch indices beyond the key range'
         ext_pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
         if self.debug:
             r = rois[..., 1:][all_roi_inds]
