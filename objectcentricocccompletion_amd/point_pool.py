@@ -34,15 +34,20 @@ def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_in
         'dynamic_point_pool_mixed')
     # the one read-back (the reference's boolean-mask compaction syncs too); ``also_read`` (a small int32 device tensor of the
     # caller's) rides on it and comes back as a list in also_read.host
+    # ... and so does the number of RoIs that received a point: the grouping of the pooled points by RoI
+    # (sst_ops.unique_with_inverse) then knows its output size without a read-back of its own
+    head = torch.stack([meta[0], (meta[1:] > 0).sum().to(torch.int32)])
     if also_read is None:
-        m = int(meta[0].item())
+        m, nonempty = head.tolist()
     else:
-        got = torch.cat([meta[:1], also_read.to(torch.int32)]).tolist()
-        m, also_read.host = int(got[0]), got[1:]
+        got = torch.cat([head, also_read.to(torch.int32)]).tolist()
+        m, nonempty, also_read.host = int(got[0]), int(got[1]), got[2:]
     if m == 0:
         out = (out_pts_idx.new_full((1,), -1), out_roi_idx.new_full((1,), -1), out_feats.new_zeros((1, 13)))
+        nonempty = 1   # (the one fake row is a group of its own)
     else:
         out = (out_pts_idx[:m], out_roi_idx[:m], out_feats[:m])
+    out[1]._ococc_num_groups = int(nonempty)
     if return_counts:
         return out + (meta[1:],)
     return out

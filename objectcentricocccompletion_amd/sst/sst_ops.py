@@ -21,7 +21,12 @@ def unique_with_inverse(coors, dims=None, return_counts=False):
         new_coors, inv, counts = memo[2]
     else:
         shifted = coors + 1  # -1 -> 0: the bitmap ranks only non-negative keys
-        new_coors, inv, counts = grid_unique(shifted, None if dims is None else [int(d) + 1 for d in dims])
+        known = getattr(coors, '_ococc_num_groups', None)   # (point_pool: the producer already read the group count back)
+        if known is not None and dims is not None:
+            new_coors, inv, counts, _ = grid_unique(shifted, [int(d) + 1 for d in dims], static=True)
+            new_coors, counts = new_coors[:known], counts[:known]
+        else:
+            new_coors, inv, counts = grid_unique(shifted, None if dims is None else [int(d) + 1 for d in dims])
         new_coors = new_coors - 1
         inv._ococc_counts = counts
         if not coors.requires_grad:
