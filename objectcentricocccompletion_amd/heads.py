@@ -57,6 +57,9 @@ class _GraphTable(dict):
         return (_GraphTable, ())
 
 
+HOST_POSITIVE_COUNTS = True   # False: OccBBoxHead.loss reads its two positive counts back from the device (tests)
+
+
 class _Graphed(object):
     """`owner in _graphed_encoders` / `_graphed_encoders.get(owner)`: the owner's table, if it has replayed anything"""
 
@@ -658,6 +661,9 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             cluster_feat_list.append(out_cluster_feats)
         final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
         nonempty_roi_mask = self.get_nonempty_roi_mask(out_coors, len(rois))
+        counts = getattr(roi_inds, '_ococc_roi_counts', None)   # (point_pool: points per RoI, already on the host)
+        if counts is not None and len(counts) == len(rois):
+            nonempty_roi_mask._ococc_host = [c > 0 for c in counts]
         final_cluster_feats = self.align_roi_feature_and_rois(final_cluster_feats, out_coors, len(rois))
         return final_cluster_feats, nonempty_roi_mask, out_coors
 
@@ -818,6 +824,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         sel_trk = [t for t in range(len(p_i)) for _ in range(n_occ[t])]
         live = [t for t in range(len(p_i)) if p_i[t] > 0]
         slot = {t: k for k, t in enumerate(live)}
+        pos_rows_host = [starts[t] + j for t in range(len(n_i)) for j in range(p_i[t])]
+        occ_rows_host = [starts[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])]
         pos_rows, sel_pos, occ_rows, sel_slot = host_index_many([
             [starts[t] + j for t in range(len(n_i)) for j in range(p_i[t])],
             [pstart[t] + p_i[t] - n_occ[t] + j for t in range(len(p_i)) for j in range(n_occ[t])],
@@ -856,6 +864,9 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
             pos_gt_bboxes_occ = pos_gt_bboxes.new_empty((0, 7))
         label_weights = label_weights / torch.clamp(label_weights.sum(), min=1.0)
         bbox_weights = bbox_weights / torch.clamp(bbox_weights.sum(), min=1.0)
+        # (which rows the two masks set, as host lists: with the host copy of the non-empty mask the loss counts its
+        # positives without a read-back)
+        reg_mask._ococc_rows, occ_reg_mask._ococc_rows = pos_rows_host, (occ_rows_host if P > 0 else [])
         return (label, bbox_targets, bbox_target_batch_idx, pos_gt_bboxes, pos_gt_labels, reg_mask, label_weights,
                 bbox_weights, roi_local_xyz, gt_occ, occ_score, occ_reg_mask, occ_target_batch_idx, pos_gt_bboxes_occ)
 
@@ -983,6 +994,8 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         assert n_total > 0 and not self.with_corner_loss
         # (ococc_bbox_head.py:464-477 sets the weights of non-empty RoIs to 1, of empty ones to 0, every box weight to 1 and
         # clears the regression mask of empty RoIs, on clones, with masked assignments: the same tensors in one launch each)
+        host_hint = (getattr(reg_mask, '_ococc_rows', None), getattr(occ_reg_mask, '_ococc_rows', None),
+                     getattr(nonempty, '_ococc_host', None))
         label_weights = nonempty.to(label_weights.dtype)
         bbox_weights = torch.ones_like(bbox_weights)
         reg_mask = torch.where(nonempty, reg_mask, 0)
@@ -996,7 +1009,12 @@ class OccBBoxHead(nn.Module, SparseHeadMixin):
         # the ONE read-back of the loss: how many RoIs are positive for the box loss and for the occupancy loss (the row
         # lists below and in loss_occ are then built at a known size)
         occ_reg_mask = torch.where(nonempty, occ_reg_mask, 0)
-        n_pos, n_occ = torch.stack([pos_inds.sum(), (occ_reg_mask > 0).sum()]).tolist()
+        if HOST_POSITIVE_COUNTS and all(h is not None for h in host_hint) and len(host_hint[2]) == n_total:
+            # (the rows the masks set and which RoIs have points are both known on the host: no read-back)
+            n_pos = sum(1 for r in host_hint[0] if host_hint[2][r])
+            n_occ = sum(1 for r in host_hint[1] if host_hint[2][r])
+        else:
+            n_pos, n_occ = torch.stack([pos_inds.sum(), (occ_reg_mask > 0).sum()]).tolist()
         pos_rows = _true_rows(pos_inds, n_pos)
         reg_avg = pos_rows.numel()
         if self.train_cfg.get('sync_reg_avg_factor', False):

@@ -36,18 +36,21 @@ def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_in
     # caller's) rides on it and comes back as a list in also_read.host
     # ... and so does the number of RoIs that received a point: the grouping of the pooled points by RoI
     # (sst_ops.unique_with_inverse) then knows its output size without a read-back of its own
-    head = torch.stack([meta[0], (meta[1:] > 0).sum().to(torch.int32)])
+    # (the per-RoI counts come along whole -- R small integers: the loss then knows on the host which of its positive RoIs are empty)
     if also_read is None:
-        m, nonempty = head.tolist()
+        got = meta.tolist()
     else:
-        got = torch.cat([head, also_read.to(torch.int32)]).tolist()
-        m, nonempty, also_read.host = int(got[0]), int(got[1]), got[2:]
+        got = torch.cat([meta, also_read.to(torch.int32)]).tolist()
+        also_read.host = got[R + 1:]
+    m, roi_counts = int(got[0]), got[1:R + 1]
+    nonempty = sum(1 for c in roi_counts if c > 0)
     if m == 0:
         out = (out_pts_idx.new_full((1,), -1), out_roi_idx.new_full((1,), -1), out_feats.new_zeros((1, 13)))
         nonempty = 1   # (the one fake row is a group of its own)
     else:
         out = (out_pts_idx[:m], out_roi_idx[:m], out_feats[:m])
     out[1]._ococc_num_groups = int(nonempty)
+    out[1]._ococc_roi_counts = roi_counts
     if return_counts:
         return out + (meta[1:],)
     return out

@@ -181,6 +181,41 @@ def test_head_loss_and_backward_runs(dev, gold, head):
         head.zero_grad(set_to_none=True)
 
 
+def test_loss_counts_its_positives_on_the_host(dev):
+    """OccBBoxHead.loss needs the number of positive RoIs that received points (row lists of a known size, the averaging
+    factors).  The rows the targets mark are host lists and the point pooling reads the per-RoI point counts back with its
+    own output size, so the count is host arithmetic; `heads.HOST_POSITIVE_COUNTS = False` reads it back from the device as
+    before.  Same losses either way -- on a batch in which a third of one tracklet's RoIs have no points."""
+    from objectcentricocccompletion_amd import heads, point_pool, roi_head  # noqa: F401
+    from objectcentricocccompletion_amd.ococcnet_cfg import ococcnet_model_cfg
+    from objectcentricocccompletion_amd.registry import DETECTORS
+    from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
+    torch.manual_seed(0)
+    cfg = ococcnet_model_cfg()
+    cfg['train_cfg']['random_shift_frame_inds'] = False
+    model = DETECTORS.build(cfg).to(dev).eval()      # (eval mode of the modules: no dropout)
+    batch = synthetic_training_batch(2, 12, pts_per_frame=48, occ_queries=64, seed=3, device=dev)
+    keep = batch['pts_frame_inds'][1] % 3 != 0        # the points of every third frame of tracklet 1 are gone: empty RoIs
+    batch['points'][1], batch['pts_frame_inds'][1] = batch['points'][1][keep], batch['pts_frame_inds'][1][keep]
+    runs = []
+    for host in (True, False):
+        heads.HOST_POSITIVE_COUNTS = host
+        try:
+            with torch.no_grad():
+                runs.append(model.forward_train(**{k: v for k, v in batch.items()}))
+        finally:
+            heads.HOST_POSITIVE_COUNTS = True
+    a, b = runs
+    assert set(a) == set(b) and float(a['num_pos_rois']) > 0
+    for k in a:   # (the counts exactly; the losses up to the float atomics of the cluster means, which differ run to run)
+        p, q = torch.as_tensor(a[k]).float(), torch.as_tensor(b[k]).float()
+        assert p.shape == q.shape, k
+        if k.startswith('num_'):
+            assert torch.equal(p, q), k
+        else:
+            assert torch.allclose(p, q, rtol=1e-4, atol=1e-6), k
+
+
 def test_aligned_iou3d_vs_oracle(dev):
     from objectcentricocccompletion_amd.tracklet import aligned_iou_3d
     rng = np.random.default_rng(8)
