@@ -55,9 +55,11 @@ def _gather_rows(rows, inv):
 
 
 def _dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_inbox_point, max_all_pts=200000,
-                              return_counts=False):
+                              return_counts=False, also_read=None):
     pi, ri, fe, cnt = O.point_pool(rois.detach().numpy(), rois_batch.numpy(), pts.detach().numpy(), pts_batch.numpy(),
                                    list(extra_wlh), int(max_inbox_point), int(max_all_pts))
+    if also_read is not None:   # (the product reads this small tensor back together with its output size)
+        also_read.host = [int(v) for v in also_read.tolist()]
     if len(pi) == 0:
         out = (torch.full((1,), -1, dtype=torch.long), torch.full((1,), -1, dtype=torch.long), torch.zeros((1, 13)))
     else:
