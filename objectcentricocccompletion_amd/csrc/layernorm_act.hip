@@ -159,6 +159,111 @@ ln_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t n, 
   }
 }
 
+// ---- few, wide rows (the RoI-level MLPs and the temporal transformer of configs[2]: 128 .. 1024 rows of 1024 .. 2048 f32
+// channels): ONE ROW PER WORKGROUP, channel tid + 256 j in thread tid.  The generic kernels above put 256 / 64 = 4 rows in
+// a workgroup and 32 channels in a lane: 32 workgroups for 128 rows, a chain of 32 dependent loads each -- 16 us forward and
+// 25 us backward for 1 MB.  Sums cross the four waves through LDS; the backward's parameter partial row IS the row's own
+// dz * xhat | dz (one partial row per input row).
+constexpr int kRowKernelMaxRows = 1024, kRowKernelMaxC = 2048;   // (<= kBwdMaxBlocks partial rows: the backward workspace holds that many)
+inline bool row_kernel_ok(int64_t n, int c) { return n <= kRowKernelMaxRows && c > 512 && c <= kRowKernelMaxC; }
+
+// (a, b) summed over the 256 threads of the workgroup; every thread gets both sums.  Two barriers.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    a += __shfl_xor(a, d, 64);
+    b += __shfl_xor(b, d, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();   // (red may still be read from the previous use)
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * wave] = a;
+    red[2 * wave + 1] = b;
+  }
+  __syncthreads();
+  a = (red[0] + red[2]) + (red[4] + red[6]);
+  b = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_act_fwd_row_kernel(const T* __restrict__ x, int c, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                      int act, T* __restrict__ y, float* __restrict__ mean_rstd) {
+  __shared__ float red[8];
+  const int64_t r = blockIdx.x;
+  const float inv_c = 1.f / (float)c;
+  float v[8];
+  float s = 0.f, zero = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = threadIdx.x + 256 * j;
+    v[j] = ch < c ? ld<T>(x + r * c + ch) : 0.f;
+    s += v[j];
+  }
+  block_sum2(s, zero, red);
+  const float mean = s * inv_c;
+  float sq = 0.f;
+  zero = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float d = threadIdx.x + 256 * j < c ? v[j] - mean : 0.f;
+    sq += d * d;
+  }
+  block_sum2(sq, zero, red);
+  const float rstd = rsqrtf(sq * inv_c + eps);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = threadIdx.x + 256 * j;
+    if (ch < c) {
+      float z = (v[j] - mean) * rstd * gamma[ch] + beta[ch];
+      if (act == 1) z = gelu(z);
+      st<T>(y + r * c + ch, z);
+    }
+  }
+  if (mean_rstd && threadIdx.x == 0) {
+    mean_rstd[r * 2] = mean;
+    mean_rstd[r * 2 + 1] = rstd;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ln_act_bwd_row_kernel(const T* __restrict__ x, const T* __restrict__ dy, int c, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, const float* __restrict__ mean_rstd, int act, T* __restrict__ dx,
+                      float* __restrict__ partials) {
+  __shared__ float red[8];
+  const int64_t r = blockIdx.x;
+  const float inv_c = 1.f / (float)c;
+  const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+  float xh[8], dzg[8];
+  float s1 = 0.f, s2 = 0.f;
+  float* slab = partials + r * 2 * c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = threadIdx.x + 256 * j;
+    xh[j] = dzg[j] = 0.f;
+    if (ch < c) {
+      const float g = gamma[ch];
+      xh[j] = (ld<T>(x + r * c + ch) - mean) * rstd;
+      float dz = ld<T>(dy + r * c + ch);
+      if (act == 1) dz *= gelu_grad(xh[j] * g + beta[ch]);
+      slab[ch] = dz * xh[j];
+      slab[c + ch] = dz;
+      dzg[j] = dz * g;
+      s1 += dzg[j];
+      s2 += dzg[j] * xh[j];
+    }
+  }
+  block_sum2(s1, s2, red);
+  s1 *= inv_c;
+  s2 *= inv_c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = threadIdx.x + 256 * j;
+    if (ch < c) st<T>(dx + r * c + ch, rstd * (dzg[j] - s1 - xh[j] * s2));
+  }
+}
+
 // ---- vectorised bf16 path: c = 8 * LPR with LPR a power of two <= 64.  Lane li owns the 8
 // contiguous channels 8*li .. 8*li+7 (one 16-byte load/store), so a wave instruction moves
 // 1 KiB of whole rows; gamma/beta live in registers for the whole kernel.
@@ -538,6 +643,13 @@ int launch_fwd(const T* x, int64_t n, int c, const float* gamma, const float* be
     return OCOCC_OK;
   }
   if (drop.thr) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused dropout: bf16 rows of 16..512 (x8) or 1024/1536/2048 channels");
+  if (row_kernel_ok(n, c)) {
+    if (n > 0)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_fwd_row_kernel<T>), dim3((unsigned)n), dim3(256), 0, stream, x, c, gamma, beta, eps,
+                         act, y, mean_rstd);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = ococc_grid_1d(ococc_cdiv(n, 256 / lpr) * 256, 256);
@@ -560,6 +672,7 @@ inline int bwd_partial_rows(int64_t n, int c, bool two_byte) {
     int64_t gb = ococc_cdiv(n, 4);
     return (int)(gb > kBwdMaxBlocks ? kBwdMaxBlocks : (gb < 1 ? 1 : gb));
   }
+  if (row_kernel_ok(n, c)) return (int)(n < 1 ? 1 : n);   // one partial row per input row
   return bwd_blocks(n, pick_lpr(c));
 }
 
@@ -592,6 +705,16 @@ int launch_bwd(const T* x, const T* dy, int64_t n, int c, const float* gamma, co
     return OCOCC_OK;
   }
   if (drop.thr) return ococc_fail(OCOCC_EUNSUPPORTED, __func__, "fused dropout: bf16 rows of 16..512 (x8) or 1024/1536/2048 channels");
+  if (row_kernel_ok(n, c)) {
+    const int rows = bwd_partial_rows(n, c, sizeof(T) == 2);   // (= n)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ln_act_bwd_row_kernel<T>), dim3((unsigned)n), dim3(256), 0, stream, x, dy, c, gamma, beta,
+                       mean_rstd, act, dx, partials);
+    OCOCC_CHECK_LAUNCH();
+    if (!dgamma && !dbeta) return OCOCC_OK;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * c + 7) / 8), dim3(256), 0, stream, partials, rows, c, dgamma, dbeta);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   const int lpr = pick_lpr(c);
   const int vpl = (int)ococc_cdiv(c, lpr);
   const int grid = bwd_blocks(n, lpr);

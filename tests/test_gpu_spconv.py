@@ -152,7 +152,7 @@ def test_user_supplied_rulebook_without_cached_tables(dev):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('c', [16, 32, 128, 131, 1024, 1536, 2048])
+@pytest.mark.parametrize('c', [16, 32, 128, 131, 777, 1024, 1536, 2048])   # (f32 rows wider than 512 channels: one row per workgroup)
 @pytest.mark.parametrize('act', ['none', 'gelu'])
 def test_layernorm_act_vs_torch(dev, dtype, c, act):
     from objectcentricocccompletion_amd.norm import layer_norm_act
@@ -178,6 +178,29 @@ def test_layernorm_act_vs_torch(dev, dtype, c, act):
         tol = dict(rtol=2 ** -8, atol=2 ** -8)
     assert torch.allclose(y.detach().cpu().double(), yr.detach(), **tol)
     assert torch.allclose(xd.grad.cpu().double(), xr.grad, rtol=tol['rtol'], atol=tol['atol'] * 4)
+    assert torch.allclose(wd.grad.cpu().double(), wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
+    assert torch.allclose(bd.grad.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize('n,c', [(1, 1024), (1024, 1024), (1025, 2048), (3000, 1536)])
+def test_layernorm_of_few_wide_f32_rows(dev, n, c):
+    """f32 rows wider than 512 channels: one row per workgroup up to 1024 rows (the backward's workspace holds 1024 partial
+    rows), the generic kernel beyond -- both against torch in float64, and the partial-row count the library reports."""
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.norm import layer_norm_act
+    assert L.lib.ococc_layernorm_act_bwd_partial_rows(n, c, L.dtype_code(torch.float32)) == (n if n <= 1024 else min(-(-n // 4), 1024))
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) * 2 + 0.5
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    dy = torch.randn(n, c, generator=g)
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = layer_norm_act(xd, wd, bd, 1e-3, 'gelu')
+    y.backward(dy.to(dev))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xr, (c,), wr, br, 1e-3))
+    yr.backward(dy.double())
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(xd.grad.cpu().double(), xr.grad, rtol=1e-4, atol=4e-5)
     assert torch.allclose(wd.grad.cpu().double(), wr.grad, rtol=1e-3, atol=1e-3 * float(wr.grad.abs().max()))
     assert torch.allclose(bd.grad.cpu().double(), br.grad, rtol=1e-3, atol=1e-3 * float(br.grad.abs().max()))
 
