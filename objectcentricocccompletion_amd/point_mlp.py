@@ -138,6 +138,40 @@ class PackPlan(object):
         self.state = (versions, bool(backward))
 
 
+def refresh_plans(plans, backward=True):
+    """PackPlan.refresh for several private plans at once: the stale ones share launches of 32 matrices (the twelve plans of
+    a SIR stack -- 60 matrices -- are two launches per step instead of twelve)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    import ctypes
+    stale = []
+    for p in plans:
+        versions = tuple(w._version for w in p.weights)
+        if p.private and p.state is not None and p.state[0] == versions and (p.state[1] or not backward):
+            continue
+        stale.append((p, versions))
+    if not stale:
+        return
+    cols = [[], [], [], [], [], []]   # src, n, k, stride 0, stride 1, dst
+    for p, _ in stale:
+        c, src, n, k, s0, s1, dst, _ = p._args[bool(backward)]
+        for col, arr in zip(cols, (src, n, k, s0, s1, dst)):
+            col.extend(arr[:c])
+    total = len(cols[0])
+    for lo in range(0, total, 32):
+        m = min(32, total - lo)
+        sl = lambda col, ty: (ty * m)(*col[lo:lo + m])
+        L.check(L.lib.ococc_point_mlp_pack_multi_f32(
+            m, sl(cols[0], ctypes.c_void_p), sl(cols[1], ctypes.c_int32), sl(cols[2], ctypes.c_int32), sl(cols[3], ctypes.c_int64),
+            sl(cols[4], ctypes.c_int64), sl(cols[5], ctypes.c_void_p), L.stream()), 'point_mlp_pack_multi')
+    for p, versions in stale:
+        if not p.private:
+            for i in p._args[bool(backward)][7]:
+                w, tr, v = p.views[i]
+                _packed[(id(w), tr)] = (weakref.ref(w), w._version, v.data_ptr(), p.outs[i])
+        p.state = (versions, bool(backward))
+
+
 def _f32(t):
     return None if t is None else t.detach().float().contiguous()
 

@@ -19,7 +19,7 @@ from ._lib import const_tensor
 from .linear import Linear
 from . import _deferred
 from . import _lib as L
-from .point_mlp import PackPlan, layer_backward, layer_forward, ln_param_grads, pack_weight, point_layer, prepack
+from .point_mlp import PackPlan, layer_backward, layer_forward, ln_param_grads, pack_weight, point_layer, prepack, refresh_plans
 from .registry import BACKBONES, VOXEL_ENCODERS, build_norm_layer
 from .sst.sst_ops import build_mlp, fuse_norm_act, get_activation_layer, unique_with_inverse
 from .voxel.scatter_points import gather_rows, segment_reduce
@@ -367,9 +367,11 @@ def rel_gates(layers, f_cluster):
             plan = _REL_PLANS[layer] = _RelPlan(rel, f_cluster.shape[1], rel_cs)
         if not plan.ok or (plans and plan.nl != plans[0].nl):
             return None
-        plan.pack.refresh(backward=torch.is_grad_enabled())
         plans.append(plan)
         params += ps
+    # the weight fragments of the whole stack (the rel plans, and the layers' vfe plans once they exist) in shared launches
+    vfe_plans = [_VFE_PLANS[layer] for layer in layers if layer in _VFE_PLANS]
+    refresh_plans([p.pack for p in plans] + [p.pack for p in vfe_plans], backward=torch.is_grad_enabled())
     return list(_RelChains.apply(plans, f_cluster, *params))
 
 
