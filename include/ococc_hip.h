@@ -815,7 +815,10 @@ int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features,
  * ococc_sir_layer_set_fused(1) takes the one-launch form at any row count (a workgroup then walks several tiles);
  * -1 restores the default (OCOCC_SIR_FUSED=0 in the environment = 0).  A barrier wait is bounded (2 s): instead of
  * hanging the device an incomplete barrier leaves its index + 1 in a status word, which ococc_sir_layer_fused_status
- * reads back (synchronises the stream; 0 = every barrier completed). */
+ * reads back (synchronises the stream; 0 = every barrier completed).  The persistent grid takes at most 7/8 of the workgroup
+ * slots the device has for the kernel and needs all of its workgroups resident at once: meant for one process per GPU, as the
+ * reference trains (tools/dist_train.sh) -- two processes that put such launches of ~a thousand tiles on ONE device at the same
+ * time can starve each other until the bounded wait gives up (ococc_sir_layer_set_fused(0) / OCOCC_SIR_FUSED=0 for that case). */
 int ococc_sir_layer_set_fused(int32_t mode);
 /* The rel_mlp chains of several SIRLayers in one launch per direction (the layers of a SIR stack share the cluster
  * offsets their gates are computed from: mmdet3d/models/backbones/sir.py:67-88, ococc_bbox_head.py:237-316).
