@@ -224,6 +224,10 @@ def _finish_param_grads(plan, slab, ln_off, w_off, tiles, slices, all_needed):
 
 # ---- the rel_mlp chains of several layers in one launch per direction (csrc/sir_rel_chains.hip) ----------------------
 BATCH_REL_CHAINS = os.environ.get('OCOCC_SIR_BATCH_REL', '1') == '1'
+# (no row threshold of their own: three blocks of <= 32 input channels are skinny products the library runs at a few percent of
+# the memory rate -- 52 + 52 + 65 us at 131 k rows, plus three LayerNorm launches, against 33 + 34 + 70 us for these kernels --
+# so above POINT_LAYER_MAX_ROWS the gates still come from here and the vfe blocks run operator by operator)
+REL_CHAINS_MAX_ROWS = int(os.environ.get('OCOCC_REL_CHAINS_MAX_ROWS', 4000000))
 _REL_PLANS = weakref.WeakKeyDictionary()      # SIRLayer -> _RelPlan
 _VFE_PLANS = weakref.WeakKeyDictionary()      # SIRLayer -> _NativePlan of its vfe blocks alone (the gate comes from outside)
 
@@ -347,7 +351,7 @@ def rel_gates(layers, f_cluster):
     layers = list(layers)
     if not (BATCH_REL_CHAINS and NATIVE_LAYER and WHOLE_LAYER_NODE and POINT_LAYER_KERNEL and 2 <= len(layers) <= 8
             and f_cluster is not None and f_cluster.is_cuda and f_cluster.dtype == torch.float32 and not f_cluster.requires_grad
-            and 0 < f_cluster.shape[0] <= POINT_LAYER_MAX_ROWS and not torch.cuda.is_current_stream_capturing()):
+            and 0 < f_cluster.shape[0] <= REL_CHAINS_MAX_ROWS and not torch.cuda.is_current_stream_capturing()):
         return None
     plans, params = [], []
     scale = None
@@ -667,13 +671,13 @@ class SIRLayer(nn.Module):
             maxima.append(m)
         return y, torch.cat(maxima, dim=1), False
 
-    def _forward_ops(self, features, f_cluster, inv, num_groups):
+    def _forward_ops(self, features, f_cluster, inv, num_groups, gate=None):
         xyz = features[:, :3]
         scaled = f_cluster / self.rel_dist_scaler
         head = torch.cat([xyz / const_tensor(self.xyz_normalizer, features.device, features.dtype)[None, :],
                           features[:, 3:]], dim=1)
         if self._with_rel_mlp:
-            head = head * self.rel_mlp(scaled)
+            head = head * (self.rel_mlp(scaled) if gate is None else gate)
         parts = [head]
         if self._with_cluster_center:
             parts.append(scaled / 10.0)
@@ -696,13 +700,13 @@ class SIRLayer(nn.Module):
         num_groups = group_coors.size(0)
         f_cluster = self._cluster_offsets(features[:, :3], f_cluster, inv, num_groups)
         want_points = return_both or self.return_point_feats
-        assert gate is None or (self._blocks()[0] and features.shape[0] <= POINT_LAYER_MAX_ROWS)
+        assert gate is None or self._blocks()[0]
         if self._blocks()[0] and features.shape[0] <= POINT_LAYER_MAX_ROWS:
             n_out = self.vfe_layers[-1].linear.out_features
             shortcut = bool(want_points and self.with_shortcut and n_out == features.shape[1] - 3)
             point_feats, group_feats, shortcut_done = self._forward_fused(features, f_cluster, inv, num_groups, shortcut, gate)
         else:
-            point_feats, group_feats = self._forward_ops(features, f_cluster, inv, num_groups)
+            point_feats, group_feats = self._forward_ops(features, f_cluster, inv, num_groups, gate)
             shortcut_done = False
         if want_points:
             if not shortcut_done and self.with_shortcut and point_feats.shape[1] == features.shape[1] - 3:

@@ -354,6 +354,43 @@ def test_rel_mlp_chains_of_a_stack_in_one_launch(dev, stack, rows):
         assert rel(p, q) < 1e-5
 
 
+def test_rel_gates_in_front_of_the_operator_path(dev):
+    """Above POINT_LAYER_MAX_ROWS the vfe blocks of a layer run operator by operator (library GEMMs); the rel_mlp gates of the
+    stack still come from the one launch (three blocks of <= 32 input channels are skinny products for the library).  Same
+    function as the stack with every rel_mlp run operator by operator, to the accuracy of two f32 realisations."""
+    from objectcentricocccompletion_amd import sir
+    g = torch.Generator().manual_seed(5)
+    nb = 3
+    net = sir.SIR(num_blocks=nb, in_channels=[15] + [131] * (nb - 1), feat_channels=[[128, 128]] * nb,
+                  rel_mlp_hidden_dims=[[16, 32]] * nb, with_rel_mlp=True, with_cluster_center=False, with_distance=False,
+                  norm_cfg=dict(type='LN', eps=1e-3), mode='max', xyz_normalizer=[1, 1, 1], act='gelu', dropout=0,
+                  unique_once=True).to(dev)
+    sizes = torch.randint(1, 90, (60,), generator=g)
+    inv = torch.repeat_interleave(torch.arange(sizes.numel()), sizes)
+    M = inv.numel()
+    coors = inv.to(dev).int()
+    pts, feats = torch.randn(M, 3, generator=g).to(dev), torch.randn(M, 12, generator=g).to(dev)
+    fc = torch.randn(M, 3, generator=g).to(dev)
+    keep = sir.POINT_LAYER_MAX_ROWS
+
+    def run(batched):
+        sir.BATCH_REL_CHAINS, sir.POINT_LAYER_MAX_ROWS = batched, 10
+        try:
+            net.zero_grad(set_to_none=True)
+            x = feats.clone().requires_grad_(True)
+            pf, gf, _ = net(pts, x, coors[:, None], f_cluster=fc, dims=[int(inv.max()) + 1])
+            ((pf * 0.7).sum() + gf.sum()).backward()
+            return pf.detach(), gf.detach(), x.grad.clone(), [p.grad.clone() for p in net.parameters()]
+        finally:
+            sir.BATCH_REL_CHAINS, sir.POINT_LAYER_MAX_ROWS = True, keep
+
+    a, b = run(True), run(False)
+    rel = lambda p, q: float((p - q).norm() / q.norm().clamp(min=1e-30))
+    assert rel(a[0], b[0]) < 1e-4 and rel(a[1], b[1]) < 1e-4 and rel(a[2], b[2]) < 1e-3
+    for p, q in zip(a[3], b[3]):
+        assert rel(p, q) < 1e-3
+
+
 @pytest.mark.parametrize('rows,n,k', [(1, 16, 13), (31, 32, 3), (300, 128, 131), (5000, 144, 256), (70001, 64, 24),
                                        (8192, 128, 259 - 3)])
 def test_weight_gradient_kernel(dev, rows, n, k):
