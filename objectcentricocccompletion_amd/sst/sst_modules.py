@@ -163,13 +163,21 @@ class SSTInputLayerV2(nn.Module):
                 and pos_length % 2 == 0):
             import ctypes
             ciw = coors_in_win.contiguous()
-            pos = torch.empty((ciw.size(0), feat_dim), dtype=dtype, device=ciw.device)
             win3 = (ctypes.c_int32 * 3)(int(win_x), int(win_y), int(win_z))
-            L.check(L.lib.ococc_sst_pos_embed(L.ptr(ciw), ciw.size(0), win3, ndim, int(bool(self.normalize_pos)),
-                                              L.ptr(inv_freq), pos_length, feat_dim, L.ptr(pos), L.dtype_code(dtype), L.stream()),
-                    'sst_pos_embed')
-            inds_dict['_ococc_pos_flat_f32'] = pos   # flat token order: what the fused encoder layers read
-            return LazyWindowDict(lambda: flat2window_v2(pos, inds_dict))
+            made = {}
+
+            def pos_of(dt):
+                # the table in the dtype its reader wants (the kernel rounds once): the bf16 encoder layers ask for bf16 and
+                # the f32 table -- 33 M sines and cosines at configs[4]'s size -- is only built if somebody reads it
+                if dt not in made:
+                    pos = torch.empty((ciw.size(0), feat_dim), dtype=dt, device=ciw.device)
+                    L.check(L.lib.ococc_sst_pos_embed(L.ptr(ciw), ciw.size(0), win3, ndim, int(bool(self.normalize_pos)),
+                                                      L.ptr(inv_freq), pos_length, feat_dim, L.ptr(pos), L.dtype_code(dt),
+                                                      L.stream()), 'sst_pos_embed')
+                    made[dt] = pos
+                return made[dt]
+            inds_dict['_ococc_pos_fn'] = pos_of   # flat token order: what the fused encoder layers read
+            return LazyWindowDict(lambda: flat2window_v2(pos_of(dtype), inds_dict))
         emb = []
         for a in ([x, y, z] if ndim == 3 else [x, y]):
             e = a[:, None] / inv_freq[None, :]
@@ -178,7 +186,7 @@ class SSTInputLayerV2(nn.Module):
         gap = feat_dim - pos.size(1)
         if gap > 0:
             pos = torch.cat([pos, torch.zeros((pos.size(0), gap), dtype=dtype, device=pos.device)], dim=1)
-        inds_dict['_ococc_pos_flat_f32'] = pos   # flat token order: what the fused encoder layers read
+        inds_dict['_ococc_pos_fn'] = lambda dt: pos.to(dt)   # flat token order: what the fused encoder layers read
         return LazyWindowDict(lambda: flat2window_v2(pos, inds_dict))
 
     @torch.no_grad()
@@ -546,8 +554,8 @@ def _fused_maps(ind_dict, pos_dict, key_padding_dict, num_tokens, dtype):
         maps = _window_maps(ind_dict, key_padding_dict)
         pos_flat = ind_dict.get('_ococc_pos_flat')
         if pos_flat is None:
-            flat32 = ind_dict.get('_ococc_pos_flat_f32')
-            pos_flat = (flat32 if flat32 is not None else window2flat_v2(pos_dict, ind_dict)).to(dtype).contiguous()
+            fn = ind_dict.get('_ococc_pos_fn')
+            pos_flat = (fn(dtype) if fn is not None else window2flat_v2(pos_dict, ind_dict).to(dtype)).contiguous()
             ind_dict['_ococc_pos_flat'] = pos_flat
         small = [(tok, key_len, nW, T) for (slot, pos, nW, T, key_len, tok) in maps.values() if T <= TILE]
         large = {dl: m for dl, m in maps.items() if m[3] > TILE and m[2] > 0 and m[1].numel() > 0}

@@ -465,7 +465,7 @@ def test_input_layer_kernels_equal_the_torch_formulation(dev, window, sparse, no
         assert sorted(k for k in f_ref if isinstance(k, int)) == sorted(k for k in f_got if isinstance(k, int))
         for dl in (k for k in f_ref if isinstance(k, int)):
             assert torch.equal(f_ref[dl][0], f_got[dl][0].cpu()) and torch.equal(f_ref[dl][1][0], f_got[dl][1][0].cpu())
-        p_ref, p_got = f_ref['_ococc_pos_flat_f32'], f_got['_ococc_pos_flat_f32'].cpu()
+        p_ref, p_got = f_ref['_ococc_pos_fn'](torch.float32), f_got['_ococc_pos_fn'](torch.float32).cpu()
         assert p_ref.shape == p_got.shape and float((p_ref - p_got).abs().max()) < 1e-6
     assert torch.equal(ref['voxel_keep_inds'], got['voxel_keep_inds'].cpu())
     assert torch.equal(ref['voxel_coors'], got['voxel_coors'].cpu())
