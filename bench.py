@@ -249,6 +249,8 @@ def bench_ococcnet(args, world, rank, dev):
     dt = time.perf_counter() - t0
     decoder.forward = real_forward
     fm.set_probe(None)
+    from objectcentricocccompletion_amd.sir import check_barriers
+    check_barriers()   # a line from steps in which a one-launch SIR layer could not gather its grid is not a measurement: raise
     dump_params(args, rank, params)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -272,8 +274,8 @@ def bench_ococcnet(args, world, rank, dev):
             'config': {'workload': f'configs[2]: full ococcnet.py model (66.55 M parameters), {B} tracklets x {L} '
                                    f'frames = {B * L} object grids/GPU/step, 64 points/frame, K=512 occupancy '
                                    'queries, fwd+bwd+AdamW, all-reduce of 266 MB gradients at N>1',
-                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}', 'launch': 'eager, ~1.5 k launches per step (the temporal transformer and the head\'s tail '
-                       'replayed as HIP-graph pairs); on its device time from 4 tracklets on'},
+                       'grids_per_gpu': B * L, 'parallelism': f'dp{world}', 'launch': 'eager, ~1.0 k launches per step at 4 tracklets (the temporal transformer and the head\'s tail '
+                       'replayed as HIP-graph pairs; one launch per SIR layer and direction up to 28 k points)'},
             'roofline': {'kernel': 'OccDecoder forward (MLP 60|1536 -> 512 -> 1024 -> 1024 -> 1 over all query points: '
                                    + ('library f32 GEMMs + LN/GELU kernels)' if args.f32_decoder else
                                       'positional encoding, weight fragments, per-RoI GEMM and the one-launch bf16 MLP kernel in its '
@@ -561,6 +563,34 @@ def also_workloads():
             out[key]['wall_s'] = round(time.time() - t_child, 1)
         except Exception as e:   # noqa: BLE001 (timeout, missing device, ...)
             out[key] = {'error': repr(e)[:300]}
+    out['conv_sweep'] = conv_sweep()
+    return out
+
+
+def conv_sweep(sizes=(256, 512)):
+    """The per-kernel roofline table of configs[1]'s step at 4 x and 8 x the benchmark's 64 grids (the same density, the same
+    kernel choices; 512 grids = 1.02 M rows is what the pattern-order records hold): does a convolution kernel's fraction of the
+    HBM roofline climb once a compute unit works through several rounds of tiles (the 64-grid step is then bound by its single
+    round: the tail), or does it stay (the kernel is)?  Each size a child process: graph replays for the step time, the event
+    pairs around the kernels in the eager steps behind them, as in the line of record."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    out = {}
+    for grids in sizes:
+        cmd = [sys.executable, here, '--grids', str(grids), '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-also']
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+            d = json.loads(line[-1]) if line else {'error': (r.stderr or 'no output')[-300:]}
+            if 'roofline' in d:
+                out[str(grids)] = {'ms_per_step': d['ms_per_step'], 'object_grids_per_s': d['value'],
+                                   'active_voxels': d['config']['active_voxels'],
+                                   'per_kernel': {k: {'us': round(v['avg_launch_ms'] * 1e3, 1), 'frac': v['frac']}
+                                                  for k, v in d['roofline']['per_kernel'].items()}}
+            else:
+                out[str(grids)] = d
+        except Exception as e:   # noqa: BLE001
+            out[str(grids)] = {'error': repr(e)[:300]}
     return out
 
 

@@ -35,6 +35,7 @@ extern "C" {
 #define OCOCC_EINVAL (-1)      /* bad argument (message says which) */
 #define OCOCC_EHIP (-2)        /* HIP runtime error */
 #define OCOCC_EUNSUPPORTED (-3) /* shape / dtype outside the compiled kernels */
+#define OCOCC_ESTRANDED (-4)   /* a grid barrier of an earlier one-launch SIR layer gave up: its results are incomplete */
 
 /* element types of feature buffers */
 #define OCOCC_F32 0
@@ -814,12 +815,22 @@ int ococc_sir_layer_bwd_f32(const ococc_sir_layer* layer, const float* features,
  * bodies run as one launch per block: the same arithmetic, the forward results are equal to the bit.
  * ococc_sir_layer_set_fused(1) takes the one-launch form at any row count (a workgroup then walks several tiles);
  * -1 restores the default (OCOCC_SIR_FUSED=0 in the environment = 0).  A barrier wait is bounded (2 s): instead of
- * hanging the device an incomplete barrier leaves its index + 1 in a status word, which ococc_sir_layer_fused_status
- * reads back (synchronises the stream; 0 = every barrier completed).  The persistent grid takes at most 7/8 of the workgroup
- * slots the device has for the kernel and needs all of its workgroups resident at once: meant for one process per GPU, as the
- * reference trains (tools/dist_train.sh) -- two processes that put such launches of ~a thousand tiles on ONE device at the same
- * time can starve each other until the bounded wait gives up (ococc_sir_layer_set_fused(0) / OCOCC_SIR_FUSED=0 for that case). */
+ * hanging the device an incomplete barrier leaves its index + 1 in a sticky device word, which ococc_sir_layer_fused_status
+ * reads back (synchronises the stream; 0 = every barrier completed), AND in a host-mapped word that the library reads in
+ * front of its next one-launch layer: that call (ococc_sir_layer_fwd_f32 / _bwd_f32) then returns OCOCC_ESTRANDED and every
+ * later layer of the process runs as per-block launches.  ococc_sir_layer_fused_check() is the same test without a launch
+ * (no synchronisation, no copy: call it wherever the host has waited for the device anyway -- end of a step, a checkpoint).
+ * The persistent grid takes at most 7/8 of the workgroups that were resident TOGETHER in a one-off census launch of the same
+ * kernel with the same LDS size (never more than hipOccupancyMaxActiveBlocksPerMultiprocessor promises: that API reads high
+ * for some register counts) and needs all of its workgroups resident at once: meant for one process per GPU, as the
+ * reference trains (tools/dist_train.sh), with ONE such layer in flight per device -- two processes or streams that put
+ * such launches of ~a thousand tiles on one device at the same time can starve each other until the bounded wait gives up
+ * (ococc_sir_layer_set_fused(0) / OCOCC_SIR_FUSED=0 for that case).
+ * ococc_sir_layer_fused_debug(grid, timeout_ms): test hooks -- launch `grid` workgroups whatever the device holds, bound a
+ * wait by `timeout_ms`; 0 restores either default, (0, 0) also clears the status words (synchronises the device). */
 int ococc_sir_layer_set_fused(int32_t mode);
+int ococc_sir_layer_fused_check(void);
+int ococc_sir_layer_fused_debug(int32_t grid, int32_t timeout_ms);
 /* The rel_mlp chains of several SIRLayers in one launch per direction (the layers of a SIR stack share the cluster
  * offsets their gates are computed from: mmdet3d/models/backbones/sir.py:67-88, ococc_bbox_head.py:237-316).
  * Chain c, block j: y = act(LayerNorm(W x)), x = f_cluster * rel_colscale (j = 0) or the block before (build_mlp,

@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 constexpr int kSirMaxBlocks = 8;
-constexpr int kSirBarWords = 64, kSirBarError = 63;   // per-stream barrier buffer: [0] epoch, [1 + 2 b] count, [2 + 2 b] generation of barrier b
+// per-stream barrier buffer: [0] epoch, [1 + 2 b] count, [2 + 2 b] generation of barrier b; [56..58] the residency census
+// (arrived, left, resident together); [62] the epoch target of the last launch in which a wait gave up; [63] which wait (sticky)
+constexpr int kSirBarWords = 64, kSirBarError = 63, kSirBarStranded = 62, kSirBarCensus = 56;
 
 struct SirBlockArgs {
   const float* wf;       // weight fragments (ococc_point_mlp_pack_f32)
@@ -52,6 +54,9 @@ struct SirFusedArgs {
   int64_t rows_per_slice;
   int32_t slices;
   uint32_t* bar;         // grid-barrier words of this stream (sir_fused_barrier_words)
+  uint32_t* err_host;    // host-mapped word: which wait gave up (0: none); read by the library before its next launch
+  uint64_t bar_ticks;    // bound of a barrier wait in ticks of the 100 MHz clock
+  uint32_t* census;      // non-null: the launch only counts how many of its workgroups are resident together
 };
 
 // a block signature: which instantiation of the tile bodies every block of the layer runs on (output-channel blocks per
@@ -73,15 +78,16 @@ constexpr SirSignature kSirSignature[kSirSignatures] = {{3, 2, {1, 1, 3, 2, 2}, 
 int point_mlp_tile_rows(int64_t rows);   // csrc/point_mlp.hip
 // per tile size (csrc/sir_fused_mb{1,2,4}.hip): set the kernel up for `lds` bytes, size the persistent grid, launch
 int sir_fused_launch_mb1(const SirFusedArgs& args, int signature, bool backward, int lds, int64_t tiles, bool one_tile_each,
-                         hipStream_t stream);
+                         int grid_override, hipStream_t stream);
 int sir_fused_launch_mb2(const SirFusedArgs& args, int signature, bool backward, int lds, int64_t tiles, bool one_tile_each,
-                         hipStream_t stream);
+                         int grid_override, hipStream_t stream);
 int sir_fused_launch_mb4(const SirFusedArgs& args, int signature, bool backward, int lds, int64_t tiles, bool one_tile_each,
-                         hipStream_t stream);
+                         int grid_override, hipStream_t stream);
 
-// 0 = launched; a negative value = this call cannot take the one-launch form (no signature fits the layer; stream
-// under capture with no barrier words yet):
-// the caller issues the per-block launches instead.  Errors are reported like every other entry point (positive codes).
+// 0 = launched; OCOCC_ESTRANDED = a barrier wait of an EARLIER one-launch layer of this process gave up (reported once;
+// the per-block launches are pinned from then on); any other negative value = this call cannot take the one-launch form
+// (no signature fits the layer; stream under capture with no barrier words or no residency census yet): the caller
+// issues the per-block launches instead.
 int sir_fused_forward(const SirFusedArgs& args, hipStream_t stream);
 int sir_fused_backward(const SirFusedArgs& args, hipStream_t stream);
 bool sir_fused_enabled();

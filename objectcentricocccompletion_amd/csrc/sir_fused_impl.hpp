@@ -13,6 +13,7 @@
 // Which instantiation of a tile body a block runs on is a compile-time property (SirSignature): with the choice made at
 // run time inside one kernel -- a switch over the 12 backward bodies -- the register allocator spilled 500-1100 VGPRs.
 #pragma once
+#include <mutex>
 #include <type_traits>
 
 #include "point_mlp_tile.hpp"
@@ -23,9 +24,11 @@ namespace {
 struct GridBar {
   uint32_t* w;
   uint32_t target;
+  uint32_t* err_host;   // host-mapped word: a wait that gave up (bar_wait)
+  uint64_t ticks;       // how long a wait lasts at most (100 MHz clock)
 };
-__device__ __forceinline__ GridBar bar_begin(uint32_t* w) {
-  return GridBar{w, __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u};
+__device__ __forceinline__ GridBar bar_begin(uint32_t* w, uint32_t* err_host, uint64_t ticks) {
+  return GridBar{w, __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u, err_host, ticks};
 }
 // No cache maintenance at the barriers: a device-scope fence on this multi-die part writes back and invalidates the L2
 // of the die (measured with one fence per workgroup and barrier: the forward launch 113 us where its five bodies take
@@ -35,9 +38,13 @@ __device__ __forceinline__ GridBar bar_begin(uint32_t* w) {
 // with device-scope atomic loads (load_shared_result<true>), both of which act past the non-coherent cache levels;
 // everything else a phase reads was written by the same workgroup (workgroup scope: one compute unit, one cache) or by an
 // earlier launch.  That is why the weight-gradient products -- which read every tile's dz and input rows -- stay a
-// launch of their own.  A barrier is then: all waves' memory operations complete (__syncthreads waits for them), one
-// arrival; the last arrival publishes the generation.
+// launch of their own.  A barrier is then: every wave drains its outstanding vector-memory operations -- an explicit
+// s_waitcnt vmcnt(0): the workgroup barrier alone compiles to a bare s_barrier, which does NOT wait for the no-return
+// atomics on the maxima / arg-max rows / collected gradients still in flight (round-5 advisor finding, checked on the
+// built code object by tools/check_sir_barrier_isa.py); it is a counter wait, no cache write-back or invalidate -- then
+// the workgroup's barrier, one arrival; the last arrival publishes the generation.
 __device__ __forceinline__ void bar_arrive(const GridBar& g, int b, bool last_of_launch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t old = atomicAdd(&g.w[1 + 2 * b], 1u);
@@ -48,18 +55,45 @@ __device__ __forceinline__ void bar_arrive(const GridBar& g, int b, bool last_of
     }
   }
 }
+// A wait that cannot complete (a workgroup of the grid is not resident: another process or stream holds its slot) gives
+// up after `ticks` of the constant 100 MHz clock and says so in TWO places: the sticky device word kSirBarError
+// (ococc_sir_layer_fused_status) and a host-mapped word that the library reads, without any synchronisation, in front
+// of its next one-launch layer and turns into an error return (csrc/sir_fused.hip: the product path raises instead of
+// training on incomplete maxima).  Once a launch is marked, its later waits give up at once.
 __device__ __forceinline__ void bar_wait(const GridBar& g, int b) {
+  const uint64_t ticks = g.ticks;
+  uint32_t* err_host = g.err_host;
   if (threadIdx.x == 0) {
     const uint64_t t0 = wall_clock64();
     while (__hip_atomic_load(&g.w[2 + 2 * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.target) {
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > 200000000ull) {
+      if (wall_clock64() - t0 > ticks ||
+          __hip_atomic_load(&g.w[kSirBarStranded], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.target) {
         atomicExch(&g.w[kSirBarError], 1u + (uint32_t)b);
+        atomicExch(&g.w[kSirBarStranded], g.target);
+        if (err_host) __hip_atomic_store(err_host, 1u + (uint32_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
   }
   __syncthreads();
+}
+// How many workgroups of THIS kernel (its registers, its LDS) the device really holds at once: every workgroup announces
+// itself, stays for 200 us, and the ones that leave before anybody else has left record how many had arrived -- all of
+// those were resident together.  Launched once per (kernel, LDS size, device) with twice the grid the occupancy API
+// promises (that API reads one workgroup per compute unit high for some register counts on this stack,
+// MI355X_MICROARCH.md "Correctness boundaries": a grid sized by it alone strands a workgroup per CU at the first barrier).
+// Foreign work on the device during the census can only lower the count.
+__device__ __forceinline__ void census_body(uint32_t* c) {
+  if (threadIdx.x == 0) {
+    atomicAdd(&c[0], 1u);
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);
+    const uint32_t arrived = __hip_atomic_load(&c[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t left = __hip_atomic_load(&c[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == 0) atomicMax(&c[2], arrived);
+    atomicAdd(&c[1], 1u);
+  }
 }
 // between two blocks of one tile: the rows a block wrote are read by other waves of the same workgroup (workgroup scope:
 // the waves share the compute unit's cache), and the LDS tile changes hands
@@ -170,7 +204,11 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_fwd_kernel(SirFusedArgs) {
   KArgs* A = kernel_args();
   const int64_t rows = A->rows, groups = A->groups;
   const int64_t tiles = (rows + TRM - 1) / TRM;
-  const GridBar gb = bar_begin(A->bar);
+  if (A->census) {   // (once per kernel, LDS size and device: how many workgroups are resident together)
+    census_body(A->census);
+    return;
+  }
+  const GridBar gb = bar_begin(A->bar, A->err_host, A->bar_ticks);
   // maxima start at -inf, arg-max rows at "none"
   static_for<0, SIG::nv>([&](auto iv) {
     auto& B = A->b[SIG::nr + decltype(iv)::value];
@@ -257,7 +295,11 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
   KArgs* A = kernel_args();
   const int64_t rows = A->rows, groups = A->groups;
   const int64_t tiles = (rows + TRM - 1) / TRM;
-  const GridBar gb = bar_begin(A->bar);
+  if (A->census) {
+    census_body(A->census);
+    return;
+  }
+  const GridBar gb = bar_begin(A->bar, A->err_host, A->bar_ticks);
   // the gradients the gathered maxima collect (float atomics at run ends) start at zero
   static_for<1, nv>([&](auto iv) {
     constexpr int i = decltype(iv)::value;
@@ -316,29 +358,49 @@ __global__ void __launch_bounds__(kT, 2) sir_fused_bwd_kernel(SirFusedArgs) {
 }
 
 constexpr int kImplMaxDevices = 64;
+std::mutex g_launch_mutex;   // the per-kernel caches below (ctypes callers may hold several host threads)
 
+// The persistent grid of a kernel: min(what the occupancy API promises, what a census launch of the SAME kernel with the
+// SAME LDS size saw resident together) less an eighth (a collective's kernels launched from gradient hooks run beside the
+// backward pass and must find room while this grid spins at a barrier).  The form assumes ONE one-launch layer in flight
+// per device: two persistent grids (two processes, two streams) can hold each other's slots -- then a bounded wait gives
+// up and the library reports it (csrc/sir_fused.hip).
 template <typename K>
-int persistent_launch(K kernel, const SirFusedArgs& A, int lds, int64_t tiles, bool one_tile_each, hipStream_t stream,
-                      int* lds_set, int* cached_lds, int* cached_cap) {
+int persistent_launch(K kernel, const SirFusedArgs& A, int lds, int64_t tiles, bool one_tile_each, int grid_override,
+                      hipStream_t stream, int* lds_set, int* cached_lds, int* cached_cap) {
   int device = 0;
   OCOCC_HIP(hipGetDevice(&device));
   const int dev = device % kImplMaxDevices;
+  std::lock_guard<std::mutex> lock(g_launch_mutex);
   if (lds > lds_set[dev]) {
     OCOCC_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     lds_set[dev] = lds;
   }
   if (cached_lds[dev] != lds) {   // how many workgroups the device holds at once: every one of them must be running
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;   // (the census reads back)
     int per_cu = 0, cus = 0;
     OCOCC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kT, (size_t)lds));
     OCOCC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     OCOCC_REQUIRE(per_cu >= 1 && cus >= 1, "the kernel does not fit a compute unit");
+    const int promised = per_cu * cus;
+    SirFusedArgs C = A;
+    C.census = A.bar + kSirBarCensus;
+    OCOCC_HIP(hipMemsetAsync(C.census, 0, 3 * sizeof(uint32_t), stream));
+    hipLaunchKernelGGL(kernel, dim3(2u * (unsigned)promised), dim3(kT), lds, stream, C);
+    OCOCC_CHECK_LAUNCH();
+    uint32_t seen = 0;
+    OCOCC_HIP(hipMemcpyAsync(&seen, C.census + 2, sizeof(seen), hipMemcpyDeviceToHost, stream));
+    OCOCC_HIP(hipStreamSynchronize(stream));
+    OCOCC_REQUIRE(seen >= 1, "the residency census of the one-launch SIR layer saw no workgroup");
+    const int resident = (int)seen < promised ? (int)seen : promised;
     cached_lds[dev] = lds;
-    // (an eighth of the slots stays free: a collective's kernels launched from gradient hooks run beside the backward
-    // pass and must find room while this grid spins at a barrier -- every workgroup of the grid has to be resident)
-    cached_cap[dev] = per_cu * cus - per_cu * cus / 8;
+    cached_cap[dev] = resident - resident / 8 > 0 ? resident - resident / 8 : 1;
   }
   if (one_tile_each && tiles > cached_cap[dev]) return -1;   // (see sir_fused.hip: more tiles than resident workgroups)
-  const unsigned grid = (unsigned)(tiles < cached_cap[dev] ? tiles : cached_cap[dev]);
+  unsigned grid = (unsigned)(tiles < cached_cap[dev] ? tiles : cached_cap[dev]);
+  // (tests: a grid the device cannot hold at once -- the barrier must strand and the library must say so)
+  if (grid_override > 0) grid = (unsigned)grid_override;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(kT), lds, stream, A);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
@@ -350,16 +412,16 @@ int persistent_launch(K kernel, const SirFusedArgs& A, int lds, int64_t tiles, b
 #define OCOCC_SIR_CAT(a, b) OCOCC_SIR_CAT_(a, b)
 
 int OCOCC_SIR_CAT(sir_fused_launch_mb, OCOCC_SIR_MB)(const SirFusedArgs& args, int signature, bool backward, int lds,
-                                                    int64_t tiles, bool one_tile_each, hipStream_t stream) {
+                                                    int64_t tiles, bool one_tile_each, int grid_override, hipStream_t stream) {
   OCOCC_REQUIRE(signature >= 0 && signature < kSirSignatures, "unknown block signature");
   static int lds_set[2 * kSirSignatures][kImplMaxDevices] = {}, c_lds[2 * kSirSignatures][kImplMaxDevices] = {},
              c_cap[2 * kSirSignatures][kImplMaxDevices] = {};
   const int slot = 2 * signature + (backward ? 1 : 0);
 #define OCOCC_SIR_GO(S)                                                                                              \
-  (backward ? persistent_launch(sir_fused_bwd_kernel<OCOCC_SIR_MB, Sig<S>>, args, lds, tiles, one_tile_each, stream, lds_set[slot], \
-                                c_lds[slot], c_cap[slot])                                                            \
-            : persistent_launch(sir_fused_fwd_kernel<OCOCC_SIR_MB, Sig<S>>, args, lds, tiles, one_tile_each, stream, lds_set[slot], \
-                                c_lds[slot], c_cap[slot]))
+  (backward ? persistent_launch(sir_fused_bwd_kernel<OCOCC_SIR_MB, Sig<S>>, args, lds, tiles, one_tile_each, grid_override, stream, \
+                                lds_set[slot], c_lds[slot], c_cap[slot])                                             \
+            : persistent_launch(sir_fused_fwd_kernel<OCOCC_SIR_MB, Sig<S>>, args, lds, tiles, one_tile_each, grid_override, stream, \
+                                lds_set[slot], c_lds[slot], c_cap[slot]))
   static_assert(kSirSignatures == 4, "one case per signature");
   switch (signature) {
     case 0: return OCOCC_SIR_GO(0);

@@ -220,7 +220,8 @@ extern "C" int ococc_sir_layer_fwd_f32(const ococc_sir_layer* d, const float* fe
     fused_args(d, D, L, feats, f_cluster, inv, rows, groups, slab, y_out, &A);
     A.groups_out = groups_out;
     const int rc = sir_fused_forward(A, stream);
-    if (rc >= 0) return rc;   // (negative: not available for this call -- the per-block launches below)
+    // (other negative values: not available for this call -- the per-block launches below)
+    if (rc >= 0 || rc == OCOCC_ESTRANDED) return rc;
   }
   auto y_of = [&](int b) -> float* { return (b == last && !d->shortcut) ? y_out : slab + L.y[b]; };
   const float* x = f_cluster;
@@ -318,7 +319,7 @@ extern "C" int ococc_sir_layer_bwd_f32(const ococc_sir_layer* d, const float* fe
     A.slices = L.slices;
     A.rows_per_slice = ococc_align_up(ococc_cdiv(rows, L.slices), 32);
     const int rc = sir_fused_backward(A, stream);
-    if (rc > 0) return rc;
+    if (rc > 0 || rc == OCOCC_ESTRANDED) return rc;
     if (rc == 0) {   // dW partials of all blocks: they read every tile's dz and input rows -- a launch of their own
       const float *zs[kMaxBlocks], *xs[kMaxBlocks];
       float* ps[kMaxBlocks];

@@ -154,6 +154,11 @@ struct SortedLn {
   const float* beta;
   int act;                 // 0 none, 1 GELU(erf)
   float* partials;         // [gridDim.x][2 NC]
+  // LayerNorm (+ GELU) FORWARD epilogue (LNF instantiations: the conv -> norm -> act block of make_sparse_convmodule,
+  // sparse_block.py:216-289, in one launch): the activation and the row statistics leave beside the conv output
+  float eps;
+  uint16_t* act_out;       // [n_out, NC] bf16
+  float* stats_out;        // [n_out, 2] mean, rstd
 };
 
 template <int KD, int NC, bool LNB = false>
@@ -162,7 +167,7 @@ constexpr int sorted_lds_bytes(int kvol) {
          (LNB ? (kSortThreads / 64) * 2 * NC * 4 : 0);
 }
 
-template <int KD, int NC, bool OUT_BF16, bool LNB = false>
+template <int KD, int NC, bool OUT_BF16, bool LNB = false, bool LNF = false>
 __global__ void __launch_bounds__(kSortThreads, 2)
 gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes, const uint16_t* __restrict__ wn, int kvol,
                           const int32_t* __restrict__ table, const i32x4_t* __restrict__ rec,
@@ -196,7 +201,7 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
   // the matrix instructions, the same rows gathered twice (a few KB), every output element still summed by one lane in
   // ascending offset order -- the results do not change.
   // (never with the LayerNorm-backward epilogue: a row's statistics need all of its columns in one place)
-  constexpr bool kCanSplit = !LNB && CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
+  constexpr bool kCanSplit = !LNB && !LNF && CPW % 2 == 0 && CHUNKS % (2 * NWAVES) == 0 && NB % 4 == 0;
   // ... while such tiles are FEW: they are then the launch's tail on slots that would idle (the benchmark: 79 tiles on
   // 512 slots).  Where they are many, two workgroups per tile double their fixed cost (table batch, first operands) for
   // nothing: 2.5 pairs per row took 103 us split against 70 us unsplit.
@@ -563,6 +568,84 @@ gather_gemm_sorted_kernel(const uint16_t* __restrict__ feat, uint32_t feat_bytes
           }
         return;
       }
+      if constexpr (LNF) {
+        // LayerNorm (+ GELU) forward on the finished rows.  The norm sees the bf16-rounded conv output, as the unfused pair
+        // of launches does (conv store, ln_act_fwd_vec_kernel load), and the arithmetic is that kernel's, sums included:
+        // there a lane holds ONE 8-channel piece c8 and the row sums run over the pieces as a butterfly (c8 ^ 8, ^ 4, ^ 2,
+        // ^ 1); here a lane holds the pieces c8 = 4 p + kg, p = 0..3 -- the same butterfly is (p ^ 2), (p ^ 1) inside
+        // the lane, then kg ^ 2 (lane ^ 32), kg ^ 1 (lane ^ 16).
+        static_assert(CS == 1 || !LNF, "the LayerNorm epilogue needs whole rows");
+        constexpr int NP = NB / 2;
+        ln_f32x2 g[NP][4], bt[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          const f32x4 g0 = *(const f32x4*)(ln.gamma + p * 32 + kg * 8), g1 = *(const f32x4*)(ln.gamma + p * 32 + kg * 8 + 4);
+          const f32x4 b0 = *(const f32x4*)(ln.beta + p * 32 + kg * 8), b1 = *(const f32x4*)(ln.beta + p * 32 + kg * 8 + 4);
+          g[p][0] = ln_f32x2{g0.x, g0.y}; g[p][1] = ln_f32x2{g0.z, g0.w}; g[p][2] = ln_f32x2{g1.x, g1.y}; g[p][3] = ln_f32x2{g1.z, g1.w};
+          bt[p][0] = ln_f32x2{b0.x, b0.y}; bt[p][1] = ln_f32x2{b0.z, b0.w}; bt[p][2] = ln_f32x2{b1.x, b1.y}; bt[p][3] = ln_f32x2{b1.z, b1.w};
+        }
+        auto over_pieces = [&](const float (&t)[NP]) -> float {
+          float s;
+          if constexpr (NP == 4) s = (t[0] + t[2]) + (t[1] + t[3]);
+          else if constexpr (NP == 2) s = t[0] + t[1];
+          else s = t[0];
+          s += __shfl_xor(s, 32, 64);
+          s += __shfl_xor(s, 16, 64);
+          return s;
+        };
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          const int32_t r = __shfl(myrow, b * 16 + lrow, 64);
+          if (r < 0) continue;   // (the four lanes of a slot agree: the exchanges below stay inside a slot)
+          ln_f32x2 v[NP][4];
+          float t[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            const f32x4 v0 = acc[b][2 * p], v1 = acc[b][2 * p + 1];
+            u32x4 q;
+            q.x = ococc_pack_bf16x2(v0.x, v0.y);
+            q.y = ococc_pack_bf16x2(v0.z, v0.w);
+            q.z = ococc_pack_bf16x2(v1.x, v1.y);
+            q.w = ococc_pack_bf16x2(v1.z, v1.w);
+            *(u32x4*)((uint16_t*)out_ + (int64_t)r * NC + p * 32 + kg * 8) = q;
+            ln_unpack8(q, v[p]);
+            const ln_f32x2 sv = (v[p][0] + v[p][1]) + (v[p][2] + v[p][3]);
+            t[p] = sv.x + sv.y;
+          }
+          const float mean = over_pieces(t) * (1.f / NC);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            ln_f32x2 sq = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[p][c] = v[p][c] - mean;
+              sq += v[p][c] * v[p][c];
+            }
+            t[p] = sq.x + sq.y;
+          }
+          const float rstd = rsqrtf(over_pieces(t) * (1.f / NC) + ln.eps);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            u32x4 q;
+            ln_f32x2 z[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              z[c] = (v[p][c] * rstd) * g[p][c] + bt[p][c];
+              if (ln.act == 1) z[c] = ln_gelu2(z[c]);
+            }
+            q.x = ln_pack2(z[0]);
+            q.y = ln_pack2(z[1]);
+            q.z = ln_pack2(z[2]);
+            q.w = ln_pack2(z[3]);
+            *(u32x4*)(ln.act_out + (int64_t)r * NC + p * 32 + kg * 8) = q;
+          }
+          if (kg == 0) {
+            ln.stats_out[(int64_t)r * 2] = mean;
+            ln.stats_out[(int64_t)r * 2 + 1] = rstd;
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int b = 0; b < BPW; ++b) {
         const int32_t r = __shfl(myrow, b * 16 + lrow, 64);
@@ -622,6 +705,15 @@ int launch_sorted(const uint16_t* feat, int64_t n_in, const uint16_t* wn, int kv
                   const OrderHdr* hdr, int64_t n_out, const float* bias, void* out, int out_dtype, hipStream_t stream,
                   const SortedLn* ln = nullptr) {
   const dim3 grid(sorted_grid(n_out));
+  if (ln && ln->act_out) {   // LayerNorm (+ GELU) forward epilogue
+    const int lds = sorted_lds_bytes<KD, NC>(kvol);
+    auto kern = gather_gemm_sorted_kernel<KD, NC, true, false, true>;
+    OCOCC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, grid, dim3(kSortThreads), lds, stream, feat, (uint32_t)(n_in * KD * 2), wn, kvol, table,
+                       (const i32x4_t*)rec, hdr, n_out, bias, out, *ln);
+    OCOCC_CHECK_LAUNCH();
+    return OCOCC_OK;
+  }
   if (ln) {
     if constexpr (NC <= 64) {
       const int lds = sorted_lds_bytes<KD, NC, true>(kvol);
@@ -743,6 +835,24 @@ extern "C" int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in,
                       nullptr);
 }
 
+extern "C" int ococc_sparse_conv_sorted_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn,
+                                                int32_t kvol, int32_t ncols, const int32_t* table, const int32_t* rec,
+                                                const int32_t* hdr, int64_t n_out, const float* gamma, const float* beta,
+                                                float eps, int32_t act, uint16_t* conv_out, uint16_t* y, float* mean_rstd,
+                                                ococc_stream_t stream_) {
+  OCOCC_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (gelu)");
+  OCOCC_REQUIRE(n_out == 0 || (gamma && beta && conv_out && y && mean_rstd), "null pointer");
+  SortedLn ln{};
+  ln.gamma = gamma;
+  ln.beta = beta;
+  ln.act = act;
+  ln.eps = eps;
+  ln.act_out = y;
+  ln.stats_out = mean_rstd;
+  return sorted_entry(feat, n_in, kd, wn, kvol, ncols, table, rec, hdr, n_out, nullptr, conv_out, OCOCC_BF16,
+                      (hipStream_t)stream_, &ln);
+}
+
 extern "C" int64_t ococc_sparse_conv_sorted_lnbwd_partial_rows(int64_t n_out) {
   return n_out < 0 ? -1 : (int64_t)sorted_grid(n_out > 0 ? n_out : 1);
 }
@@ -757,7 +867,7 @@ extern "C" int ococc_sparse_conv_sorted_lnbwd_bf16(const uint16_t* feat, int64_t
   OCOCC_REQUIRE(ncols == 32 || ncols == 64, "fused LayerNorm backward: 32 or 64 output columns");
   OCOCC_REQUIRE(n_out == 0 || (gamma && beta && block_conv_out && mean_rstd && d_conv_out && partials), "null pointer");
   OCOCC_REQUIRE(partial_rows >= ococc_sparse_conv_sorted_lnbwd_partial_rows(n_out), "partials too small");
-  const SortedLn ln{block_conv_out, mean_rstd, gamma, beta, act, partials};
+  const SortedLn ln{block_conv_out, mean_rstd, gamma, beta, act, partials, 0.f, nullptr, nullptr};
   return sorted_entry(feat, n_in, kd, wn, kvol, ncols, table, rec, hdr, n_out, nullptr, d_conv_out, OCOCC_BF16,
                       (hipStream_t)stream_, &ln);
 }

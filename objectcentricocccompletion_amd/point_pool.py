@@ -42,6 +42,9 @@ def dynamic_point_pool_mixed(rois, rois_batch, pts, pts_batch, extra_wlh, max_in
     else:
         got = torch.cat([meta, also_read.to(torch.int32)]).tolist()
         also_read.host = got[R + 1:]
+    # (the host has just waited for the device: the cheapest place to learn that a grid barrier of a one-launch SIR layer
+    # of the step before gave up -- csrc/sir_fused.hip; raises)
+    L.check(L.lib.ococc_sir_layer_fused_check(), 'sir_layer barrier check')
     m, roi_counts = int(got[0]), got[1:R + 1]
     nonempty = sum(1 for c in roi_counts if c > 0)
     if m == 0:

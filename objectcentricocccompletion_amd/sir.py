@@ -58,6 +58,16 @@ def _f32_rows(t):
 NATIVE_LAYER = os.environ.get('OCOCC_SIR_NATIVE_LAYER', '1') == '1'
 
 
+def check_barriers():
+    """Raise if a grid barrier of a one-launch SIRLayer gave up since the last check (csrc/sir_fused.hip: not every
+    workgroup of the persistent grid was resident -- two processes or streams with such grids on one device).  A host
+    load of a word the device writes: no synchronisation, no copy.  The library makes the same test in front of every
+    one-launch layer; callers add it where they have waited for the device anyway (the pooled-point read-back of every
+    step: point_pool.py; tools/train.py per iteration and before a checkpoint; bench.py after its timed loop), so that a
+    stranded barrier in the LAST layer of a pass is reported too."""
+    L.check(L.lib.ococc_sir_layer_fused_check(), 'sir_layer barrier check')
+
+
 class _SirLayerDesc(ctypes.Structure):   # ococc_sir_layer of include/ococc_hip.h
     _fields_ = [('n_rel', ctypes.c_int32), ('n_vfe', ctypes.c_int32), ('feat_cols', ctypes.c_int32),
                 ('cluster_cols', ctypes.c_int32), ('with_cluster_center', ctypes.c_int32), ('shortcut', ctypes.c_int32),
@@ -176,6 +186,10 @@ class _SirLayerNative(torch.autograd.Function):
         need = ctx.needs_input_grad
         d = plan.desc
         d.shortcut = int(ctx.shortcut)
+        # (the descriptor is shared by every call on this plan: a no_grad forward of the same layer between this node's
+        # forward and backward -- validation inside a step, a teacher pass -- leaves inference = 1 behind; THIS node's
+        # forward recorded its arg-max rows, or there would be no backward)
+        d.inference = 0
         dgate = None if gate is None else torch.empty_like(gate)
         d.gate, d.dgate = (None if gate is None else gate.data_ptr()), (None if dgate is None else dgate.data_ptr())
         ln_off, w_off, tiles, slices, total = plan.bwd_layout(rows, G)
@@ -603,6 +617,7 @@ class SIRLayer(nn.Module):
         scale = 1.0 / float(self.rel_dist_scaler)
         col = const_tensor([1.0 / v for v in self.xyz_normalizer] + [1.0] * (raw - 3), dev)
         rel_cs = const_tensor([scale] * rel[0][0].in_features, dev) if rel else None
+        inv_in = inv
         if inv.dtype != torch.int32:   # (the blocks of a SIR stack share one inverse: converted once, kept on the tensor)
             i32 = getattr(inv, '_ococc_i32', None)
             if i32 is None:
@@ -620,7 +635,11 @@ class SIRLayer(nn.Module):
             if plan is None or not plan.valid_for(params) or plan.consts[1] is not col:
                 plan = _VFE_PLANS[self] = _NativePlan(vfe, 0, features.shape[1], f_cluster.shape[1], self._with_cluster_center,
                                                       scale / 10.0, None, col)
-            assert whole and plan.ok and gate.shape == features.shape, 'rel_gates() hands out gates only where this form applies'
+            if not (whole and plan.ok and gate.shape == features.shape and gate.dtype == torch.float32):
+                # (rel_gates() hands out gates before the layers see their features: half-precision features under autocast,
+                # an unusual vfe shape -- the same arithmetic operator by operator, with the gate as an input)
+                y, groups = self._forward_ops(features, f_cluster, inv_in, num_groups, gate)
+                return y, groups, False
             plan.pack.refresh(backward=torch.is_grad_enabled())
             y, groups = _SirLayerNative.apply(plan, bool(shortcut), features, f_cluster, inv, int(num_groups), gate, *params)
             return y, groups, shortcut

@@ -89,6 +89,10 @@ def test_two_ranks_on_one_gpu_equal_one_process_on_both_shards(dev, tmp_path):
 
 
 def test_two_ranks_on_one_gpu_ococcnet_parameters_stay_identical(dev, tmp_path):
+    # Two processes with persistent one-launch SIR grids on ONE device is the set-up DESIGN 3.5 warns about.  At 2 tracklets
+    # a layer is 128 workgroups, so both grids are resident together and every barrier completes; if one ever did not,
+    # bench.py's sir.check_barriers() after its timed loop raises and the rank exits non-zero (asserted in _two_ranks) --
+    # "both ranks agree" can no longer hide a stranded barrier.
     dump = str(tmp_path / 'q')
     _two_ranks(['--workload', 'ococcnet', '--tracklets', '2', '--warmup', '1', '--steps', '2'], dump)
     a, b = torch.load(dump + '.rank0.pt'), torch.load(dump + '.rank1.pt')

@@ -288,6 +288,64 @@ def test_sir_layer_in_one_launch_equals_the_launch_per_block(dev, cfg, rows, use
         assert rel(p, q) < 1e-5, rel(p, q)
 
 
+def test_a_stranded_grid_barrier_raises_in_the_product_path(dev):
+    """A one-launch SIRLayer whose persistent grid is not resident as a whole (here: forced to 8192 workgroups, several
+    times what the device holds; in the field: two processes or streams with such grids on one device) cannot complete its
+    grid barriers.  The bounded wait gives up, the kernel says so in a host-mapped word, and the PRODUCT path raises at the
+    next layer (sir.SIRLayer.forward -> ococc_sir_layer_fwd_f32 -> OCOCC_ESTRANDED) or at the caller's next check
+    (sir.check_barriers, as point_pool / tools/train.py / bench.py call it) -- never a finite loss on incomplete maxima.
+    After the report the process runs the per-block launches, whose results equal the one-launch form's to the bit."""
+    import ctypes
+    from objectcentricocccompletion_amd import _lib as L, sir
+    g = torch.Generator().manual_seed(5)
+    layer = sir.SIRLayer(in_channels=24, feat_channels=[128, 128], with_cluster_center=False, rel_mlp_hidden_dims=[16, 32],
+                         rel_mlp_in_channel=13, norm_cfg=dict(type='LN', eps=1e-3), mode='max', return_point_feats=True,
+                         rel_dist_scaler=10.0, xyz_normalizer=[20, 20, 4], act='gelu', dropout=0).to(dev)
+    rows = 3000
+    inv = torch.sort(torch.randint(0, 40, (rows,), generator=g)).values.to(dev)
+    feats, fc = torch.randn(rows, 24, generator=g).to(dev), torch.randn(rows, 13, generator=g).to(dev)
+    with torch.no_grad():
+        good = layer(feats, inv, fc)   # (also sizes the persistent grid: the residency census runs once per kernel)
+    torch.cuda.synchronize()
+    sir.check_barriers()
+    try:
+        L.check(L.lib.ococc_sir_layer_set_fused(1), 'set_fused')
+        L.check(L.lib.ococc_sir_layer_fused_debug(8192, 20), 'fused_debug')
+        with torch.no_grad():
+            layer(feats, inv, fc)      # strands: 8192 workgroups are never resident together
+        torch.cuda.synchronize()
+        status = ctypes.c_int32(-1)
+        L.check(L.lib.ococc_sir_layer_fused_status(L.stream(), ctypes.byref(status)), 'fused_status')
+        assert status.value != 0
+        L.check(L.lib.ococc_sir_layer_fused_debug(0, 20), 'fused_debug')   # (the next launch would fit -- it must not happen)
+        with pytest.raises(L.OcoccError, match='gave up'):
+            with torch.no_grad():
+                layer(feats, inv, fc)
+        sir.check_barriers()           # reported once
+        with torch.no_grad():
+            after = layer(feats, inv, fc)   # the per-block launches from here on
+        torch.cuda.synchronize()
+        assert torch.equal(after[0], good[0]) and torch.equal(after[1], good[1])
+        # ... and the caller-side check alone (the last layer of a pass has no next layer to report it)
+        L.check(L.lib.ococc_sir_layer_set_fused(1), 'set_fused')
+        L.check(L.lib.ococc_sir_layer_fused_debug(8192, 20), 'fused_debug')
+        with torch.no_grad():
+            layer(feats, inv, fc)
+        torch.cuda.synchronize()
+        with pytest.raises(L.OcoccError, match='gave up'):
+            sir.check_barriers()
+    finally:
+        L.check(L.lib.ococc_sir_layer_fused_debug(0, 0), 'fused_debug')
+        L.check(L.lib.ococc_sir_layer_set_fused(-1), 'set_fused')
+    with torch.no_grad():
+        again = layer(feats, inv, fc)       # the one-launch form again, whole
+    torch.cuda.synchronize()
+    sir.check_barriers()
+    status = ctypes.c_int32(-1)
+    L.check(L.lib.ococc_sir_layer_fused_status(L.stream(), ctypes.byref(status)), 'fused_status')
+    assert status.value == 0 and torch.equal(again[0], good[0]) and torch.equal(again[1], good[1])
+
+
 @pytest.mark.parametrize('rows', [60, 5000])
 @pytest.mark.parametrize('stack', ['sir', 'head'])
 def test_rel_mlp_chains_of_a_stack_in_one_launch(dev, stack, rows):

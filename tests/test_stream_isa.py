@@ -18,3 +18,15 @@ def test_stream_kernel_isa_keeps_in_flight_registers_untouched():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert 'touches of in-flight registers:   0' in r.stdout
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='hipcc not on PATH')
+def test_sir_grid_barrier_drains_vector_memory_before_it_arrives():
+    """bar_arrive of csrc/sir_fused_impl.hpp: `s_waitcnt vmcnt(0)` in front of the workgroup barrier of every arrival
+    (the no-return atomics on maxima / arg-max rows / collected gradients must have landed before another workgroup
+    passes the grid barrier); tools/check_sir_barrier_isa.py walks the generated gfx950 code of all three tile sizes."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_sir_barrier_isa.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert 'grid-barrier arrivals checked: 72' in r.stdout
+    assert 'arrivals without vmcnt(0) in front of the barrier: 0' in r.stdout

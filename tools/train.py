@@ -55,6 +55,7 @@ def main():
     from objectcentricocccompletion_amd.synthetic import synthetic_training_batch
     import ast
     from objectcentricocccompletion_amd.optim import AdamW, cyclic_lr, param_groups_from_cfg
+    from objectcentricocccompletion_amd.sir import check_barriers
     cfg = config.fromfile(args.config)
     opts = {}
     for kv in args.cfg_options:
@@ -138,11 +139,14 @@ def main():
         if clip:
             torch.nn.utils.clip_grad_norm_(model.parameters(), **clip)
         opt.step()
+        check_barriers()   # (no synchronisation: a host load; raises when a one-launch SIR layer's grid barrier gave up)
         if rank == 0:
             torch.cuda.synchronize()
             print(f'iter {it + 1}: lr {lr:.3e} loss {float(total):.4f} cls {float(losses["loss_rcnn_cls"]):.4f} '
                   f'bbox {float(losses["loss_rcnn_bbox"]):.4f} occ {float(losses["loss_rcnn_occ"].mean()):.4f} '
                   f'({(time.perf_counter() - t0) * 1e3:.1f} ms)', flush=True)
+    torch.cuda.synchronize()
+    check_barriers()   # nothing is written from a run whose last layers could not gather their grids
     if rank == 0:
         os.makedirs(args.work_dir, exist_ok=True)
         torch.save(dict(state_dict=model.state_dict(), optimizer=opt.state_dict(),
