@@ -45,7 +45,7 @@ PMC_JSON = {'stationary<64,128>': 'r02_pmc_gather_gemm_stream_64_128.json',
             'sorted_lnbwd<128,64>': 'r05_pmc_sorted_lnbwd_128_64.json',
             'tile_lnbwd<128,64>': 'r05_pmc_tile_lnbwd_128_64.json'}
 KERNEL_NAMES = {'stationary': 'gather_gemm_stream_kernel', 'stationary_ln': 'gather_gemm_kernel (+LN epilogue)',
-                'sorted': 'gather_gemm_sorted_kernel', 'sorted_lnbwd': 'gather_gemm_sorted_kernel (+LN-backward epilogue)',
+                'sorted': 'gather_gemm_sorted_kernel', 'sorted_ln': 'gather_gemm_sorted_kernel (+LN epilogue)', 'sorted_lnbwd': 'gather_gemm_sorted_kernel (+LN-backward epilogue)',
                 'tile': 'subm_tile_conv_kernel', 'tile_ln': 'subm_tile_conv_kernel (+LN epilogue)',
                 'tile_lnbwd': 'subm_tile_conv_kernel (+LN-backward epilogue)'}
 

@@ -363,6 +363,17 @@ int ococc_subm_row_order_place(const int32_t* rowrec, int32_t kvol, int32_t dens
 int ococc_sparse_conv_sorted_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
                                   int32_t ncols, const int32_t* table, const int32_t* rec, const int32_t* hdr,
                                   int64_t n_out, const float* bias, void* out, int32_t out_dtype, ococc_stream_t stream);
+/* ococc_sparse_conv_sorted_bf16 with the LayerNorm (+ GELU) of the enclosing conv -> norm -> act block
+ * (make_sparse_convmodule, mmdet3d/ops/sparse_block.py:216-289) in its epilogue: the contract of
+ * ococc_sparse_conv_tile_ln_bf16 below (conv_out, y = act(LN(conv_out)), mean_rstd [n_out, 2]) for rulebooks that run in
+ * neighbour-pattern order.  The finished f32 row sits in the registers of the four lanes that share a slot; the norm
+ * sees the bf16-rounded conv output and sums in the order of ococc_layernorm_act_fwd, so y and mean_rstd equal the
+ * two-launch pair's (conv, then LN).  kd, ncols in {32, 64, 128}, not both 128 (round 6: the 64 -> 128 forward of
+ * configs[1], whose separate LN launch re-read 32 MB). */
+int ococc_sparse_conv_sorted_ln_bf16(const uint16_t* feat, int64_t n_in, int32_t kd, const uint16_t* wn, int32_t kvol,
+                                     int32_t ncols, const int32_t* table, const int32_t* rec, const int32_t* hdr,
+                                     int64_t n_out, const float* gamma, const float* beta, float eps, int32_t act,
+                                     uint16_t* conv_out, uint16_t* y, float* mean_rstd, ococc_stream_t stream);
 /* ococc_sparse_conv_sorted_bf16 as the input-gradient pass of layer L+1 with the LayerNorm (+ GELU) BACKWARD of the
  * conv -> LN -> act block L in its epilogue -- the contract of ococc_sparse_conv_tile_lnbwd_bf16 below (same operands
  * besides the row order rec / hdr and the row-major dgrad operand wn; d_conv_out bit-identical to it and to

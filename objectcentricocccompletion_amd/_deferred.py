@@ -26,6 +26,7 @@ import os
 import torch
 
 ENABLED = os.environ.get('OCOCC_DEFER_PARAM_REDUCE', '1') != '0'  # 0: always the per-layer reductions
+JOINT = os.environ.get('OCOCC_DEFER_JOINT', '1') != '0'   # 0: one launch per kind of sum (profiling: which kind takes the time)
 # Data-parallel wrappers that consume a gradient from a hook on its AccumulateGrad node (torch DDP's reducer: a C++
 # post hook, invisible from Python) never see a gradient that bypasses the engine.  With more than one rank the
 # queue therefore stays off until the code that owns the gradient exchange says it reads gradients only AFTER
@@ -234,7 +235,7 @@ def _flush(task=None):
         return
     jobs, grads = q[0], q[1]
     for (a, b), fn in _joint.items():
-        if jobs.get(a) and jobs.get(b) and fn(jobs[a], jobs[b]):
+        if JOINT and jobs.get(a) and jobs.get(b) and fn(jobs[a], jobs[b]):
             jobs[a], jobs[b] = [], []
     for kind, items in jobs.items():
         if items:

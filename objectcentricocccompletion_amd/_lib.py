@@ -81,6 +81,8 @@ SIGNATURES = {
     'ococc_subm_row_order': (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_sorted_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64,
                                               c_vp, c_vp, c_i32, c_vp]),
+    'ococc_sparse_conv_sorted_ln_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                                 c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ococc_sparse_conv_sorted_lnbwd_partial_rows': (c_i64, [c_i64]),
     'ococc_sparse_conv_sorted_lnbwd_bf16': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
                                                     c_vp, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp]),

@@ -13,22 +13,29 @@ __device__ __forceinline__ void ln_param_reduce_block(const float* __restrict__ 
                                                       int block) {
   const int i = block * 8 + (threadIdx.x >> 5);
   const int l = threadIdx.x & 31;
-  // eight running sums per lane (fixed combination order): one sum made the 16 strided loads of a lane a
-  // chain of dependent L2 round trips (6.8 us per call whatever the width)
-  float a[8];
+  // 32 running sums per lane (fixed combination order): ONE round of independent loads for up to 1 024 partial rows.
+  // (One sum made a lane's strided loads a chain of dependent L2 round trips, 6.8 us per call whatever the width; eight
+  // sums left four dependent rounds, and inside the joint end-of-backward launch -- 2 048 workgroups reading slabs beside
+  // these few -- every round took ~3 us: the launch lasted 15.5 us for 10.6 us of slab sums.)
+  constexpr int U = 32;
+  float a[U];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  for (int u = 0; u < U; ++u) a[u] = 0.f;
   if (i < 2 * c) {
     const float* src = partials + i;
     int b = l;
-    for (; b + 32 * 7 < nblocks; b += 32 * 8) {
+    for (; b + 32 * (U - 1) < nblocks; b += 32 * U) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += src[(int64_t)(b + 32 * u) * 2 * c];
+      for (int u = 0; u < U; ++u) a[u] += src[(int64_t)(b + 32 * u) * 2 * c];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       if (b + 32 * u < nblocks) a[u] += src[(int64_t)(b + 32 * u) * 2 * c];
   }
+#pragma unroll
+  for (int w = U / 2; w >= 8; w >>= 1)   // (32 -> 8 sums: row j of the former eight-sum form is a[j] + a[j + 8] + ...)
+#pragma unroll
+    for (int u = 0; u < w; ++u) a[u] += a[u + w];
   float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 #pragma unroll
   for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d, 32);

@@ -1083,22 +1083,26 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ sla
   wg_span(num, k, &base, &nslabs);
   const int e = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int64_t i = (int64_t)chunk * 16 + e;
-  // eight running sums per lane: the centre offset has hundreds of slabs, and one sum per lane made its
-  // blocks a chain of dependent L2 round trips (11-16 us whatever the layer size)
-  float a[8];
+  // sixteen running sums per lane: the centre offset has hundreds of slabs, and one sum per lane made its
+  // blocks a chain of dependent L2 round trips (11-16 us whatever the layer size); with sixteen the ~250 slabs of
+  // the benchmark's centre offset are ONE round of independent loads per lane
+  constexpr int U = 16;
+  float a[U];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[u] = 0.f;
+  for (int u = 0; u < U; ++u) a[u] = 0.f;
   if (i < elems) {
     const float* src = slabs + (int64_t)base * elems + i;
     int j = part;
-    for (; j + 16 * 7 < nslabs; j += 16 * 8) {
+    for (; j + 16 * (U - 1) < nslabs; j += 16 * U) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += src[(int64_t)(j + 16 * u) * elems];
+      for (int u = 0; u < U; ++u) a[u] += src[(int64_t)(j + 16 * u) * elems];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       if (j + 16 * u < nslabs) a[u] += src[(int64_t)(j + 16 * u) * elems];
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) a[u] += a[u + 8];
   float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
@@ -1128,66 +1132,92 @@ struct ReducePack {
 // cut into units of 16 elements x 16 slab lanes (wgrad_reduce_block); an offset with at most 16 slabs (every other
 // offset of a sparse grid) into units of 256 elements, one thread each -- 27 x fewer, fatter units than one block per
 // 16 elements of every offset (18 k blocks of which 26/27 summed 8 values: 23 us for three layers).
-constexpr int kReduceGrid = 1024;
+// Round 6: the units of ALL layers form one flat list (layer after layer) that the grid walks once.  Before, every
+// workgroup went through the layers one after the other -- up to two units of the widest layer, then one of the next, ...:
+// four dependent unit lifetimes (each a chain of scans, two rounds of loads and a store) for ~1 800 units on 1 024
+// workgroups, 17.1 us in the configs[1] step.  With one list and 2 048 workgroups (all resident) a workgroup has ONE unit.
+constexpr int kReduceGrid = 2048;
 __device__ __forceinline__ void wgrad_reduce_multi_body(const ReducePack& pk, int first_unit, int unit_stride) {
-  const int lane = threadIdx.x & 63;
-  for (int t = 0; t < pk.count; ++t) {
+  // per layer, lane = offset: units of the offset (inclusive scan + own count), its slab count, its first slab
+  __shared__ int s_inc[kMaxReduce][64], s_cnt[kMaxReduce][64], s_slabs[kMaxReduce][64], s_base[kMaxReduce][64];
+  __shared__ int s_total[kMaxReduce];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = wave; t < pk.count; t += 4) {
     const int kvol = pk.kvol[t];
     const int64_t elems = pk.elems[t];
     const int deep_units = (int)((elems + 15) / 16), wide_units = (int)((elems + 255) / 256);
-    // units per offset (kvol <= 64 here: one lane per offset; larger kernels fall back to deep units for all)
-    for (int unit = first_unit;; unit += unit_stride) {
-      int k = -1, local = 0, nsl = 0, sbase = 0;
-      if (kvol <= 64) {
-        // lane = offset: its slab count and (exclusive scan) the index of its first slab
-        const int my_slabs = lane < kvol ? wg_items(pk.num[t][lane]) : 0;
-        int sinc = my_slabs;
+    if (kvol <= 64) {
+      const int my_slabs = lane < kvol ? wg_items(pk.num[t][lane]) : 0;
+      int sinc = my_slabs;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int v = __shfl_up(sinc, d, 64);
-          if (lane >= d) sinc += v;
-        }
-        const int my_base = sinc - my_slabs;
-        const int cnt = lane < kvol ? (my_slabs > 16 ? deep_units : wide_units) : 0;
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int v = __shfl_up(inc, d, 64);
-          if (lane >= d) inc += v;
-        }
-        const int total = __shfl(inc, 63, 64);
-        if (unit >= total) break;
-        const unsigned long long hit = __ballot(cnt > 0 && unit >= inc - cnt && unit < inc);
-        const int src = __ffsll((long long)hit) - 1;
-        k = src;
-        local = unit - (__shfl(inc, src, 64) - __shfl(cnt, src, 64));
-        nsl = __shfl(my_slabs, src, 64);
-        sbase = __shfl(my_base, src, 64);
-      } else {
-        if (unit >= deep_units * kvol) break;
-        k = unit / deep_units;
-        local = unit % deep_units;
-        wg_span(pk.num[t], k, &sbase, &nsl);
-        nsl = 17;  // force the deep path
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(sinc, d, 64);
+        if (lane >= d) sinc += v;
       }
-      if (kvol <= 64 && nsl <= 16) {
-        const int64_t i = (int64_t)local * 256 + threadIdx.x;
-        if (i < elems) {
-          const float* src = pk.slabs[t] + (int64_t)sbase * elems + i;
-          float a[8];
+      const int cnt = lane < kvol ? (my_slabs > 16 ? deep_units : wide_units) : 0;
+      int inc = cnt;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) a[u] = 0.f;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (u < nsl) a[u] = src[(int64_t)u * elems];
-            if (u + 8 < nsl) a[u] += src[(int64_t)(u + 8) * elems];
-          }
-          pk.dw[t][(int64_t)k * elems + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        }
-      } else {
-        __syncthreads();  // red[] of a previous deep unit
-        wgrad_reduce_block(pk.slabs[t], pk.num[t], k, local, elems, pk.dw[t]);
+      for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += v;
       }
+      s_inc[t][lane] = inc;
+      s_cnt[t][lane] = cnt;
+      s_slabs[t][lane] = my_slabs;
+      s_base[t][lane] = sinc - my_slabs;
+      if (lane == 63) s_total[t] = inc;
+    } else if (lane == 0) {   // (larger kernels: deep units for every offset, located by division)
+      s_total[t] = deep_units * kvol;
+    }
+  }
+  __syncthreads();
+  int first[kMaxReduce + 1];
+  first[0] = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxReduce; ++t) first[t + 1] = first[t] + (t < pk.count ? s_total[t] : 0);
+  bool deep_before = false;
+  for (int unit = first_unit; unit < first[kMaxReduce]; unit += unit_stride) {
+    int t = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxReduce; ++q) t += (unit >= first[q]) ? 1 : 0;
+    int lu = unit;
+#pragma unroll
+    for (int q = 1; q < kMaxReduce; ++q) lu -= (unit >= first[q]) ? (first[q] - first[q - 1]) : 0;
+    const int kvol = pk.kvol[t];
+    const int64_t elems = pk.elems[t];
+    int k, local, nsl, sbase = 0;
+    if (kvol <= 64) {
+      const int inc = s_inc[t][lane], cnt = s_cnt[t][lane];
+      const unsigned long long hit = __ballot(cnt > 0 && lu >= inc - cnt && lu < inc);
+      const int src = __ffsll((long long)hit) - 1;
+      k = src;
+      local = lu - (s_inc[t][src] - s_cnt[t][src]);
+      nsl = s_slabs[t][src];
+      sbase = s_base[t][src];
+    } else {
+      const int deep_units = (int)((elems + 15) / 16);
+      k = lu / deep_units;
+      local = lu % deep_units;
+      nsl = 17;  // force the deep path
+    }
+    if (kvol <= 64 && nsl <= 16) {
+      const int64_t i = (int64_t)local * 256 + threadIdx.x;
+      if (i < elems) {
+        const float* src = pk.slabs[t] + (int64_t)sbase * elems + i;
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < nsl) a[u] = src[(int64_t)u * elems];
+          if (u + 8 < nsl) a[u] += src[(int64_t)(u + 8) * elems];
+        }
+        pk.dw[t][(int64_t)k * elems + i] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      }
+    } else {
+      if (deep_before) __syncthreads();  // red[] of a previous deep unit
+      deep_before = true;
+      wgrad_reduce_block(pk.slabs[t], pk.num[t], k, local, elems, pk.dw[t]);
     }
   }
 }
@@ -1195,15 +1225,18 @@ __device__ __forceinline__ void wgrad_reduce_multi_body(const ReducePack& pk, in
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(ReducePack pk) {
   wgrad_reduce_multi_body(pk, (int)blockIdx.x, (int)gridDim.x);
 }
-// both kinds of end-of-backward sums in one launch: the first wgrad_grid workgroups walk the slab units, the ones
-// behind them sum the LayerNorm partial rows (the two launches were 15 + 8 us of mostly latency, one after the other)
+// both kinds of end-of-backward sums in one launch (the two launches were 15 + 8 us of mostly latency, one after the
+// other).  The FIRST ln_blocks workgroups sum the LayerNorm partial rows, the wgrad_grid workgroups behind them walk the
+// slab units (round 6: the other way round the few LayerNorm workgroups -- an 8 us chain of strided loads -- were
+// dispatched only when the first of the 2 048 slab workgroups, which fill every slot of the chip, had left: 16.0 us for
+// 10.6 + 8.3 us of separate launches).
 __global__ void __launch_bounds__(256) backward_reduce_multi_kernel(ReducePack pk, LnReducePack lp, int ln_count,
-                                                                    int wgrad_grid) {
-  if ((int)blockIdx.x >= wgrad_grid) {
-    ln_param_reduce_multi_body(lp, ln_count, (int)blockIdx.x - wgrad_grid);
+                                                                    int ln_blocks, int wgrad_grid) {
+  if ((int)blockIdx.x < ln_blocks) {
+    ln_param_reduce_multi_body(lp, ln_count, (int)blockIdx.x);
     return;
   }
-  wgrad_reduce_multi_body(pk, (int)blockIdx.x, wgrad_grid);
+  wgrad_reduce_multi_body(pk, (int)blockIdx.x - ln_blocks, wgrad_grid);
 }
 
 inline int64_t wgrad_max_groups(int kvol, int64_t cap) {
@@ -1407,7 +1440,7 @@ extern "C" int ococc_backward_param_reduce_multi(int32_t wcount, const void* con
   }
   lp.first[lcount] = lblocks;
   hipLaunchKernelGGL(backward_reduce_multi_kernel, dim3(wgrad_grid + lblocks), dim3(256), 0, stream, pk, lp, (int)lcount,
-                     wgrad_grid);
+                     lblocks, wgrad_grid);
   OCOCC_CHECK_LAUNCH();
   return OCOCC_OK;
 }

@@ -18,6 +18,9 @@ from . import _lib as L
 
 REFRESH_CONV_OPERANDS = __import__('os').environ.get('OCOCC_ADAMW_OPERANDS', '1') == '1'   # see AdamW.step
 _MAX = 48
+# who bumps the device-side step count: 2 = the last workgroup of the update launch (a ticket atomic per workgroup),
+# 1 = a one-thread launch behind it (profiling: what the tickets cost)
+_BUMP = int(__import__('os').environ.get('OCOCC_ADAMW_BUMP', '2'))
 
 
 class AdamW(torch.optim.Optimizer):
@@ -98,7 +101,7 @@ class AdamW(torch.optim.Optimizer):
                         arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
                         (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']),
                         group['lr_dev'].data_ptr() if self.device_lr else None, float(b1), float(b2), float(group['eps']),
-                        float(group['weight_decay']), group['step_dev'].data_ptr(), 2 if last else 0, no,
+                        float(group['weight_decay']), group['step_dev'].data_ptr(), _BUMP if last else 0, no,
                         i32(*[t[0] for t in targets]), i32(*[t[1] for t in targets]), i32(*[t[2] for t in targets]),
                         i32(*[t[3] for t in targets]), i32(*[t[4] for t in targets]),
                         (ctypes.c_void_p * no)(*[t[5].data_ptr() for t in targets]), L.stream()), 'adamw_operands')
@@ -112,7 +115,7 @@ class AdamW(torch.optim.Optimizer):
                     arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
                     (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), lr_arg, float(b1),
                     float(b2), float(group['eps']), float(group['weight_decay']), group['step_dev'].data_ptr(),
-                    2 if last else 0, L.stream()), 'adamw')
+                    _BUMP if last else 0, L.stream()), 'adamw')
             for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
                 torch.autograd.graph.increment_version(p)
             if refreshed:

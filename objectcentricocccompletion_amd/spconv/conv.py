@@ -70,7 +70,7 @@ class SparseConvolution(SparseModule):
         from . import ops as _ops
         kind = _ops.ln_fusion_kind(indice_pairs, indice_pair_num, num_out, self.inverse, self.subm,
                                    self.in_channels, self.out_channels)
-        return _m.FUSE_CONV_LN or (kind in ('tile', 'first') and _m.FUSE_TILE_CONV_LN)
+        return _m.FUSE_CONV_LN or (kind in ('tile', 'first', 'sorted') and _m.FUSE_TILE_CONV_LN)
 
     def _ln_fusable(self, features):
         import torch

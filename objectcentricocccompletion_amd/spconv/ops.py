@@ -19,7 +19,7 @@ from .. import _lib as L
 
 _KD_OK = (16, 32, 64, 128)
 
-# launches per convolution kernel family ('tile', 'tile_ln', 'tile_lnbwd', 'sorted', 'sorted_lnbwd', 'stationary',
+# launches per convolution kernel family ('tile', 'tile_ln', 'tile_lnbwd', 'sorted', 'sorted_ln', 'sorted_lnbwd', 'stationary',
 # 'stationary_ln') since import: what tests, __graft_entry__.smoke() and bench.py read to state WHICH kernel produced
 # the numbers they check (the choice depends on the measured rulebook density, see DensityTracker)
 launches = collections.Counter()
@@ -986,6 +986,13 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     return out if nc == cout else out[:, :cout].contiguous()
 
 
+SORTED_CONV_LN = os.environ.get('OCOCC_SORTED_CONV_LN', '1') == '1'
+
+
+def _sorted_ln_shape(rb, cin, cout, rows):
+    return _use_sorted_kernel(rb, cin, cout) and 0 < rows < ORDER_MAX_ROWS
+
+
 def _tile_ln_shape(cin, cout):
     return cin in (32, 64) and cout in (32, 64)  # instantiations of ococc_sparse_conv_tile_ln_bf16
 
@@ -997,10 +1004,16 @@ def ln_fusion_kind(indice_pairs, indice_pair_num, num_activate_out, inverse, sub
     faster than the two launches, opt-in)."""
     if (cin, cout) == (16, 32):
         return 'first'  # the resident-weights kernel at two 16-row blocks per wave: 19.9 us against 15.5 + 7.4 us
-    if not subm or not _tile_ln_shape(cin, cout):
+    if not subm:
         return 'stationary'
     rb, _ = _tables_for(indice_pairs, indice_pair_num, inverse, 'fwd', int(num_activate_out), subm)
-    return 'tile' if _use_tile_kernel(rb, cin, cout) else 'stationary'
+    if _tile_ln_shape(cin, cout) and _use_tile_kernel(rb, cin, cout):
+        return 'tile'
+    # 'sorted' (round 6): rows in neighbour-pattern order, the finished row in the registers of four lanes -- the
+    # 64 -> 128 forward of configs[1], whose separate LN launch read 32 MB straight back
+    if SORTED_CONV_LN and _sorted_ln_shape(rb, cin, cout, int(num_activate_out)):
+        return 'sorted'
+    return 'stationary'
 
 
 def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indice_pair_num, num_activate_out,
@@ -1016,6 +1029,7 @@ def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indic
                                           int(num_activate_out), subm)
     x = _to_bf16_padded(features, cin)
     tile = subm and _tile_ln_shape(cin, cout) and _use_tile_kernel(rb, cin, cout)
+    in_order = (not tile) and subm and SORTED_CONV_LN and _sorted_ln_shape(rb, cin, cout, rows)
     wn = _prep_weights(filters, 4 if tile else 0, cin, cout)
     conv_out = torch.empty((rows, cout), dtype=torch.bfloat16, device=x.device)
     y = torch.empty_like(conv_out)
@@ -1027,13 +1041,20 @@ def indice_conv_ln(features, filters, gamma, beta, eps, act, indice_pairs, indic
             return L.lib.ococc_sparse_conv_tile_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
                                                         kvol // 2, rows, L.ptr(g32), L.ptr(b32), float(eps), int(act),
                                                         L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
+    elif in_order:
+        rec, hdr = row_order(rb, table, rows)
+
+        def run():
+            return L.lib.ococc_sparse_conv_sorted_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout, L.ptr(table),
+                                                          L.ptr(rec), L.ptr(hdr), rows, L.ptr(g32), L.ptr(b32), float(eps),
+                                                          int(act), L.ptr(conv_out), L.ptr(y), L.ptr(stats), L.stream())
     else:
         def run():
             return L.lib.ococc_sparse_conv_gather_gemm_ln_bf16(L.ptr(x), x.size(0), cin, L.ptr(wn), kvol, cout,
                                                                L.ptr(table), L.ptr(mask), rows, L.ptr(g32), L.ptr(b32),
                                                                float(eps), int(act), L.ptr(conv_out), L.ptr(y),
                                                                L.ptr(stats), L.stream())
-    family = 'tile_ln' if tile else 'stationary_ln'
+    family = 'tile_ln' if tile else ('sorted_ln' if in_order else 'stationary_ln')
     rc = _launch(family, cin, cout, run)
     if rc == -3:  # OCOCC_EUNSUPPORTED: no fused kernel for this shape
         launches[family] -= 1

@@ -32,7 +32,7 @@ def dev():
 _SWITCH_DEFAULTS = {}   # module name -> {switch: value at import}: restored in front of every test
 _SWITCHES = {
     'objectcentricocccompletion_amd.spconv.ops': ('SORTED_CONV', 'SPARSE_TILE_CONV', 'DEFAULT_PAIRS_PER_ROW', 'AUTO_DENSITY',
-                                                  'FUSE_LN_BACKWARD', 'SORTED_TILES', '_TILE_SHAPES'),
+                                                  'FUSE_LN_BACKWARD', 'SORTED_TILES', '_TILE_SHAPES', 'SORTED_CONV_LN'),
     'objectcentricocccompletion_amd.spconv.modules': ('FUSE_CONV_LN', 'FUSE_TILE_CONV_LN'),
 }
 

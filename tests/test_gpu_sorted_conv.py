@@ -212,7 +212,7 @@ def test_layernorm_backward_in_the_pattern_order_dgrad(dev, static):
         ran[mode] = {k: v - before.get(k, 0) for k, v in ops.launches.items() if v - before.get(k, 0)}
     assert ran['sorted'].get('sorted_lnbwd') == 2 and 'tile_lnbwd' not in ran['sorted'], ran
     assert ran['tile'].get('tile_lnbwd') == 2 and 'sorted_lnbwd' not in ran['tile'], ran
-    assert 'sorted_lnbwd' not in ran['unfused'] and ran['unfused'].get('sorted', 0) >= 3, ran
+    assert 'sorted_lnbwd' not in ran['unfused'] and ran['unfused'].get('sorted', 0) + ran['unfused'].get('sorted_ln', 0) >= 3, ran
     for mode in ('sorted', 'tile'):
         assert torch.equal(outs['unfused'], outs[mode])
         for k in grads['unfused']:
@@ -226,3 +226,93 @@ def test_layernorm_backward_in_the_pattern_order_dgrad(dev, static):
                 assert float((a - b).norm()) <= 2e-3 * float(a.norm()), (mode, k)
             else:                                # LayerNorm gamma / beta
                 assert float((a - b).abs().max()) <= (1e-4 if mode == 'sorted' else 2e-3) * max(float(a.abs().max()), 1e-6), (mode, k)
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 128), (32, 64), (128, 64), (32, 128), (64, 32), (32, 32)])
+@pytest.mark.parametrize('density', [0.04, 0.12, 0.45])
+@pytest.mark.parametrize('act', [0, 1])
+def test_pattern_order_kernel_layernorm_epilogue(dev, cin, cout, density, act):
+    """ococc_sparse_conv_sorted_ln_bf16 (round 6: the conv -> LayerNorm -> GELU block of make_sparse_convmodule,
+    sparse_block.py:216-289, in ONE launch on the neighbour-pattern-order kernel) = ococc_sparse_conv_sorted_bf16 followed
+    by ococc_layernorm_act_fwd: the conv output bit for bit; the epilogue rounds to bf16 where the pair stores bf16 and
+    sums in the LayerNorm kernel's order, so the statistics agree to f32 rounding and the activation except where a
+    rounding tie flips.  Densities: tiles of all three classes (256-, 128- and 64-row tiles: four, two, one block per
+    wave); a row count that is no multiple of anything; fixed-capacity padding rows (-1 coordinates) behind the live ones."""
+    from objectcentricocccompletion_amd import _lib as L
+    from objectcentricocccompletion_amd.spconv import ops
+    shape = [14, 13, 11]
+    coors = _scene(dev, 5, shape, density, seed=7 * cin + cout + act)
+    pad = torch.full((37, 4), -1, dtype=torch.int32, device=dev)     # inert rows of the fixed-capacity form
+    coors = torch.cat([coors, pad])
+    n = coors.shape[0]
+    _, pairs, num = ops.get_indice_pairs(coors, 5, shape, 3, subm=True)
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=g) * 0.1).to(dev)
+    x = torch.randn(n, cin, generator=g).to(dev).bfloat16()
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    beta = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    keep = ops.SORTED_CONV, ops.SPARSE_TILE_CONV
+    before = dict(ops.launches)
+    try:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = True, False
+        conv = ops.indice_conv(x, w, pairs, num, n, False, True)
+        assert ops.ln_fusion_kind(pairs, num, n, False, True, cin, cout) == 'sorted'
+        fused = ops.indice_conv_ln(x, w, gamma, beta, 1e-3, act, pairs, num, n, False, True)
+    finally:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = keep
+    assert ops.launches['sorted_ln'] - before.get('sorted_ln', 0) == 1 and ops.launches['sorted'] - before.get('sorted', 0) == 1
+    conv_out, y, stats = fused
+    assert torch.equal(conv_out, conv)
+    y_ref = torch.empty_like(conv)
+    stats_ref = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    L.check(L.lib.ococc_layernorm_act_fwd(L.ptr(conv), n, cout, L.ptr(gamma), L.ptr(beta), 1e-3, act, L.ptr(y_ref),
+                                          L.ptr(stats_ref), L.BF16, L.stream()), 'ln')
+    torch.cuda.synchronize()
+    assert float((stats - stats_ref).abs().max()) <= 2e-6 * float(stats_ref.abs().max())
+    d = (y.float() - y_ref.float()).abs()
+    assert float(d.max()) <= 2e-2 * float(y_ref.float().abs().max())          # <= one bf16 step at the top value
+    assert float((d > 0).float().mean()) < 2e-3                                # and only where a rounding tie flips
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 128), (32, 64), (128, 64)])
+@pytest.mark.parametrize('act', [0, 1])
+def test_pattern_order_kernel_layernorm_epilogue_vs_oracle(dev, cin, cout, act):
+    """ococc_sparse_conv_sorted_ln_bf16 against the oracle's indiceConv (spconv_ops.h:300-354) followed by a float64
+    LayerNorm(+GELU) on the bf16 conv output (what oracle/encoder_ref.py does for a make_sparse_convmodule block): conv
+    output = RNE bf16 of the oracle's f32 result up to summation order, activation within a bf16 rounding of the float64
+    value, row statistics to f32 accuracy."""
+    import numpy as np
+    from oracle import oracle as O
+    from objectcentricocccompletion_amd.spconv import ops
+    rng = np.random.default_rng(cin * 13 + cout + act)
+    shape = (12, 11, 13)
+    coors = _scene(dev, 3, list(shape), 0.12, seed=cin + 2 * cout)
+    n = coors.shape[0]
+    idx = coors.cpu().numpy()
+    _, pairs, num = ops.get_indice_pairs(coors, 3, list(shape), 3, subm=True)
+    ep, en = O.subm_rulebook(idx, 3, shape, (3, 3, 3))
+    x = O.bf16_round(rng.standard_normal((n, cin)).astype(np.float32))
+    w = O.bf16_round((rng.standard_normal((3, 3, 3, cin, cout)) * 0.1).astype(np.float32))
+    gamma = (rng.random(cout) + 0.5).astype(np.float32)
+    beta = (rng.random(cout) - 0.5).astype(np.float32)
+    keep = ops.SORTED_CONV, ops.SPARSE_TILE_CONV
+    before = ops.launches['sorted_ln']
+    try:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = True, False
+        fused = ops.indice_conv_ln(torch.from_numpy(x).to(dev).bfloat16(), torch.from_numpy(w).to(dev),
+                                   torch.from_numpy(gamma).to(dev), torch.from_numpy(beta).to(dev), 1e-3, act, pairs, num,
+                                   n, False, True)
+    finally:
+        ops.SORTED_CONV, ops.SPARSE_TILE_CONV = keep
+    assert fused is not None and ops.launches['sorted_ln'] == before + 1
+    conv_out, y, stats = (t.float().cpu().numpy() for t in fused)
+    ey = O.indice_conv(x, w, ep, en, n, subm=True)
+    # (one bf16 step where the f32 sums differ in their last bits; sums of ~100 terms of size one that cancel to nearly
+    # zero differ by the terms' f32 rounding, not by the result's)
+    ulp = np.maximum(np.abs(ey), 2.0 ** -126) * 2.0 ** -7 + 1e-5
+    assert (np.abs(conv_out - O.bf16_round(ey)) <= ulp).all() and (conv_out != O.bf16_round(ey)).mean() < 5e-3
+    ez = O.layernorm_act(conv_out, gamma, beta, 1e-3, bool(act))
+    assert (np.abs(y - ez) <= np.abs(ez) * 2.0 ** -8 + 1e-5).all()       # half an ulp of bf16
+    c64 = conv_out.astype(np.float64)
+    mu, rstd = c64.mean(1), 1.0 / np.sqrt(c64.var(1) + 1e-3)
+    assert np.allclose(stats[:, 0], mu, rtol=1e-5, atol=1e-6) and np.allclose(stats[:, 1], rstd, rtol=1e-5)

@@ -158,10 +158,14 @@ def test_block_fuses_layernorm_only_on_the_tile_kernel(dev):
 
     res = {}
     orig = (spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN)
+    keep_sorted = ops.SORTED_CONV
     ops.indice_conv_ln = spy
     try:
-        for name, tile, fuse in (('tile_fused', True, True), ('tile_unfused', True, False), ('stationary', False, True)):
-            ops.SPARSE_TILE_CONV, spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN = tile, fuse, False
+        # ('stationary': the output-stationary kernels -- neither the tile kernel nor, round 6, the pattern-order kernel,
+        # which has the epilogue too: 'sorted')
+        for name, tile, fuse, in_order in (('tile_fused', True, True, False), ('tile_unfused', True, False, False),
+                                           ('stationary', False, True, False), ('sorted', False, True, True)):
+            ops.SPARSE_TILE_CONV, spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN, ops.SORTED_CONV = tile, fuse, False, in_order
             del calls[:]
             xin = feats.clone().requires_grad_(True)
             block.zero_grad(set_to_none=True)
@@ -172,14 +176,16 @@ def test_block_fuses_layernorm_only_on_the_tile_kernel(dev):
     finally:
         ops.indice_conv_ln = real
         ops.SPARSE_TILE_CONV = None
+        ops.SORTED_CONV = keep_sorted
         spm.FUSE_TILE_CONV_LN, spm.FUSE_CONV_LN = orig
-    assert res['tile_fused'][0] == 1 and res['tile_unfused'][0] == 0 and res['stationary'][0] == 0
+    assert res['tile_fused'][0] == 1 and res['tile_unfused'][0] == 0 and res['stationary'][0] == 0 and res['sorted'][0] == 1
     _, yu, gxu, gpu = res['tile_unfused']
-    _, yf, gxf, gpf = res['tile_fused']
-    assert float((yf - yu).abs().max()) <= 2e-2 * float(yu.abs().max())
-    assert float((gxf - gxu).abs().max()) <= 2e-2 * float(gxu.abs().max())
-    for a, b in zip(gpf, gpu):
-        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
+    for fused in ('tile_fused', 'sorted'):
+        _, yf, gxf, gpf = res[fused]
+        assert float((yf - yu).abs().max()) <= 2e-2 * float(yu.abs().max())
+        assert float((gxf - gxu).abs().max()) <= 2e-2 * float(gxu.abs().max())
+        for a, b in zip(gpf, gpu):
+            assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6
 
 
 # ------------------------------------------------------------------ directly against the oracle
