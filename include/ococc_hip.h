@@ -875,6 +875,20 @@ int ococc_sir_rel_chains_bwd_f32(int32_t count, const ococc_sir_rel_chain* chain
 int ococc_sir_layer_fused_status(ococc_stream_t stream, int32_t* status);
 
 /* ------------------------------------------------------------------------
+ * A9 / A10  f32 matrix products on the bf16 matrix cores at f32-level accuracy: the operand split.
+ * Replaces the f32 GEMMs behind nn.Linear / nn.MultiheadAttention of the temporal transformer and the RoI-level MLPs
+ * (mmdet3d/models/occ/layers.py:35-87, mmdet3d/models/roi_heads/bbox_heads/ococc_bbox_head.py:116-193,849-908) from a few
+ * hundred rows on: x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi), and
+ *   x w ~ hi_x hi_w + hi_x lo_w + lo_x hi_w   (relative error 4.5e-6 against f64; the f32 GEMM: 7e-7; bf16 operands: 2.3e-3)
+ * is ONE bf16 GEMM with f32 accumulation over a three times longer contraction.  ococc_split3_bf16 makes the three-part
+ * operand of an f32 matrix src [rows, cols] (row stride ld_src floats) in one pass, in either or both forms:
+ *   cat_cols   [rows, 3 cols] bf16: the parts side by side (the matrix's ROWS are contracted against another's rows)
+ *   stack_rows [3 rows, cols] bf16: the parts stacked (its COLUMNS stay, the three row blocks are contracted)
+ * pattern 0 = (hi, hi, lo), 1 = (hi, lo, hi): one operand of a product takes 0, the other 1.  cols % 8 == 0. */
+int ococc_split3_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld_src, uint16_t* cat_cols, int32_t cat_pattern,
+                      uint16_t* stack_rows, int32_t stack_pattern, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A11 / A10, fused  the occupancy decoder's per-query MLP, one launch per layer (or one for the whole MLP):
  *   y = dropout(act(LayerNorm(x W^T + bias + add_rows[add_index]))),  optionally  head = y . head_weight + head_bias
  * replaces OccDecoder.forward's conv_occ (mmdet3d/models/occ/occ_base.py:99-153): build_mlp's

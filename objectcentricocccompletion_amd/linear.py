@@ -83,4 +83,8 @@ class Linear(nn.Linear):
         if (x.dim() == 2 and x.size(0) >= TALL_ROWS and max(self.in_features, self.out_features) <= 256
                 and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled()):
             return _TallLinear.apply(x, self.weight, self.bias)
+        if min(self.in_features, self.out_features) >= 256 and gemm._split3_ok(x, self.weight, self.bias):
+            # the RoI-level MLPs (ococc_bbox_head.py:116-193: 3072 -> 2048 -> 2048 -> 1536, ...) from a few hundred RoIs on:
+            # one bf16 GEMM over three-way split operands, f32-level accuracy (gemm.py)
+            return gemm.linear(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)

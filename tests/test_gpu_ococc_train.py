@@ -91,7 +91,15 @@ LOSS_KEYS = ['loss_rcnn_cls', 'num_pos_rois', 'num_neg_rois', 'loss_rcnn_bbox', 
              'recall_posbox', 'precision_negbox', 'recall_negbox']
 
 
-def test_forward_train_losses_and_gradients_equal_reference(dev, gold, model):
+@pytest.mark.parametrize('split3', ['default', 'everywhere'])
+def test_forward_train_losses_and_gradients_equal_reference(dev, gold, model, split3, monkeypatch):
+    # 'everywhere': every f32 Linear of the model -- at the test scene's ~100 RoIs they would stay on the f32 library GEMM --
+    # as one bf16 GEMM over three-way split operands (gemm.py, csrc/split3.hip: the default from 384 rows on): the SAME
+    # tolerances against the imported reference's losses and gradients, which plain bf16 operands do not meet
+    if split3 == 'everywhere':
+        from objectcentricocccompletion_amd import gemm
+        monkeypatch.setattr(gemm, 'SPLIT3_MIN_ROWS', 1)
+        monkeypatch.setattr(gemm, 'SPLIT3_MIN_WORK', 0)
     samples, points, frames, trks, cands, occs, occ_scores = _scene(dev)
     torch.manual_seed(123)
     model.zero_grad(set_to_none=True)
