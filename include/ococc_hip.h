@@ -889,6 +889,28 @@ int ococc_split3_bf16(const float* src, int64_t rows, int64_t cols, int64_t ld_s
                       uint16_t* stack_rows, int32_t stack_pattern, ococc_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A9  the attention core of the temporal transformer, one launch per direction (csrc/causal_attn.hip).
+ * Replaces, inside nn.MultiheadAttention as SimpleEncoderLayer calls it (mmdet3d/models/occ/layers.py:35-87; callers
+ * ococc_bbox_head.py:849-995), the chain  (q / sqrt(D)) k^T -> masked_fill(attn_mask, key_padding_mask) -> softmax ->
+ * dropout -> @ v  and its backward (ten launches on [B H, L, S] tensors at L = 32).
+ * q, k, v: f32 token-major rows t = l * batch + b (the reference's [L, B, E] layout flattened), head h in columns
+ * h * head_dim .. + head_dim - 1, row strides ldq / ldk / ldv floats (q and k may be column slices of one projection).
+ * attn_mask [L, S] / key_padding_mask [batch, S]: bytes, 1 = masked, or null.  dropout_p in [0, 1): the keep mask is a
+ * counter-based hash of (seed, element), regenerated by the backward call from the same seed; seed_dev non-null: the seed
+ * is read from device memory (inside a captured graph every replay then draws its own).  probs [batch * heads, L, S]: the
+ * probabilities before dropout, written by the forward call and read by the backward call.  out [L * batch, ldo].
+ * L, S <= 256, head_dim % 4 == 0 and <= 384 (OCOCC_EUNSUPPORTED otherwise).  No atomics; deterministic. */
+int ococc_temporal_attention_fwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                     const uint8_t* attn_mask, const uint8_t* key_padding_mask, int32_t batch, int32_t heads,
+                                     int32_t L, int32_t S, int32_t head_dim, float scale, float dropout_p, uint64_t seed,
+                                     const uint64_t* seed_dev, float* probs, float* out, int64_t ldo, ococc_stream_t stream);
+int ococc_temporal_attention_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                     int32_t batch, int32_t heads, int32_t L, int32_t S, int32_t head_dim, float scale,
+                                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, const float* probs,
+                                     const float* out, int64_t ldo, const float* d_out, int64_t lddo, float* dq, int64_t lddq,
+                                     float* dk, int64_t lddk, float* dv, int64_t lddv, ococc_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A11 / A10, fused  the occupancy decoder's per-query MLP, one launch per layer (or one for the whole MLP):
  *   y = dropout(act(LayerNorm(x W^T + bias + add_rows[add_index]))),  optionally  head = y . head_weight + head_bias
  * replaces OccDecoder.forward's conv_occ (mmdet3d/models/occ/occ_base.py:99-153): build_mlp's

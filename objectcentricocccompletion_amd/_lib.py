@@ -163,6 +163,11 @@ SIGNATURES = {
     'ococc_sir_layer_set_fused': (c_i32, [c_i32]),
     'ococc_sir_layer_fused_status': (c_i32, [c_vp, ctypes.POINTER(c_i32)]),
     'ococc_split3_bf16': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    'ococc_temporal_attention_fwd_f32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                 c_i32, c_f32, c_f32, ctypes.c_uint64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ococc_temporal_attention_bwd_f32': (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,
+                                                 c_f32, ctypes.c_uint64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                                 c_i64, c_vp, c_i64, c_vp]),
     'ococc_sir_layer_fused_check': (c_i32, []),
     'ococc_sir_layer_fused_debug': (c_i32, [c_i32, c_i32]),
     'ococc_point_mlp_wgrad_f32': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),

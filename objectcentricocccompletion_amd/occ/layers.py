@@ -9,9 +9,56 @@ import math
 import torch
 from torch import nn
 
+import os
+
 from .. import gemm
 from ..norm import layer_norm_act
 from ..sst.sst_ops import get_activation_layer
+
+# the attention core (scores, masks, softmax, dropout, @ v) as ONE launch per direction: csrc/causal_attn.hip (round 6).
+# 0: the operator chain below (bmm, masked_fill, softmax, dropout, bmm)
+FUSED_ATTENTION = os.environ.get('OCOCC_FUSED_ATTENTION', '1') == '1'
+
+
+class _TemporalAttention(torch.autograd.Function):
+    """ctx rows [L B, E] = softmax(mask(q k^T / sqrt(D))) v per (tracklet, head): ococc_temporal_attention_{fwd,bwd}_f32.
+    q / k / v: f32 token-major [L B, H D] (q and k may be column slices of one projection); masks: uint8 or None;
+    seed: a device int64 tensor (dropout; drawn by torch's generator, so a captured graph draws a new one per replay)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, attn_mask, key_pad, dims, p_drop, seed):
+        from .. import _lib as L
+        B, H, Lq, S, D = dims
+        out = torch.empty((Lq * B, H * D), dtype=torch.float32, device=q.device)
+        probs = torch.empty((B * H, Lq, S), dtype=torch.float32, device=q.device)
+        L.check(L.lib.ococc_temporal_attention_fwd_f32(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), L.ptr(attn_mask), L.ptr(key_pad),
+            B, H, Lq, S, D, float(D) ** -0.5, float(p_drop), 0, L.ptr(seed), probs.data_ptr(), out.data_ptr(), out.stride(0),
+            L.stream()), 'temporal_attention_fwd')
+        ctx.save_for_backward(q, k, v, probs, out, *(() if seed is None else (seed,)))
+        ctx.meta = (dims, float(p_drop), seed is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from .. import _lib as L
+        q, k, v, probs, out = ctx.saved_tensors[:5]
+        dims, p_drop, has_seed = ctx.meta
+        seed = ctx.saved_tensors[5] if has_seed else None
+        B, H, Lq, S, D = dims
+        d_out = d_out.contiguous()
+        # (q and k are the two halves of one projection in the encoder layers: their gradients are written as the two
+        # halves of one buffer, which is what the slices' backward would assemble)
+        dqk = torch.empty((Lq * B, 2 * H * D), dtype=torch.float32, device=q.device) if Lq == S else None
+        dq = dqk[:, :H * D] if dqk is not None else torch.empty((Lq * B, H * D), dtype=torch.float32, device=q.device)
+        dk = dqk[:, H * D:] if dqk is not None else torch.empty((S * B, H * D), dtype=torch.float32, device=q.device)
+        dv = torch.empty((S * B, H * D), dtype=torch.float32, device=q.device)
+        L.check(L.lib.ococc_temporal_attention_bwd_f32(
+            q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), B, H, Lq, S, D, float(D) ** -0.5,
+            p_drop, 0, L.ptr(seed), probs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0),
+            dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), L.stream()),
+            'temporal_attention_bwd')
+        return dq, dk, dv, None, None, None, None, None
 
 
 class PositionalEncoding(nn.Module):
@@ -48,6 +95,15 @@ class MultiheadAttention(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
+    def _fused_ok(self, q, k, v, L, S, attn_mask, key_padding_mask):
+        """the one-launch attention core takes f32 device tensors with 16-byte aligned rows, boolean masks of the shapes
+        the reference passes, sequences up to 256 frames (the reference's PositionalEncoding stops at 200), heads up to 384 wide"""
+        ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+        return (FUSED_ATTENTION and ok(q) and ok(k) and ok(v) and L <= 256 and S <= 256 and self.head_dim % 4 == 0
+                and self.head_dim <= 384 and (attn_mask is None or (attn_mask.dtype == torch.bool and attn_mask.shape == (L, S)))
+                and (key_padding_mask is None or (key_padding_mask.dtype == torch.bool and key_padding_mask.dim() == 2
+                                                  and key_padding_mask.shape[1] == S)))
+
     def _heads(self, t, n):
         """[n * B, E] token-major -> [B * H, n, D]"""
         return t.reshape(n, -1, self.head_dim).transpose(0, 1)
@@ -64,6 +120,13 @@ class MultiheadAttention(nn.Module):
             q = gemm.linear(query.reshape(L * B, E), w[:E], b[:E])
             k = gemm.linear(key.reshape(S * B, E), w[E:2 * E], b[E:2 * E])
         v = gemm.linear(value.reshape(S * B, E), w[2 * E:], b[2 * E:])
+        p_drop = self.dropout if self.training else 0.0
+        if self._fused_ok(q, k, v, L, S, attn_mask, key_padding_mask):
+            am = None if attn_mask is None else attn_mask.contiguous().view(torch.uint8)
+            kp = None if key_padding_mask is None else key_padding_mask.contiguous().view(torch.uint8)
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=q.device) if p_drop > 0 else None
+            ctx = _TemporalAttention.apply(q, k, v, am, kp, (B, H, L, S, self.head_dim), p_drop, seed)
+            return gemm.linear(ctx, self.out_proj.weight, self.out_proj.bias).view(L, B, E), None
         scores = gemm.bmm(self._heads(q * (self.head_dim ** -0.5), L), self._heads(k, S).transpose(1, 2))   # [B H, L, S]
         if attn_mask is not None:
             scores = scores.masked_fill(attn_mask[None], float('-inf')) if attn_mask.dtype == torch.bool \
