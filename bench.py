@@ -42,8 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # that kernel (tools/pmc_hbm.sh), keyed the same way; null for a kernel no PMC pass exists for.
 PMC_JSON = {'stationary<64,128>': 'r02_pmc_gather_gemm_stream_64_128.json',
             'sorted<64,128>': 'r04_pmc_gather_gemm_sorted_64_128.json',
+            'sorted_ln<64,128>': 'r06_pmc_sorted_ln_64_128.json',
             'sorted_lnbwd<128,64>': 'r05_pmc_sorted_lnbwd_128_64.json',
-            'tile_lnbwd<128,64>': 'r05_pmc_tile_lnbwd_128_64.json'}
+            'tile_lnbwd<128,64>': 'r06_pmc_tile_lnbwd_128_64.json'}
 KERNEL_NAMES = {'stationary': 'gather_gemm_stream_kernel', 'stationary_ln': 'gather_gemm_kernel (+LN epilogue)',
                 'sorted': 'gather_gemm_sorted_kernel', 'sorted_ln': 'gather_gemm_sorted_kernel (+LN epilogue)', 'sorted_lnbwd': 'gather_gemm_sorted_kernel (+LN-backward epilogue)',
                 'tile': 'subm_tile_conv_kernel', 'tile_ln': 'subm_tile_conv_kernel (+LN epilogue)',
@@ -891,6 +892,8 @@ def main():
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 'traffic': pmc_traffic(top),
+                # (`traffic` is NOT measured in this run: it is the committed counter pass of the same kernel on the same workload)
+                'traffic_source': ('profiles/' + PMC_JSON[top]) if top in PMC_JSON and pmc_traffic(top) is not None else None,
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'mfma_over_issue_pattern_order': sorted_over_issue if sorted_used else None,   # 16-row blocks multiplied x 16 / rulebook pairs
                 'mfma_over_issue_voxel_order': over_issue,
