@@ -105,7 +105,10 @@ SPLIT3 = os.environ.get('OCOCC_GEMM_SPLIT3', '1') == '1'
 SPLIT3_MIN_ROWS = int(os.environ.get('OCOCC_GEMM_SPLIT3_MIN_ROWS', '1024'))
 SPLIT3_MIN_WORK = 1 << 29          # rows x N x K below which the product is a launch's worth either way
 _HHL, _HLH = 0, 1                   # (hi, hi, lo) / (hi, lo, hi): one operand of a product takes the one, the other the other
-_w_operands = {}                    # (data_ptr, N, K, row stride) -> [parameter version, cat [N, 3K], stack [3N, K]]
+# parameter (the BASE tensor of a row slice) -> {(data_ptr, N, K, row stride): [version, cat [N, 3K], stack [3N, K]]}, keyed by the
+# tensor OBJECT and weakly: an address is reused by the caching allocator, a dead parameter's operands must not be
+from torch.utils.weak import WeakIdKeyDictionary   # noqa: E402
+_w_operands = WeakIdKeyDictionary()
 
 
 def split3(t, cat=None, stack=None):
@@ -131,13 +134,17 @@ def _weight_operands(w, want):
     if torch.cuda.is_current_stream_capturing():
         cat, stack = split3(w.detach(), cat=_HLH if want == 'cat' else None, stack=_HLH if want == 'stack' else None)
         return cat if want == 'cat' else stack
+    base = w._base if w._base is not None else w
+    table = _w_operands.get(base)
+    if table is None:
+        table = _w_operands[base] = {}
     key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0))
-    hit = _w_operands.get(key)
+    hit = table.get(key)
     if hit is None or hit[0] != w._version or hit[1].device != w.device:
-        if len(_w_operands) > 512:
-            _w_operands.clear()
+        if len(table) > 16:
+            table.clear()
         cat, stack = split3(w.detach(), cat=_HLH, stack=_HLH)
-        hit = _w_operands[key] = [w._version, cat, stack]
+        hit = table[key] = [w._version, cat, stack]
     return hit[1] if want == 'cat' else hit[2]
 
 

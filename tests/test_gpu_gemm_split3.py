@@ -92,6 +92,27 @@ def test_weight_operands_follow_the_parameter(dev):
     assert float((half - y1[:, :512]).abs().max()) <= 1e-5 * float(y1.abs().max())
 
 
+def test_operands_die_with_their_parameter(dev):
+    """the cache is keyed by the parameter OBJECT, weakly: the caching allocator hands a freed weight's address to the next
+    model's weight of the same shape (same version counter, too) -- its operands must not be found there"""
+    import gc
+    from objectcentricocccompletion_amd import gemm
+    x = torch.randn(1024, 1024, device=dev)
+    outs = []
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        w = torch.nn.Parameter(torch.randn(1024, 1024, device=dev) / 32)
+        ptr = w.data_ptr()
+        y = gemm.linear(x, w).detach()
+        ref = x.double() @ w.detach().double().t()
+        assert float((y.double() - ref).norm() / ref.norm()) <= 2e-5, seed
+        outs.append(ptr)
+        del w, y, ref
+        gc.collect()
+    assert len(gemm._w_operands) == 0
+    assert outs[0] == outs[1] or outs[1] == outs[2] or True      # (the addresses usually repeat; the products are right either way)
+
+
 def test_a_replayed_graph_splits_the_weights_of_its_own_step(dev):
     """heads.graphed_call replays the temporal transformer as a HIP-graph pair: the weight split must be PART of the graph
     (recorded at capture, run at every replay), not a lookup decided at capture time."""
