@@ -30,6 +30,7 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError('invalid AdamW hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.device_lr = bool(device_lr)
+        self._plans = {}   # group index -> the per-step pointer tables of step() (see there)
 
     def set_lr(self, lr, group=None):
         """New learning rate for one group (or all): the host value and, with device_lr, the device scalar the kernel
@@ -65,29 +66,54 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if not group['params']:
                 continue
-            self._init_group(group)
             ps = [p for p in group['params'] if p.grad is not None]
+            # Host side of a step with hundreds of tensors (configs[2]: 269; at 4 tracklets the step is bound by the host): what
+            # does not change from step to step -- the parameters' and moments' addresses, sizes, the checks on them, which of
+            # them are convolution weights with cached operand layouts -- is kept per group and validated by identity + address;
+            # only the gradients' addresses are collected every step (backward allocates them anew).
+            plan = self._plans.get(gi)
+            if plan is not None and ps and self.state[ps[0]].get('exp_avg') is not plan['m0']:
+                plan = None   # (the moments were replaced: a state dict loaded behind our back)
+            if plan is None or len(plan['ps']) != len(ps) or any(a is not b for a, b in zip(plan['ps'], ps)) \
+                    or plan['ptrs'] != [p.data_ptr() for p in ps]:
+                self._init_group(group)
+                for p in ps:
+                    L.require_device(p, p.grad)
+                    if p.dtype != torch.float32:
+                        raise L.OcoccError('AdamW kernel takes float32 parameters and gradients')
+                    if not p.is_contiguous():
+                        raise L.OcoccError('AdamW kernel takes contiguous parameters and gradients')
+                chunks = []
+                for lo in range(0, len(ps), _MAX):
+                    chunk = ps[lo:lo + _MAX]
+                    n = len(chunk)
+                    arr = ctypes.c_void_p * n
+                    chunks.append((chunk, n, arr, arr(*[p.data_ptr() for p in chunk]),
+                                   arr(*[self.state[p]['exp_avg'].data_ptr() for p in chunk]),
+                                   arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
+                                   (ctypes.c_int64 * n)(*[p.numel() for p in chunk]),
+                                   any(p.dim() >= 3 for p in chunk)))   # (only convolution weights have operand layouts)
+                plan = self._plans[gi] = dict(ps=list(ps), ptrs=[p.data_ptr() for p in ps], chunks=chunks,
+                                             m0=self.state[ps[0]]['exp_avg'] if ps else None)
             for p in ps:
-                L.require_device(p, p.grad)
-                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                g = p.grad
+                if g.dtype != torch.float32 or not g.is_cuda:
                     raise L.OcoccError('AdamW kernel takes float32 parameters and gradients')
-                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                if not g.is_contiguous():
                     raise L.OcoccError('AdamW kernel takes contiguous parameters and gradients')
             b1, b2 = group['betas']
             refreshed = []
             # every launch of one step must see the same step count: only the last one bumps it
-            for lo in range(0, len(ps), _MAX):
-                chunk = ps[lo:lo + _MAX]
-                n = len(chunk)
-                arr = ctypes.c_void_p * n
-                last = lo + _MAX >= len(ps)
+            for ci, (chunk, n, arr, p_arr, m_arr, v_arr, n_arr, has_conv) in enumerate(plan['chunks']):
+                last = ci + 1 == len(plan['chunks'])
+                g_arr = arr(*[p.grad.data_ptr() for p in chunk])
                 # convolution weights whose bf16 kernel operands are cached for the current step: the update rewrites the
                 # operands too (ococc_adamw_operands_f32) and the preparation launch of the next step disappears
                 targets = []
-                if REFRESH_CONV_OPERANDS:
+                if REFRESH_CONV_OPERANDS and has_conv:
                     from .spconv import ops as sp_ops
                     for i, p in enumerate(chunk):
                         for mode, kvol, cin, cout, wn in sp_ops.refresh_targets(p):
@@ -96,10 +122,7 @@ class AdamW(torch.optim.Optimizer):
                     no = len(targets)
                     i32 = ctypes.c_int32 * no
                     L.check(L.lib.ococc_adamw_operands_f32(
-                        n, arr(*[p.data_ptr() for p in chunk]), arr(*[p.grad.data_ptr() for p in chunk]),
-                        arr(*[self.state[p]['exp_avg'].data_ptr() for p in chunk]),
-                        arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
-                        (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), float(group['lr']),
+                        n, p_arr, g_arr, m_arr, v_arr, n_arr, float(group['lr']),
                         group['lr_dev'].data_ptr() if self.device_lr else None, float(b1), float(b2), float(group['eps']),
                         float(group['weight_decay']), group['step_dev'].data_ptr(), _BUMP if last else 0, no,
                         i32(*[t[0] for t in targets]), i32(*[t[1] for t in targets]), i32(*[t[2] for t in targets]),
@@ -109,13 +132,8 @@ class AdamW(torch.optim.Optimizer):
                     continue
                 fn, lr_arg = ((L.lib.ococc_adamw_lr_dev_f32, group['lr_dev'].data_ptr()) if self.device_lr
                               else (L.lib.ococc_adamw_f32, float(group['lr'])))
-                L.check(fn(
-                    n, arr(*[p.data_ptr() for p in chunk]), arr(*[p.grad.data_ptr() for p in chunk]),
-                    arr(*[self.state[p]['exp_avg'].data_ptr() for p in chunk]),
-                    arr(*[self.state[p]['exp_avg_sq'].data_ptr() for p in chunk]),
-                    (ctypes.c_int64 * n)(*[p.numel() for p in chunk]), lr_arg, float(b1),
-                    float(b2), float(group['eps']), float(group['weight_decay']), group['step_dev'].data_ptr(),
-                    _BUMP if last else 0, L.stream()), 'adamw')
+                L.check(fn(n, p_arr, g_arr, m_arr, v_arr, n_arr, lr_arg, float(b1), float(b2), float(group['eps']),
+                           float(group['weight_decay']), group['step_dev'].data_ptr(), _BUMP if last else 0, L.stream()), 'adamw')
             for p in ps:  # the kernel wrote through raw pointers: tell autograd / version-keyed caches
                 torch.autograd.graph.increment_version(p)
             if refreshed:
@@ -137,6 +155,7 @@ class AdamW(torch.optim.Optimizer):
         for g in state_dict['param_groups']:
             g.pop('step_dev', None)
         super().load_state_dict(state_dict)
+        self._plans.clear()   # (new moment tensors: the cached pointer tables of step() are stale)
         self.init_state()
         for g, c in zip(self.param_groups, counts):
             g['step_dev'][0] = float(c)
