@@ -83,6 +83,9 @@ def parse():
     ap.add_argument('--workload', default='submconv', choices=['submconv', 'ococcnet', 'sst', 'decode'],
                     help='submconv = BASELINE.json configs[1] (the quoted metric); ococcnet = configs[2]; sst = configs[4] per-GPU share')
     ap.add_argument('--tracklets', type=int, default=4)
+    ap.add_argument('--sst-grids', type=int, default=32,
+                    help='sst workload: object grids on this GPU (32 = one GPU\'s share of configs[4]\'s 256 objects over 8 GPUs; 256 = the\n'
+                         'whole configs[4] batch on one GPU)')
     ap.add_argument('--f32-decoder', action='store_true',
                     help='ococcnet workload: keep the occupancy-decoder MLP in f32 (default: bf16 GEMMs, f32 accumulate)')
     ap.add_argument('--split-graph', action='store_true',
@@ -380,7 +383,7 @@ def bench_sst(args, world, rank, dev):
     from objectcentricocccompletion_amd.sst import sst_modules as sm
     from objectcentricocccompletion_amd.voxel import dynamic_scatter, voxelization
     torch.manual_seed(0)
-    G, P = 32, 8200
+    G, P = args.sst_grids, 8200
     shape = (64, 80, 80)   # (D, H, W) = (z, y, x) cells
     rng = [-4, -4, -3.2, 4, 4, 3.2]
     drop = {0: dict(max_tokens=30, drop_range=(0, 30)), 1: dict(max_tokens=60, drop_range=(30, 60)),
@@ -453,7 +456,8 @@ def bench_sst(args, world, rank, dev):
             'unit': 'object-grids/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'configs[4] per-GPU share: {G} grids x 80x80x64 cells at 0.1 m, {P} random points each, '
+            'config': {'workload': ('configs[4] per-GPU share' if G == 32 else 'configs[4], the WHOLE 256-object batch on one GPU' if G == 256
+                                    else 'configs[4] shape') + f': {G} grids x 80x80x64 cells at 0.1 m, {P} random points each, '
                                    'SST path (windows 8x8x8, drop levels 30/60/100, d_model 128, 8 heads, ffn 256, '
                                    '2 BasicShiftBlockV2), fwd+bwd+AdamW', 'grids_per_gpu': G, 'active_voxels': int(n_act),
                        'parallelism': f'dp{world}', 'launch': 'eager launches'},
@@ -546,8 +550,9 @@ def also_workloads():
                        ('ococcnet_b64', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('ococcnet_b64_bf16_operands', ['--workload', 'ococcnet', '--tracklets', '64']),
                        ('sst', ['--workload', 'sst']),
+                       ('sst_all_256_objects', ['--workload', 'sst', '--sst-grids', '256']),
                        ('decode_b64', ['--workload', 'decode', '--tracklets', '64'])):
-        steps = '30' if key in ('ococcnet_b4', 'ococcnet_b16') else '10'   # (the short steps: more of them, the host's load shows)
+        steps = '30' if key in ('ococcnet_b4', 'ococcnet_b16') else ('5' if key == 'sst_all_256_objects' else '10')   # (the short steps: more of them, the host's load shows)
         cmd = [sys.executable, here, '--steps', steps, '--warmup', '8', '--no-cpu-baseline'] + extra
         env = dict(os.environ)
         if key.endswith('_bf16_operands'):

@@ -240,8 +240,11 @@ def test_f32_block_path_vs_oracle_with_bf16_attention_core(dev, golden_dir):
     assert e_norm < 1e-3
 
 
-def test_fused_sst_at_the_configs4_per_gpu_share(dev):
-    """configs[4], one GPU's share: 32 object grids of 80 x 80 x 64 cells at 0.1 m with 8 200 points each (~260 k voxels),
+@pytest.mark.parametrize('G', [32, 256])
+def test_fused_sst_at_the_configs4_per_gpu_share(dev, G):
+    """configs[4]: one GPU's share of its 256 objects over 8 GPUs (G = 32) and, round 6, the WHOLE 256-object batch on the one
+    GPU there is (G = 256, ~2.1 M voxels: the size the 8-GPU run would shard) --
+    G object grids of 80 x 80 x 64 cells at 0.1 m with 8 200 points each (~260 k voxels at 32),
     windows 8x8x8, drop levels 30 / 60 / 100, d_model 128, 8 heads, two shifted blocks on the fused kernels.  Checked:
     the tile plan covers every token once; the first encoder layer against the oracle on sampled windows of both ends
     of the token range; forward + backward of the whole backbone finite, bit-reproducible, and identical when replayed
@@ -249,7 +252,7 @@ def test_fused_sst_at_the_configs4_per_gpu_share(dev):
     from objectcentricocccompletion_amd.occ_encoder import synthetic_object_grids
     from objectcentricocccompletion_amd.sst.sst_modules import SSTInputLayerV2, SSTv2, _fused_maps
     from objectcentricocccompletion_amd.voxel import dynamic_scatter, voxelization
-    G, P = 32, 8200
+    P = 8200
     xyz, feats, bidx = synthetic_object_grids(G, P, seed=5, device=dev)
     xyz[:, 2] *= 0.8
     zyx = voxelization(xyz, [0.1, 0.1, 0.1], [-4, -4, -3.2, 4, 4, 3.2], -1, -1)
