@@ -98,19 +98,15 @@ def test_operands_die_with_their_parameter(dev):
     import gc
     from objectcentricocccompletion_amd import gemm
     x = torch.randn(1024, 1024, device=dev)
-    outs = []
     for seed in (1, 2, 3):
         torch.manual_seed(seed)
         w = torch.nn.Parameter(torch.randn(1024, 1024, device=dev) / 32)
-        ptr = w.data_ptr()
         y = gemm.linear(x, w).detach()
         ref = x.double() @ w.detach().double().t()
         assert float((y.double() - ref).norm() / ref.norm()) <= 2e-5, seed
-        outs.append(ptr)
         del w, y, ref
         gc.collect()
     assert len(gemm._w_operands) == 0
-    assert outs[0] == outs[1] or outs[1] == outs[2] or True      # (the addresses usually repeat; the products are right either way)
 
 
 def test_a_replayed_graph_splits_the_weights_of_its_own_step(dev):
