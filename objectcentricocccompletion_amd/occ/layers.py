@@ -27,15 +27,21 @@ class _TemporalAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, attn_mask, key_pad, dims, p_drop, seed):
+        # ``k`` None: ``q`` is the packed projection [L B, 2 H D] = q | k (the encoder layers: one product for both) -- the
+        # gradient then leaves as ONE [L B, 2 H D] tensor too, and no slice backward (a zero fill + a copy per half) runs
         from .. import _lib as L
         B, H, Lq, S, D = dims
+        ctx.packed = k is None
+        if ctx.packed:
+            qk = q
+            q, k = qk[:, :H * D], qk[:, H * D:]
         out = torch.empty((Lq * B, H * D), dtype=torch.float32, device=q.device)
         probs = torch.empty((B * H, Lq, S), dtype=torch.float32, device=q.device)
         L.check(L.lib.ococc_temporal_attention_fwd_f32(
             q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), L.ptr(attn_mask), L.ptr(key_pad),
             B, H, Lq, S, D, float(D) ** -0.5, float(p_drop), 0, L.ptr(seed), probs.data_ptr(), out.data_ptr(), out.stride(0),
             L.stream()), 'temporal_attention_fwd')
-        ctx.save_for_backward(q, k, v, probs, out, *(() if seed is None else (seed,)))
+        ctx.save_for_backward(qk if ctx.packed else q, v if ctx.packed else k, v, probs, out, *(() if seed is None else (seed,)))
         ctx.meta = (dims, float(p_drop), seed is not None)
         return out
 
@@ -47,17 +53,23 @@ class _TemporalAttention(torch.autograd.Function):
         seed = ctx.saved_tensors[5] if has_seed else None
         B, H, Lq, S, D = dims
         d_out = d_out.contiguous()
-        # (q and k are the two halves of one projection in the encoder layers: their gradients are written as the two
-        # halves of one buffer, which is what the slices' backward would assemble)
-        dqk = torch.empty((Lq * B, 2 * H * D), dtype=torch.float32, device=q.device) if Lq == S else None
-        dq = dqk[:, :H * D] if dqk is not None else torch.empty((Lq * B, H * D), dtype=torch.float32, device=q.device)
-        dk = dqk[:, H * D:] if dqk is not None else torch.empty((S * B, H * D), dtype=torch.float32, device=q.device)
+        dqk = None
+        if ctx.packed:
+            qk = q
+            q, k = qk[:, :H * D], qk[:, H * D:]
+            dqk = torch.empty_like(qk)
+            dq, dk = dqk[:, :H * D], dqk[:, H * D:]
+        else:
+            dq = torch.empty((Lq * B, H * D), dtype=torch.float32, device=q.device)
+            dk = torch.empty((S * B, H * D), dtype=torch.float32, device=q.device)
         dv = torch.empty((S * B, H * D), dtype=torch.float32, device=q.device)
         L.check(L.lib.ococc_temporal_attention_bwd_f32(
             q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), B, H, Lq, S, D, float(D) ** -0.5,
             p_drop, 0, L.ptr(seed), probs.data_ptr(), out.data_ptr(), out.stride(0), d_out.data_ptr(), d_out.stride(0),
             dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), L.stream()),
             'temporal_attention_bwd')
+        if ctx.packed:
+            return dqk, None, dv, None, None, None, None, None
         return dq, dk, dv, None, None, None, None, None
 
 
@@ -125,7 +137,9 @@ class MultiheadAttention(nn.Module):
             am = None if attn_mask is None else attn_mask.contiguous().view(torch.uint8)
             kp = None if key_padding_mask is None else key_padding_mask.contiguous().view(torch.uint8)
             seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=q.device) if p_drop > 0 else None
-            ctx = _TemporalAttention.apply(q, k, v, am, kp, (B, H, L, S, self.head_dim), p_drop, seed)
+            packed = key is query and qk.is_contiguous()
+            ctx = _TemporalAttention.apply(qk if packed else q, None if packed else k, v, am, kp, (B, H, L, S, self.head_dim),
+                                           p_drop, seed)
             return gemm.linear(ctx, self.out_proj.weight, self.out_proj.bias).view(L, B, E), None
         scores = gemm.bmm(self._heads(q * (self.head_dim ** -0.5), L), self._heads(k, S).transpose(1, 2))   # [B H, L, S]
         if attn_mask is not None:
